@@ -1,0 +1,186 @@
+/*
+ * syncfusion_amd -- C ABI of the MI355X (gfx950) implementation of SyncFusion's
+ * generation hot path.
+ *
+ * The reference (mcomunita/syncfusion) has no FFI: its "plugin API" is Hydra
+ * `_target_` instantiation plus Python duck typing.  The
+ * entry points below are what a binding for that path would bind; each cites the
+ * reference interface it replaces.  All pointers are DEVICE pointers unless
+ * marked host; all tensors are fp32, contiguous, in the reference's own
+ * (channels-first PyTorch) layout at the boundary.  No ownership is transferred,
+ * no exceptions cross the ABI, every call returns SF_OK (0) or an SF_ERR_* code
+ * and leaves a message in sf_last_error().  `stream` is a hipStream_t passed as
+ * void* (NULL = the null stream).  Nothing here allocates inside the timed path:
+ * activations live in a caller-provided workspace.
+ */
+#ifndef SYNCFUSION_AMD_H
+#define SYNCFUSION_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SF_MAX_DEPTH 12
+
+enum {
+  SF_OK = 0,
+  SF_ERR_INVALID = 1,        /* bad argument / inconsistent config                       */
+  SF_ERR_MISSING_WEIGHT = 2, /* a named parameter was not supplied or has the wrong size  */
+  SF_ERR_SHAPE = 3,          /* B/L0/T/H/W not supported by this model (stride, length)   */
+  SF_ERR_HIP = 4,            /* a HIP runtime call failed                                 */
+  SF_ERR_WORKSPACE = 5,      /* workspace missing or too small                            */
+  SF_ERR_UNSUPPORTED = 6
+};
+
+enum { SF_F32 = 0, SF_BF16 = 1 }; /* arithmetic/storage type of the activations and packed weights */
+
+/* One named parameter of a torch state_dict: fp32, contiguous, PyTorch layout, device memory. */
+typedef struct {
+  const char *name;
+  const void *data;
+  int64_t numel;
+} sf_tensor;
+
+const char *sf_version(void);
+const char *sf_last_error(void);
+/* 1 when a gfx950 device is visible to the HIP runtime, else 0 (never fails). */
+int sf_device_ok(void);
+
+/* ------------------------------------------------------------------------------------------
+ * U-Net denoiser + v-sampler
+ *   replaces: audio_diffusion_pytorch.UNetV0 / DiffusionModel.sample as instantiated by
+ *   exp/model/diffusion.yaml:11-33 and called from main/generation.py:77-83,
+ *   main/module_diffusion.py:77,200-206.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t n_layers;
+  int32_t in_channels;
+  int32_t channels[SF_MAX_DEPTH];
+  int32_t factors[SF_MAX_DEPTH];
+  int32_t items[SF_MAX_DEPTH];
+  int32_t attentions[SF_MAX_DEPTH];
+  int32_t cross_attentions[SF_MAX_DEPTH];
+  int32_t context_channels[SF_MAX_DEPTH];
+  int32_t attention_heads;
+  int32_t attention_features;
+  int32_t embedding_features;
+  int32_t embedding_max_length;
+  int32_t modulation_features;
+  int32_t resnet_groups;
+  int32_t dtype; /* SF_F32 (parity path) or SF_BF16 */
+} sf_unet_config;
+
+typedef struct sf_unet sf_unet;
+
+/* Build the engine: packs/folds the named fp32 parameters into its own device buffers
+ * (weights are copied; the caller may free `weights` afterwards).  Parameter names are
+ * listed by sf_unet_param_name(). */
+int sf_unet_create(const sf_unet_config *cfg, const sf_tensor *weights, int n_weights, void *stream, sf_unet **out);
+void sf_unet_destroy(sf_unet *h);
+
+/* Enumerate the parameter names/sizes the engine expects for `cfg` (host strings). */
+int sf_unet_param_count(const sf_unet_config *cfg);
+int sf_unet_param_name(const sf_unet_config *cfg, int index, char *name_out, int name_cap, int64_t *numel_out);
+
+/* Bytes of caller-allocated workspace needed for batch B and length L0 (two_pass != 0 when
+ * embedding_scale != 1: cond and uncond evaluations run as one 2B batch). */
+int64_t sf_unet_workspace_bytes(const sf_unet *h, int B, int L0, int two_pass);
+
+/* One denoiser evaluation  v = net(x, sigma; channels, embedding, embedding_scale)
+ *   (replaces UNetV0.forward, reached from main/module_diffusion.py:77 through VDiffusion).
+ *   x, out: (B, in_channels, L0).  sigma: (B).  ctx[d]: (B, context_channels[d], L0/prod(factors[:d+1])).
+ *   emb: (B, embedding_max_length, embedding_features). */
+int sf_unet_forward(sf_unet *h, const float *x, const float *sigma, const float *const *ctx, const float *emb,
+                    int B, int L0, float embedding_scale, float *out, void *ws, int64_t ws_bytes, void *stream);
+
+/* The whole sampling loop  x <- VSampler(net)(x_noisy, num_steps, ...)  in place
+ *   (replaces DiffusionModel.sample, main/generation.py:77-83, main/module_diffusion.py:200-206).
+ *   use_graph != 0 captures one step into a hipGraph and replays it. */
+int sf_vsample(sf_unet *h, float *x_inout, const float *const *ctx, const float *emb, int B, int L0,
+               int num_steps, float embedding_scale, int use_graph, void *ws, int64_t ws_bytes, void *stream);
+
+/* Debug taps (tests only): after the next sf_unet_forward, every block-level activation is
+ * copied as fp32 channels-last rows into `buf` (device).  Query the table afterwards. */
+int sf_unet_debug_enable(sf_unet *h, float *buf, int64_t cap_floats);
+int sf_unet_debug_count(const sf_unet *h);
+int sf_unet_debug_info(const sf_unet *h, int i, char *name_out, int name_cap, int64_t *offset, int64_t *rows, int32_t *cols);
+
+/* Per-kernel launch accounting of the last forward (host side, for bench.py's roofline):
+ * number of kernel launches in one evaluation. */
+int sf_unet_launch_count(const sf_unet *h);
+
+/* ------------------------------------------------------------------------------------------
+ * Encoder1d (onset-track feature pyramid)
+ *   replaces: audio_encoders_pytorch.Encoder1d as instantiated by exp/model/diffusion.yaml:35-43
+ *   and called as onsets_encoder(y, with_info=True) at main/generation.py:71,
+ *   main/module_diffusion.py:76,196.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t n_layers; /* len(factors) */
+  int32_t in_channels;
+  int32_t channels;
+  int32_t multipliers[SF_MAX_DEPTH + 1];
+  int32_t factors[SF_MAX_DEPTH];
+  int32_t num_blocks[SF_MAX_DEPTH];
+  int32_t resnet_groups;
+  int32_t patch_size; /* must be 1 */
+} sf_encoder1d_config;
+
+typedef struct sf_encoder1d sf_encoder1d;
+
+int sf_encoder1d_create(const sf_encoder1d_config *cfg, const sf_tensor *weights, int n_weights, void *stream, sf_encoder1d **out);
+void sf_encoder1d_destroy(sf_encoder1d *h);
+int64_t sf_encoder1d_workspace_bytes(const sf_encoder1d *h, int B, int L0);
+/* y: (B, in_channels, L0).  xs_out[0] = to_in(y), xs_out[1+i] = downsample_i output, each
+ * (B, C_i, L_i) fp32 channels-first: n_layers + 1 pointers (info["xs"][1:-1] of the reference). */
+int sf_encoder1d_forward(sf_encoder1d *h, const float *y, int B, int L0, float *const *xs_out,
+                         void *ws, int64_t ws_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * VideoOnsetNet (R(2+1)D-18 with the temporal stride removed + FC head)
+ *   replaces: main/onset_net.py:46-63 (VideoOnsetNet.forward), main/resnet.py:234-251.
+ *   Weights use the reference's own state_dict names (net.model.stem.0.weight ... fc.2.bias),
+ *   BatchNorm in eval mode (running statistics are folded into the convolutions).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct sf_onsetnet sf_onsetnet;
+
+int sf_onsetnet_create(const sf_tensor *weights, int n_weights, int dtype, void *stream, sf_onsetnet **out);
+void sf_onsetnet_destroy(sf_onsetnet *h);
+int64_t sf_onsetnet_workspace_bytes(const sf_onsetnet *h, int N, int T, int H, int W);
+/* frames: (N, 3, T, H, W); logits: (N, T) raw (no sigmoid), as the reference returns them. */
+int sf_onsetnet_forward(sf_onsetnet *h, const float *frames, int N, int T, int H, int W, float *logits,
+                        void *ws, int64_t ws_bytes, void *stream);
+int sf_onsetnet_debug_enable(sf_onsetnet *h, float *buf, int64_t cap_floats);
+int sf_onsetnet_debug_count(const sf_onsetnet *h);
+int sf_onsetnet_debug_info(const sf_onsetnet *h, int i, char *name_out, int name_cap, int64_t *offset, int64_t *rows, int32_t *cols);
+
+/* ------------------------------------------------------------------------------------------
+ * Onset glue on device: logits -> one-hot impulse track
+ *   replaces: main/module_onset.py:160-183 (threshold raw logits > 0.5, t = (idx+start)/fps,
+ *   "%.4f" rounding) + main/dataset_diffusion.py:69-72 (track[:, int(t*sr)] = 1).
+ *   logits: (N, T); track: (N, 1, L) is zero-filled then set. */
+int sf_onsets_to_track(const float *logits, int N, int T, const int32_t *start_frame /* (N) or NULL */,
+                       float frame_rate, float sample_rate, float threshold, float *track, int L, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Op-level entry points (channels-last, used by tests/ to localise kernel bugs).
+ *   dtype selects the storage type of x / w / out (fp32 or bf16 bit patterns).
+ * ---------------------------------------------------------------------------------------- */
+/* out = conv1d(silu(groupnorm(x))) + bias (+ residual).  x:(B,L,C) and out/residual:(B,Lout,N) channels-last in
+ * `dtype`; w:(N,C,taps) fp32 in PyTorch layout (packed internally); groups==0 -> no norm/activation;
+ * upsample = nearest-neighbour factor applied before the convolution.  Lout = (L*upsample + 2*pad - taps)/stride + 1. */
+int sf_op_conv1d_cl(int dtype, const void *x, const float *w, const float *bias, const float *gamma, const float *beta,
+                    int groups, float eps, const void *residual, int B, int L, int C, int N, int taps, int stride,
+                    int pad, int upsample, void *out, void *ws, int64_t ws_bytes, void *stream);
+/* y = layer_norm(x; eps, no affine) * (1 + scale[b]) + shift[b]   (scale/shift NULL -> plain normalise) */
+int sf_op_ln_modulate(int dtype, const void *x, const float *scale_shift /* (B, 2C) or NULL */, float eps,
+                      int B, int L, int C, void *out, void *stream);
+/* multi-head attention on packed projections: q:(B,L,H*D), kv:(B,L,2*H*D) -> out:(B,L,H*D) */
+int sf_op_attention(int dtype, const void *q, const void *kv, int B, int L, int heads, int head_dim, void *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SYNCFUSION_AMD_H */

@@ -1,0 +1,87 @@
+"""Generate tests/golden/onsetnet_*.npz from the REFERENCE itself (run in the build container only).
+
+    python oracle/gen_golden_onsetnet.py
+
+Imports ``main.onset_net.VideoOnsetNet`` from /root/reference (read-only), loads the seeded weights of
+``tests/helpers.seeded_state`` into it (strict ``load_state_dict`` -- which also proves that the product's
+parameter holder exposes exactly the reference's state_dict keys and shapes), runs small seeded inputs in
+eval mode and stores inputs, logits and per-stage activation summaries.  Weights are NOT stored (31 M
+parameters); the tests regenerate them from the same seed.  The reference's source never leaves
+/root/reference.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, "/root/reference")
+
+from helpers import GOLDEN, seeded_state  # noqa: E402
+from main.onset_net import VideoOnsetNet as RefNet  # noqa: E402  (the reference)
+from oracle.onsetnet_ref import onsetnet_forward  # noqa: E402
+from syncfusion_amd.onset_net import VideoOnsetNet as OurNet  # noqa: E402
+
+CASES = {  # name: (seed, N, T, H, W)
+    "small": (7, 2, 8, 32, 32),
+    "rect": (11, 1, 5, 48, 40),
+}
+
+
+def main():
+    torch.set_num_threads(8)
+    os.makedirs(GOLDEN, exist_ok=True)
+    ours = OurNet(pretrained=False)
+    ref = RefNet(pretrained=False).eval()
+    ref_sd = ref.state_dict()
+    our_sd = ours.state_dict()
+    assert list(ref_sd.keys()) == list(our_sd.keys()), "state_dict keys differ from the reference"
+    assert all(ref_sd[k].shape == our_sd[k].shape for k in ref_sd), "state_dict shapes differ from the reference"
+    for name, (seed, N, T, H, W) in CASES.items():
+        sd = seeded_state(ours, seed)
+        ref.load_state_dict(sd, strict=True)
+        g = torch.Generator().manual_seed(seed + 1000)
+        x = torch.randn(N, 3, T, H, W, generator=g)
+        stages = {}
+        hooks = []
+        for nm in ("stem", "layer1", "layer2", "layer3", "layer4"):
+            mod = getattr(ref.net.model, nm)
+            hooks.append(mod.register_forward_hook(lambda m, i, o, nm=nm: stages.__setitem__(nm, o.detach().clone())))
+        with torch.no_grad():
+            y = ref(x)
+        for h in hooks:
+            h.remove()
+        taps = {}
+        with torch.no_grad():
+            y_or = onsetnet_forward({k: v.float() for k, v in sd.items()}, x, taps)
+        err = float((y_or - y).abs().max())
+        print(f"{name}: logits {tuple(y.shape)}  oracle-vs-reference max|diff| = {err:.3e}")
+        assert err < 1e-5
+        out = dict(x=x.numpy(), y=y.numpy(), seed=np.int64(seed), keys_hash=np.int64(hash(tuple(ref_sd.keys())) & 0x7FFFFFFF))
+        for nm, t in stages.items():
+            out[f"{nm}_mean"] = np.float64(t.double().mean())
+            out[f"{nm}_absmean"] = np.float64(t.double().abs().mean())
+            out[f"{nm}_shape"] = np.array(t.shape, dtype=np.int64)
+            # a strided sample of the activation (channels-first) so layout mistakes cannot hide in a mean
+            flat = t.reshape(-1)
+            idx = torch.linspace(0, flat.numel() - 1, 257).long()
+            out[f"{nm}_idx"] = idx.numpy()
+            out[f"{nm}_val"] = flat[idx].numpy()
+            assert float((taps[nm] - t).abs().max()) < 1e-4
+        np.savez_compressed(os.path.join(GOLDEN, f"onsetnet_{name}.npz"), **out)
+    # survey KAT: reference default init under manual_seed(0), y[0,:4] at (2,3,8,32,32)
+    torch.manual_seed(0)
+    m = RefNet(False).eval()
+    xk = torch.randn(2, 3, 8, 32, 32)
+    with torch.no_grad():
+        yk = m(xk)
+        yo = onsetnet_forward(m.state_dict(), xk)
+    print("survey KAT y[0,:4] =", [round(float(v), 6) for v in yk[0, :4]], " oracle diff", float((yo - yk).abs().max()))
+    np.savez_compressed(os.path.join(GOLDEN, "onsetnet_kat_seed0.npz"), y=yk.numpy())
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,261 @@
+"""Thin Python owners of the C-ABI engine handles (weights snapshot, workspace, stream plumbing)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import SF_MAX_DEPTH, EncoderConfig, UnetConfig, check
+
+
+def _params_version(module: torch.nn.Module) -> Tuple:
+    return tuple((p.data_ptr(), p._version) for p in list(module.parameters()) + list(module.buffers()))
+
+
+def _fill(arr, values: Sequence[int]) -> None:
+    if len(values) > len(arr):
+        raise ValueError(f"at most {len(arr)} levels are supported, got {len(values)}")
+    for i, v in enumerate(values):
+        arr[i] = int(v)
+
+
+class _Base:
+    handle: Optional[int] = None
+    _destroy = None
+
+    def __del__(self):
+        try:
+            if self.handle and self._destroy is not None:
+                self._destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def _workspace(self, nbytes: int, device: torch.device) -> torch.Tensor:
+        ws = getattr(self, "_ws", None)
+        if ws is None or ws.numel() < nbytes or ws.device != device:
+            self._ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        return self._ws
+
+
+class UNetEngine(_Base):
+    """sf_unet_* : one handle per (UNetV0 module weights, dtype, device)."""
+
+    def __init__(self, net: torch.nn.Module, dtype: str):
+        lib = _lib.load()
+        self.lib = lib
+        self._destroy = lib.sf_unet_destroy
+        p = next(net.parameters())
+        _lib.require_gpu_tensor(p, "UNetV0 parameters")
+        self.device = p.device
+        hp = net.hparams
+        cfg = UnetConfig()
+        cfg.n_layers = len(hp["channels"])
+        cfg.in_channels = hp["in_channels"]
+        for field in ("channels", "factors", "items", "attentions", "cross_attentions", "context_channels"):
+            _fill(getattr(cfg, field), hp[field])
+        for field in ("attention_heads", "attention_features", "embedding_features", "embedding_max_length",
+                      "modulation_features", "resnet_groups"):
+            setattr(cfg, field, int(hp[field]))
+        cfg.dtype = _lib.DTYPES[dtype]
+        self.cfg = cfg
+        self.hp = dict(hp)
+        self.dtype = dtype
+        self.version = _params_version(net)
+        with torch.cuda.device(self.device):
+            table = _lib.TensorTable(((("net." + k), v) for k, v in net.state_dict().items()), self.device)
+            h = C.c_void_p()
+            check(lib.sf_unet_create(C.byref(cfg), table.array, table.n, _lib.stream_ptr(self.device), C.byref(h)), "sf_unet_create")
+            torch.cuda.synchronize(self.device)
+        self.handle = h.value
+
+    def stale(self, net: torch.nn.Module, dtype: str) -> bool:
+        return dtype != self.dtype or _params_version(net) != self.version
+
+    # -- helpers -------------------------------------------------------------------------------
+    def _check_inputs(self, x, channels, embedding):
+        hp = self.hp
+        if x.dim() != 3 or x.shape[1] != hp["in_channels"]:
+            raise ValueError(f"expected x of shape (B, {hp['in_channels']}, L), got {tuple(x.shape)}")
+        if embedding is None:
+            raise AssertionError("ClassifierFreeGuidancePlugin requires embedding")
+        B, _, L0 = x.shape
+        if tuple(embedding.shape) != (B, hp["embedding_max_length"], hp["embedding_features"]):
+            raise ValueError(f"embedding must be (B, {hp['embedding_max_length']}, {hp['embedding_features']}), got {tuple(embedding.shape)}")
+        if channels is None or len(channels) != len(hp["channels"]):
+            raise AssertionError(f"context `channels` must be a list of {len(hp['channels'])} tensors")
+        L = L0
+        for d, c in enumerate(channels):
+            L //= hp["factors"][d]
+            want = (B, hp["context_channels"][d], L)
+            if tuple(c.shape) != want:
+                raise AssertionError(f"context channels at depth {d}: expected {want}, got {tuple(c.shape)}")
+
+    def _ws_for(self, B: int, L0: int, two: bool) -> torch.Tensor:
+        n = self.lib.sf_unet_workspace_bytes(self.handle, B, L0, int(two))
+        if n < 0:
+            raise _lib.SyncFusionAmdError(f"unsupported shape B={B}, L0={L0}: {self.lib.sf_last_error().decode()}")
+        return self._workspace(n, self.device)
+
+    def forward(self, x: torch.Tensor, sigma: torch.Tensor, channels: Sequence[torch.Tensor], embedding: torch.Tensor,
+                embedding_scale: float = 1.0) -> torch.Tensor:
+        _lib.require_gpu_tensor(x, "UNetV0.forward")
+        self._check_inputs(x, channels, embedding)
+        B, _, L0 = x.shape
+        with torch.cuda.device(self.device):
+            xs = _lib.f32c(x)
+            sg = _lib.f32c(sigma).reshape(-1)
+            if sg.numel() != B:
+                raise ValueError("time/sigma must have one value per batch element")
+            ctx = [_lib.f32c(c) for c in channels]
+            emb = _lib.f32c(embedding)
+            out = torch.empty_like(xs)
+            ws = self._ws_for(B, L0, float(embedding_scale) != 1.0)
+            check(self.lib.sf_unet_forward(self.handle, xs.data_ptr(), sg.data_ptr(), _lib.ptr_array(ctx), emb.data_ptr(), B, L0,
+                                           float(embedding_scale), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                           _lib.stream_ptr(self.device)), "sf_unet_forward")
+        return out
+
+    def sample(self, x_noisy: torch.Tensor, num_steps: int, channels: Sequence[torch.Tensor], embedding: torch.Tensor,
+               embedding_scale: float = 1.0, use_graph: bool = True) -> torch.Tensor:
+        _lib.require_gpu_tensor(x_noisy, "DiffusionModel.sample")
+        self._check_inputs(x_noisy, channels, embedding)
+        B, _, L0 = x_noisy.shape
+        with torch.cuda.device(self.device):
+            x = _lib.f32c(x_noisy).clone()  # the caller's noise is not mutated (main/generation.py:69,77-83)
+            ctx = [_lib.f32c(c) for c in channels]
+            emb = _lib.f32c(embedding)
+            ws = self._ws_for(B, L0, float(embedding_scale) != 1.0)
+            check(self.lib.sf_vsample(self.handle, x.data_ptr(), _lib.ptr_array(ctx), emb.data_ptr(), B, L0, int(num_steps),
+                                      float(embedding_scale), int(bool(use_graph)), ws.data_ptr(), ws.numel(),
+                                      _lib.stream_ptr(self.device)), "sf_vsample")
+        return x
+
+    def launch_count(self) -> int:
+        return int(self.lib.sf_unet_launch_count(self.handle))
+
+    def forward_with_taps(self, x, sigma, channels, embedding, embedding_scale=1.0, cap_floats: int = 1 << 26):
+        """tests only: returns (out, {name: (rows, cols) fp32 tensor})."""
+        buf = torch.empty(cap_floats, dtype=torch.float32, device=self.device)
+        check(self.lib.sf_unet_debug_enable(self.handle, buf.data_ptr(), buf.numel()), "sf_unet_debug_enable")
+        try:
+            out = self.forward(x, sigma, channels, embedding, embedding_scale)
+            torch.cuda.synchronize(self.device)
+            taps: Dict[str, torch.Tensor] = {}
+            for i in range(self.lib.sf_unet_debug_count(self.handle)):
+                name = C.create_string_buffer(128)
+                off, rows, cols = C.c_int64(), C.c_int64(), C.c_int32()
+                check(self.lib.sf_unet_debug_info(self.handle, i, name, 128, C.byref(off), C.byref(rows), C.byref(cols)), "debug_info")
+                taps[name.value.decode()] = buf[off.value: off.value + rows.value * cols.value].reshape(rows.value, cols.value).clone()
+        finally:
+            self.lib.sf_unet_debug_enable(self.handle, None, 0)
+        return out, taps
+
+
+class EncoderEngine(_Base):
+    """sf_encoder1d_*"""
+
+    def __init__(self, enc: torch.nn.Module):
+        lib = _lib.load()
+        self.lib = lib
+        self._destroy = lib.sf_encoder1d_destroy
+        p = next(enc.parameters())
+        _lib.require_gpu_tensor(p, "Encoder1d parameters")
+        self.device = p.device
+        hp = enc.hparams
+        cfg = EncoderConfig()
+        cfg.n_layers = len(hp["factors"])
+        cfg.in_channels = hp["in_channels"]
+        cfg.channels = hp["channels"]
+        _fill(cfg.multipliers, hp["multipliers"])
+        _fill(cfg.factors, hp["factors"])
+        _fill(cfg.num_blocks, hp["num_blocks"])
+        cfg.resnet_groups = hp["resnet_groups"]
+        cfg.patch_size = hp["patch_size"]
+        self.hp = dict(hp)
+        self.version = _params_version(enc)
+        with torch.cuda.device(self.device):
+            table = _lib.TensorTable(enc.state_dict().items(), self.device)
+            h = C.c_void_p()
+            check(lib.sf_encoder1d_create(C.byref(cfg), table.array, table.n, _lib.stream_ptr(self.device), C.byref(h)), "sf_encoder1d_create")
+            torch.cuda.synchronize(self.device)
+        self.handle = h.value
+
+    def stale(self, enc: torch.nn.Module) -> bool:
+        return _params_version(enc) != self.version
+
+    def forward(self, y: torch.Tensor) -> List[torch.Tensor]:
+        _lib.require_gpu_tensor(y, "Encoder1d.forward")
+        hp = self.hp
+        if y.dim() != 3 or y.shape[1] != hp["in_channels"]:
+            raise ValueError(f"expected (B, {hp['in_channels']}, L), got {tuple(y.shape)}")
+        B, _, L0 = y.shape
+        with torch.cuda.device(self.device):
+            ys = _lib.f32c(y)
+            outs = [torch.empty(B, hp["channels"] * hp["multipliers"][0], L0, dtype=torch.float32, device=self.device)]
+            L = L0
+            for i, f in enumerate(hp["factors"]):
+                L = (L - 1) // f + 1
+                outs.append(torch.empty(B, hp["channels"] * hp["multipliers"][i + 1], L, dtype=torch.float32, device=self.device))
+            n = self.lib.sf_encoder1d_workspace_bytes(self.handle, B, L0)
+            if n < 0:
+                raise _lib.SyncFusionAmdError(self.lib.sf_last_error().decode())
+            ws = self._workspace(n, self.device)
+            check(self.lib.sf_encoder1d_forward(self.handle, ys.data_ptr(), B, L0, _lib.ptr_array(outs), ws.data_ptr(), ws.numel(),
+                                                _lib.stream_ptr(self.device)), "sf_encoder1d_forward")
+        return outs
+
+
+class OnsetNetEngine(_Base):
+    """sf_onsetnet_*"""
+
+    def __init__(self, net: torch.nn.Module, dtype: str):
+        lib = _lib.load()
+        self.lib = lib
+        self._destroy = lib.sf_onsetnet_destroy
+        p = next(net.parameters())
+        _lib.require_gpu_tensor(p, "VideoOnsetNet parameters")
+        self.device = p.device
+        self.dtype = dtype
+        self.version = _params_version(net)
+        with torch.cuda.device(self.device):
+            sd = {k: v for k, v in net.state_dict().items() if not k.endswith("num_batches_tracked")}
+            table = _lib.TensorTable(sd.items(), self.device)
+            h = C.c_void_p()
+            check(lib.sf_onsetnet_create(table.array, table.n, _lib.DTYPES[dtype], _lib.stream_ptr(self.device), C.byref(h)),
+                  "sf_onsetnet_create")
+            torch.cuda.synchronize(self.device)
+        self.handle = h.value
+
+    def stale(self, net: torch.nn.Module) -> bool:
+        return _params_version(net) != self.version or getattr(net, "compute_dtype", self.dtype) != self.dtype
+
+    def forward(self, x: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
+        N, _, T, H, W = x.shape
+        with torch.cuda.device(self.device):
+            xs = _lib.f32c(x)
+            out = torch.empty(N, T, dtype=torch.float32, device=self.device)
+            n = self.lib.sf_onsetnet_workspace_bytes(self.handle, N, T, H, W)
+            if n < 0:
+                raise _lib.SyncFusionAmdError(self.lib.sf_last_error().decode())
+            ws = self._workspace(n, self.device)
+            buf = None
+            if taps is not None:
+                buf = torch.empty(1 << 27, dtype=torch.float32, device=self.device)
+                check(self.lib.sf_onsetnet_debug_enable(self.handle, buf.data_ptr(), buf.numel()), "debug_enable")
+            try:
+                check(self.lib.sf_onsetnet_forward(self.handle, xs.data_ptr(), N, T, H, W, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                   _lib.stream_ptr(self.device)), "sf_onsetnet_forward")
+                if taps is not None:
+                    torch.cuda.synchronize(self.device)
+                    for i in range(self.lib.sf_onsetnet_debug_count(self.handle)):
+                        name = C.create_string_buffer(128)
+                        off, rows, cols = C.c_int64(), C.c_int64(), C.c_int32()
+                        check(self.lib.sf_onsetnet_debug_info(self.handle, i, name, 128, C.byref(off), C.byref(rows), C.byref(cols)), "debug_info")
+                        taps[name.value.decode()] = buf[off.value: off.value + rows.value * cols.value].reshape(rows.value, cols.value).clone()
+            finally:
+                if taps is not None:
+                    self.lib.sf_onsetnet_debug_enable(self.handle, None, 0)
+        return out

@@ -1,0 +1,148 @@
+"""ctypes binding of ``libsyncfusion_amd.so`` (the C ABI declared in include/syncfusion_amd.h).
+
+The product path has no CPU fallback: if the shared library is missing, or a CPU tensor reaches a
+forward/sample call, this module raises.  ``torch`` is used for device memory and streams only;
+no torch type crosses the ABI (raw ``data_ptr()`` integers and the HIP stream handle do).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import torch
+
+SF_MAX_DEPTH = 12
+SF_F32, SF_BF16 = 0, 1
+DTYPES = {"fp32": SF_F32, "float32": SF_F32, "f32": SF_F32, "bf16": SF_BF16, "bfloat16": SF_BF16}
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsyncfusion_amd.so")
+
+
+class SfTensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("numel", C.c_int64)]
+
+
+class UnetConfig(C.Structure):
+    _fields_ = [
+        ("n_layers", C.c_int32), ("in_channels", C.c_int32),
+        ("channels", C.c_int32 * SF_MAX_DEPTH), ("factors", C.c_int32 * SF_MAX_DEPTH),
+        ("items", C.c_int32 * SF_MAX_DEPTH), ("attentions", C.c_int32 * SF_MAX_DEPTH),
+        ("cross_attentions", C.c_int32 * SF_MAX_DEPTH), ("context_channels", C.c_int32 * SF_MAX_DEPTH),
+        ("attention_heads", C.c_int32), ("attention_features", C.c_int32),
+        ("embedding_features", C.c_int32), ("embedding_max_length", C.c_int32),
+        ("modulation_features", C.c_int32), ("resnet_groups", C.c_int32), ("dtype", C.c_int32),
+    ]
+
+
+class EncoderConfig(C.Structure):
+    _fields_ = [
+        ("n_layers", C.c_int32), ("in_channels", C.c_int32), ("channels", C.c_int32),
+        ("multipliers", C.c_int32 * (SF_MAX_DEPTH + 1)), ("factors", C.c_int32 * SF_MAX_DEPTH),
+        ("num_blocks", C.c_int32 * SF_MAX_DEPTH), ("resnet_groups", C.c_int32), ("patch_size", C.c_int32),
+    ]
+
+
+# every symbol include/syncfusion_amd.h declares: (restype, argtypes)
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+SYMBOLS = {
+    "sf_version": (C.c_char_p, []),
+    "sf_last_error": (C.c_char_p, []),
+    "sf_device_ok": (_I, []),
+    "sf_unet_create": (_I, [C.POINTER(UnetConfig), C.POINTER(SfTensor), _I, _P, C.POINTER(_P)]),
+    "sf_unet_destroy": (None, [_P]),
+    "sf_unet_param_count": (_I, [C.POINTER(UnetConfig)]),
+    "sf_unet_param_name": (_I, [C.POINTER(UnetConfig), _I, C.c_char_p, _I, C.POINTER(_L)]),
+    "sf_unet_workspace_bytes": (_L, [_P, _I, _I, _I]),
+    "sf_unet_forward": (_I, [_P, _P, _P, C.POINTER(_P), _P, _I, _I, _F, _P, _P, _L, _P]),
+    "sf_vsample": (_I, [_P, _P, C.POINTER(_P), _P, _I, _I, _I, _F, _I, _P, _L, _P]),
+    "sf_unet_debug_enable": (_I, [_P, _P, _L]),
+    "sf_unet_debug_count": (_I, [_P]),
+    "sf_unet_debug_info": (_I, [_P, _I, C.c_char_p, _I, C.POINTER(_L), C.POINTER(_L), C.POINTER(C.c_int32)]),
+    "sf_unet_launch_count": (_I, [_P]),
+    "sf_encoder1d_create": (_I, [C.POINTER(EncoderConfig), C.POINTER(SfTensor), _I, _P, C.POINTER(_P)]),
+    "sf_encoder1d_destroy": (None, [_P]),
+    "sf_encoder1d_workspace_bytes": (_L, [_P, _I, _I]),
+    "sf_encoder1d_forward": (_I, [_P, _P, _I, _I, C.POINTER(_P), _P, _L, _P]),
+    "sf_onsetnet_create": (_I, [C.POINTER(SfTensor), _I, _I, _P, C.POINTER(_P)]),
+    "sf_onsetnet_destroy": (None, [_P]),
+    "sf_onsetnet_workspace_bytes": (_L, [_P, _I, _I, _I, _I]),
+    "sf_onsetnet_forward": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _L, _P]),
+    "sf_onsetnet_debug_enable": (_I, [_P, _P, _L]),
+    "sf_onsetnet_debug_count": (_I, [_P]),
+    "sf_onsetnet_debug_info": (_I, [_P, _I, C.c_char_p, _I, C.POINTER(_L), C.POINTER(_L), C.POINTER(C.c_int32)]),
+    "sf_onsets_to_track": (_I, [_P, _I, _I, _P, _F, _F, _F, _P, _I, _P]),
+    "sf_op_conv1d_cl": (_I, [_I, _P, _P, _P, _P, _P, _I, _F, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _L, _P]),
+    "sf_op_ln_modulate": (_I, [_I, _P, _P, _F, _I, _I, _I, _P, _P]),
+    "sf_op_attention": (_I, [_I, _P, _P, _I, _I, _I, _I, _P, _P]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class SyncFusionAmdError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the shared library (once) and declare every prototype.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SyncFusionAmdError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C syncfusion_amd/csrc`).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the header and the library drift apart
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().sf_last_error()
+        raise SyncFusionAmdError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")
+
+
+def require_gpu_tensor(t: torch.Tensor, where: str) -> None:
+    if not t.is_cuda:
+        raise SyncFusionAmdError(f"{where}: expected a tensor on an MI355X (cuda/hip) device, got {t.device}; "
+                                 "this build has no CPU execution path")
+
+
+def stream_ptr(device: torch.device) -> int:
+    return int(torch.cuda.current_stream(device).cuda_stream)
+
+
+def f32c(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to(torch.float32).contiguous()
+
+
+class TensorTable:
+    """Keeps the (name, fp32 contiguous device tensor) pairs alive while the C side reads them."""
+
+    def __init__(self, named: Iterable[Tuple[str, torch.Tensor]], device: torch.device):
+        self.keep: List[torch.Tensor] = []
+        self.names: List[bytes] = []
+        items = list(named)
+        self.array = (SfTensor * max(1, len(items)))()
+        self.n = len(items)
+        for i, (name, t) in enumerate(items):
+            tt = f32c(t).to(device)
+            self.keep.append(tt)
+            self.names.append(name.encode())
+            self.array[i].name = self.names[-1]
+            self.array[i].data = tt.data_ptr()
+            self.array[i].numel = tt.numel()
+
+
+def ptr_array(tensors: Sequence[torch.Tensor]):
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr

@@ -1,0 +1,90 @@
+// Shared device helpers for the gfx950 kernels (wave64, MFMA, 16-byte vector access).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sf {
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+constexpr int WAVE = 64;
+
+// 16-byte vector of T: 4 floats or 8 bf16.
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+  static constexpr int N = 4;
+  f32x4 v;
+  __device__ __forceinline__ float get(int i) const { return v[i]; }
+  __device__ __forceinline__ void set(int i, float x) { v[i] = x; }
+};
+template <> struct Vec16<bf16> {
+  static constexpr int N = 8;
+  bf16x8 v;
+  __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+  __device__ __forceinline__ void set(int i, float x) { v[i] = (bf16)x; }
+};
+
+template <typename T> __device__ __forceinline__ Vec16<T> ld16(const T *p) {
+  Vec16<T> r;
+  u32x4 raw = *reinterpret_cast<const u32x4 *>(p);
+  r.v = __builtin_bit_cast(decltype(r.v), raw);
+  return r;
+}
+template <typename T> __device__ __forceinline__ void st16(T *p, const Vec16<T> &x) {
+  *reinterpret_cast<u32x4 *>(p) = __builtin_bit_cast(u32x4, x.v);
+}
+template <typename T> __device__ __forceinline__ Vec16<T> zero16() {
+  Vec16<T> r;
+  u32x4 z = {0u, 0u, 0u, 0u};
+  r.v = __builtin_bit_cast(decltype(r.v), z);
+  return r;
+}
+
+template <typename T> __device__ __forceinline__ float to_f(T x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f(float x) { return (T)x; }
+
+// exp: accurate on the fp32 parity path, v_exp_f32 based on the bf16 path.
+template <bool FAST> __device__ __forceinline__ float exp_t(float x) {
+  if constexpr (FAST) return __expf(x);
+  else return expf(x);
+}
+template <bool FAST> __device__ __forceinline__ float silu_t(float x) { return x / (1.0f + exp_t<FAST>(-x)); }
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// epilogue activation codes shared by the conv kernels: 0 none, 1 relu, 2 gelu(erf), 3 silu(gelu(v))
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == 1) return fmaxf(v, 0.f);
+  if (act == 2) return gelu_erf(v);
+  if (act == 3) {
+    float g = gelu_erf(v);
+    return g / (1.0f + expf(-g));
+  }
+  return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Chan/Welford merge of (n, mean, M2) partials.
+__device__ __forceinline__ void welford_merge(float &n, float &mean, float &m2, float nb, float mb, float m2b) {
+  if (nb <= 0.f) return;
+  float tot = n + nb;
+  float delta = mb - mean;
+  mean += delta * (nb / tot);
+  m2 += m2b + delta * delta * (n * nb / tot);
+  n = tot;
+}
+
+}  // namespace sf

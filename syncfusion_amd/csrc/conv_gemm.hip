@@ -1,0 +1,404 @@
+// Implicit-GEMM convolution on the CDNA4 matrix cores (wave64 MFMA 32x32).
+//
+//   out[m][n] = epi( sum_k A(m,k) * W[n][k] ),  m = output row (channels-last), n = output channel.
+//
+// One 256-thread workgroup (4 waves) owns a BM x BN output tile; the K loop walks 32-wide
+// slices of the (tap, channel) axis.  Because activations are channels-last, a K slice of one
+// tap is a contiguous 128-byte (fp32) / 64-byte (bf16) run of one source row, so the A tile is
+// gathered with 16-byte loads, transformed in registers (GroupNorm+SiLU prologue: one fma and
+// one SiLU per element from a per-(clip,channel) table in LDS) and staged in LDS; the W tile is
+// K-contiguous too.  Global loads of slice t+1 are issued before the MFMAs of slice t and
+// written to LDS after them (issue-early / write-late).
+//
+//   fp32 path : v_mfma_f32_32x32x2_f32  (exact fp32 fma chain; K order permuted {s, 16+s})
+//   bf16 path : v_mfma_f32_32x32x16_bf16 (fp32 accumulate)
+#include "common.h"
+#include "kernels.h"
+
+namespace sf {
+
+namespace {
+
+constexpr int BK = 32;
+
+template <typename T> struct Lds {
+  // row stride of an LDS tile in elements: 32 + one 16-byte pad
+  static constexpr int LD = BK + 16 / (int)sizeof(T);
+};
+
+struct RowState {  // per staged A row held by a thread
+  int valid_m;     // m < M
+  int b_rel;       // clip index relative to the tile's first clip (GN table)
+  int p0;          // 1-D: l*stride - pad ;  video: unused
+  int base;        // 1-D: b*Lsrc ; video: n
+  int t, h, w;     // video coordinates (already multiplied by stride, minus pad)
+};
+
+template <typename T, int BM, int BN, int WM_, int WN_, bool SCALAR_A>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
+  constexpr int VEC = Vec16<T>::N;
+  constexpr int VPR = BK / VEC;        // 16-byte vectors per tile row
+  constexpr int RPP = 256 / VPR;       // rows staged per pass
+  constexpr int PA = BM / RPP;
+  constexpr int PB = (BN + RPP - 1) / RPP;   // BN < RPP: only the first BN*VPR threads stage W
+  static_assert(PA >= 1 && BM % RPP == 0, "tile too small for the staging pattern");
+  constexpr int LD = Lds<T>::LD;
+  constexpr int WTM = BM / WM_, WTN = BN / WN_;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr bool FAST = sizeof(T) == 2;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T *As = reinterpret_cast<T *>(smem);
+  T *Bs = As + BM * LD;
+  float2 *tab = reinterpret_cast<float2 *>(Bs + BN * LD);  // GN: (scale, shift) per (clip, channel)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wr = wave / WN_, wc = wave % WN_;
+  const int m0 = blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+
+  const T *src = static_cast<const T *>(a.src);
+  const T *src2 = static_cast<const T *>(a.src2);
+  const T *wgt = static_cast<const T *>(a.w);
+
+  const int srow = tid / VPR;   // row within a pass
+  const int svec = tid % VPR;   // vector within the row
+
+  // ---- per-row state of the A rows this thread stages -------------------------------------
+  RowState rs[PA];
+  const int b_first = (a.geom == 0) ? (m0 / a.Lout) : 0;
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    int m = m0 + i * RPP + srow;
+    rs[i].valid_m = m < a.M;
+    int mm = rs[i].valid_m ? m : 0;
+    if (a.geom == 0) {
+      int b = mm / a.Lout;
+      int l = mm - b * a.Lout;
+      rs[i].b_rel = b - b_first;
+      rs[i].p0 = l * a.stride - a.pad;
+      rs[i].base = b * a.Lsrc;
+      rs[i].t = rs[i].h = rs[i].w = 0;
+    } else {
+      int w_ = mm % a.Wo;
+      int r = mm / a.Wo;
+      int h_ = r % a.Ho;
+      r /= a.Ho;
+      int t_ = r % a.To;
+      int n_ = r / a.To;
+      rs[i].b_rel = 0;
+      rs[i].p0 = 0;
+      rs[i].base = n_;
+      rs[i].t = t_ * a.st - a.pt;
+      rs[i].h = h_ * a.sh - a.ph;
+      rs[i].w = w_ * a.sw - a.pw;
+    }
+  }
+
+  // ---- GroupNorm+SiLU prologue table ----------------------------------------------------------
+  if (a.pro == 1) {
+    const int b_last = min(a.M - 1, m0 + BM - 1) / a.Lout;
+    const int nb = b_last - b_first + 1;
+    float2 *mr = tab + (size_t)a.cin * nb;  // (mean, rstd) per (clip, group), behind the table
+    const int cpg = a.cin / a.G;
+    for (int idx = tid; idx < nb * a.G; idx += 256) {
+      int bl = idx / a.G, g = idx - bl * a.G;
+      const float *sl = a.stats + ((size_t)(b_first + bl) * a.nch) * a.G * 2 + g * 2;
+      float n = 0.f, mean = 0.f, m2 = 0.f;
+      for (int c = 0; c < a.nch; ++c) {
+        int r0 = c * a.chunk_rows;
+        int rows = min(a.chunk_rows, a.Lsrc - r0);
+        welford_merge(n, mean, m2, (float)rows * (float)cpg, sl[(size_t)c * a.G * 2], sl[(size_t)c * a.G * 2 + 1]);
+      }
+      float var = m2 / n;
+      mr[idx] = make_float2(mean, rsqrtf(var + a.eps));
+    }
+    __syncthreads();
+    for (int idx = tid; idx < nb * a.cin; idx += 256) {
+      int bl = idx / a.cin, c = idx - bl * a.cin;
+      float2 s = mr[bl * a.G + c / cpg];
+      float sc = s.y * a.gamma[c];
+      tab[idx] = make_float2(sc, a.beta[c] - s.x * sc);
+    }
+    __syncthreads();
+  }
+
+  // ---- accumulators ---------------------------------------------------------------------------
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  Vec16<T> ra[PA], rb[PB];
+  int rvalid[PA];  // source row in range (bit) for the prefetched slice
+  int rci0 = 0;    // first channel of the prefetched slice (GN table index)
+  int rsecond = 0; // slice comes from src2
+
+  const int nkt = (a.K + BK - 1) / BK;
+  const int k_taps = a.taps * a.cin;
+
+  auto prefetch = [&](int kt) {
+    const int k0 = kt * BK;
+    // ---- W tile ----
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      int n = n0 + i * RPP + srow;
+      int k = k0 + svec * VEC;
+      if (i * RPP + srow >= BN) n = a.N;  // outside the tile
+      if (n < a.N && k + VEC <= a.K) rb[i] = ld16<T>(wgt + (size_t)n * a.K + k);
+      else if (n < a.N && k < a.K) {
+        Vec16<T> v = zero16<T>();
+        for (int j = 0; j < VEC; ++j)
+          if (k + j < a.K) v.set(j, to_f(wgt[(size_t)n * a.K + k + j]));
+        rb[i] = v;
+      } else rb[i] = zero16<T>();
+    }
+    // ---- A tile ----
+    if constexpr (!SCALAR_A) {
+      if (k0 < k_taps) {
+        const int tap = k0 / a.cin;
+        const int ci0 = k0 - tap * a.cin;
+        rci0 = ci0 + svec * VEC;
+        rsecond = 0;
+        int dt = 0, dh = 0, dw = 0;
+        if (a.geom == 1) {
+          dw = tap % a.kw;
+          int r = tap / a.kw;
+          dh = r % a.kh;
+          dt = r / a.kh;
+        }
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+          int ok = rs[i].valid_m;
+          size_t row;
+          if (a.geom == 0) {
+            int p = rs[i].p0 + tap;
+            ok = ok && p >= 0 && p < (a.Lsrc << a.up_shift);
+            row = (size_t)(rs[i].base + (max(p, 0) >> a.up_shift));
+          } else {
+            int ti = rs[i].t + dt, hi = rs[i].h + dh, wi = rs[i].w + dw;
+            ok = ok && ti >= 0 && ti < a.Ti && hi >= 0 && hi < a.Hi && wi >= 0 && wi < a.Wi;
+            row = ((size_t)(rs[i].base * a.Ti + max(ti, 0)) * a.Hi + max(hi, 0)) * a.Wi + max(wi, 0);
+          }
+          rvalid[i] = ok;
+          if (ok) ra[i] = ld16<T>(src + row * a.src_ld + rci0);
+          else ra[i] = zero16<T>();
+        }
+      } else {
+        const int ci0 = k0 - k_taps + svec * VEC;
+        rsecond = 1;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+          int m = m0 + i * RPP + srow;
+          rvalid[i] = rs[i].valid_m;
+          if (rs[i].valid_m) ra[i] = ld16<T>(src2 + (size_t)m * a.src2_ld + ci0);
+          else ra[i] = zero16<T>();
+        }
+      }
+    } else {
+      // per-element (tap, channel) decode: thin-channel layers such as the RGB stem
+      rsecond = 0;
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        Vec16<T> v = zero16<T>();
+        rvalid[i] = 0;
+        if (rs[i].valid_m) {
+          for (int j = 0; j < VEC; ++j) {
+            int k = k0 + svec * VEC + j;
+            if (k >= k_taps) break;
+            int tap = k / a.cin, ci = k - tap * a.cin;
+            int ok;
+            size_t row;
+            if (a.geom == 0) {
+              int p = rs[i].p0 + tap;
+              ok = p >= 0 && p < (a.Lsrc << a.up_shift);
+              row = (size_t)(rs[i].base + (max(p, 0) >> a.up_shift));
+            } else {
+              int dw = tap % a.kw;
+              int r = tap / a.kw;
+              int dh = r % a.kh;
+              int dt = r / a.kh;
+              int ti = rs[i].t + dt, hi = rs[i].h + dh, wi = rs[i].w + dw;
+              ok = ti >= 0 && ti < a.Ti && hi >= 0 && hi < a.Hi && wi >= 0 && wi < a.Wi;
+              row = ((size_t)(rs[i].base * a.Ti + max(ti, 0)) * a.Hi + max(hi, 0)) * a.Wi + max(wi, 0);
+            }
+            if (ok) v.set(j, to_f(src[row * a.src_ld + ci]));
+          }
+        }
+        ra[i] = v;
+      }
+    }
+  };
+
+  auto stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < PB; ++i)
+      if (i * RPP + srow < BN) st16<T>(Bs + (i * RPP + srow) * LD + svec * VEC, rb[i]);
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      Vec16<T> v = ra[i];
+      if (a.pro == 1 && !rsecond && rvalid[i]) {
+        const float2 *tb = tab + (size_t)rs[i].b_rel * a.cin + rci0;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          float2 sd = tb[j];
+          float y = fmaf(v.get(j), sd.x, sd.y);
+          v.set(j, silu_t<FAST>(y));
+        }
+      }
+      st16<T>(As + (i * RPP + srow) * LD + svec * VEC, v);
+    }
+  };
+
+  const int fr = lane & 31, fh = lane >> 5;
+
+  auto compute = [&]() {
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 af[TM], bfr[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          af[i] = *reinterpret_cast<const bf16x8 *>(As + (wr * WTM + i * 32 + fr) * LD + 16 * s + 8 * fh);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          bfr[j] = *reinterpret_cast<const bf16x8 *>(Bs + (wc * WTN + j * 32 + fr) * LD + 16 * s + 8 * fh);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 af[TM], bfr[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          af[i] = *reinterpret_cast<const f32x4 *>(As + (wr * WTM + i * 32 + fr) * LD + 16 * fh + 4 * q);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          bfr[j] = *reinterpret_cast<const f32x4 *>(Bs + (wc * WTN + j * 32 + fr) * LD + 16 * fh + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bfr[j][e], acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+
+  // ---- main loop ------------------------------------------------------------------------------
+  prefetch(0);
+  stage();
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const bool more = kt + 1 < nkt;
+    if (more) prefetch(kt + 1);
+    compute();
+    __syncthreads();
+    if (more) {
+      stage();
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue -------------------------------------------------------------------------------
+  T *out = static_cast<T *>(a.out);
+  const T *res = static_cast<const T *>(a.res);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wc * WTN + j * 32 + fr;
+    if (n >= a.n_store) continue;
+    const bool real = n < a.N;
+    const float bias = (real && a.bias) ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wr * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        if (m >= a.M) continue;
+        float v = 0.f;
+        if (real) {
+          v = acc[i][j][r] + bias;
+          if (a.bscale || a.badd) {
+            int b = m / a.Lout;
+            if (a.bscale) v *= a.bscale[(size_t)b * a.bscale_ld + n];
+            if (res) v += to_f(res[(size_t)m * a.res_ld + n]);
+            if (a.badd) v += a.badd[(size_t)b * a.badd_ld + n];
+          } else if (res) {
+            v += to_f(res[(size_t)m * a.res_ld + n]);
+          }
+          v = apply_act(v, a.act);
+        }
+        if (a.out_f32) static_cast<float *>(a.out)[(size_t)m * a.out_ld + n] = v;
+        else out[(size_t)m * a.out_ld + n] = from_f<T>(v);
+      }
+    }
+  }
+}
+
+template <typename T, int BM, int BN, int WM_, int WN_, bool SC>
+hipError_t launch_cfg(const ConvGemmArgs &a, hipStream_t s) {
+  constexpr int LD = Lds<T>::LD;
+  size_t lds = (size_t)(BM + BN) * LD * sizeof(T);
+  if (a.pro == 1) {
+    int nb = min(a.M / a.Lout + (a.M % a.Lout ? 1 : 0), BM / a.Lout + 2);
+    lds += (size_t)nb * (a.cin + a.G) * sizeof(float2);
+  }
+  dim3 grid((a.M + BM - 1) / BM, (a.n_store + BN - 1) / BN);
+  auto kern = conv_gemm_kernel<T, BM, BN, WM_, WN_, SC>;
+  static bool big_lds_enabled = false;  // one-time opt-in to > 48 KiB of dynamic LDS (never inside graph capture)
+  if (!big_lds_enabled) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    if (e != hipSuccess) return e;
+    big_lds_enabled = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  return hipGetLastError();
+}
+
+template <typename T> hipError_t dispatch(const ConvGemmArgs &a, hipStream_t s) {
+  const bool scalar_a = (a.cin % BK) != 0 || (a.cin2 % BK) != 0;
+  if (scalar_a) {
+    if (a.cin2 != 0 || a.pro != 0) return hipErrorInvalidValue;
+    return launch_cfg<T, 64, 64, 2, 2, true>(a, s);
+  }
+  const long M = a.M, N = a.n_store;
+  auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+  if (N <= 32) return launch_cfg<T, 128, 32, 4, 1, false>(a, s);
+  if (N <= 64) {
+    if (blocks(128, 64) >= 512) return launch_cfg<T, 128, 64, 2, 2, false>(a, s);
+    return launch_cfg<T, 64, 64, 2, 2, false>(a, s);
+  }
+  if (blocks(128, 128) >= 512) return launch_cfg<T, 128, 128, 2, 2, false>(a, s);
+  if (blocks(128, 64) >= 384) return launch_cfg<T, 128, 64, 2, 2, false>(a, s);
+  return launch_cfg<T, 64, 64, 2, 2, false>(a, s);
+}
+
+}  // namespace
+
+bool conv_gemm_supported(int dt, const ConvGemmArgs &a) {
+  (void)dt;
+  if (a.M <= 0 || a.N <= 0 || a.K <= 0) return false;
+  if (a.pro == 1) {
+    if (a.geom != 0 || a.cin % BK || a.cin % a.G) return false;
+    int nb = min(a.M / a.Lout + 1, 128 / a.Lout + 2);
+    if ((size_t)nb * (a.cin + a.G) * 8 > 96 * 1024) return false;
+  }
+  return true;
+}
+
+hipError_t launch_conv_gemm(int dt, const ConvGemmArgs &a, hipStream_t s) {
+  if (!conv_gemm_supported(dt, a)) return hipErrorInvalidValue;
+  return dt == F32 ? dispatch<float>(a, s) : dispatch<bf16>(a, s);
+}
+
+}  // namespace sf

@@ -1,0 +1,113 @@
+// Host-side launchers of the gfx950 kernels.  Everything is channels-last:
+// a 1-D activation is rows x channels with row = b * L + l; a video activation is
+// rows = ((n * T + t) * H + h) * W + w.  `DT` selects fp32 (parity path) or bf16.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sf {
+
+enum DType { F32 = 0, BF16 = 1 };
+inline size_t dsize(int dt) { return dt == F32 ? 4 : 2; }
+
+// ---------------------------------------------------------------------------------------
+// Implicit-GEMM convolution on the matrix cores:  out[m][n] = epi( sum_k A(m,k) * W[n][k] )
+//   A(m, tap*cin + ci)       = pro( src[row(m,tap)][ci] )       (0 outside the padding)
+//   A(m, taps*cin + ci2)     = src2[m][ci2]                      (channel concat, taps==1)
+// ---------------------------------------------------------------------------------------
+struct ConvGemmArgs {
+  const void *src = nullptr, *src2 = nullptr, *w = nullptr, *res = nullptr;
+  void *out = nullptr;
+  const float *bias = nullptr, *gamma = nullptr, *beta = nullptr, *stats = nullptr;
+  const float *badd = nullptr, *bscale = nullptr;
+  int M = 0, N = 0, K = 0;  // K = taps*cin + cin2 (weights row length)
+  int cin = 0, cin2 = 0, src_ld = 0, src2_ld = 0, out_ld = 0, res_ld = 0, n_store = 0;
+  int geom = 0;  // 0: 1-D, 1: video (T,H,W)
+  // 1-D: source position p = l*stride + tap - pad, valid when 0 <= p < Lsrc*up, source row = p >> up_shift
+  int Lout = 1, Lsrc = 1, taps = 1, stride = 1, pad = 0, up_shift = 0;
+  // video
+  int To = 1, Ho = 1, Wo = 1, Ti = 1, Hi = 1, Wi = 1, kt = 1, kh = 1, kw = 1, st = 1, sh = 1, sw = 1, pt = 0, ph = 0, pw = 0;
+  // prologue: 0 none, 1 GroupNorm+SiLU from a partial-statistics slab [B][nch][G][2] (mean, M2 per chunk)
+  int pro = 0, G = 1, nch = 1, chunk_rows = 1;
+  float eps = 1e-5f;
+  // epilogue: v = acc + bias; v *= bscale[b][n]; v += res[m][n]; v += badd[b][n]; v = act(v)
+  //   act: 0 none, 1 relu, 2 gelu(erf), 3 silu(gelu(v))   out_f32: store fp32 whatever the compute type
+  int badd_ld = 0, bscale_ld = 0, act = 0, out_f32 = 0;
+};
+hipError_t launch_conv_gemm(int dt, const ConvGemmArgs &a, hipStream_t s);
+// bytes of dynamic LDS the GN table needs is bounded; returns false when the shape is unsupported.
+bool conv_gemm_supported(int dt, const ConvGemmArgs &a);
+
+// ---------------------------------------------------------------------------------------
+// Direct (VALU) convolution for thin layers (Cin*taps small, N <= 32): one output row per thread.
+// Same A/epilogue semantics as ConvGemmArgs (1-D geometry only); weights fp32 [N][taps*cin + cin2].
+// ---------------------------------------------------------------------------------------
+hipError_t launch_conv_direct(int dt_in, int dt_out, const ConvGemmArgs &a, hipStream_t s);
+
+// GroupNorm partial statistics: x:(B*L, C) (row stride ld) -> slab [B][nch][G][2] = (mean, M2) per chunk of rows.
+struct GnPlan {
+  int nch = 1, chunk_rows = 1;
+};
+GnPlan gn_plan(int B, int L, int C);
+hipError_t launch_gn_stats(int dt, const void *x, int ld, int B, int L, int C, int G, int nch, int chunk_rows, float *slab,
+                           hipStream_t s);
+
+// y = LN_C(x; eps) * (1 + scale[b][c]) + shift[b][c]   (ss == nullptr: plain normalise);  ss:(B, ss_ld) = [scale | shift]
+hipError_t launch_ln_modulate(int dt, const void *x, int ld, const float *ss, int ss_ld, float eps, int B, int L, int C,
+                              void *out, int out_ld, hipStream_t s);
+
+// Multi-head softmax attention on packed projections.  q row stride ldq, k/v inside kv with row stride ldkv
+// (k at column 0, v at column H*D).  out row stride ldo.
+hipError_t launch_attention(int dt, const void *q, int ldq, const void *kv, int ldkv, int B, int L, int H, int D,
+                            void *out, int ldo, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------
+// Element-wise / layout helpers
+// ---------------------------------------------------------------------------------------
+// channels-first fp32 (B, C, L) -> channels-last DT (B*L, ld) with zero padding of columns [C, ld)
+hipError_t launch_cf_to_cl(int dt, const float *x, int B, int C, int L, void *out, int ld, hipStream_t s);
+// channels-last DT (B*L, ld) -> channels-first fp32 (B, C, L)
+hipError_t launch_cl_to_cf(int dt, const void *x, int ld, int B, int C, int L, float *out, hipStream_t s);
+// video (N,3,T,H,W) fp32 -> channels-last DT rows x ld (ld >= 3, zero padded)
+hipError_t launch_video_to_cl(int dt, const float *x, int N, int C, int T, int H, int W, void *out, int ld, hipStream_t s);
+// DT rows x ld -> fp32 rows x C (debug taps)
+hipError_t launch_to_f32(int dt, const void *x, int ld, int64_t rows, int C, float *out, hipStream_t s);
+
+// learned-Fourier time embedding input: out[b] = [sigma, sin(2 pi sigma w), cos(2 pi sigma w), 0...]  (B, ld) as DT.
+// sigma is read from sig[b] when sig_idx == nullptr, else from sig[*sig_idx] for every b (graph replay).
+hipError_t launch_time_fourier(int dt, const float *sig, const int *sig_idx, const float *w, int B, int half, void *out, int ld,
+                               hipStream_t s);
+
+// v-sampler step (in place on x, fp32):  v = v_uncond ? v_u + (v_c - v_u)*scale : v ;
+//   x <- a1*(a0*x - b0*v) + b1*(b0*x + a0*v),  (a0,b0,a1,b1) = sched[*step_idx][0..3].
+hipError_t launch_vsampler_update(float *x, const float *v, const float *v_uncond, float scale, const float *sched,
+                                  const int *step_idx, int64_t n, hipStream_t s);
+// (*step_idx)++ -- its own 1-thread launch so that no kernel of a step races with the increment
+hipError_t launch_step_advance(int *step_idx, hipStream_t s);
+// out = v_u + (v_c - v_u) * scale   (single forward with CFG)
+hipError_t launch_cfg_combine(const float *v_c, const float *v_u, float scale, float *out, int64_t n, hipStream_t s);
+
+// mean over the spatial rows of a video activation: x:(N*T*HW, ld) -> out:(N*T, C) fp32
+hipError_t launch_spatial_mean(int dt, const void *x, int ld, int NT, int HW, int C, float *out, hipStream_t s);
+
+// onset glue (sf_onsets_to_track)
+hipError_t launch_onsets_to_track(const float *logits, int N, int T, const int32_t *start_frame, float frame_rate,
+                                  float sample_rate, float threshold, float *track, int L, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------
+// Weight packing (run once at engine creation)
+// ---------------------------------------------------------------------------------------
+// conv weight (N, Ctot, taps) fp32, channels [c_off, c_off+Cin) -> out[n*out_row + col0 + tap*cin_pad + ci] as DT,
+// zero for ci in [Cin, cin_pad)  (+ optional per-N scale = folded BatchNorm)
+hipError_t launch_pack_conv(int dt, const float *w, int N, int Ctot, int c_off, int Cin, int taps, int cin_pad, const float *nscale,
+                            void *out, int64_t out_row, int64_t col0, hipStream_t s);
+// generic strided copy/convert: out[r*ldo + c] = (DT) in[r*ldi + c] * (cscale ? cscale[c] : 1)
+hipError_t launch_pack_rows(int dt, const float *in, int64_t rows, int cols, int64_t ldi, const float *cscale, void *out,
+                            int64_t ldo, hipStream_t s);
+// out[n] = sum_k w[n][k] * v[k] (+ add[n])   fp32 gemv used for folding LayerNorm biases at pack time
+hipError_t launch_fold_bias(const float *w, int N, int K, const float *v, const float *add, float *out, hipStream_t s);
+// BatchNorm (eval) -> per-channel scale / shift
+hipError_t launch_bn_fold(const float *gamma, const float *beta, const float *mean, const float *var, float eps, int C,
+                          float *scale, float *shift, hipStream_t s);
+
+}  // namespace sf

@@ -1,0 +1,243 @@
+// Element-wise, layout and weight-packing kernels (all HBM-bound streaming; grid-stride loops).
+#include "common.h"
+#include "kernels.h"
+
+namespace sf {
+namespace {
+
+constexpr int TPB = 256;
+inline dim3 grid_for(int64_t n) {
+  int64_t b = (n + TPB - 1) / TPB;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return dim3((unsigned)b);
+}
+#define SF_GRID_STRIDE(i, n) for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
+
+template <typename T>
+__global__ void cf_to_cl_kernel(const float *__restrict__ x, int B, int C, int L, T *__restrict__ out, int ld) {
+  SF_GRID_STRIDE(i, (int64_t)B * L) {
+    int64_t b = i / L, l = i - b * L;
+    for (int c = 0; c < ld; ++c)
+      out[i * ld + c] = from_f<T>(c < C ? x[(b * C + c) * L + l] : 0.f);
+  }
+}
+template <typename T>
+__global__ void cl_to_cf_kernel(const T *__restrict__ x, int ld, int B, int C, int L, float *__restrict__ out) {
+  SF_GRID_STRIDE(i, (int64_t)B * L) {
+    int64_t b = i / L, l = i - b * L;
+    for (int c = 0; c < C; ++c) out[(b * C + c) * L + l] = to_f(x[i * ld + c]);
+  }
+}
+template <typename T>
+__global__ void video_to_cl_kernel(const float *__restrict__ x, int N, int C, int T_, int H, int W, T *__restrict__ out, int ld) {
+  const int64_t thw = (int64_t)T_ * H * W;
+  SF_GRID_STRIDE(i, (int64_t)N * thw) {
+    int64_t n = i / thw, r = i - n * thw;
+    for (int c = 0; c < ld; ++c) out[i * ld + c] = from_f<T>(c < C ? x[(n * C + c) * thw + r] : 0.f);
+  }
+}
+template <typename T>
+__global__ void to_f32_kernel(const T *__restrict__ x, int ld, int64_t rows, int C, float *__restrict__ out) {
+  SF_GRID_STRIDE(i, rows * C) {
+    int64_t r = i / C;
+    int c = (int)(i - r * C);
+    out[i] = to_f(x[r * ld + c]);
+  }
+}
+
+template <typename T>
+__global__ void time_fourier_kernel(const float *__restrict__ sig, const int *__restrict__ sig_idx, const float *__restrict__ w,
+                                    int B, int half, T *__restrict__ out, int ld) {
+  const int width = 1 + 2 * half;
+  SF_GRID_STRIDE(i, (int64_t)B * ld) {
+    int b = (int)(i / ld), c = (int)(i - (int64_t)b * ld);
+    const float x = sig_idx ? sig[*sig_idx] : sig[b];
+    float v = 0.f;
+    if (c == 0) v = x;
+    else if (c < width) {
+      const int j = (c - 1) % half;
+      float f = x * w[j];
+      f = f * 2.0f;
+      f = f * 3.14159265358979323846f;
+      v = (c - 1 < half) ? sinf(f) : cosf(f);
+    }
+    out[i] = from_f<T>(v);
+  }
+}
+
+__global__ void vsampler_update_kernel(float *__restrict__ x, const float *__restrict__ v, const float *__restrict__ vu,
+                                       float scale, const float *__restrict__ sched, const int *__restrict__ step_idx, int64_t n) {
+  const float *sc = sched + 4 * (*step_idx);
+  const float a0 = sc[0], b0 = sc[1], a1 = sc[2], b1 = sc[3];
+  SF_GRID_STRIDE(i, n) {
+    float vv = v[i];
+    if (vu) {
+      float m = vu[i];
+      vv = m + (vv - m) * scale;
+    }
+    const float xx = x[i];
+    const float x_pred = a0 * xx - b0 * vv;
+    const float n_pred = b0 * xx + a0 * vv;
+    x[i] = a1 * x_pred + b1 * n_pred;
+  }
+}
+__global__ void step_advance_kernel(int *step_idx) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *step_idx = *step_idx + 1;
+}
+__global__ void cfg_combine_kernel(const float *__restrict__ vc, const float *__restrict__ vu, float scale, float *__restrict__ out,
+                                   int64_t n) {
+  SF_GRID_STRIDE(i, n) {
+    float m = vu[i];
+    out[i] = m + (vc[i] - m) * scale;
+  }
+}
+
+template <typename T>
+__global__ void spatial_mean_kernel(const T *__restrict__ x, int ld, int HW, int C, float *__restrict__ out) {
+  const int nt = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int r = 0; r < HW; ++r) s += to_f(x[((size_t)nt * HW + r) * ld + c]);
+    out[(size_t)nt * C + c] = s / (float)HW;
+  }
+}
+
+__global__ void onsets_to_track_kernel(const float *__restrict__ logits, int N, int T_, const int32_t *__restrict__ start,
+                                       double fps, double sr, float thr, float *__restrict__ track, int L) {
+  SF_GRID_STRIDE(i, (int64_t)N * T_) {
+    int n = (int)(i / T_), t = (int)(i - (int64_t)n * T_);
+    if (logits[i] > thr) {
+      double tm = ((double)t + (double)(start ? start[n] : 0)) / fps;
+      double t4 = rint(tm * 1e4) / 1e4;  // "%.4f" round trip of main/module_onset.py:180-183
+      long pos = (long)(t4 * sr);        // int(k * sr), main/dataset_diffusion.py:69
+      if (pos >= 0 && pos < L) track[(size_t)n * L + pos] = 1.0f;
+    }
+  }
+}
+
+template <typename T>
+__global__ void pack_conv_kernel(const float *__restrict__ w, int N, int Ctot, int c_off, int Cin, int taps, int cin_pad,
+                                 const float *__restrict__ nscale, T *__restrict__ out, int64_t out_row, int64_t col0) {
+  SF_GRID_STRIDE(i, (int64_t)N * taps * cin_pad) {
+    int ci = (int)(i % cin_pad);
+    int64_t r = i / cin_pad;
+    int tap = (int)(r % taps);
+    int n = (int)(r / taps);
+    float v = 0.f;
+    if (ci < Cin) v = w[((size_t)n * Ctot + c_off + ci) * taps + tap] * (nscale ? nscale[n] : 1.0f);
+    out[(size_t)n * out_row + col0 + (size_t)tap * cin_pad + ci] = from_f<T>(v);
+  }
+}
+template <typename T>
+__global__ void pack_rows_kernel(const float *__restrict__ in, int64_t rows, int cols, int64_t ldi, const float *__restrict__ cscale,
+                                 T *__restrict__ out, int64_t ldo) {
+  SF_GRID_STRIDE(i, rows * cols) {
+    int64_t r = i / cols;
+    int c = (int)(i - r * cols);
+    out[r * ldo + c] = from_f<T>(in[r * ldi + c] * (cscale ? cscale[c] : 1.0f));
+  }
+}
+__global__ void fold_bias_kernel(const float *__restrict__ w, int N, int K, const float *__restrict__ v, const float *__restrict__ add,
+                                 float *__restrict__ out) {
+  const int n = blockIdx.x;
+  float s = 0.f;
+  for (int k = threadIdx.x; k < K; k += 64) s = fmaf(w[(size_t)n * K + k], v[k], s);
+  s = wave_sum(s);
+  if (threadIdx.x == 0) out[n] = s + (add ? add[n] : 0.f);
+}
+__global__ void bn_fold_kernel(const float *g, const float *b, const float *m, const float *v, float eps, int C, float *scale, float *shift) {
+  SF_GRID_STRIDE(i, C) {
+    float sc = g[i] / sqrtf(v[i] + eps);
+    scale[i] = sc;
+    shift[i] = b[i] - m[i] * sc;
+  }
+}
+
+}  // namespace
+
+#define SF_DT(dt, CALL_F, CALL_B) \
+  if ((dt) == F32) { CALL_F; } else { CALL_B; }
+
+hipError_t launch_cf_to_cl(int dt, const float *x, int B, int C, int L, void *out, int ld, hipStream_t s) {
+  dim3 g = grid_for((int64_t)B * L);
+  SF_DT(dt, hipLaunchKernelGGL(cf_to_cl_kernel<float>, g, dim3(TPB), 0, s, x, B, C, L, (float *)out, ld),
+        hipLaunchKernelGGL(cf_to_cl_kernel<bf16>, g, dim3(TPB), 0, s, x, B, C, L, (bf16 *)out, ld));
+  return hipGetLastError();
+}
+hipError_t launch_cl_to_cf(int dt, const void *x, int ld, int B, int C, int L, float *out, hipStream_t s) {
+  dim3 g = grid_for((int64_t)B * L);
+  SF_DT(dt, hipLaunchKernelGGL(cl_to_cf_kernel<float>, g, dim3(TPB), 0, s, (const float *)x, ld, B, C, L, out),
+        hipLaunchKernelGGL(cl_to_cf_kernel<bf16>, g, dim3(TPB), 0, s, (const bf16 *)x, ld, B, C, L, out));
+  return hipGetLastError();
+}
+hipError_t launch_video_to_cl(int dt, const float *x, int N, int C, int T, int H, int W, void *out, int ld, hipStream_t s) {
+  dim3 g = grid_for((int64_t)N * T * H * W);
+  SF_DT(dt, hipLaunchKernelGGL(video_to_cl_kernel<float>, g, dim3(TPB), 0, s, x, N, C, T, H, W, (float *)out, ld),
+        hipLaunchKernelGGL(video_to_cl_kernel<bf16>, g, dim3(TPB), 0, s, x, N, C, T, H, W, (bf16 *)out, ld));
+  return hipGetLastError();
+}
+hipError_t launch_to_f32(int dt, const void *x, int ld, int64_t rows, int C, float *out, hipStream_t s) {
+  dim3 g = grid_for(rows * C);
+  SF_DT(dt, hipLaunchKernelGGL(to_f32_kernel<float>, g, dim3(TPB), 0, s, (const float *)x, ld, rows, C, out),
+        hipLaunchKernelGGL(to_f32_kernel<bf16>, g, dim3(TPB), 0, s, (const bf16 *)x, ld, rows, C, out));
+  return hipGetLastError();
+}
+hipError_t launch_time_fourier(int dt, const float *sig, const int *sig_idx, const float *w, int B, int half, void *out, int ld,
+                               hipStream_t s) {
+  dim3 g = grid_for((int64_t)B * ld);
+  SF_DT(dt, hipLaunchKernelGGL(time_fourier_kernel<float>, g, dim3(TPB), 0, s, sig, sig_idx, w, B, half, (float *)out, ld),
+        hipLaunchKernelGGL(time_fourier_kernel<bf16>, g, dim3(TPB), 0, s, sig, sig_idx, w, B, half, (bf16 *)out, ld));
+  return hipGetLastError();
+}
+hipError_t launch_vsampler_update(float *x, const float *v, const float *v_uncond, float scale, const float *sched,
+                                  const int *step_idx, int64_t n, hipStream_t s) {
+  hipLaunchKernelGGL(vsampler_update_kernel, grid_for(n), dim3(TPB), 0, s, x, v, v_uncond, scale, sched, step_idx, n);
+  return hipGetLastError();
+}
+hipError_t launch_step_advance(int *step_idx, hipStream_t s) {
+  hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, s, step_idx);
+  return hipGetLastError();
+}
+hipError_t launch_cfg_combine(const float *v_c, const float *v_u, float scale, float *out, int64_t n, hipStream_t s) {
+  hipLaunchKernelGGL(cfg_combine_kernel, grid_for(n), dim3(TPB), 0, s, v_c, v_u, scale, out, n);
+  return hipGetLastError();
+}
+hipError_t launch_spatial_mean(int dt, const void *x, int ld, int NT, int HW, int C, float *out, hipStream_t s) {
+  SF_DT(dt, hipLaunchKernelGGL(spatial_mean_kernel<float>, dim3(NT), dim3(TPB), 0, s, (const float *)x, ld, HW, C, out),
+        hipLaunchKernelGGL(spatial_mean_kernel<bf16>, dim3(NT), dim3(TPB), 0, s, (const bf16 *)x, ld, HW, C, out));
+  return hipGetLastError();
+}
+hipError_t launch_onsets_to_track(const float *logits, int N, int T, const int32_t *start_frame, float frame_rate,
+                                  float sample_rate, float threshold, float *track, int L, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(track, 0, (size_t)N * L * sizeof(float), s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(onsets_to_track_kernel, grid_for((int64_t)N * T), dim3(TPB), 0, s, logits, N, T, start_frame,
+                     (double)frame_rate, (double)sample_rate, threshold, track, L);
+  return hipGetLastError();
+}
+hipError_t launch_pack_conv(int dt, const float *w, int N, int Ctot, int c_off, int Cin, int taps, int cin_pad, const float *nscale,
+                            void *out, int64_t out_row, int64_t col0, hipStream_t s) {
+  dim3 g = grid_for((int64_t)N * taps * cin_pad);
+  SF_DT(dt, hipLaunchKernelGGL(pack_conv_kernel<float>, g, dim3(TPB), 0, s, w, N, Ctot, c_off, Cin, taps, cin_pad, nscale, (float *)out, out_row, col0),
+        hipLaunchKernelGGL(pack_conv_kernel<bf16>, g, dim3(TPB), 0, s, w, N, Ctot, c_off, Cin, taps, cin_pad, nscale, (bf16 *)out, out_row, col0));
+  return hipGetLastError();
+}
+hipError_t launch_pack_rows(int dt, const float *in, int64_t rows, int cols, int64_t ldi, const float *cscale, void *out,
+                            int64_t ldo, hipStream_t s) {
+  dim3 g = grid_for(rows * cols);
+  SF_DT(dt, hipLaunchKernelGGL(pack_rows_kernel<float>, g, dim3(TPB), 0, s, in, rows, cols, ldi, cscale, (float *)out, ldo),
+        hipLaunchKernelGGL(pack_rows_kernel<bf16>, g, dim3(TPB), 0, s, in, rows, cols, ldi, cscale, (bf16 *)out, ldo));
+  return hipGetLastError();
+}
+hipError_t launch_fold_bias(const float *w, int N, int K, const float *v, const float *add, float *out, hipStream_t s) {
+  hipLaunchKernelGGL(fold_bias_kernel, dim3(N), dim3(64), 0, s, w, N, K, v, add, out);
+  return hipGetLastError();
+}
+hipError_t launch_bn_fold(const float *gamma, const float *beta, const float *mean, const float *var, float eps, int C,
+                          float *scale, float *shift, hipStream_t s) {
+  hipLaunchKernelGGL(bn_fold_kernel, grid_for(C), dim3(TPB), 0, s, gamma, beta, mean, var, eps, C, scale, shift);
+  return hipGetLastError();
+}
+
+}  // namespace sf

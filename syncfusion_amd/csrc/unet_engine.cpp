@@ -1,0 +1,847 @@
+// U-Net denoiser + v-sampler engine behind sf_unet_* / sf_vsample (include/syncfusion_amd.h).
+//
+// Restates audio_diffusion_pytorch.UNetV0 (a-unet XUNet; SURVEY.md appendix A.3, config
+// exp/model/diffusion.yaml:11-33 of the reference) as a static launch plan over channels-last
+// activations:
+//   * every Conv1d (k=3 ResnetItem convs, patchify down-convs, nearest-upsample+conv3 up-convs, the 1x1
+//     InjectChannels conv over cat[x, ctx], attention projections, per-clip Linear layers) is ONE kernel
+//     family: the MFMA implicit GEMM (conv_gemm.hip) -- or the VALU direct conv for thin layers (C < 32);
+//   * GroupNorm+SiLU is the A-operand prologue of the following conv (statistics from gn_stats);
+//   * Modulation = ln_modulate; all 34+8 Modulation / SkipModulate Linear layers of a step are one GEMM;
+//   * the cross-attention over the single CLAP token collapses to a per-clip bias (softmax over one key is
+//     exactly 1), computed once per sample() call and added in the preceding conv's epilogue;
+//   * LayerNorm affines of the attention pre-norms are folded into the q/kv projection weights;
+//   * with classifier-free guidance the conditional and unconditional evaluations run as one 2B batch.
+#include <cmath>
+#include <cstring>
+#include <exception>
+#include <memory>
+
+#include "engine_common.h"
+
+using namespace sf;
+
+namespace {
+
+struct Group {
+  float *gn1_g = nullptr, *gn1_b = nullptr, *gn2_g = nullptr, *gn2_b = nullptr;
+  ConvW conv1, conv2, inject, qkv, attn_out, cross_out;
+  int mod_off = 0;  // column of [scale | shift] inside mod_all
+  bool attn = false, cross = false;
+  int ca_off = 0;   // column of the collapsed cross-attention bias inside ca_all
+  int ca_idx = 0;   // index of this group's v projection inside wv_cat
+};
+
+struct Block {
+  int C = 0, cin = 0, factor = 1, ctx = 0, ctx_ld = 0, up_shift = 0;
+  ConvW down, up;
+  int skip_off = 0;
+  std::vector<Group> down_items, up_items;
+};
+
+struct Level {
+  int L = 0, C = 0;
+  int64_t rows = 0;
+  void *buf[3] = {nullptr, nullptr, nullptr};
+  void *qkv = nullptr, *ao = nullptr, *ctx = nullptr;
+};
+
+struct Plan {  // everything carved out of the caller's workspace for one (B, L0, two_pass)
+  int B = 0, Bt = 0, L0 = 0;
+  bool two = false;
+  std::vector<Level> lv;
+  float *x2 = nullptr, *vout = nullptr, *mod_all = nullptr, *ca_all = nullptr, *slab = nullptr, *emb2 = nullptr;
+  float *sched = nullptr;  // [steps][4] = (alpha_i, beta_i, alpha_{i+1}, beta_{i+1})
+  float *sigs = nullptr;   // [steps] schedule sigmas, then [Bt] per-row sigmas of a single forward
+  void *four = nullptr, *f1 = nullptr, *f2 = nullptr, *sf = nullptr, *emb_t = nullptr, *xhat_e = nullptr, *v_all = nullptr;
+  int *step = nullptr;
+};
+
+}  // namespace
+
+struct sf_unet {
+  sf_unet_config cfg{};
+  int dt = SF_F32;
+  DeviceArena arena;
+  float *fourier_w = nullptr;
+  int half = 0, four_ld = 0, mf = 0, hd = 0;
+  ConvW lin0, mlp0, mlp1, mod, wv_cat;
+  int mod_cols = 0, mod_ld = 0, ca_cols = 0, ca_ld = 0, n_ca = 0;
+  float *fixed_emb = nullptr;
+  std::vector<Block> blocks;
+  DebugTaps dbg;
+  int launches = 0;
+  bool listing = false;
+  std::vector<std::pair<std::string, int64_t>> names;
+  // graph cache for sf_vsample
+  hipGraphExec_t gexec = nullptr;
+  struct {
+    const void *x = nullptr, *ws = nullptr;
+    int B = 0, L0 = 0;
+    float scale = 0.f;
+  } gkey;
+
+  ~sf_unet() {
+    if (gexec) (void)hipGraphExecDestroy(gexec);
+  }
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------
+// construction: name lookup + packing
+// ---------------------------------------------------------------------------------------------------
+struct Builder {
+  sf_unet &u;
+  const WeightMap *wm;
+  hipStream_t s;
+
+  const float *get(const std::string &name, int64_t numel) {
+    if (u.listing) {
+      u.names.push_back({name, numel});
+      return nullptr;
+    }
+    return wm->get(name, numel);
+  }
+  float *copy_f32(const std::string &name, int64_t numel) {
+    const float *src = get(name, numel);
+    if (u.listing) return nullptr;
+    float *dst = u.arena.alloc_n<float>(numel);
+    SF_HIP(hipMemcpyAsync(dst, src, numel * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return dst;
+  }
+
+  // Conv1d weight (N, C1 + C2, taps); channels [0,C1) -> taps x cin_pad block, [C1, C1+C2) -> cin2_pad block (taps == 1)
+  ConvW conv(const std::string &pre, int N, int C1, int taps, int C2, bool bias, bool direct, int cin_pad, int cin2_pad) {
+    ConvW c;
+    c.N = N;
+    c.taps = taps;
+    c.direct = direct;
+    c.cin = direct ? C1 : cin_pad;
+    c.cin2 = C2 ? (direct ? C2 : cin2_pad) : 0;
+    c.K = taps * c.cin + c.cin2;
+    const int Ctot = C1 + C2;
+    const float *w = get(pre + ".weight", (int64_t)N * Ctot * taps);
+    const float *b = bias ? get(pre + ".bias", N) : nullptr;
+    if (u.listing) return c;
+    const int wdt = direct ? F32 : u.dt;
+    c.w = u.arena.alloc((int64_t)N * c.K * dsize(wdt));
+    SF_HIP(launch_pack_conv(wdt, w, N, Ctot, 0, C1, taps, c.cin, nullptr, c.w, c.K, 0, s));
+    if (C2) SF_HIP(launch_pack_conv(wdt, w, N, Ctot, C1, C2, 1, c.cin2, nullptr, c.w, c.K, (int64_t)taps * c.cin, s));
+    if (b) {
+      c.bias = u.arena.alloc_n<float>(N);
+      SF_HIP(hipMemcpyAsync(c.bias, b, N * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    return c;
+  }
+
+  // Linear weight (N, K) [+ per-column scale] -> [N][Kpad] in the compute type, rows appended at row0 of dst
+  void linear_into(ConvW &dst, int row0, const float *w, int N, int K, const float *cscale) {
+    if (u.listing) return;
+    char *p = static_cast<char *>(dst.w) + (int64_t)row0 * dst.K * dsize(u.dt);
+    SF_HIP(launch_pack_rows(u.dt, w, N, K, K, cscale, p, dst.K, s));
+  }
+  ConvW linear_alloc(int N, int Kpad, bool bias) {
+    ConvW c;
+    c.N = N;
+    c.K = Kpad;
+    c.cin = Kpad;
+    c.taps = 1;
+    if (u.listing) return c;
+    c.w = u.arena.alloc((int64_t)N * Kpad * dsize(u.dt));
+    SF_HIP(hipMemsetAsync(c.w, 0, (int64_t)N * Kpad * dsize(u.dt), s));
+    if (bias) {
+      c.bias = u.arena.alloc_n<float>(N);
+      SF_HIP(hipMemsetAsync(c.bias, 0, N * sizeof(float), s));
+    }
+    return c;
+  }
+  ConvW linear(const std::string &pre, int N, int K, int Kpad, bool bias) {
+    const float *w = get(pre + ".weight", (int64_t)N * K);
+    const float *b = bias ? get(pre + ".bias", N) : nullptr;
+    ConvW c = linear_alloc(N, Kpad, bias);
+    linear_into(c, 0, w, N, K, nullptr);
+    if (b && !u.listing) SF_HIP(hipMemcpyAsync(c.bias, b, N * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return c;
+  }
+};
+
+void build_group(Builder &bd, Group &g, const std::string &pre, int d, int &mod_cols, int &ca_cols, int &n_ca) {
+  sf_unet &u = bd.u;
+  const sf_unet_config &c = u.cfg;
+  const int C = c.channels[d];
+  const bool thin = (C % 32) != 0;
+  g.gn1_g = bd.copy_f32(pre + ".resnet.gn1.weight", C);
+  g.gn1_b = bd.copy_f32(pre + ".resnet.gn1.bias", C);
+  g.conv1 = bd.conv(pre + ".resnet.conv1", C, C, 3, 0, true, thin, C, 0);
+  g.gn2_g = bd.copy_f32(pre + ".resnet.gn2.weight", C);
+  g.gn2_b = bd.copy_f32(pre + ".resnet.gn2.bias", C);
+  g.conv2 = bd.conv(pre + ".resnet.conv2", C, C, 3, 0, true, thin, C, 0);
+  // Modulation Linear -> rows of the shared per-step GEMM (filled by build())
+  g.mod_off = mod_cols;
+  mod_cols += 2 * C;
+  const int ctx = c.context_channels[d];
+  g.inject = bd.conv(pre + ".inject.conv", C, C, 1, ctx, true, thin, C, pad_to(ctx, 32));
+  g.attn = c.attentions[d] != 0;
+  g.cross = c.cross_attentions[d] != 0;
+  const int hd = u.hd;
+  if (g.attn) {
+    if (thin) fail(SF_ERR_UNSUPPORTED, "self-attention at depth %d needs channels %% 32 == 0 (got %d)", d, C);
+    const std::string a = pre + ".attn";
+    const float *ng = bd.get(a + ".norm.weight", C), *nb = bd.get(a + ".norm.bias", C);
+    const float *cg = bd.get(a + ".norm_context.weight", C), *cb = bd.get(a + ".norm_context.bias", C);
+    const float *wq = bd.get(a + ".to_q.weight", (int64_t)hd * C);
+    const float *wkv = bd.get(a + ".to_kv.weight", (int64_t)2 * hd * C);
+    const float *wo = bd.get(a + ".to_out.weight", (int64_t)C * hd);
+    g.qkv = bd.linear_alloc(3 * hd, C, true);
+    g.attn_out = bd.linear_alloc(C, hd, false);
+    if (!u.listing) {
+      // fold the LayerNorm affines:  W (g*xhat + b) = (W diag g) xhat + W b
+      bd.linear_into(g.qkv, 0, wq, hd, C, ng);
+      bd.linear_into(g.qkv, hd, wkv, 2 * hd, C, cg);
+      SF_HIP(launch_fold_bias(wq, hd, C, nb, nullptr, g.qkv.bias, bd.s));
+      SF_HIP(launch_fold_bias(wkv, 2 * hd, C, cb, nullptr, g.qkv.bias + hd, bd.s));
+      bd.linear_into(g.attn_out, 0, wo, C, hd, nullptr);
+    }
+  }
+  if (g.cross) {
+    // CrossAttentionItem over ONE context token: softmax == 1, so out = x + W_o (W_v LN(e)).
+    // norm / to_q / the k half of to_kv cannot influence the result; they are still required parameters.
+    const std::string a = pre + ".cross";
+    const int E = c.embedding_features;
+    bd.get(a + ".norm.weight", C);
+    bd.get(a + ".norm.bias", C);
+    bd.get(a + ".to_q.weight", (int64_t)hd * C);
+    const float *cg = bd.get(a + ".norm_context.weight", E), *cb = bd.get(a + ".norm_context.bias", E);
+    const float *wkv = bd.get(a + ".to_kv.weight", (int64_t)2 * hd * E);
+    const float *wo = bd.get(a + ".to_out.weight", (int64_t)C * hd);
+    g.ca_idx = n_ca++;
+    g.ca_off = ca_cols;
+    ca_cols += C;
+    g.cross_out = bd.linear_alloc(C, hd, false);
+    if (!u.listing) {
+      bd.linear_into(u.wv_cat, g.ca_idx * hd, wkv + (int64_t)hd * E, hd, E, cg);
+      SF_HIP(launch_fold_bias(wkv + (int64_t)hd * E, hd, E, cb, nullptr, u.wv_cat.bias + g.ca_idx * hd, bd.s));
+      bd.linear_into(g.cross_out, 0, wo, C, hd, nullptr);
+    }
+  }
+}
+
+void build(sf_unet &u, const WeightMap *wm, hipStream_t s) {
+  const sf_unet_config &c = u.cfg;
+  if (c.n_layers < 1 || c.n_layers > SF_MAX_DEPTH) fail(SF_ERR_INVALID, "n_layers out of range");
+  if (c.attention_features != 64) fail(SF_ERR_UNSUPPORTED, "attention_features must be 64 (got %d)", c.attention_features);
+  if (c.embedding_max_length != 1) fail(SF_ERR_UNSUPPORTED, "embedding_max_length must be 1 (CLAP embedding), got %d", c.embedding_max_length);
+  if (c.modulation_features % 32 || c.embedding_features % 32) fail(SF_ERR_UNSUPPORTED, "modulation/embedding features must be multiples of 32");
+  if (c.dtype != SF_F32 && c.dtype != SF_BF16) fail(SF_ERR_INVALID, "bad dtype");
+  u.dt = c.dtype;
+  u.mf = c.modulation_features;
+  u.hd = c.attention_heads * c.attention_features;
+  u.half = u.mf / 2;
+  u.four_ld = pad_to(1 + 2 * u.half, 32);
+  Builder bd{u, wm, s};
+
+  int n_cross = 0;
+  for (int d = 0; d < c.n_layers; ++d) {
+    if (c.context_channels[d] <= 0) fail(SF_ERR_UNSUPPORTED, "context_channels[%d] must be > 0", d);
+    if (c.channels[d] % c.resnet_groups) fail(SF_ERR_INVALID, "channels[%d] not divisible by resnet_groups", d);
+    if (c.channels[d] % 8) fail(SF_ERR_UNSUPPORTED, "channels[%d] must be a multiple of 8", d);
+    int f = c.factors[d];
+    if (f < 1 || (f & (f - 1))) fail(SF_ERR_UNSUPPORTED, "factors[%d] must be a power of two", d);
+    if (c.cross_attentions[d]) n_cross += 2 * c.items[d];
+  }
+  u.wv_cat = bd.linear_alloc(n_cross > 0 ? n_cross * u.hd : 1, c.embedding_features, true);
+
+  u.fourier_w = bd.copy_f32("net.time.fourier_w", u.half);
+  u.lin0 = bd.linear("net.time.lin0", u.mf, 1 + 2 * u.half, u.four_ld, true);
+  u.mlp0 = bd.linear("net.time.mlp.0", u.mf, u.mf, u.mf, true);
+  u.mlp1 = bd.linear("net.time.mlp.1", u.mf, u.mf, u.mf, true);
+  u.fixed_emb = bd.copy_f32("net.cfg.fixed_embedding.weight", (int64_t)c.embedding_max_length * c.embedding_features);
+
+  int mod_cols = 0, ca_cols = 0, n_ca = 0;
+  u.blocks.assign(c.n_layers, Block());
+  int cin = c.in_channels;
+  for (int d = 0; d < c.n_layers; ++d) {
+    Block &b = u.blocks[d];
+    b.C = c.channels[d];
+    b.cin = cin;
+    b.factor = c.factors[d];
+    b.ctx = c.context_channels[d];
+    while ((1 << b.up_shift) < b.factor) ++b.up_shift;
+    const bool thin = (b.C % 32) != 0;
+    b.ctx_ld = thin ? b.ctx : pad_to(b.ctx, 32);
+    const std::string pre = "net.blocks." + std::to_string(d);
+    // Downsample: Conv1d(cin, C, kernel=f, stride=f).  As a GEMM it is a plain matrix product over the
+    // (rows/f, f*cin) view of the input when that width is MFMA-friendly; else the direct kernel.
+    const bool down_direct = ((b.factor * cin) % 32) != 0;
+    if (down_direct && b.C > 32) fail(SF_ERR_UNSUPPORTED, "down conv at depth %d: %d -> %d needs (factor*in) %% 32 == 0", d, cin, b.C);
+    b.down = bd.conv(pre + ".down", b.C, cin, b.factor, 0, true, down_direct, cin, 0);
+    // Upsample: nearest x f then Conv1d(C, cin, 3, padding=1)
+    if (thin && cin > 32) fail(SF_ERR_UNSUPPORTED, "up conv at depth %d unsupported (%d -> %d)", d, b.C, cin);
+    b.up = bd.conv(pre + ".up", cin, b.C, 3, 0, true, thin, b.C, 0);
+    b.skip_off = mod_cols;
+    mod_cols += cin;
+    b.down_items.assign(c.items[d], Group());
+    b.up_items.assign(c.items[d], Group());
+    for (int j = 0; j < c.items[d]; ++j) build_group(bd, b.down_items[j], pre + ".items_down." + std::to_string(j), d, mod_cols, ca_cols, n_ca);
+    for (int j = 0; j < c.items[d]; ++j) build_group(bd, b.up_items[j], pre + ".items_up." + std::to_string(j), d, mod_cols, ca_cols, n_ca);
+    cin = b.C;
+  }
+  u.mod_cols = mod_cols;
+  u.mod_ld = pad_to(mod_cols, 4);
+  u.ca_cols = ca_cols;
+  u.ca_ld = pad_to(ca_cols > 0 ? ca_cols : 1, 4);
+  u.n_ca = n_ca;
+
+  // All Modulation / SkipModulate Linear layers share their input SiLU(features): one GEMM per step.
+  u.mod = bd.linear_alloc(mod_cols, u.mf, true);
+  for (int d = 0; d < c.n_layers; ++d) {
+    Block &b = u.blocks[d];
+    const std::string pre = "net.blocks." + std::to_string(d);
+    {
+      const float *w = bd.get(pre + ".skip.to_scale.weight", (int64_t)b.cin * u.mf);
+      const float *bi = bd.get(pre + ".skip.to_scale.bias", b.cin);
+      if (!u.listing) {
+        bd.linear_into(u.mod, b.skip_off, w, b.cin, u.mf, nullptr);
+        SF_HIP(hipMemcpyAsync(u.mod.bias + b.skip_off, bi, b.cin * sizeof(float), hipMemcpyDeviceToDevice, s));
+      }
+    }
+    for (int pass = 0; pass < 2; ++pass) {
+      auto &items = pass == 0 ? b.down_items : b.up_items;
+      for (size_t j = 0; j < items.size(); ++j) {
+        const std::string gp = pre + (pass == 0 ? ".items_down." : ".items_up.") + std::to_string(j) + ".mod.to_scale_shift";
+        const float *w = bd.get(gp + ".weight", (int64_t)2 * b.C * u.mf);
+        const float *bi = bd.get(gp + ".bias", 2 * b.C);
+        if (!u.listing) {
+          bd.linear_into(u.mod, items[j].mod_off, w, 2 * b.C, u.mf, nullptr);
+          SF_HIP(hipMemcpyAsync(u.mod.bias + items[j].mod_off, bi, 2 * b.C * sizeof(float), hipMemcpyDeviceToDevice, s));
+        }
+      }
+    }
+  }
+  if (!u.listing) SF_HIP(hipStreamSynchronize(s));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// workspace plan
+// ---------------------------------------------------------------------------------------------------
+Plan make_plan(const sf_unet &u, Workspace &ws, int B, int L0, bool two, int num_steps) {
+  const sf_unet_config &c = u.cfg;
+  Plan p;
+  p.B = B;
+  p.Bt = two ? 2 * B : B;
+  p.L0 = L0;
+  p.two = two;
+  int64_t stride = 1;
+  for (int d = 0; d < c.n_layers; ++d) stride *= c.factors[d];
+  if (B < 1 || L0 < 1 || L0 % stride) fail(SF_ERR_SHAPE, "L0=%d must be a positive multiple of the U-Net stride %lld", L0, (long long)stride);
+  const size_t es = dsize(u.dt);
+  p.lv.resize(c.n_layers);
+  int L = L0;
+  int64_t slab_floats = 16;
+  for (int d = 0; d < c.n_layers; ++d) {
+    Level &l = p.lv[d];
+    L /= c.factors[d];
+    l.L = L;
+    l.C = c.channels[d];
+    l.rows = (int64_t)p.Bt * L;
+    for (int i = 0; i < 3; ++i) l.buf[i] = ws.alloc(l.rows * l.C * es);
+    if (c.attentions[d]) {
+      l.qkv = ws.alloc(l.rows * 3 * u.hd * es);
+      l.ao = ws.alloc(l.rows * u.hd * es);
+    }
+    l.ctx = ws.alloc(l.rows * u.blocks[d].ctx_ld * es);
+    GnPlan gp = gn_plan(p.Bt, L, l.C);
+    int64_t need = (int64_t)p.Bt * gp.nch * c.resnet_groups * 2;
+    if (need > slab_floats) slab_floats = need;
+  }
+  const int64_t n0 = (int64_t)p.Bt * L0 * c.in_channels;
+  p.x2 = ws.alloc_n<float>(n0);
+  p.vout = ws.alloc_n<float>(n0);
+  p.mod_all = ws.alloc_n<float>((int64_t)p.Bt * u.mod_ld);
+  p.ca_all = ws.alloc_n<float>((int64_t)p.Bt * u.ca_ld);
+  p.slab = ws.alloc_n<float>(slab_floats);
+  p.four = ws.alloc((int64_t)p.Bt * u.four_ld * es);
+  p.f1 = ws.alloc((int64_t)p.Bt * u.mf * es);
+  p.f2 = ws.alloc((int64_t)p.Bt * u.mf * es);
+  p.sf = ws.alloc((int64_t)p.Bt * u.mf * es);
+  p.emb2 = ws.alloc_n<float>((int64_t)p.Bt * c.embedding_features);
+  p.emb_t = ws.alloc((int64_t)p.Bt * c.embedding_features * es);
+  p.xhat_e = ws.alloc((int64_t)p.Bt * c.embedding_features * es);
+  p.v_all = ws.alloc((int64_t)p.Bt * (u.n_ca > 0 ? u.n_ca : 1) * u.hd * es);
+  const int64_t ns = num_steps > 0 ? num_steps : 1;
+  p.sched = ws.alloc_n<float>(4 * ns);
+  p.sigs = ws.alloc_n<float>(ns + p.Bt);
+  p.step = ws.alloc_n<int>(4);
+  return p;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// execution
+// ---------------------------------------------------------------------------------------------------
+struct Exec {
+  sf_unet &u;
+  Plan &p;
+  hipStream_t s;
+
+  void conv(const ConvW &w, ConvGemmArgs a, int dt_in, int dt_out) {
+    a.w = w.w;
+    a.bias = w.bias;
+    a.N = w.N;
+    a.K = w.K;
+    a.cin = w.cin;
+    a.cin2 = w.cin2;
+    a.taps = w.taps;
+    if (a.n_store == 0) a.n_store = w.N;
+    if (w.direct) SF_HIP(launch_conv_direct(dt_in, dt_out, a, s));
+    else {
+      if (dt_in != u.dt || (dt_out != u.dt && !a.out_f32)) fail(SF_ERR_INVALID, "internal: dtype mismatch on the MFMA path");
+      SF_HIP(launch_conv_gemm(u.dt, a, s));
+    }
+    ++u.launches;
+  }
+
+  // rows x K GEMM on per-clip vectors (time MLP, modulation, cross-attention collapse)
+  void dense(const ConvW &w, const void *src, int src_ld, int rows, void *out, int out_ld, int act, bool out_f32, int col0 = 0,
+             int ncols = -1) {
+    ConvGemmArgs a;
+    a.src = src;
+    a.src_ld = src_ld;
+    a.M = rows;
+    a.Lout = a.Lsrc = 1;
+    a.out = out;
+    a.out_ld = out_ld;
+    a.act = act;
+    a.out_f32 = out_f32 ? 1 : 0;
+    (void)col0;
+    (void)ncols;
+    conv(w, a, u.dt, out_f32 ? F32 : u.dt);
+  }
+
+  void gn(const void *x, int d, int C) {
+    const Level &l = p.lv[d];
+    GnPlan gp = gn_plan(p.Bt, l.L, C);
+    SF_HIP(launch_gn_stats(u.dt, x, C, p.Bt, l.L, C, u.cfg.resnet_groups, gp.nch, gp.chunk_rows, p.slab, s));
+    ++u.launches;
+  }
+
+  // One item-group: Resnet -> Modulation -> InjectChannels -> [Attention] -> [CrossAttention]
+  // cur is consumed; returns the buffer that holds the result.  tA / tB are the two free buffers.
+  void group(const Group &g, int d, void *&cur, void *&tA, void *&tB, const std::string &tapname) {
+    const Level &l = p.lv[d];
+    const Block &b = u.blocks[d];
+    const int C = l.C, G = u.cfg.resnet_groups;
+    GnPlan gp = gn_plan(p.Bt, l.L, C);
+    auto conv3 = [&](const ConvW &w, const void *in, void *out, const float *gam, const float *bet, const void *res) {
+      gn(in, d, C);
+      ConvGemmArgs a;
+      a.src = in;
+      a.src_ld = C;
+      a.M = (int)l.rows;
+      a.Lout = a.Lsrc = l.L;
+      a.stride = 1;
+      a.pad = 1;
+      a.pro = 1;
+      a.G = G;
+      a.nch = gp.nch;
+      a.chunk_rows = gp.chunk_rows;
+      a.stats = p.slab;
+      a.gamma = gam;
+      a.beta = bet;
+      a.eps = 1e-5f;
+      a.out = out;
+      a.out_ld = C;
+      a.res = res;
+      a.res_ld = C;
+      conv(w, a, u.dt, u.dt);
+    };
+    conv3(g.conv1, cur, tA, g.gn1_g, g.gn1_b, nullptr);
+    conv3(g.conv2, tA, tB, g.gn2_g, g.gn2_b, cur);
+    // Modulation: LN_C(x; eps 1e-6) * (1 + scale) + shift
+    SF_HIP(launch_ln_modulate(u.dt, tB, C, p.mod_all + g.mod_off, u.mod_ld, 1e-6f, p.Bt, l.L, C, tA, C, s));
+    ++u.launches;
+    // InjectChannels: Conv1x1(cat[x, ctx]) + x   (+ collapsed cross-attention bias when no self-attention follows)
+    {
+      ConvGemmArgs a;
+      a.src = tA;
+      a.src_ld = C;
+      a.src2 = l.ctx;
+      a.src2_ld = b.ctx_ld;
+      a.M = (int)l.rows;
+      a.Lout = a.Lsrc = l.L;
+      a.out = tB;
+      a.out_ld = C;
+      a.res = tA;
+      a.res_ld = C;
+      if (g.cross && !g.attn) {
+        a.badd = p.ca_all + g.ca_off;
+        a.badd_ld = u.ca_ld;
+      }
+      conv(g.inject, a, u.dt, u.dt);
+    }
+    if (g.attn) {
+      // x + W_o MHA(W_q LN_a(x), W_kv LN_b(x)): the two LayerNorms share (mean, rstd); their affines are folded.
+      SF_HIP(launch_ln_modulate(u.dt, tB, C, nullptr, 0, 1e-5f, p.Bt, l.L, C, tA, C, s));
+      ++u.launches;
+      {
+        ConvGemmArgs a;
+        a.src = tA;
+        a.src_ld = C;
+        a.M = (int)l.rows;
+        a.Lout = a.Lsrc = l.L;
+        a.out = l.qkv;
+        a.out_ld = 3 * u.hd;
+        conv(g.qkv, a, u.dt, u.dt);
+      }
+      const size_t es = dsize(u.dt);
+      SF_HIP(launch_attention(u.dt, l.qkv, 3 * u.hd, static_cast<char *>(l.qkv) + (size_t)u.hd * es, 3 * u.hd, p.Bt, l.L,
+                              u.cfg.attention_heads, u.cfg.attention_features, l.ao, u.hd, s));
+      ++u.launches;
+      {
+        ConvGemmArgs a;
+        a.src = l.ao;
+        a.src_ld = u.hd;
+        a.M = (int)l.rows;
+        a.Lout = a.Lsrc = l.L;
+        a.out = cur;
+        a.out_ld = C;
+        a.res = tB;
+        a.res_ld = C;
+        if (g.cross) {
+          a.badd = p.ca_all + g.ca_off;
+          a.badd_ld = u.ca_ld;
+        }
+        conv(g.attn_out, a, u.dt, u.dt);
+      }
+      // result in cur's buffer; tA, tB free again
+    } else {
+      void *o = cur;
+      cur = tB;
+      tB = tA;
+      tA = o;
+    }
+    u.dbg.tap(tapname, u.dt, cur, C, l.rows, C, s);
+  }
+
+  // Block d: skip + scale * Up(items_up(inner(items_down(Down(x)))))
+  void block(int d, const void *xin, int xin_dt, void *xout, int xout_dt) {
+    const sf_unet_config &c = u.cfg;
+    const Block &b = u.blocks[d];
+    Level &l = p.lv[d];
+    const int Lprev = l.L * b.factor;
+    void *cur = l.buf[0], *tA = l.buf[1], *tB = l.buf[2];
+    {
+      ConvGemmArgs a;
+      a.src = xin;
+      a.M = (int)l.rows;
+      a.out = cur;
+      a.out_ld = l.C;
+      if (b.down.direct) {
+        a.src_ld = b.cin;
+        a.Lout = l.L;
+        a.Lsrc = Lprev;
+        a.stride = b.factor;
+        a.pad = 0;
+      } else {
+        a.src_ld = b.factor * b.cin;  // (rows/f, f*cin) view: taps folded into channels
+        a.Lout = a.Lsrc = l.L;
+      }
+      ConvW w = b.down;
+      if (!w.direct) {
+        w.cin = b.factor * b.cin;
+        w.taps = 1;
+      }
+      conv(w, a, xin_dt, u.dt);
+    }
+    const std::string pre = "d" + std::to_string(d);
+    u.dbg.tap(pre + ".down", u.dt, cur, l.C, l.rows, l.C, s);
+    for (size_t j = 0; j < b.down_items.size(); ++j) group(b.down_items[j], d, cur, tA, tB, pre + ".items_down." + std::to_string(j));
+    if (d + 1 < c.n_layers) {
+      block(d + 1, cur, u.dt, tA, u.dt);
+      void *o = cur;
+      cur = tA;
+      tA = o;
+    }
+    for (size_t j = 0; j < b.up_items.size(); ++j) group(b.up_items[j], d, cur, tA, tB, pre + ".items_up." + std::to_string(j));
+    {
+      ConvGemmArgs a;
+      a.src = cur;
+      a.src_ld = l.C;
+      a.M = (int)(l.rows * b.factor);
+      a.Lout = Lprev;
+      a.Lsrc = l.L;
+      a.stride = 1;
+      a.pad = 1;
+      a.up_shift = b.up_shift;
+      a.out = xout;
+      a.out_ld = b.cin;
+      a.res = xin;
+      a.res_ld = b.cin;
+      a.bscale = p.mod_all + b.skip_off;
+      a.bscale_ld = u.mod_ld;
+      if (xout_dt != u.dt && !b.up.direct) fail(SF_ERR_UNSUPPORTED, "depth 0 must be a thin level (channels[0] %% 32 != 0)");
+      conv(b.up, a, u.dt, xout_dt);
+    }
+    u.dbg.tap(pre + ".out", xout_dt, xout, b.cin, l.rows * b.factor, b.cin, s);
+  }
+
+  // features + modulation vectors of one step; sigma from sig[b] (sig_idx == nullptr) or sig[*sig_idx]
+  void features(const float *sig, const int *sig_idx) {
+    SF_HIP(launch_time_fourier(u.dt, sig, sig_idx, u.fourier_w, p.Bt, u.half, p.four, u.four_ld, s));
+    ++u.launches;
+    dense(u.lin0, p.four, u.four_ld, p.Bt, p.f1, u.mf, /*gelu*/ 2, false);
+    dense(u.mlp0, p.f1, u.mf, p.Bt, p.f2, u.mf, 2, false);
+    dense(u.mlp1, p.f2, u.mf, p.Bt, p.sf, u.mf, /*silu(gelu)*/ 3, false);
+    dense(u.mod, p.sf, u.mf, p.Bt, p.mod_all, u.mod_ld, 0, true);
+  }
+
+  // per-call conditioning: context pyramids to channels-last, cross-attention collapse
+  void conditioning(const float *const *ctx, const float *emb) {
+    const sf_unet_config &c = u.cfg;
+    const size_t es = dsize(u.dt);
+    for (int d = 0; d < c.n_layers; ++d) {
+      const Level &l = p.lv[d];
+      const Block &b = u.blocks[d];
+      SF_HIP(launch_cf_to_cl(u.dt, ctx[d], p.B, b.ctx, l.L, l.ctx, b.ctx_ld, s));
+      if (p.two)
+        SF_HIP(hipMemcpyAsync(static_cast<char *>(l.ctx) + (size_t)p.B * l.L * b.ctx_ld * es, l.ctx, (size_t)p.B * l.L * b.ctx_ld * es,
+                              hipMemcpyDeviceToDevice, s));
+    }
+    if (u.n_ca == 0) return;
+    const int E = c.embedding_features;
+    SF_HIP(hipMemcpyAsync(p.emb2, emb, (size_t)p.B * E * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (p.two)  // unconditional rows use the learned FixedEmbedding (ClassifierFreeGuidancePlugin)
+      for (int b = 0; b < p.B; ++b)
+        SF_HIP(hipMemcpyAsync(p.emb2 + (size_t)(p.B + b) * E, u.fixed_emb, E * sizeof(float), hipMemcpyDeviceToDevice, s));
+    // LN(e) without affine (folded into wv_cat); ln_modulate wants the compute type
+    SF_HIP(launch_pack_rows(u.dt, p.emb2, p.Bt, E, E, nullptr, p.emb_t, E, s));
+    SF_HIP(launch_ln_modulate(u.dt, p.emb_t, E, nullptr, 0, 1e-5f, p.Bt, 1, E, p.xhat_e, E, s));
+    dense(u.wv_cat, p.xhat_e, E, p.Bt, p.v_all, u.n_ca * u.hd, 0, false);
+    for (int d = 0; d < c.n_layers; ++d) {
+      const Block &b = u.blocks[d];
+      for (int pass = 0; pass < 2; ++pass)
+        for (const Group &g : (pass == 0 ? b.down_items : b.up_items)) {
+          if (!g.cross) continue;
+          dense(g.cross_out, static_cast<char *>(p.v_all) + (size_t)g.ca_idx * u.hd * es, u.n_ca * u.hd, p.Bt,
+                p.ca_all + g.ca_off, u.ca_ld, 0, true);
+        }
+    }
+  }
+
+  // one U-Net evaluation of the (possibly doubled) batch: x (B rows) -> p.vout (Bt rows)
+  void eval(const float *x, const float *sig, const int *sig_idx) {
+    const int64_t n = (int64_t)p.B * p.L0 * u.cfg.in_channels;
+    SF_HIP(hipMemcpyAsync(p.x2, x, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (p.two) SF_HIP(hipMemcpyAsync(p.x2 + n, x, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    features(sig, sig_idx);
+    block(0, p.x2, F32, p.vout, F32);
+  }
+};
+
+void check_ws(const sf_unet *h, void *ws, int64_t ws_bytes, int B, int L0, bool two, int steps) {
+  if (!ws) fail(SF_ERR_WORKSPACE, "workspace is null");
+  Workspace dry(nullptr, 0);
+  make_plan(*h, dry, B, L0, two, steps);
+  if (dry.used() > ws_bytes) fail(SF_ERR_WORKSPACE, "workspace too small: need %lld bytes, have %lld", (long long)dry.used(), (long long)ws_bytes);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------
+#define SF_API_BEGIN try {
+#define SF_API_END                 \
+  }                                \
+  catch (const EngineError &e) {   \
+    return e.code;                 \
+  }                                \
+  catch (const std::exception &e) {\
+    set_error("%s", e.what());     \
+    return SF_ERR_INVALID;         \
+  }
+
+extern "C" {
+
+int sf_unet_create(const sf_unet_config *cfg, const sf_tensor *weights, int n_weights, void *stream, sf_unet **out) {
+  SF_API_BEGIN
+  if (!cfg || !out || (!weights && n_weights > 0)) fail(SF_ERR_INVALID, "null argument");
+  *out = nullptr;
+  std::unique_ptr<sf_unet> u(new sf_unet());
+  u->cfg = *cfg;
+  WeightMap wm(weights, n_weights);
+  build(*u, &wm, static_cast<hipStream_t>(stream));
+  *out = u.release();
+  return SF_OK;
+  SF_API_END
+}
+
+void sf_unet_destroy(sf_unet *h) { delete h; }
+
+static int list_params(const sf_unet_config *cfg, std::vector<std::pair<std::string, int64_t>> &names) {
+  SF_API_BEGIN
+  if (!cfg) fail(SF_ERR_INVALID, "null config");
+  sf_unet u;
+  u.cfg = *cfg;
+  u.listing = true;
+  build(u, nullptr, nullptr);
+  names = u.names;
+  return SF_OK;
+  SF_API_END
+}
+
+int sf_unet_param_count(const sf_unet_config *cfg) {
+  std::vector<std::pair<std::string, int64_t>> names;
+  if (list_params(cfg, names) != SF_OK) return -1;
+  return (int)names.size();
+}
+
+int sf_unet_param_name(const sf_unet_config *cfg, int index, char *name_out, int name_cap, int64_t *numel_out) {
+  std::vector<std::pair<std::string, int64_t>> names;
+  int rc = list_params(cfg, names);
+  if (rc != SF_OK) return rc;
+  if (index < 0 || index >= (int)names.size() || !name_out || name_cap <= 0) return SF_ERR_INVALID;
+  snprintf(name_out, name_cap, "%s", names[index].first.c_str());
+  if (numel_out) *numel_out = names[index].second;
+  return SF_OK;
+}
+
+int64_t sf_unet_workspace_bytes(const sf_unet *h, int B, int L0, int two_pass) {
+  try {
+    if (!h) fail(SF_ERR_INVALID, "null handle");
+    Workspace dry(nullptr, 0);
+    make_plan(*h, dry, B, L0, two_pass != 0, 4096);
+    return dry.used();
+  } catch (const EngineError &) {
+    return -1;
+  }
+}
+
+int sf_unet_forward(sf_unet *h, const float *x, const float *sigma, const float *const *ctx, const float *emb, int B, int L0,
+                    float embedding_scale, float *out, void *ws, int64_t ws_bytes, void *stream) {
+  SF_API_BEGIN
+  if (!h || !x || !sigma || !ctx || !out) fail(SF_ERR_INVALID, "null argument");
+  if (!emb) fail(SF_ERR_INVALID, "ClassifierFreeGuidancePlugin requires embedding");
+  const bool two = embedding_scale != 1.0f;
+  check_ws(h, ws, ws_bytes, B, L0, two, 1);
+  Workspace w(ws, ws_bytes);
+  Plan p = make_plan(*h, w, B, L0, two, 1);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  Exec ex{*h, p, s};
+  h->dbg.reset();
+  ex.conditioning(ctx, emb);
+  h->launches = 0;
+  // sigma for the doubled batch: rows [B, 2B) repeat rows [0, B)
+  float *sig2 = p.sigs + 1;
+  SF_HIP(hipMemcpyAsync(sig2, sigma, B * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (two) SF_HIP(hipMemcpyAsync(sig2 + B, sigma, B * sizeof(float), hipMemcpyDeviceToDevice, s));
+  ex.eval(x, sig2, nullptr);
+  const int64_t n = (int64_t)B * L0 * h->cfg.in_channels;
+  if (two) SF_HIP(launch_cfg_combine(p.vout, p.vout + n, embedding_scale, out, n, s));
+  else SF_HIP(hipMemcpyAsync(out, p.vout, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return SF_OK;
+  SF_API_END
+}
+
+int sf_vsample(sf_unet *h, float *x, const float *const *ctx, const float *emb, int B, int L0, int num_steps, float embedding_scale,
+               int use_graph, void *ws, int64_t ws_bytes, void *stream) {
+  SF_API_BEGIN
+  if (!h || !x || !ctx) fail(SF_ERR_INVALID, "null argument");
+  if (!emb) fail(SF_ERR_INVALID, "ClassifierFreeGuidancePlugin requires embedding");
+  if (num_steps < 1) fail(SF_ERR_INVALID, "num_steps must be >= 1");
+  const bool two = embedding_scale != 1.0f;
+  check_ws(h, ws, ws_bytes, B, L0, two, num_steps);
+  Workspace w(ws, ws_bytes);
+  Plan p = make_plan(*h, w, B, L0, two, num_steps);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  Exec ex{*h, p, s};
+  h->dbg.reset();
+  float *dbg_buf = h->dbg.buf;
+  h->dbg.buf = nullptr;  // taps are a forward()-only facility
+  ex.conditioning(ctx, emb);
+
+  // LinearSchedule(1 -> 0) and (alpha, beta) = (cos, sin)(sigma*pi/2), exactly as VSampler builds them in fp32
+  // (torch.linspace: start + i*step for the first half, end - (steps-1-i)*step for the second).
+  const int T = num_steps;
+  std::vector<float> sig(T + 1), host(4 * (size_t)T + (size_t)T);
+  {
+    const float step = (0.0f - 1.0f) / (float)T;
+    const int halfway = (T + 1) / 2;
+    for (int i = 0; i <= T; ++i) sig[i] = (i < halfway) ? (1.0f + step * (float)i) : (0.0f - step * (float)(T - i));
+  }
+  const float hp = (float)(M_PI / 2.0);
+  for (int i = 0; i < T; ++i) {
+    float a0 = cosf(sig[i] * hp), b0 = sinf(sig[i] * hp), a1 = cosf(sig[i + 1] * hp), b1 = sinf(sig[i + 1] * hp);
+    host[4 * i + 0] = a0;
+    host[4 * i + 1] = b0;
+    host[4 * i + 2] = a1;
+    host[4 * i + 3] = b1;
+    host[4 * (size_t)T + i] = sig[i];
+  }
+  float *sched = p.sched;
+  float *sigs = p.sigs;
+  SF_HIP(hipMemcpyAsync(sched, host.data(), 4 * (size_t)T * sizeof(float), hipMemcpyHostToDevice, s));
+  SF_HIP(hipMemcpyAsync(sigs, host.data() + 4 * (size_t)T, (size_t)T * sizeof(float), hipMemcpyHostToDevice, s));
+  SF_HIP(hipMemsetAsync(p.step, 0, 4 * sizeof(int), s));
+  SF_HIP(hipStreamSynchronize(s));  // `host` goes out of scope; pageable H2D copies are staged, but be explicit
+
+  const int64_t n = (int64_t)B * L0 * h->cfg.in_channels;
+  auto one_step = [&]() {
+    ex.eval(x, sigs, p.step);
+    SF_HIP(launch_vsampler_update(x, p.vout, two ? p.vout + n : nullptr, embedding_scale, sched, p.step, n, s));
+    SF_HIP(launch_step_advance(p.step, s));
+  };
+
+  h->launches = 0;
+  one_step();  // step 0 eagerly (also performs every one-time kernel attribute setup outside capture)
+  h->launches += 2;
+  if (T > 1) {
+    if (use_graph) {
+      hipGraph_t graph = nullptr;
+      SF_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      try {
+        one_step();
+      } catch (...) {
+        hipGraph_t g2 = nullptr;
+        (void)hipStreamEndCapture(s, &g2);
+        if (g2) (void)hipGraphDestroy(g2);
+        throw;
+      }
+      SF_HIP(hipStreamEndCapture(s, &graph));
+      if (h->gexec) {
+        (void)hipGraphExecDestroy(h->gexec);
+        h->gexec = nullptr;
+      }
+      hipError_t e = hipGraphInstantiate(&h->gexec, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      if (e != hipSuccess) fail(SF_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+      for (int i = 1; i < T; ++i) SF_HIP(hipGraphLaunch(h->gexec, s));
+    } else {
+      for (int i = 1; i < T; ++i) one_step();
+    }
+  }
+  h->dbg.buf = dbg_buf;
+  return SF_OK;
+  SF_API_END
+}
+
+int sf_unet_debug_enable(sf_unet *h, float *buf, int64_t cap_floats) {
+  if (!h) return SF_ERR_INVALID;
+  h->dbg.buf = buf;
+  h->dbg.cap = cap_floats;
+  h->dbg.reset();
+  return SF_OK;
+}
+int sf_unet_debug_count(const sf_unet *h) { return h ? (int)h->dbg.entries.size() : -1; }
+int sf_unet_debug_info(const sf_unet *h, int i, char *name_out, int name_cap, int64_t *offset, int64_t *rows, int32_t *cols) {
+  if (!h || i < 0 || i >= (int)h->dbg.entries.size()) return SF_ERR_INVALID;
+  const auto &e = h->dbg.entries[i];
+  if (name_out && name_cap > 0) snprintf(name_out, name_cap, "%s", e.name.c_str());
+  if (offset) *offset = e.offset;
+  if (rows) *rows = e.rows;
+  if (cols) *cols = e.cols;
+  return SF_OK;
+}
+int sf_unet_launch_count(const sf_unet *h) { return h ? h->launches : -1; }
+
+}  // extern "C"

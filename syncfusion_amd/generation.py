@@ -1,0 +1,96 @@
+"""Device side of the reference's denoising driver, ``main.generation.generate_dataset``.
+
+Reference loop body (main/generation.py:49-103): ``noise = randn(B,1,length)`` ->
+``onsets_encoder(y, with_info=True)`` -> CLAP embedding -> ``model.model.sample(...)`` -> per clip:
+zero everything before the first onset (``cut_prefix``), crop to ``cut_length``, resample, save.
+``generate_batch`` is that body up to (not including) the CPU resample/save, with the same keyword
+names; the DataLoader / WebDataset / torchaudio.save plumbing around it is out of scope (SURVEY.md
+section 2 rows 5 and 8f-2) -- ``generate_dataset`` accepts any iterable of reference-shaped batches
+``(x, y, z, text, filenames)`` and writes 16-bit PCM wav files with the standard library.
+"""
+from __future__ import annotations
+
+import wave
+from pathlib import Path
+from typing import Iterable, List, Optional, Sequence, Union
+
+import torch
+
+from . import _lib
+
+Tensor = torch.Tensor
+
+
+@torch.no_grad()
+def generate_batch(model, y: Tensor, z: Optional[Tensor] = None, text: Optional[Sequence[str]] = None, *,
+                   num_steps: int = 150, length: int = 2 ** 18, embedding_scale: float = 7.5, cut_prefix: bool = False,
+                   cond_text: bool = False, cut_length: Optional[int] = None, noise: Optional[Tensor] = None,
+                   generator: Optional[torch.Generator] = None) -> Tensor:
+    """One batch of main/generation.py:69-89,100 on the device of ``model``.  Returns ``(B, 1, cut_length)``."""
+    device = model.device
+    _lib.require_gpu_tensor(torch.empty(0, device=device), "generate_batch")
+    B = y.shape[0]
+    if noise is None:
+        noise = torch.randn((B, 1, length), device=device, generator=generator)   # the ONLY RNG on the path (:69)
+    y = y.to(device)
+    _, y_latent = model.onsets_encoder(y, with_info=True)                        # :71
+    if cond_text:
+        z_latent = model.clap_encode_text(list(text))                             # :73
+    else:
+        z_latent = model.clap_encode_audio(z.to(device))                          # :75
+    gen = model.model.sample(x_noisy=noise.to(device), num_steps=num_steps, channels=y_latent["xs"][2:-1],
+                             embedding=z_latent.to(device), embedding_scale=embedding_scale)   # :77-83
+    if cut_prefix:
+        for i in range(B):
+            nz = torch.nonzero(y[i][0]).squeeze(-1)
+            if nz.numel() == 0:
+                # the reference indexes [0] unconditionally and raises IndexError on a track without onsets (:88)
+                raise IndexError(f"clip {i}: cut_prefix=True needs at least one onset in y")
+            gen[i, :, : int(nz[0])] = 0.0                                          # :88-89
+    return gen[:, :, : (cut_length or length)]                                     # :91,100
+
+
+def save_wav(path: Union[str, Path], audio: Tensor, sample_rate: int) -> None:
+    """(channels, n) float tensor in [-1, 1] -> 16-bit PCM wav (stand-in for torchaudio.save, :104-122)."""
+    a = (audio.detach().cpu().clamp(-1.0, 1.0) * 32767.0).round().to(torch.int16)
+    with wave.open(str(path), "wb") as f:
+        f.setnchannels(a.shape[0])
+        f.setsampwidth(2)
+        f.setframerate(int(sample_rate))
+        f.writeframes(a.t().contiguous().numpy().tobytes())
+
+
+@torch.no_grad()
+def generate_dataset(experiment_path: Union[str, Path], model, dataset: Iterable, device: str = "cuda",
+                     model_path: Optional[str] = None, batch_size: int = 16, num_workers: int = 4, sample_rate: int = 48000,
+                     num_steps: int = 150, length: int = 2 ** 18, embedding_scale: float = 7.5, cut_prefix: bool = False,
+                     cond_text: bool = False, one_chunk_per_track: bool = False, cut_length: Optional[int] = None,
+                     downsample_rate: Optional[int] = None, save_cond: bool = False) -> List[Path]:
+    """Same signature as main/generation.py:12-30.  ``dataset`` yields already-collated batches."""
+    if downsample_rate:
+        raise NotImplementedError("48 kHz -> 22.05 kHz polyphase resampling is the next row of the scope table (SURVEY 8f-2); "
+                                  "files are written at sample_rate")
+    experiment_path = Path(experiment_path)
+    experiment_path.mkdir(exist_ok=True, parents=True)
+    if model_path:
+        checkpoint = torch.load(model_path, map_location=device)
+        model.load_state_dict(checkpoint["state_dict"])
+    model.to(device)
+    written: List[Path] = []
+    chunk_id = 0
+    for batch in dataset:
+        x, y, z, text, filenames = batch
+        B = x.shape[0]
+        if not one_chunk_per_track:
+            last = experiment_path / f"{chunk_id + B - 1}.wav"
+            if last.exists():                                                       # crude resume, :52-59
+                chunk_id += B
+                continue
+        gen = generate_batch(model, y, z, text, num_steps=num_steps, length=length, embedding_scale=embedding_scale,
+                             cut_prefix=cut_prefix, cond_text=cond_text, cut_length=cut_length)
+        for i in range(B):
+            name = f"{chunk_id}.wav" if not one_chunk_per_track else f"{str(filenames[i]).split('/')[-1]}.wav"
+            save_wav(experiment_path / name, gen[i], sample_rate)
+            written.append(experiment_path / name)
+            chunk_id += 1
+    return written

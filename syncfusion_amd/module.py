@@ -1,0 +1,124 @@
+"""Boundary object of the generation path: mirror of ``main.module_diffusion.Model``.
+
+Reference: main/module_diffusion.py:22-87.  Same constructor arguments, same attributes
+(``model``, ``onsets_encoder``, ``clap``), same helper methods (``clap_encode_audio`` /
+``clap_encode_text`` / ``step``).  ``pytorch_lightning`` is used as the base class when it is
+importable (it is not in this image), otherwise ``torch.nn.Module`` with the two attributes the
+callers touch (``device``, ``log``).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+try:  # pragma: no cover - not installed in the build image
+    import pytorch_lightning as pl
+
+    _Base = pl.LightningModule
+except Exception:  # noqa: BLE001
+    class _Base(nn.Module):
+        @property
+        def device(self) -> torch.device:
+            try:
+                return next(self.parameters()).device
+            except StopIteration:
+                return torch.device("cpu")
+
+        def log(self, *args, **kwargs) -> None:  # Lightning's self.log is a no-op without a Trainer
+            return None
+
+Tensor = torch.Tensor
+
+
+def int16_to_float32(x: Tensor) -> Tensor:
+    """main/utils.py:22-23."""
+    return (x / 32767.0).to(torch.float32)
+
+
+def float32_to_int16(x: Tensor) -> Tensor:
+    """main/utils.py:26-28."""
+    x = torch.clip(x, min=-1.0, max=1.0)
+    return (x * 32767.0).to(torch.int16)
+
+
+class RandomEmbedder(nn.Module):
+    """Offline stand-in for ``laion_clap.CLAP_Module`` (out of scope).
+
+    Implements the four members the reference touches (main/module_diffusion.py:48-51,67,71) and returns
+    deterministic unit-norm ``(B, 512)`` vectors derived from the input, so benchmarks and tests have a
+    well-defined conditioning tensor without the CLAP checkpoint."""
+
+    def __init__(self, features: int = 512, **_ignored):
+        super().__init__()
+        self.features = features
+        self.register_buffer("proj", torch.randn(64, features, generator=torch.Generator().manual_seed(2000)))
+
+    def load_ckpt(self, path=None) -> None:
+        return None
+
+    def _embed(self, feats: Tensor) -> Tensor:
+        e = feats.to(self.proj.dtype) @ self.proj
+        return torch.nn.functional.normalize(e, dim=-1)
+
+    def get_audio_embedding_from_data(self, x: Tensor, use_tensor: bool = True) -> Tensor:
+        B = x.shape[0]
+        frames = x.reshape(B, -1)
+        n = frames.shape[1] // 64 * 64
+        feats = frames[:, :n].reshape(B, 64, -1).abs().mean(-1) if n else torch.zeros(B, 64, device=x.device)
+        return self._embed(feats + 1e-3)
+
+    def get_text_embedding(self, text: List[str], use_tensor: bool = True) -> Tensor:
+        feats = torch.zeros(len(text), 64)
+        for i, t in enumerate(text):
+            for j, ch in enumerate(t.encode()):
+                feats[i, (j * 31 + ch) % 64] += 1.0
+        return self._embed(feats.to(self.proj.device) + 1e-3)
+
+
+class Model(_Base):
+    def __init__(self, lr: float, lr_beta1: float, lr_beta2: float, lr_eps: float, lr_weight_decay: float,
+                 model: nn.Module, onsets_encoder: nn.Module, embedder: nn.Module, embedder_checkpoint: Optional[str]):
+        super().__init__()
+        self.lr = lr
+        self.lr_beta1 = lr_beta1
+        self.lr_beta2 = lr_beta2
+        self.lr_eps = lr_eps
+        self.lr_weight_decay = lr_weight_decay
+        self.model = model
+        self.onsets_encoder = onsets_encoder
+        print(f"Loading CLAP embedder from {embedder_checkpoint}...")
+        self.clap = embedder
+        self.clap.load_ckpt(embedder_checkpoint)
+        for param in self.clap.parameters():
+            param.requires_grad = False
+
+    def configure_optimizers(self):
+        return torch.optim.AdamW(list(self.model.parameters()) + list(self.onsets_encoder.parameters()), lr=self.lr,
+                                 betas=(self.lr_beta1, self.lr_beta2), eps=self.lr_eps, weight_decay=self.lr_weight_decay)
+
+    @torch.no_grad()
+    def clap_encode_audio(self, x: Tensor) -> Tensor:
+        x = int16_to_float32(float32_to_int16(x[:, 0, :])).float()
+        return self.clap.get_audio_embedding_from_data(x=x, use_tensor=True).unsqueeze(1)
+
+    @torch.no_grad()
+    def clap_encode_text(self, text: List[str]) -> Tensor:
+        return self.clap.get_text_embedding(text, use_tensor=True).unsqueeze(1)
+
+    def step(self, batch):
+        x, y, z, _, _ = batch
+        z_latent = self.clap_encode_audio(z)
+        _, y_latent = self.onsets_encoder(y, with_info=True)
+        return self.model(x, channels=y_latent["xs"][2:-1], embedding=z_latent)
+
+    def training_step(self, batch, batch_idx):
+        loss = self.step(batch)
+        self.log("train_loss", loss)
+        return loss
+
+    def validation_step(self, batch, batch_idx):
+        loss = self.step(batch)
+        self.log("valid_loss", loss)
+        return loss
