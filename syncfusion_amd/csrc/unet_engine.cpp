@@ -81,8 +81,16 @@ struct sf_unet {
     float scale = 0.f;
   } gkey;
 
+  // stream capture is illegal on the legacy null stream (torch's default): the sampling loop runs on an
+  // engine-owned stream, fenced against the caller's stream with events on both sides
+  hipStream_t own_stream = nullptr;
+  hipEvent_t ev_in = nullptr, ev_out = nullptr;
+
   ~sf_unet() {
     if (gexec) (void)hipGraphExecDestroy(gexec);
+    if (ev_in) (void)hipEventDestroy(ev_in);
+    if (ev_out) (void)hipEventDestroy(ev_out);
+    if (own_stream) (void)hipStreamDestroy(own_stream);
   }
 };
 
@@ -753,7 +761,18 @@ int sf_vsample(sf_unet *h, float *x, const float *const *ctx, const float *emb, 
   check_ws(h, ws, ws_bytes, B, L0, two, num_steps);
   Workspace w(ws, ws_bytes);
   Plan p = make_plan(*h, w, B, L0, two, num_steps);
-  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipStream_t user = static_cast<hipStream_t>(stream);
+  hipStream_t s = user;
+  if (use_graph && num_steps > 1) {
+    if (!h->own_stream) {
+      SF_HIP(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+      SF_HIP(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
+      SF_HIP(hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming));
+    }
+    SF_HIP(hipEventRecord(h->ev_in, user));
+    SF_HIP(hipStreamWaitEvent(h->own_stream, h->ev_in, 0));
+    s = h->own_stream;
+  }
   Exec ex{*h, p, s};
   h->dbg.reset();
   float *dbg_buf = h->dbg.buf;
@@ -819,6 +838,10 @@ int sf_vsample(sf_unet *h, float *x, const float *const *ctx, const float *emb, 
     } else {
       for (int i = 1; i < T; ++i) one_step();
     }
+  }
+  if (s != user) {
+    SF_HIP(hipEventRecord(h->ev_out, s));
+    SF_HIP(hipStreamWaitEvent(user, h->ev_out, 0));
   }
   h->dbg.buf = dbg_buf;
   return SF_OK;

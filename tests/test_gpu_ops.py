@@ -1,0 +1,155 @@
+"""Kernel-level parity (MI355X): each HIP kernel family, through the C ABI, against the same op in fp32 torch on the CPU.
+
+These localise a failure to one kernel; the model-level parity tests are in test_gpu_models.py.
+Tolerances: fp32 path 2e-5 rel-L2 (exact-fp32 MFMA, different summation order); bf16 path 2e-2.
+"""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"fp32": 2e-5, "bf16": 2e-2}
+TD = {"fp32": torch.float32, "bf16": torch.bfloat16}
+
+
+def _lib():
+    from syncfusion_amd import _lib
+
+    return _lib, _lib.load()
+
+
+def _conv_case(cuda, dtype, B, L, C, N, taps, stride, pad, up, groups, residual, seed=0):
+    _l, lib = _lib()
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, C, L, generator=g) * 1.5 + 0.3
+    w = torch.randn(N, C, taps, generator=g) / (C * taps) ** 0.5
+    bias = torch.randn(N, generator=g) * 0.1
+    gamma = 1 + 0.2 * torch.randn(C, generator=g)
+    beta = 0.1 * torch.randn(C, generator=g)
+    td = TD[dtype]
+    # the reference op on the CPU, from the same (dtype-rounded) inputs
+    xr = x.to(td).float()
+    h = F.silu(F.group_norm(xr, groups, gamma, beta, eps=1e-5)) if groups else xr
+    if up > 1:
+        h = F.interpolate(h, scale_factor=up, mode="nearest")
+    wr = w.to(td).float() if C % 32 == 0 else w
+    ref = F.conv1d(h, wr, bias, stride=stride, padding=pad)
+    Lout = ref.shape[-1]
+    res = None
+    if residual:
+        res = torch.randn(B, N, Lout, generator=g)
+        ref = ref + res.to(td).float()
+    x_cl = x.transpose(1, 2).contiguous().to(td).to(cuda)
+    res_cl = res.transpose(1, 2).contiguous().to(td).to(cuda) if residual else None
+    out = torch.empty(B, Lout, N, dtype=td, device=cuda)
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=cuda)
+    wd, bd, gd, bed = w.to(cuda), bias.to(cuda), gamma.to(cuda), beta.to(cuda)
+    rc = lib.sf_op_conv1d_cl(_l.DTYPES[dtype], x_cl.data_ptr(), wd.data_ptr(), bd.data_ptr(), gd.data_ptr(), bed.data_ptr(), groups, 1e-5,
+                             res_cl.data_ptr() if residual else None, B, L, C, N, taps, stride, pad, up, out.data_ptr(), ws.data_ptr(),
+                             ws.numel(), _l.stream_ptr(cuda))
+    _l.check(rc, "sf_op_conv1d_cl")
+    torch.cuda.synchronize()
+    got = out.float().cpu().transpose(1, 2)
+    return rel_l2(got, ref)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("shape", [
+    # B, L, C, N, taps, stride, pad, up, groups, residual
+    (2, 352, 64, 64, 3, 1, 1, 1, 8, True),      # ResnetItem conv, 64x64 tile
+    (3, 704, 128, 128, 3, 1, 1, 1, 8, True),    # 128-wide
+    (2, 1408, 32, 32, 3, 1, 1, 1, 8, False),    # BN=32 tile
+    (2, 44, 256, 256, 3, 1, 1, 1, 8, True),     # short clips: tiles span several clips
+    (5, 3, 64, 64, 3, 1, 1, 1, 8, False),       # clips shorter than the kernel halo
+    (2, 88, 64, 32, 3, 1, 1, 2, 0, True),       # nearest x2 upsample + conv3 (UpsampleItem)
+    (2, 88, 64, 8, 3, 1, 1, 4, 0, False),       # x4 upsample, N < 32
+    (2, 176, 128, 256, 1, 1, 0, 1, 0, False),   # 1x1 / Linear
+    (2, 352, 32, 64, 5, 2, 2, 1, 0, False),     # Encoder1d strided conv k=2f+1
+    (1, 1000, 64, 96, 3, 1, 1, 1, 4, False),    # ragged M, N not a tile multiple
+])
+def test_conv_gemm(cuda, dtype, shape):
+    assert _conv_case(cuda, dtype, *shape) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("shape", [
+    (2, 2816, 8, 8, 3, 1, 1, 1, 8, True),       # U-Net depth 0 ResnetItem
+    (2, 704, 1, 8, 1, 1, 0, 1, 0, False),       # 1 -> 8 entry conv
+    (2, 704, 8, 1, 3, 1, 1, 1, 0, True),        # 8 -> 1 exit conv
+    (2, 1024, 2, 8, 9, 4, 4, 1, 0, False),      # Encoder1d 2 -> 8, k=9, stride 4
+    (3, 500, 16, 32, 9, 4, 4, 1, 0, False),     # ragged length: Lout = ceil(L/4)
+    (2, 640, 2, 2, 3, 1, 1, 1, 2, True),        # Encoder1d ResnetBlock1d(groups=2)
+    (2, 640, 1, 2, 3, 1, 1, 1, 1, False),       # to_in: GroupNorm(1 group, 1 channel)
+])
+def test_conv_direct(cuda, dtype, shape):
+    assert _conv_case(cuda, dtype, *shape) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("C", [8, 32, 64, 256, 1024])
+@pytest.mark.parametrize("mod", [True, False])
+def test_ln_modulate(cuda, dtype, C, mod):
+    _l, lib = _lib()
+    B, L = 3, 37
+    g = torch.Generator().manual_seed(C)
+    td = TD[dtype]
+    x = (torch.randn(B, L, C, generator=g) * 2 + 0.5).to(td)
+    ss = torch.randn(B, 2 * C, generator=g) * 0.3
+    eps = 1e-6 if mod else 1e-5
+    ref = F.layer_norm(x.float(), (C,), None, None, eps=eps)
+    if mod:
+        ref = ref * (1 + ss[:, None, :C]) + ss[:, None, C:]
+    xd, sd = x.to(cuda), ss.to(cuda)
+    out = torch.empty_like(xd)
+    _l.check(lib.sf_op_ln_modulate(_l.DTYPES[dtype], xd.data_ptr(), sd.data_ptr() if mod else None, eps, B, L, C, out.data_ptr(),
+                                   _l.stream_ptr(cuda)), "sf_op_ln_modulate")
+    torch.cuda.synchronize()
+    assert rel_l2(out.float().cpu(), ref) < (1e-5 if dtype == "fp32" else 8e-3)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("L", [1, 44, 64, 100, 352])
+def test_attention(cuda, dtype, L):
+    _l, lib = _lib()
+    B, H, D = 2, 3, 64
+    g = torch.Generator().manual_seed(L)
+    td = TD[dtype]
+    q = torch.randn(B, L, H * D, generator=g).to(td)
+    kv = torch.randn(B, L, 2 * H * D, generator=g).to(td)
+    qf = q.float().reshape(B, L, H, D).transpose(1, 2)
+    k, v = kv.float().chunk(2, dim=-1)
+    kf = k.reshape(B, L, H, D).transpose(1, 2)
+    vf = v.reshape(B, L, H, D).transpose(1, 2)
+    sim = torch.einsum("bhnd,bhmd->bhnm", qf, kf) * D ** -0.5
+    ref = torch.einsum("bhnm,bhmd->bhnd", sim.softmax(-1), vf).transpose(1, 2).reshape(B, L, H * D)
+    qd, kvd = q.to(cuda), kv.to(cuda)
+    out = torch.empty_like(qd)
+    _l.check(lib.sf_op_attention(_l.DTYPES[dtype], qd.data_ptr(), kvd.data_ptr(), B, L, H, D, out.data_ptr(), _l.stream_ptr(cuda)),
+             "sf_op_attention")
+    torch.cuda.synchronize()
+    assert rel_l2(out.float().cpu(), ref) < (1e-5 if dtype == "fp32" else 8e-3)
+
+
+def test_onsets_to_track_matches_reference_formatting(cuda):
+    """sf_onsets_to_track vs the reference chain restated with real "%.4f" formatting
+    (main/module_onset.py:160-183 + main/dataset_diffusion.py:69-72)."""
+    from syncfusion_amd.onset_glue import onsets_to_track
+
+    g = torch.Generator().manual_seed(5)
+    N, T, L, fps, sr = 4, 30, 96000, 15.0, 48000
+    logits = torch.randn(N, T, generator=g)
+    start = torch.tensor([0, 30, 45, 7], dtype=torch.int32)
+    want = torch.zeros(N, 1, L)
+    for i in range(N):
+        for idx in torch.nonzero(logits[i] > 0.5).flatten().tolist():
+            t = float("%.4f" % ((idx + int(start[i])) / fps))
+            pos = int(t * sr)
+            if pos < L:
+                want[i, 0, pos] = 1.0
+    got = onsets_to_track(logits.to(cuda), L, fps, sr, 0.5, start.to(cuda)).cpu()
+    assert torch.equal(got, want)
