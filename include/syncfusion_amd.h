@@ -110,6 +110,11 @@ int sf_unet_debug_info(const sf_unet *h, int i, char *name_out, int name_cap, in
 /* Per-kernel launch accounting of the last forward (host side, for bench.py's roofline):
  * number of kernel launches in one evaluation. */
 int sf_unet_launch_count(const sf_unet *h);
+/* Per-launch timing of the next sf_unet_forward: HIP events recorded on `stream` around every kernel launch
+ * (label = kernel / tile variant; flops, bytes = ALGORITHMIC work of that launch). */
+int sf_unet_profile_enable(sf_unet *h, int on);
+int sf_unet_profile_count(const sf_unet *h);
+int sf_unet_profile_get(const sf_unet *h, int i, char *name_out, int name_cap, float *ms, double *flops, double *bytes);
 
 /* ------------------------------------------------------------------------------------------
  * Encoder1d (onset-track feature pyramid)

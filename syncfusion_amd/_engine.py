@@ -136,6 +136,21 @@ class UNetEngine(_Base):
     def launch_count(self) -> int:
         return int(self.lib.sf_unet_launch_count(self.handle))
 
+    def profile_forward(self, x, sigma, channels, embedding, embedding_scale=1.0):
+        """One evaluation with HIP events around every launch -> [(label, ms, algorithmic flops, algorithmic bytes)]."""
+        check(self.lib.sf_unet_profile_enable(self.handle, 1), "sf_unet_profile_enable")
+        try:
+            self.forward(x, sigma, channels, embedding, embedding_scale)
+            recs = []
+            for i in range(self.lib.sf_unet_profile_count(self.handle)):
+                name = C.create_string_buffer(128)
+                ms, fl, by = C.c_float(), C.c_double(), C.c_double()
+                check(self.lib.sf_unet_profile_get(self.handle, i, name, 128, C.byref(ms), C.byref(fl), C.byref(by)), "profile_get")
+                recs.append((name.value.decode(), ms.value, fl.value, by.value))
+        finally:
+            self.lib.sf_unet_profile_enable(self.handle, 0)
+        return recs
+
     def forward_with_taps(self, x, sigma, channels, embedding, embedding_scale=1.0, cap_floats: int = 1 << 26):
         """tests only: returns (out, {name: (rows, cols) fp32 tensor})."""
         buf = torch.empty(cap_floats, dtype=torch.float32, device=self.device)

@@ -365,22 +365,28 @@ hipError_t launch_cfg(const ConvGemmArgs &a, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <typename T> hipError_t dispatch(const ConvGemmArgs &a, hipStream_t s) {
+// tile variants: 0 scalar-A 64x64, 1 128x32, 2 128x64, 3 64x64, 4 128x128
+int pick_variant(const ConvGemmArgs &a) {
   const bool scalar_a = (a.cin % BK) != 0 || (a.cin2 % BK) != 0;
-  if (scalar_a) {
-    if (a.cin2 != 0 || a.pro != 0) return hipErrorInvalidValue;
-    return launch_cfg<T, 64, 64, 2, 2, true>(a, s);
-  }
+  if (scalar_a) return (a.cin2 != 0 || a.pro != 0) ? -1 : 0;
   const long M = a.M, N = a.n_store;
   auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
-  if (N <= 32) return launch_cfg<T, 128, 32, 4, 1, false>(a, s);
-  if (N <= 64) {
-    if (blocks(128, 64) >= 512) return launch_cfg<T, 128, 64, 2, 2, false>(a, s);
-    return launch_cfg<T, 64, 64, 2, 2, false>(a, s);
+  if (N <= 32) return 1;
+  if (N <= 64) return blocks(128, 64) >= 512 ? 2 : 3;
+  if (blocks(128, 128) >= 512) return 4;
+  if (blocks(128, 64) >= 384) return 2;
+  return 3;
+}
+
+template <typename T> hipError_t dispatch(const ConvGemmArgs &a, hipStream_t s) {
+  switch (pick_variant(a)) {
+    case 0: return launch_cfg<T, 64, 64, 2, 2, true>(a, s);
+    case 1: return launch_cfg<T, 128, 32, 4, 1, false>(a, s);
+    case 2: return launch_cfg<T, 128, 64, 2, 2, false>(a, s);
+    case 3: return launch_cfg<T, 64, 64, 2, 2, false>(a, s);
+    case 4: return launch_cfg<T, 128, 128, 2, 2, false>(a, s);
+    default: return hipErrorInvalidValue;
   }
-  if (blocks(128, 128) >= 512) return launch_cfg<T, 128, 128, 2, 2, false>(a, s);
-  if (blocks(128, 64) >= 384) return launch_cfg<T, 128, 64, 2, 2, false>(a, s);
-  return launch_cfg<T, 64, 64, 2, 2, false>(a, s);
 }
 
 }  // namespace
@@ -394,6 +400,13 @@ bool conv_gemm_supported(int dt, const ConvGemmArgs &a) {
     if ((size_t)nb * (a.cin + a.G) * 8 > 96 * 1024) return false;
   }
   return true;
+}
+
+const char *conv_gemm_variant_name(int dt, const ConvGemmArgs &a) {
+  static const char *names[2][5] = {{"conv_gemm<f32,64x64,scalarA>", "conv_gemm<f32,128x32>", "conv_gemm<f32,128x64>", "conv_gemm<f32,64x64>", "conv_gemm<f32,128x128>"},
+                                    {"conv_gemm<bf16,64x64,scalarA>", "conv_gemm<bf16,128x32>", "conv_gemm<bf16,128x64>", "conv_gemm<bf16,64x64>", "conv_gemm<bf16,128x128>"}};
+  int v = pick_variant(a);
+  return v < 0 ? "conv_gemm<invalid>" : names[dt == F32 ? 0 : 1][v];
 }
 
 hipError_t launch_conv_gemm(int dt, const ConvGemmArgs &a, hipStream_t s) {

@@ -101,6 +101,7 @@ struct ConvW {
   void *w = nullptr;       // [N][K] in the compute type (MFMA path) or fp32 (direct path)
   float *bias = nullptr;   // [N] fp32 or null
   int N = 0, K = 0, cin = 0, cin2 = 0, taps = 1;
+  int kreal = 0;           // un-padded reduction length (algorithmic FLOP accounting)
   bool direct = false;     // thin layer -> conv_direct (fp32 weights)
 };
 

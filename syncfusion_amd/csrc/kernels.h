@@ -35,6 +35,8 @@ struct ConvGemmArgs {
   int badd_ld = 0, bscale_ld = 0, act = 0, out_f32 = 0;
 };
 hipError_t launch_conv_gemm(int dt, const ConvGemmArgs &a, hipStream_t s);
+// name of the tile variant launch_conv_gemm picks for these arguments (profiling labels)
+const char *conv_gemm_variant_name(int dt, const ConvGemmArgs &a);
 // bytes of dynamic LDS the GN table needs is bounded; returns false when the shape is unsupported.
 bool conv_gemm_supported(int dt, const ConvGemmArgs &a);
 

@@ -72,6 +72,25 @@ struct sf_unet {
   DebugTaps dbg;
   int launches = 0;
   bool listing = false;
+  // per-launch HIP-event timing (bench.py's roofline leg): events are recorded on the launch stream
+  struct ProfRec {
+    const char *label;
+    double flops, bytes;
+    hipEvent_t e0, e1;
+    float ms;
+  };
+  bool prof_on = false;
+  std::vector<ProfRec> prof;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  hipEvent_t get_event() {
+    if (ev_used == ev_pool.size()) {
+      hipEvent_t e;
+      SF_HIP(hipEventCreate(&e));
+      ev_pool.push_back(e);
+    }
+    return ev_pool[ev_used++];
+  }
   std::vector<std::pair<std::string, int64_t>> names;
   // graph cache for sf_vsample
   hipGraphExec_t gexec = nullptr;
@@ -88,6 +107,7 @@ struct sf_unet {
 
   ~sf_unet() {
     if (gexec) (void)hipGraphExecDestroy(gexec);
+    for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
     if (ev_in) (void)hipEventDestroy(ev_in);
     if (ev_out) (void)hipEventDestroy(ev_out);
     if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -128,6 +148,7 @@ struct Builder {
     c.cin = direct ? C1 : cin_pad;
     c.cin2 = C2 ? (direct ? C2 : cin2_pad) : 0;
     c.K = taps * c.cin + c.cin2;
+    c.kreal = taps * C1 + C2;
     const int Ctot = C1 + C2;
     const float *w = get(pre + ".weight", (int64_t)N * Ctot * taps);
     const float *b = bias ? get(pre + ".bias", N) : nullptr;
@@ -168,6 +189,7 @@ struct Builder {
     const float *w = get(pre + ".weight", (int64_t)N * K);
     const float *b = bias ? get(pre + ".bias", N) : nullptr;
     ConvW c = linear_alloc(N, Kpad, bias);
+    c.kreal = K;
     linear_into(c, 0, w, N, K, nullptr);
     if (b && !u.listing) SF_HIP(hipMemcpyAsync(c.bias, b, N * sizeof(float), hipMemcpyDeviceToDevice, s));
     return c;
@@ -392,6 +414,19 @@ struct Exec {
   Plan &p;
   hipStream_t s;
 
+  template <class F> void timed(const char *label, double flops, double bytes, F &&f) {
+    ++u.launches;
+    if (!u.prof_on) {
+      f();
+      return;
+    }
+    hipEvent_t e0 = u.get_event(), e1 = u.get_event();
+    SF_HIP(hipEventRecord(e0, s));
+    f();
+    SF_HIP(hipEventRecord(e1, s));
+    u.prof.push_back({label, flops, bytes, e0, e1, 0.f});
+  }
+
   void conv(const ConvW &w, ConvGemmArgs a, int dt_in, int dt_out) {
     a.w = w.w;
     a.bias = w.bias;
@@ -401,12 +436,18 @@ struct Exec {
     a.cin2 = w.cin2;
     a.taps = w.taps;
     if (a.n_store == 0) a.n_store = w.N;
-    if (w.direct) SF_HIP(launch_conv_direct(dt_in, dt_out, a, s));
+    // algorithmic work of this launch: 2*M*N*K_real FLOPs; bytes = activations in + out (+ residual) + weights
+    const double kreal = w.kreal > 0 ? w.kreal : w.K;
+    const double es_in = dsize(dt_in), es_out = a.out_f32 ? 4.0 : (double)dsize(dt_out);
+    const double flops = 2.0 * a.M * w.N * kreal;
+    const double src_rows = (double)a.M / a.Lout * a.Lsrc;
+    const double bytes = src_rows * (kreal / (w.taps > 0 ? w.taps : 1)) * es_in + (double)a.M * w.N * es_out * (a.res ? 2 : 1) +
+                         (double)w.N * kreal * (w.direct ? 4.0 : (double)dsize(u.dt));
+    if (w.direct) timed("conv_direct", flops, bytes, [&] { SF_HIP(launch_conv_direct(dt_in, dt_out, a, s)); });
     else {
       if (dt_in != u.dt || (dt_out != u.dt && !a.out_f32)) fail(SF_ERR_INVALID, "internal: dtype mismatch on the MFMA path");
-      SF_HIP(launch_conv_gemm(u.dt, a, s));
+      timed(conv_gemm_variant_name(u.dt, a), flops, bytes, [&] { SF_HIP(launch_conv_gemm(u.dt, a, s)); });
     }
-    ++u.launches;
   }
 
   // rows x K GEMM on per-clip vectors (time MLP, modulation, cross-attention collapse)
@@ -429,8 +470,8 @@ struct Exec {
   void gn(const void *x, int d, int C) {
     const Level &l = p.lv[d];
     GnPlan gp = gn_plan(p.Bt, l.L, C);
-    SF_HIP(launch_gn_stats(u.dt, x, C, p.Bt, l.L, C, u.cfg.resnet_groups, gp.nch, gp.chunk_rows, p.slab, s));
-    ++u.launches;
+    timed("gn_stats", 3.0 * l.rows * C, (double)l.rows * C * dsize(u.dt),
+          [&] { SF_HIP(launch_gn_stats(u.dt, x, C, p.Bt, l.L, C, u.cfg.resnet_groups, gp.nch, gp.chunk_rows, p.slab, s)); });
   }
 
   // One item-group: Resnet -> Modulation -> InjectChannels -> [Attention] -> [CrossAttention]
@@ -466,8 +507,8 @@ struct Exec {
     conv3(g.conv1, cur, tA, g.gn1_g, g.gn1_b, nullptr);
     conv3(g.conv2, tA, tB, g.gn2_g, g.gn2_b, cur);
     // Modulation: LN_C(x; eps 1e-6) * (1 + scale) + shift
-    SF_HIP(launch_ln_modulate(u.dt, tB, C, p.mod_all + g.mod_off, u.mod_ld, 1e-6f, p.Bt, l.L, C, tA, C, s));
-    ++u.launches;
+    timed("ln_modulate", 8.0 * l.rows * C, 2.0 * l.rows * C * dsize(u.dt),
+          [&] { SF_HIP(launch_ln_modulate(u.dt, tB, C, p.mod_all + g.mod_off, u.mod_ld, 1e-6f, p.Bt, l.L, C, tA, C, s)); });
     // InjectChannels: Conv1x1(cat[x, ctx]) + x   (+ collapsed cross-attention bias when no self-attention follows)
     {
       ConvGemmArgs a;
@@ -489,8 +530,8 @@ struct Exec {
     }
     if (g.attn) {
       // x + W_o MHA(W_q LN_a(x), W_kv LN_b(x)): the two LayerNorms share (mean, rstd); their affines are folded.
-      SF_HIP(launch_ln_modulate(u.dt, tB, C, nullptr, 0, 1e-5f, p.Bt, l.L, C, tA, C, s));
-      ++u.launches;
+      timed("ln_modulate", 6.0 * l.rows * C, 2.0 * l.rows * C * dsize(u.dt),
+            [&] { SF_HIP(launch_ln_modulate(u.dt, tB, C, nullptr, 0, 1e-5f, p.Bt, l.L, C, tA, C, s)); });
       {
         ConvGemmArgs a;
         a.src = tA;
@@ -502,9 +543,10 @@ struct Exec {
         conv(g.qkv, a, u.dt, u.dt);
       }
       const size_t es = dsize(u.dt);
-      SF_HIP(launch_attention(u.dt, l.qkv, 3 * u.hd, static_cast<char *>(l.qkv) + (size_t)u.hd * es, 3 * u.hd, p.Bt, l.L,
-                              u.cfg.attention_heads, u.cfg.attention_features, l.ao, u.hd, s));
-      ++u.launches;
+      timed("attention", 4.0 * p.Bt * (double)l.L * l.L * u.hd, 4.0 * l.rows * u.hd * es, [&] {
+        SF_HIP(launch_attention(u.dt, l.qkv, 3 * u.hd, static_cast<char *>(l.qkv) + (size_t)u.hd * es, 3 * u.hd, p.Bt, l.L,
+                                u.cfg.attention_heads, u.cfg.attention_features, l.ao, u.hd, s));
+      });
       {
         ConvGemmArgs a;
         a.src = l.ao;
@@ -595,8 +637,8 @@ struct Exec {
 
   // features + modulation vectors of one step; sigma from sig[b] (sig_idx == nullptr) or sig[*sig_idx]
   void features(const float *sig, const int *sig_idx) {
-    SF_HIP(launch_time_fourier(u.dt, sig, sig_idx, u.fourier_w, p.Bt, u.half, p.four, u.four_ld, s));
-    ++u.launches;
+    timed("time_fourier", 0.0, (double)p.Bt * u.four_ld * dsize(u.dt),
+          [&] { SF_HIP(launch_time_fourier(u.dt, sig, sig_idx, u.fourier_w, p.Bt, u.half, p.four, u.four_ld, s)); });
     dense(u.lin0, p.four, u.four_ld, p.Bt, p.f1, u.mf, /*gelu*/ 2, false);
     dense(u.mlp0, p.f1, u.mf, p.Bt, p.f2, u.mf, 2, false);
     dense(u.mlp1, p.f2, u.mf, p.Bt, p.sf, u.mf, /*silu(gelu)*/ 3, false);
@@ -743,7 +785,13 @@ int sf_unet_forward(sf_unet *h, const float *x, const float *sigma, const float 
   float *sig2 = p.sigs + 1;
   SF_HIP(hipMemcpyAsync(sig2, sigma, B * sizeof(float), hipMemcpyDeviceToDevice, s));
   if (two) SF_HIP(hipMemcpyAsync(sig2 + B, sigma, B * sizeof(float), hipMemcpyDeviceToDevice, s));
+  h->prof.clear();
+  h->ev_used = 0;
   ex.eval(x, sig2, nullptr);
+  if (h->prof_on) {
+    SF_HIP(hipStreamSynchronize(s));
+    for (auto &r : h->prof) SF_HIP(hipEventElapsedTime(&r.ms, r.e0, r.e1));
+  }
   const int64_t n = (int64_t)B * L0 * h->cfg.in_channels;
   if (two) SF_HIP(launch_cfg_combine(p.vout, p.vout + n, embedding_scale, out, n, s));
   else SF_HIP(hipMemcpyAsync(out, p.vout, n * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -866,5 +914,22 @@ int sf_unet_debug_info(const sf_unet *h, int i, char *name_out, int name_cap, in
   return SF_OK;
 }
 int sf_unet_launch_count(const sf_unet *h) { return h ? h->launches : -1; }
+
+int sf_unet_profile_enable(sf_unet *h, int on) {
+  if (!h) return SF_ERR_INVALID;
+  h->prof_on = on != 0;
+  h->prof.clear();
+  return SF_OK;
+}
+int sf_unet_profile_count(const sf_unet *h) { return h ? (int)h->prof.size() : -1; }
+int sf_unet_profile_get(const sf_unet *h, int i, char *name_out, int name_cap, float *ms, double *flops, double *bytes) {
+  if (!h || i < 0 || i >= (int)h->prof.size()) return SF_ERR_INVALID;
+  const auto &r = h->prof[i];
+  if (name_out && name_cap > 0) snprintf(name_out, name_cap, "%s", r.label);
+  if (ms) *ms = r.ms;
+  if (flops) *flops = r.flops;
+  if (bytes) *bytes = r.bytes;
+  return SF_OK;
+}
 
 }  // extern "C"

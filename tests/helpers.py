@@ -82,23 +82,9 @@ SMALL_ENCODER = dict(
 def reference_model_config() -> dict:
     """The node tree ``hydra.utils.instantiate`` receives for the reference's full model
     (values of exp/model/diffusion.yaml:3-49, built from the oracle's config constants)."""
-    from oracle import encoder1d_ref, unet_ref
+    from syncfusion_amd.reference_config import model_config
 
-    u = unet_ref.DEFAULT_CONFIG
-    unet_keys = ("in_channels", "channels", "factors", "items", "attentions", "attention_heads", "attention_features",
-                 "context_channels", "embedding_max_length", "embedding_features", "cross_attentions")
-    model = {"_target_": "audio_diffusion_pytorch.DiffusionModel",
-             "net_t": {"_target_": "audio_diffusion_pytorch.UNetV0", "_partial_": True},
-             "diffusion_t": {"_target_": "audio_diffusion_pytorch.VDiffusion", "_partial_": True},
-             "sampler_t": {"_target_": "audio_diffusion_pytorch.VSampler", "_partial_": True},
-             "use_embedding_cfg": True}
-    model.update({k: u[k] for k in unet_keys})
-    enc = {"_target_": "audio_encoders_pytorch.Encoder1d"}
-    enc.update(encoder1d_ref.DEFAULT_CONFIG)
-    return {"_target_": "main.module_diffusion.Model", "lr": "1e-4", "lr_beta1": 0.95, "lr_beta2": 0.999, "lr_eps": "1e-6",
-            "lr_weight_decay": "1e-3", "model": model, "onsets_encoder": enc,
-            "embedder": {"_target_": "laion_clap.CLAP_Module", "enable_fusion": False, "amodel": "HTSAT-tiny"},
-            "embedder_checkpoint": None}
+    return model_config()
 
 
 def small_unet_module(seed: int = 1234, dtype: str = "fp32"):

@@ -1,0 +1,54 @@
+"""world_size-2 gloo test of the N>1 path: contiguous clip sharding, flat weight broadcast, output gather.
+
+The data path has no collective (clips are independent); this covers the only two collectives the
+multi-GPU run uses, on CPU tensors with the gloo backend.
+"""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import ROOT
+
+
+def _worker(rank: int, world: int, port: int, total: int, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from syncfusion_amd.dist import broadcast_module, gather_clips, rank_seed, shard_range
+
+        torch.manual_seed(100 + rank)                       # ranks start with DIFFERENT weights
+        lin = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.BatchNorm1d(5))
+        moved = broadcast_module(lin, src=0)
+        flat = torch.cat([p.detach().reshape(-1) for p in lin.parameters()])
+        lo, hi = shard_range(total, rank, world)
+        # every rank produces "clips" that depend only on the global clip index and its own seeded noise
+        g = torch.Generator().manual_seed(rank_seed(1000, rank))
+        local = torch.stack([torch.full((1, 6), float(i)) for i in range(lo, hi)]) + 0.0 * torch.randn(hi - lo, 1, 6, generator=g)
+        out = gather_clips(local, total, dst=0)
+        q.put((rank, moved, flat.tolist(), None if out is None else out[:, 0, 0].tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_broadcast_and_gather_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    total, world, port = 5, 2, 29611
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, moved0, w0, out0), (_, moved1, w1, out1) = res
+    assert w0 == w1, "weights differ after broadcast"
+    assert moved0 == moved1 > 0
+    assert out1 is None
+    assert out0 == [0.0, 1.0, 2.0, 3.0, 4.0], "gathered clips are not the rank-order concatenation"

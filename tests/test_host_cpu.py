@@ -1,0 +1,132 @@
+"""CPU suite (no GPU): host logic and the C-ABI library itself (loads, exports every declared symbol; no compute calls)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from helpers import ROOT, SMALL_UNET, reference_model_config, small_unet_module
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from syncfusion_amd import _lib
+
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "syncfusion_amd.h")).read()
+    declared = set(re.findall(r"\b(sf_[a-z0-9_]+)\s*\(", header))
+    declared -= {"sf_tensor"}
+    assert declared, "no prototypes found in the header"
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} is declared in include/syncfusion_amd.h but not exported"
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+    assert lib.sf_version().startswith(b"syncfusion_amd")
+    assert lib.sf_device_ok() in (0, 1)
+
+
+def test_param_enumeration_matches_module_state_dict():
+    """sf_unet_param_name (host-only call) lists exactly the UNetV0 state_dict with a `net.` prefix."""
+    from syncfusion_amd import _lib
+
+    lib = _lib.load()
+    net = small_unet_module()
+    cfg = _lib.UnetConfig()
+    hp = net.hparams
+    cfg.n_layers = len(hp["channels"])
+    cfg.in_channels = hp["in_channels"]
+    for f in ("channels", "factors", "items", "attentions", "cross_attentions", "context_channels"):
+        for i, v in enumerate(hp[f]):
+            getattr(cfg, f)[i] = v
+    for f in ("attention_heads", "attention_features", "embedding_features", "embedding_max_length", "modulation_features", "resnet_groups"):
+        setattr(cfg, f, hp[f])
+    n = lib.sf_unet_param_count(C.byref(cfg))
+    names = {}
+    for i in range(n):
+        buf, ne = C.create_string_buffer(256), C.c_int64()
+        assert lib.sf_unet_param_name(C.byref(cfg), i, buf, 256, C.byref(ne)) == 0
+        names[buf.value.decode()] = ne.value
+    assert names == {"net." + k: v.numel() for k, v in net.state_dict().items()}
+    # error path: unsupported config reports a message instead of crashing
+    cfg.attention_features = 32
+    assert lib.sf_unet_param_count(C.byref(cfg)) == -1
+    assert b"attention_features" in lib.sf_last_error()
+
+
+def test_instantiate_reference_model_tree():
+    import syncfusion_amd as sa
+
+    m = sa.instantiate(reference_model_config())
+    assert isinstance(m, sa.Model) and isinstance(m.model, sa.DiffusionModel) and isinstance(m.onsets_encoder, sa.Encoder1d)
+    assert m.lr == 1e-4 and m.lr_eps == 1e-6                              # "1e-4" strings are floats, as in OmegaConf
+    n_params = sum(p.numel() for p in m.model.parameters())
+    assert abs(n_params / 1e6 - 214.9) < 0.5
+    assert all(not p.requires_grad for p in m.clap.parameters())          # main/module_diffusion.py:50-51
+    opt = m.configure_optimizers()
+    assert isinstance(opt, torch.optim.AdamW)
+    sd = m.state_dict()
+    assert any(k.startswith("model.net.blocks.7.items_up.3.attn") for k in sd)
+    assert not any(k.startswith("model.diffusion.") or k.startswith("model.sampler.") for k in sd)
+
+
+def test_yaml_loader_partial_and_targets(tmp_path):
+    import syncfusion_amd as sa
+
+    y = tmp_path / "m.yaml"
+    y.write_text("model:\n  _target_: audio_encoders_pytorch.Encoder1d\n  in_channels: 1\n  channels: 2\n"
+                 "  multipliers: [1, 1, 4]\n  factors: [1, 4]\n  num_blocks: [1, 1]\n  resnet_groups: 2\n  patch_size: 1\n")
+    enc = sa.instantiate_model_yaml(str(y))
+    assert isinstance(enc, sa.Encoder1d) and enc.downsample_factor == 4
+    part = sa.instantiate({"_target_": "audio_diffusion_pytorch.UNetV0", "_partial_": True, "in_channels": 1})
+    assert part.func is sa.UNetV0 and part.keywords == {"in_channels": 1}
+
+
+def test_no_cpu_execution_path():
+    from syncfusion_amd._lib import SyncFusionAmdError
+    import syncfusion_amd as sa
+
+    net = small_unet_module()
+    x = torch.zeros(1, 1, 32)
+    with pytest.raises(SyncFusionAmdError):
+        net(x, torch.zeros(1), embedding=torch.zeros(1, 1, SMALL_UNET["embedding_features"]), channels=[])
+    with pytest.raises(SyncFusionAmdError):
+        sa.VideoOnsetNet(False).eval()(torch.zeros(1, 3, 2, 16, 16))
+    with pytest.raises(SyncFusionAmdError):
+        sa.onsets_to_track(torch.zeros(1, 4), 100)
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "syncfusion_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from syncfusion_amd import _lib\n"
+            "_lib.LIB_PATH = %r\n"
+            "try:\n    _lib.load()\nexcept _lib.SyncFusionAmdError as e:\n    print('RAISED', 'no CPU fallback' in str(e).lower() or 'missing' in str(e))\n") % (
+        ROOT, str(tmp_path / "nope.so"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "RAISED True" in out.stdout, out.stdout + out.stderr
+
+
+def test_shard_ranges():
+    from syncfusion_amd.dist import rank_seed, shard_range
+
+    assert [shard_range(256, r, 8) for r in range(8)] == [(32 * r, 32 * r + 32) for r in range(8)]
+    parts = [shard_range(10, r, 4) for r in range(4)]
+    assert parts == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert rank_seed(1000, 3) == 1003
+
+
+def test_int16_round_trip_matches_reference_utils():
+    from syncfusion_amd.module import float32_to_int16, int16_to_float32
+
+    x = torch.tensor([-2.0, -1.0, -0.5, 0.0, 0.3, 1.0, 1.7])
+    q = float32_to_int16(x)
+    assert q.dtype == torch.int16 and q.tolist() == [-32767, -32767, -16383, 0, 9830, 32767, 32767]
+    assert torch.allclose(int16_to_float32(q), torch.tensor(q.tolist()) / 32767.0)

