@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--dump-launches", default=None, help="write the per-launch event timings of one evaluation to this file")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -133,6 +134,10 @@ def main():
     sigma = torch.full((B,), 0.5, device=device)
     net.engine().profile_forward(noise, sigma, channels, emb, args.scale)          # warm
     recs = net.engine().profile_forward(noise, sigma, channels, emb, args.scale)
+    if args.dump_launches:
+        with open(args.dump_launches, "w") as f:
+            for i, (label, ms, fl, by) in enumerate(recs):
+                f.write(f"{i}\t{label}\t{ms * 1e3:.2f}us\t{fl / 1e6:.2f}MFLOP\t{by / 1e6:.3f}MB\n")
     agg = defaultdict(lambda: [0.0, 0.0, 0.0, 0])
     for label, ms, fl, by in recs:
         a = agg[label]

@@ -1,0 +1,181 @@
+// bf16 flash attention on the matrix cores (head dim 64), for the U-Net's self-attention.
+//
+// One wave owns 32 query rows; a 128-thread workgroup (2 waves) shares 64-key K / V tiles through LDS.
+// Swapped products keep everything a softmax needs on the lane that owns the query:
+//   S^T = K . Q^T      (32x32x16 MFMA: A = K tile rows from LDS, B = Q^T fragments held in registers)
+//        -> lane (q = lane&31, half h) holds 16 of the 32 keys of each S^T tile in its accumulator registers,
+//           so the row max / row sum are per-lane loops plus ONE cross-half shuffle;
+//   O^T += V^T . P^T   (A = V^T read from a transposed LDS image, B = the P^T accumulator converted to bf16 in
+//           place -- the k order of an accumulator-as-operand is permuted (cdna guide section 3), and the V^T
+//           fragment is read with the same permutation);
+//   O^T has the query on the lane too, so the online-softmax rescale is a per-lane scalar multiply.
+// K/V tiles are prefetched into registers while the previous tile is being multiplied (issue-early/write-late).
+#include "common.h"
+#include "kernels.h"
+
+namespace sf {
+namespace {
+
+constexpr int D = 64, TK = 64, QW = 32;   // head dim, keys per tile, queries per wave
+constexpr int WAVES = 2;
+constexpr int LDK = D + 8;                // bf16 elements per K-tile row   (144 B: 16-B aligned, conflict-free b128 reads)
+constexpr int LDV = TK + 8;               // bf16 elements per V^T-tile row
+constexpr int LDO = D + 8;
+
+__global__ __launch_bounds__(128) void attention_mfma_kernel(const bf16 *__restrict__ q, int ldq, const bf16 *__restrict__ kv, int ldkv,
+                                                             int L, int H, bf16 *__restrict__ out, int ldo, float scale) {
+  __shared__ __attribute__((aligned(16))) bf16 Ks[TK * LDK];
+  __shared__ __attribute__((aligned(16))) bf16 Vt[D * LDV];
+  __shared__ __attribute__((aligned(16))) bf16 Os[WAVES * QW * LDO];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const size_t rowbase = (size_t)b * L;
+  const int q0 = blockIdx.x * (WAVES * QW) + wave * QW;
+  const int qi = q0 + fr;
+  const bool qvalid = qi < L;
+
+  // Q^T as the B operand of S^T = K.Q^T: lane holds Q[q = fr][d = 16 s + 8 fh + j], pre-scaled by 1/sqrt(D)
+  bf16x8 qf[4];
+  {
+    const bf16 *qp = q + (rowbase + (qvalid ? qi : 0)) * ldq + h * D;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      Vec16<bf16> v = ld16<bf16>(qp + 16 * s + 8 * fh);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[s][j] = (bf16)((float)v.v[j] * scale);
+    }
+  }
+
+  f32x16 o[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  float mrun = -INFINITY, lrun = 0.f;
+
+  const int koff = h * D, voff = H * D + h * D;
+  // staging: 128 threads x 16 B = 16 rows of 64 bf16 per pass; 4 passes per tile for K and for V
+  const int srow = tid >> 3, svec = tid & 7;
+  Vec16<bf16> rk[4], rv[4];
+  auto prefetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int kj = k0 + i * 16 + srow;
+      if (kj < L) {
+        const bf16 *kp = kv + (rowbase + kj) * ldkv;
+        rk[i] = ld16<bf16>(kp + koff + svec * 8);
+        rv[i] = ld16<bf16>(kp + voff + svec * 8);
+      } else {
+        rk[i] = zero16<bf16>();
+        rv[i] = zero16<bf16>();
+      }
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int kr = i * 16 + srow;
+      st16<bf16>(Ks + kr * LDK + svec * 8, rk[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) Vt[(svec * 8 + j) * LDV + kr] = rv[i].v[j];   // transposed image: Vt[d][key]
+    }
+  };
+
+  prefetch(0);
+  for (int k0 = 0; k0 < L; k0 += TK) {
+    __syncthreads();   // previous tile consumed by every wave
+    stage();
+    __syncthreads();
+    if (k0 + TK < L) prefetch(k0 + TK);
+
+    // ---- S^T tiles: keys 32 t .. 32 t + 31 on the accumulator rows, queries on the lanes ----
+    f32x16 st[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        bf16x8 kf = *reinterpret_cast<const bf16x8 *>(Ks + (32 * t + fr) * LDK + 16 * s + 8 * fh);
+        st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[t], 0, 0, 0);
+      }
+    }
+    // ---- online softmax (fp32) ----
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        if (key >= L) st[t][r] = -INFINITY;
+        tmax = fmaxf(tmax, st[t][r]);
+      }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float mnew = fmaxf(mrun, tmax);
+    const float alpha = __expf(mrun - mnew);
+    float psum = 0.f;
+    bf16x8 pf[4];   // P^T as B operand: k-step (t, s) takes accumulator registers 8 s .. 8 s + 7 of tile t
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __expf(st[t][r] - mnew);
+        psum += pv;
+        pf[2 * t + (r >> 3)][r & 7] = (bf16)pv;
+      }
+    lrun = lrun * alpha + psum;
+    mrun = mnew;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+    // ---- O^T += V^T . P^T : A element j of lane half fh is key 32 t + 16 s + 8 (j>>2) + 4 fh + (j&3) ----
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16 *vp = Vt + (32 * i + fr) * LDV + 16 * ks + 4 * fh;
+        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+        bf16x4 lo = *reinterpret_cast<const bf16x4 *>(vp);
+        bf16x4 hi = *reinterpret_cast<const bf16x4 *>(vp + 8);
+        bf16x8 vf;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          vf[j] = lo[j];
+          vf[4 + j] = hi[j];
+        }
+        o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], o[i], 0, 0, 0);
+      }
+  }
+  lrun += __shfl_xor(lrun, 32, 64);
+  const float inv = 1.0f / lrun;
+  // ---- O^T (d on rows, q on lanes) -> LDS [q][d] -> 16-byte row stores ----
+  bf16 *os = Os + wave * QW * LDO;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) os[fr * LDO + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh] = (bf16)(o[i][r] * inv);
+  __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's LDS writes have landed before it reads them back
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int row = pass * 8 + (lane >> 3), c8 = lane & 7;
+    const int qq = q0 + row;
+    if (qq < L) st16<bf16>(out + (rowbase + qq) * ldo + h * D + c8 * 8, ld16<bf16>(os + row * LDO + c8 * 8));
+  }
+}
+
+}  // namespace
+
+hipError_t launch_attention_mfma(const void *q, int ldq, const void *kv, int ldkv, int B, int L, int H, int Dh, void *out, int ldo,
+                                 hipStream_t s) {
+  if (Dh != D || L <= 0) return hipErrorInvalidValue;
+  dim3 grid((L + WAVES * QW - 1) / (WAVES * QW), H, B);
+  hipLaunchKernelGGL(attention_mfma_kernel, grid, dim3(128), 0, s, static_cast<const bf16 *>(q), ldq, static_cast<const bf16 *>(kv), ldkv,
+                     L, H, static_cast<bf16 *>(out), ldo, 1.0f / sqrtf((float)D));
+  return hipGetLastError();
+}
+
+}  // namespace sf

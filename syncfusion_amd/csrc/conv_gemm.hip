@@ -135,6 +135,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   Vec16<T> ra[PA], rb[PB];
+  int bvalid[PB];
   int rvalid[PA];  // source row in range (bit) for the prefetched slice
   int rci0 = 0;    // first channel of the prefetched slice (GN table index)
   int rsecond = 0; // slice comes from src2
@@ -150,13 +151,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
       int n = n0 + i * RPP + srow;
       int k = k0 + svec * VEC;
       if (i * RPP + srow >= BN) n = a.N;  // outside the tile
-      if (n < a.N && k + VEC <= a.K) rb[i] = ld16<T>(wgt + (size_t)n * a.K + k);
-      else if (n < a.N && k < a.K) {
-        Vec16<T> v = zero16<T>();
-        for (int j = 0; j < VEC; ++j)
-          if (k + j < a.K) v.set(j, to_f(wgt[(size_t)n * a.K + k + j]));
-        rb[i] = v;
-      } else rb[i] = zero16<T>();
+      // unconditional load from a clamped address (K is a multiple of 8 on every path); zeroed at stage time
+      bvalid[i] = (n < a.N) && (k + VEC <= a.K);
+      rb[i] = ld16<T>(wgt + (size_t)min(n, a.N - 1) * a.K + min(k, a.K - VEC));
     }
     // ---- A tile ----
     if constexpr (!SCALAR_A) {
@@ -178,26 +175,25 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
           size_t row;
           if (a.geom == 0) {
             int p = rs[i].p0 + tap;
-            ok = ok && p >= 0 && p < (a.Lsrc << a.up_shift);
-            row = (size_t)(rs[i].base + (max(p, 0) >> a.up_shift));
+            const int pmax = (a.Lsrc << a.up_shift) - 1;
+            ok = ok && p >= 0 && p <= pmax;
+            row = (size_t)(rs[i].base + (min(max(p, 0), pmax) >> a.up_shift));
           } else {
             int ti = rs[i].t + dt, hi = rs[i].h + dh, wi = rs[i].w + dw;
             ok = ok && ti >= 0 && ti < a.Ti && hi >= 0 && hi < a.Hi && wi >= 0 && wi < a.Wi;
-            row = ((size_t)(rs[i].base * a.Ti + max(ti, 0)) * a.Hi + max(hi, 0)) * a.Wi + max(wi, 0);
+            row = ((size_t)(rs[i].base * a.Ti + min(max(ti, 0), a.Ti - 1)) * a.Hi + min(max(hi, 0), a.Hi - 1)) * a.Wi + min(max(wi, 0), a.Wi - 1);
           }
           rvalid[i] = ok;
-          if (ok) ra[i] = ld16<T>(src + row * a.src_ld + rci0);
-          else ra[i] = zero16<T>();
+          ra[i] = ld16<T>(src + row * a.src_ld + rci0);  // unconditional (clamped row); zeroed at stage time
         }
       } else {
         const int ci0 = k0 - k_taps + svec * VEC;
         rsecond = 1;
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
-          int m = m0 + i * RPP + srow;
+          const int m = min(m0 + i * RPP + srow, a.M - 1);
           rvalid[i] = rs[i].valid_m;
-          if (rs[i].valid_m) ra[i] = ld16<T>(src2 + (size_t)m * a.src2_ld + ci0);
-          else ra[i] = zero16<T>();
+          ra[i] = ld16<T>(src2 + (size_t)m * a.src2_ld + ci0);
         }
       }
     } else {
@@ -238,10 +234,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
   auto stage = [&]() {
 #pragma unroll
     for (int i = 0; i < PB; ++i)
-      if (i * RPP + srow < BN) st16<T>(Bs + (i * RPP + srow) * LD + svec * VEC, rb[i]);
+      if (i * RPP + srow < BN) st16<T>(Bs + (i * RPP + srow) * LD + svec * VEC, bvalid[i] ? rb[i] : zero16<T>());
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
-      Vec16<T> v = ra[i];
+      Vec16<T> v = (SCALAR_A || rvalid[i]) ? ra[i] : zero16<T>();
       if (a.pro == 1 && !rsecond && rvalid[i]) {
         const float2 *tb = tab + (size_t)rs[i].b_rel * a.cin + rci0;
 #pragma unroll
@@ -311,35 +307,37 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
   }
 
   // ---- epilogue -------------------------------------------------------------------------------
+  // Every operand load is UNCONDITIONAL (indices clamped into range) and batched per 32x32 tile, so the 16
+  // residual / per-clip loads of a lane are all in flight together; only the stores are predicated.
   T *out = static_cast<T *>(a.out);
   const T *res = static_cast<const T *>(a.res);
+  const bool has_res = res != nullptr, has_bs = a.bscale != nullptr, has_ba = a.badd != nullptr, has_b = has_bs || has_ba;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wc * WTN + j * 32 + fr;
-    if (n >= a.n_store) continue;
+    const int nc = min(n, a.N - 1);
     const bool real = n < a.N;
-    const float bias = (real && a.bias) ? a.bias[n] : 0.f;
+    const float bias = a.bias ? a.bias[nc] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+      float rv[16], sv[16], av[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = min(m0 + wr * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh, a.M - 1);
+        rv[r] = has_res ? to_f(res[(size_t)m * a.res_ld + nc]) : 0.f;
+        const int b = has_b ? m / a.Lout : 0;
+        sv[r] = has_bs ? a.bscale[(size_t)b * a.bscale_ld + nc] : 1.f;
+        av[r] = has_ba ? a.badd[(size_t)b * a.badd_ld + nc] : 0.f;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wr * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        if (m >= a.M) continue;
-        float v = 0.f;
-        if (real) {
-          v = acc[i][j][r] + bias;
-          if (a.bscale || a.badd) {
-            int b = m / a.Lout;
-            if (a.bscale) v *= a.bscale[(size_t)b * a.bscale_ld + n];
-            if (res) v += to_f(res[(size_t)m * a.res_ld + n]);
-            if (a.badd) v += a.badd[(size_t)b * a.badd_ld + n];
-          } else if (res) {
-            v += to_f(res[(size_t)m * a.res_ld + n]);
-          }
-          v = apply_act(v, a.act);
+        float v = (acc[i][j][r] + bias) * sv[r] + rv[r] + av[r];
+        v = real ? apply_act(v, a.act) : 0.f;
+        if (m < a.M && n < a.n_store) {
+          if (a.out_f32) static_cast<float *>(a.out)[(size_t)m * a.out_ld + n] = v;
+          else out[(size_t)m * a.out_ld + n] = from_f<T>(v);
         }
-        if (a.out_f32) static_cast<float *>(a.out)[(size_t)m * a.out_ld + n] = v;
-        else out[(size_t)m * a.out_ld + n] = from_f<T>(v);
       }
     }
   }
@@ -402,15 +400,31 @@ bool conv_gemm_supported(int dt, const ConvGemmArgs &a) {
   return true;
 }
 
+// short activations (the classic tiling would leave most CUs idle) go to the wave-split-K kernel
+hipError_t launch_conv_gemm_sk(int dt, const ConvGemmArgs &a, hipStream_t s);
+int conv_gemm_sk_variant(const ConvGemmArgs &a);
+
+static bool use_sk(const ConvGemmArgs &a) {
+  const int v = pick_variant(a);
+  if (v <= 0 || (a.K % 32)) return false;
+  static const int bm[5] = {64, 128, 128, 64, 128}, bn[5] = {64, 32, 64, 64, 128};
+  const long blocks = (long)((a.M + bm[v] - 1) / bm[v]) * ((a.n_store + bn[v] - 1) / bn[v]);
+  return blocks < 256 && a.K >= 256;
+}
+
 const char *conv_gemm_variant_name(int dt, const ConvGemmArgs &a) {
   static const char *names[2][5] = {{"conv_gemm<f32,64x64,scalarA>", "conv_gemm<f32,128x32>", "conv_gemm<f32,128x64>", "conv_gemm<f32,64x64>", "conv_gemm<f32,128x128>"},
                                     {"conv_gemm<bf16,64x64,scalarA>", "conv_gemm<bf16,128x32>", "conv_gemm<bf16,128x64>", "conv_gemm<bf16,64x64>", "conv_gemm<bf16,128x128>"}};
+  static const char *sk_names[2][3] = {{"conv_gemm_sk<f32,64x64>", "conv_gemm_sk<f32,64x32>", "conv_gemm_sk<f32,32x32>"},
+                                       {"conv_gemm_sk<bf16,64x64>", "conv_gemm_sk<bf16,64x32>", "conv_gemm_sk<bf16,32x32>"}};
+  if (use_sk(a)) return sk_names[dt == F32 ? 0 : 1][conv_gemm_sk_variant(a)];
   int v = pick_variant(a);
   return v < 0 ? "conv_gemm<invalid>" : names[dt == F32 ? 0 : 1][v];
 }
 
 hipError_t launch_conv_gemm(int dt, const ConvGemmArgs &a, hipStream_t s) {
   if (!conv_gemm_supported(dt, a)) return hipErrorInvalidValue;
+  if (use_sk(a)) return launch_conv_gemm_sk(dt, a, s);
   return dt == F32 ? dispatch<float>(a, s) : dispatch<bf16>(a, s);
 }
 

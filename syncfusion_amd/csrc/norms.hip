@@ -69,7 +69,36 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T *__restrict__ x, 
     __syncthreads();
     const int slots = 256 / vpr;
     const int cpg = C / G;
-    if (tid < G) {
+    if ((G & (G - 1)) == 0 && G <= 256) {
+      // 256/G threads per group: strided partial sums, then a fixed-shape LDS tree (deterministic)
+      const int tpg = 256 / G, g = tid / tpg, j = tid - g * tpg;
+      const int ne = cpg * slots;
+      float ts = 0.f, tq = 0.f;
+      for (int e = j; e < ne; e += tpg) {
+        const int sl = e / cpg, c = g * cpg + (e - sl * cpg);
+        ts += part_s[sl * C + c];
+        tq += part_q[sl * C + c];
+      }
+      __syncthreads();
+      part_s[tid] = ts;
+      part_q[tid] = tq;
+      __syncthreads();
+      for (int off = tpg >> 1; off > 0; off >>= 1) {
+        if (j < off) {
+          part_s[tid] += part_s[tid + off];
+          part_q[tid] += part_q[tid + off];
+        }
+        __syncthreads();
+      }
+      if (j == 0) {
+        const float a = part_s[tid], q2 = part_q[tid];
+        const float n = (float)rows * (float)cpg;
+        const float mean = a / n;
+        float *o = slab + (((size_t)b * nch + ch) * G + g) * 2;
+        o[0] = mean;
+        o[1] = fmaxf(q2 - a * mean, 0.f);
+      }
+    } else if (tid < G) {
       float ts = 0.f, tq = 0.f;
       for (int c = tid * cpg; c < (tid + 1) * cpg; ++c)
         for (int sl = 0; sl < slots; ++sl) {
@@ -169,6 +198,91 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const T *__restrict__ 
   }
 }
 
+// GroupNorm + SiLU materialised once:  y = silu((x - mean_bg) * rstd_bg * gamma_c + beta_c).
+// One workgroup per (clip, group): pass 1 reduces the group's L x (C/G) slab (pivot-shifted sum / sum of
+// squares, fixed-shape LDS tree -> deterministic), pass 2 re-reads it (L2-resident: a slab is 11-45 K
+// elements at every level of the reference U-Net) and writes the activated tensor.  Used in front of every
+// wide convolution: applying the activation in the GEMM's A-load instead would repeat the exp/rcp for every
+// column tile and tap (measured: 40 us instead of 5 us per layer at C = 1024).
+template <typename T, int VW>
+__global__ __launch_bounds__(512) void gn_silu_kernel(const T *__restrict__ x, int ld, int L, int C, int G,
+                                                      const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                                                      T *__restrict__ out, int out_ld) {
+  constexpr bool FAST = sizeof(T) == 2;
+  __shared__ float red_s[512], red_q[512];
+  __shared__ float stat[2];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+  const int cpg = C / G;
+  const int vr = cpg / VW;                 // accesses per row
+  const int nv = L * vr;
+  const T *base = x + (size_t)b * L * ld + (size_t)g * cpg;
+  T *obase = out + (size_t)b * L * out_ld + (size_t)g * cpg;
+  const float pivot = to_f(base[0]);
+  float s = 0.f, q = 0.f;
+  for (int i = tid; i < nv; i += 512) {
+    const int r = i / vr, cv = i - r * vr;
+    T v[VW];
+    __builtin_memcpy(v, __builtin_assume_aligned(base + (size_t)r * ld + cv * VW, VW * sizeof(T)), VW * sizeof(T));
+#pragma unroll
+    for (int j = 0; j < VW; ++j) {
+      const float d = to_f(v[j]) - pivot;
+      s += d;
+      q = fmaf(d, d, q);
+    }
+  }
+  red_s[tid] = s;
+  red_q[tid] = q;
+  __syncthreads();
+  for (int off = 256; off > 0; off >>= 1) {
+    if (tid < off) {
+      red_s[tid] += red_s[tid + off];
+      red_q[tid] += red_q[tid + off];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const float n = (float)L * (float)cpg;
+    const float md = red_s[0] / n;
+    const float var = fmaxf(red_q[0] / n - md * md, 0.f);
+    stat[0] = pivot + md;
+    stat[1] = rsqrtf(var + eps);
+  }
+  __syncthreads();
+  const float mean = stat[0], rstd = stat[1];
+  for (int i = tid; i < nv; i += 512) {
+    const int r = i / vr, cv = i - r * vr;
+    T v[VW], o[VW];
+    __builtin_memcpy(v, __builtin_assume_aligned(base + (size_t)r * ld + cv * VW, VW * sizeof(T)), VW * sizeof(T));
+#pragma unroll
+    for (int j = 0; j < VW; ++j) {
+      const int c = g * cpg + cv * VW + j;
+      const float sc = rstd * gamma[c];
+      o[j] = from_f<T>(silu_t<FAST>(fmaf(to_f(v[j]) - mean, sc, beta[c])));
+    }
+    __builtin_memcpy(__builtin_assume_aligned(obase + (size_t)r * out_ld + cv * VW, VW * sizeof(T)), o, VW * sizeof(T));
+  }
+}
+
+template <typename T>
+hipError_t gn_silu_go(const void *x, int ld, int B, int L, int C, int G, const float *gamma, const float *beta, float eps, void *out,
+                      int out_ld, hipStream_t s) {
+  if (C % G) return hipErrorInvalidValue;
+  const int cpg = C / G;
+  constexpr int V = Vec16<T>::N;
+  const T *xp = static_cast<const T *>(x);
+  T *op = static_cast<T *>(out);
+  dim3 grid(B * G);
+#define SF_GNS(VW) hipLaunchKernelGGL((gn_silu_kernel<T, VW>), grid, dim3(512), 0, s, xp, ld, L, C, G, gamma, beta, eps, op, out_ld)
+  const bool al = (ld % V == 0) && (out_ld % V == 0);
+  if (al && cpg % V == 0) SF_GNS(V);
+  else if (ld % 4 == 0 && out_ld % 4 == 0 && cpg % 4 == 0) SF_GNS(4);
+  else if (ld % 2 == 0 && out_ld % 2 == 0 && cpg % 2 == 0) SF_GNS(2);
+  else SF_GNS(1);
+#undef SF_GNS
+  return hipGetLastError();
+}
+
 template <typename T>
 hipError_t ln_go(const void *x, int ld, const float *ss, int ss_ld, float eps, int B, int L, int C, void *out, int out_ld,
                  hipStream_t s) {
@@ -217,6 +331,12 @@ hipError_t launch_gn_stats(int dt, const void *x, int ld, int B, int L, int C, i
                            hipStream_t s) {
   return dt == F32 ? gn_go<float>(x, ld, B, L, C, G, nch, chunk_rows, slab, s)
                    : gn_go<bf16>(x, ld, B, L, C, G, nch, chunk_rows, slab, s);
+}
+
+hipError_t launch_gn_silu(int dt, const void *x, int ld, int B, int L, int C, int G, const float *gamma, const float *beta, float eps,
+                          void *out, int out_ld, hipStream_t s) {
+  return dt == F32 ? gn_silu_go<float>(x, ld, B, L, C, G, gamma, beta, eps, out, out_ld, s)
+                   : gn_silu_go<bf16>(x, ld, B, L, C, G, gamma, beta, eps, out, out_ld, s);
 }
 
 hipError_t launch_ln_modulate(int dt, const void *x, int ld, const float *ss, int ss_ld, float eps, int B, int L, int C,

@@ -43,7 +43,7 @@ struct Level {
   int L = 0, C = 0;
   int64_t rows = 0;
   void *buf[3] = {nullptr, nullptr, nullptr};
-  void *qkv = nullptr, *ao = nullptr, *ctx = nullptr;
+  void *qkv = nullptr, *ao = nullptr, *ctx = nullptr, *act = nullptr;
 };
 
 struct Plan {  // everything carved out of the caller's workspace for one (B, L0, two_pass)
@@ -376,6 +376,7 @@ Plan make_plan(const sf_unet &u, Workspace &ws, int B, int L0, bool two, int num
     l.C = c.channels[d];
     l.rows = (int64_t)p.Bt * L;
     for (int i = 0; i < 3; ++i) l.buf[i] = ws.alloc(l.rows * l.C * es);
+    l.act = ws.alloc(l.rows * l.C * es);
     if (c.attentions[d]) {
       l.qkv = ws.alloc(l.rows * 3 * u.hd * es);
       l.ao = ws.alloc(l.rows * u.hd * es);
@@ -480,24 +481,36 @@ struct Exec {
     const Level &l = p.lv[d];
     const Block &b = u.blocks[d];
     const int C = l.C, G = u.cfg.resnet_groups;
+    // ResnetItem: x + Conv3(SiLU(GN(Conv3(SiLU(GN(x)))))).  GroupNorm+SiLU is materialised once per conv
+    // (gn_silu) rather than applied in the GEMM's A-load: the activation would otherwise be recomputed for every
+    // column tile and tap of the wide layers.
+    // Thin levels (C <= 64: at most two column tiles) keep the activation in the conv's A-load instead
+    // (statistics from gn_stats): their tensors are long and the extra activated copy would cost more.
+    const bool fuse_act = C <= 64;
     GnPlan gp = gn_plan(p.Bt, l.L, C);
     auto conv3 = [&](const ConvW &w, const void *in, void *out, const float *gam, const float *bet, const void *res) {
-      gn(in, d, C);
       ConvGemmArgs a;
-      a.src = in;
+      if (fuse_act) {
+        gn(in, d, C);
+        a.src = in;
+        a.pro = 1;
+        a.G = G;
+        a.nch = gp.nch;
+        a.chunk_rows = gp.chunk_rows;
+        a.stats = p.slab;
+        a.gamma = gam;
+        a.beta = bet;
+        a.eps = 1e-5f;
+      } else {
+        timed("gn_silu", 12.0 * l.rows * C, 3.0 * l.rows * C * dsize(u.dt),
+              [&] { SF_HIP(launch_gn_silu(u.dt, in, C, p.Bt, l.L, C, G, gam, bet, 1e-5f, l.act, C, s)); });
+        a.src = l.act;
+      }
       a.src_ld = C;
       a.M = (int)l.rows;
       a.Lout = a.Lsrc = l.L;
       a.stride = 1;
       a.pad = 1;
-      a.pro = 1;
-      a.G = G;
-      a.nch = gp.nch;
-      a.chunk_rows = gp.chunk_rows;
-      a.stats = p.slab;
-      a.gamma = gam;
-      a.beta = bet;
-      a.eps = 1e-5f;
       a.out = out;
       a.out_ld = C;
       a.res = res;
