@@ -110,6 +110,9 @@ int sf_unet_debug_info(const sf_unet *h, int i, char *name_out, int name_cap, in
 /* Per-kernel launch accounting of the last forward (host side, for bench.py's roofline):
  * number of kernel launches in one evaluation. */
 int sf_unet_launch_count(const sf_unet *h);
+/* Number of clip-parallel branches (independent slices of the batch run concurrently on separate HIP streams,
+ * forked/joined with events): 0 = automatic (2 for >= 4 clips), 1 = off, up to 8. */
+int sf_unet_set_branches(sf_unet *h, int n);
 /* Per-launch timing of the next sf_unet_forward: HIP events recorded on `stream` around every kernel launch
  * (label = kernel / tile variant; flops, bytes = ALGORITHMIC work of that launch). */
 int sf_unet_profile_enable(sf_unet *h, int on);

@@ -70,6 +70,14 @@ class UNetEngine(_Base):
             check(lib.sf_unet_create(C.byref(cfg), table.array, table.n, _lib.stream_ptr(self.device), C.byref(h)), "sf_unet_create")
             torch.cuda.synchronize(self.device)
         self.handle = h.value
+        import os
+
+        if os.environ.get("SF_UNET_BRANCHES"):
+            self.set_branches(int(os.environ["SF_UNET_BRANCHES"]))
+
+    def set_branches(self, n: int) -> None:
+        """Clip-parallel branches (0 = automatic, 1 = off): see sf_unet_set_branches."""
+        check(self.lib.sf_unet_set_branches(self.handle, int(n)), "sf_unet_set_branches")
 
     def stale(self, net: torch.nn.Module, dtype: str) -> bool:
         return dtype != self.dtype or _params_version(net) != self.version

@@ -87,4 +87,25 @@ __device__ __forceinline__ void welford_merge(float &n, float &mean, float &m2, 
   n = tot;
 }
 
+// Final GroupNorm statistics of one (clip, group) from its <= 32 chunk partials (mean, M2): each of the 32 lanes of
+// a half-wave loads one chunk (all loads in flight together), then a fixed-shape shuffle tree merges them (Chan) --
+// deterministic, one memory latency.  Every lane of the half-wave must call it; every lane gets the result.
+__device__ __forceinline__ float2 gn_merge32(const float *__restrict__ sl, int G, int nch, int chunk_rows, int L, int cpg,
+                                             float eps, int lane32) {
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+  if (lane32 < nch) {
+    const int rows = min(chunk_rows, L - lane32 * chunk_rows);
+    n = (float)rows * (float)cpg;
+    mean = sl[(size_t)lane32 * G * 2];
+    m2 = sl[(size_t)lane32 * G * 2 + 1];
+  }
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) {
+    const float nb = __shfl_down(n, off, 32), mb = __shfl_down(mean, off, 32), qb = __shfl_down(m2, off, 32);
+    welford_merge(n, mean, m2, nb, mb, qb);
+  }
+  const float mu = __shfl(mean, 0, 32), var = __shfl(m2, 0, 32) / __shfl(n, 0, 32);
+  return make_float2(mu, rsqrtf(var + eps));
+}
+
 }  // namespace sf

@@ -34,15 +34,11 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvGemmArgs a) 
     const int nb = b_last - b_first + 1;
     float2 *mr = tab + (size_t)a.cin * nb;
     const int cpg = a.cin / a.G;
-    for (int idx = tid; idx < nb * a.G; idx += 256) {
-      int bl = idx / a.G, g = idx - bl * a.G;
+    for (int idx = tid >> 5; idx < nb * a.G; idx += 8) {   // one half-wave per (clip, group)
+      const int bl = idx / a.G, g = idx - bl * a.G;
       const float *sl = a.stats + ((size_t)(b_first + bl) * a.nch) * a.G * 2 + g * 2;
-      float n = 0.f, mean = 0.f, m2 = 0.f;
-      for (int c = 0; c < a.nch; ++c) {
-        int rows = min(a.chunk_rows, a.Lsrc - c * a.chunk_rows);
-        welford_merge(n, mean, m2, (float)rows * (float)cpg, sl[(size_t)c * a.G * 2], sl[(size_t)c * a.G * 2 + 1]);
-      }
-      mr[idx] = make_float2(mean, rsqrtf(m2 / n + a.eps));
+      const float2 r = gn_merge32(sl, a.G, a.nch, a.chunk_rows, a.Lsrc, cpg, a.eps, tid & 31);
+      if ((tid & 31) == 0) mr[idx] = r;
     }
     __syncthreads();
     for (int idx = tid; idx < nb * a.cin; idx += 256) {

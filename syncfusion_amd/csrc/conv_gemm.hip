@@ -103,17 +103,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
     const int nb = b_last - b_first + 1;
     float2 *mr = tab + (size_t)a.cin * nb;  // (mean, rstd) per (clip, group), behind the table
     const int cpg = a.cin / a.G;
-    for (int idx = tid; idx < nb * a.G; idx += 256) {
-      int bl = idx / a.G, g = idx - bl * a.G;
+    for (int idx = tid >> 5; idx < nb * a.G; idx += 8) {   // one half-wave per (clip, group)
+      const int bl = idx / a.G, g = idx - bl * a.G;
       const float *sl = a.stats + ((size_t)(b_first + bl) * a.nch) * a.G * 2 + g * 2;
-      float n = 0.f, mean = 0.f, m2 = 0.f;
-      for (int c = 0; c < a.nch; ++c) {
-        int r0 = c * a.chunk_rows;
-        int rows = min(a.chunk_rows, a.Lsrc - r0);
-        welford_merge(n, mean, m2, (float)rows * (float)cpg, sl[(size_t)c * a.G * 2], sl[(size_t)c * a.G * 2 + 1]);
-      }
-      float var = m2 / n;
-      mr[idx] = make_float2(mean, rsqrtf(var + a.eps));
+      const float2 r = gn_merge32(sl, a.G, a.nch, a.chunk_rows, a.Lsrc, cpg, a.eps, tid & 31);
+      if ((tid & 31) == 0) mr[idx] = r;
     }
     __syncthreads();
     for (int idx = tid; idx < nb * a.cin; idx += 256) {
@@ -403,6 +397,7 @@ bool conv_gemm_supported(int dt, const ConvGemmArgs &a) {
 // short activations (the classic tiling would leave most CUs idle) go to the wave-split-K kernel
 hipError_t launch_conv_gemm_sk(int dt, const ConvGemmArgs &a, hipStream_t s);
 int conv_gemm_sk_variant(const ConvGemmArgs &a);
+bool conv_gemm_fast_ok(int dt, const ConvGemmArgs &a);
 
 static bool use_sk(const ConvGemmArgs &a) {
   const int v = pick_variant(a);
@@ -417,7 +412,9 @@ const char *conv_gemm_variant_name(int dt, const ConvGemmArgs &a) {
                                     {"conv_gemm<bf16,64x64,scalarA>", "conv_gemm<bf16,128x32>", "conv_gemm<bf16,128x64>", "conv_gemm<bf16,64x64>", "conv_gemm<bf16,128x128>"}};
   static const char *sk_names[2][3] = {{"conv_gemm_sk<f32,64x64>", "conv_gemm_sk<f32,64x32>", "conv_gemm_sk<f32,32x32>"},
                                        {"conv_gemm_sk<bf16,64x64>", "conv_gemm_sk<bf16,64x32>", "conv_gemm_sk<bf16,32x32>"}};
-  if (use_sk(a)) return sk_names[dt == F32 ? 0 : 1][conv_gemm_sk_variant(a)];
+  static const char *fast_names[2][3] = {{"conv_gemm_fast<f32,64x64>", "conv_gemm_fast<f32,64x32>", "conv_gemm_fast<f32,32x32>"},
+                                         {"conv_gemm_fast<bf16,64x64>", "conv_gemm_fast<bf16,64x32>", "conv_gemm_fast<bf16,32x32>"}};
+  if (use_sk(a)) return (conv_gemm_fast_ok(dt, a) ? fast_names : sk_names)[dt == F32 ? 0 : 1][conv_gemm_sk_variant(a)];
   int v = pick_variant(a);
   return v < 0 ? "conv_gemm<invalid>" : names[dt == F32 ? 0 : 1][v];
 }

@@ -55,6 +55,8 @@ struct Plan {  // everything carved out of the caller's workspace for one (B, L0
   float *sigs = nullptr;   // [steps] schedule sigmas, then [Bt] per-row sigmas of a single forward
   void *four = nullptr, *f1 = nullptr, *f2 = nullptr, *sf = nullptr, *emb_t = nullptr, *xhat_e = nullptr, *v_all = nullptr;
   int *step = nullptr;
+  int nbr = 1;                 // clip-parallel branches
+  int64_t slab_stride = 0;     // floats of GroupNorm scratch per branch
 };
 
 }  // namespace
@@ -104,9 +106,28 @@ struct sf_unet {
   // engine-owned stream, fenced against the caller's stream with events on both sides
   hipStream_t own_stream = nullptr;
   hipEvent_t ev_in = nullptr, ev_out = nullptr;
+  // Clip-parallel branches: at small batch every kernel of the chain is latency-bound (a few hundred short
+  // workgroups), so independent slices of the batch run the whole U-Net concurrently on separate streams
+  // (fork/join with events; captured into the step graph as parallel branches).
+  static constexpr int kMaxBranches = 8;
+  hipStream_t bstream[kMaxBranches] = {};
+  hipEvent_t ev_fork = nullptr, ev_join[kMaxBranches] = {};
+  int branches_override = 0;
+  void ensure_branch_streams(int n) {
+    if (!ev_fork) SF_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    for (int i = 1; i < n; ++i) {
+      if (!bstream[i]) SF_HIP(hipStreamCreateWithFlags(&bstream[i], hipStreamNonBlocking));
+      if (!ev_join[i]) SF_HIP(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
+    }
+  }
 
   ~sf_unet() {
     if (gexec) (void)hipGraphExecDestroy(gexec);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    for (int i = 0; i < kMaxBranches; ++i) {
+      if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
+      if (bstream[i]) (void)hipStreamDestroy(bstream[i]);
+    }
     for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
     if (ev_in) (void)hipEventDestroy(ev_in);
     if (ev_out) (void)hipEventDestroy(ev_out);
@@ -382,9 +403,16 @@ Plan make_plan(const sf_unet &u, Workspace &ws, int B, int L0, bool two, int num
       l.ao = ws.alloc(l.rows * u.hd * es);
     }
     l.ctx = ws.alloc(l.rows * u.blocks[d].ctx_ld * es);
-    GnPlan gp = gn_plan(p.Bt, L, l.C);
-    int64_t need = (int64_t)p.Bt * gp.nch * c.resnet_groups * 2;
-    if (need > slab_floats) slab_floats = need;
+  }
+  // branches: independent slices of the (doubled) batch; each gets its own GroupNorm scratch
+  {
+    // measured (B = 8, bf16, MI355X): 2 branches +15 %, 4 branches -17 % vs 1 (the per-kernel grids get too small)
+    int want = u.branches_override > 0 ? u.branches_override : (p.Bt >= 4 ? 2 : 1);
+    if (want > sf_unet::kMaxBranches) want = sf_unet::kMaxBranches;
+    while (want > 1 && p.Bt % want) --want;
+    p.nbr = u.dbg.buf ? 1 : want;
+    p.slab_stride = (int64_t)(p.Bt / p.nbr) * 32 * c.resnet_groups * 2;
+    slab_floats = p.slab_stride * p.nbr;
   }
   const int64_t n0 = (int64_t)p.Bt * L0 * c.in_channels;
   p.x2 = ws.alloc_n<float>(n0);
@@ -691,13 +719,58 @@ struct Exec {
     }
   }
 
+  // the rows [br*Bt/nbr, (br+1)*Bt/nbr) of every per-clip buffer
+  Plan branch_view(int br) const {
+    Plan v = p;
+    const size_t es = dsize(u.dt);
+    const int bt = p.Bt / p.nbr;
+    v.Bt = bt;
+    v.nbr = 1;
+    for (size_t d = 0; d < v.lv.size(); ++d) {
+      Level &l = v.lv[d];
+      l.rows = (int64_t)bt * l.L;
+      const int64_t r0 = (int64_t)br * l.rows;
+      auto off = [&](void *ptr, int64_t cols) { return ptr ? static_cast<void *>(static_cast<char *>(ptr) + r0 * cols * es) : nullptr; };
+      for (int i = 0; i < 3; ++i) l.buf[i] = off(l.buf[i], l.C);
+      l.act = off(l.act, l.C);
+      l.qkv = off(l.qkv, 3 * u.hd);
+      l.ao = off(l.ao, u.hd);
+      l.ctx = off(l.ctx, u.blocks[d].ctx_ld);
+    }
+    const int64_t n0 = (int64_t)br * bt * p.L0 * u.cfg.in_channels;
+    v.x2 = p.x2 + n0;
+    v.vout = p.vout + n0;
+    v.mod_all = p.mod_all + (int64_t)br * bt * u.mod_ld;
+    v.ca_all = p.ca_all + (int64_t)br * bt * u.ca_ld;
+    v.slab = p.slab + (int64_t)br * p.slab_stride;
+    return v;
+  }
+
   // one U-Net evaluation of the (possibly doubled) batch: x (B rows) -> p.vout (Bt rows)
   void eval(const float *x, const float *sig, const int *sig_idx) {
     const int64_t n = (int64_t)p.B * p.L0 * u.cfg.in_channels;
     SF_HIP(hipMemcpyAsync(p.x2, x, n * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (p.two) SF_HIP(hipMemcpyAsync(p.x2 + n, x, n * sizeof(float), hipMemcpyDeviceToDevice, s));
     features(sig, sig_idx);
-    block(0, p.x2, F32, p.vout, F32);
+    if (p.nbr <= 1) {
+      block(0, p.x2, F32, p.vout, F32);
+      return;
+    }
+    const bool serial = u.prof_on;   // instrumented pass: same kernel shapes, one after another on the launch stream
+    if (!serial) {
+      u.ensure_branch_streams(p.nbr);
+      SF_HIP(hipEventRecord(u.ev_fork, s));
+    }
+    for (int br = 0; br < p.nbr; ++br) {
+      Plan v = branch_view(br);
+      hipStream_t sb = (serial || br == 0) ? s : u.bstream[br];
+      if (sb != s) SF_HIP(hipStreamWaitEvent(sb, u.ev_fork, 0));
+      Exec eb{u, v, sb};
+      eb.block(0, v.x2, F32, v.vout, F32);
+      if (sb != s) SF_HIP(hipEventRecord(u.ev_join[br], sb));
+    }
+    if (!serial)
+      for (int br = 1; br < p.nbr; ++br) SF_HIP(hipStreamWaitEvent(s, u.ev_join[br], 0));
   }
 };
 
@@ -927,6 +1000,12 @@ int sf_unet_debug_info(const sf_unet *h, int i, char *name_out, int name_cap, in
   return SF_OK;
 }
 int sf_unet_launch_count(const sf_unet *h) { return h ? h->launches : -1; }
+
+int sf_unet_set_branches(sf_unet *h, int n) {
+  if (!h || n < 0 || n > sf_unet::kMaxBranches) return SF_ERR_INVALID;
+  h->branches_override = n;
+  return SF_OK;
+}
 
 int sf_unet_profile_enable(sf_unet *h, int on) {
   if (!h) return SF_ERR_INVALID;
