@@ -182,6 +182,11 @@ int sf_onsets_to_track(const float *logits, int N, int T, const int32_t *start_f
 int sf_op_conv1d_cl(int dtype, const void *x, const float *w, const float *bias, const float *gamma, const float *beta,
                     int groups, float eps, const void *residual, int B, int L, int C, int N, int taps, int stride,
                     int pad, int upsample, void *out, void *ws, int64_t ws_bytes, void *stream);
+/* Kernel tuning aid: average milliseconds of `iters` back-to-back launches of one channels-last conv1d
+ * (x:(B,L,C) -> (B,L*upsample,N), `taps` taps, bias + residual epilogue) with a forced kernel family
+ * (path 0 auto, 1 classic, 2 wave-split-K, 4 v2), tile variant (-1 auto) and grid split-K factor (-1 auto). */
+int sf_bench_conv1d(int dtype, int B, int L, int C, int N, int taps, int upsample, int path, int tile, int sk, int iters,
+                    float *ms_out);
 /* y = layer_norm(x; eps, no affine) * (1 + scale[b]) + shift[b]   (scale/shift NULL -> plain normalise) */
 int sf_op_ln_modulate(int dtype, const void *x, const float *scale_shift /* (B, 2C) or NULL */, float eps,
                       int B, int L, int C, void *out, void *stream);

@@ -1,4 +1,5 @@
 // Version / error / device probes, the onset glue and the op-level test entry points of the C ABI.
+#include <algorithm>
 #include <exception>
 
 #include "engine_common.h"
@@ -88,8 +89,87 @@ int sf_op_conv1d_cl(int dtype, const void *x, const float *w, const float *bias,
     a.beta = beta;
     a.eps = eps;
   }
+  if (!direct) {   // scratch for the grid split-K variant (short activations), as the engines provide it
+    const int64_t slab_floats = std::min<int64_t>((int64_t)8 * a.M * N, (int64_t)1 << 24);
+    a.sk_slab = wk.alloc_n<float>(slab_floats);
+    a.sk_slab_bytes = (size_t)slab_floats * sizeof(float);
+    a.sk_cnt = wk.alloc_n<int>(1024);
+    a.sk_cnt_ints = 1024;
+    SF_HIP(hipMemsetAsync(a.sk_cnt, 0, 1024 * sizeof(int), s));
+  }
   if (direct) SF_HIP(launch_conv_direct(dtype, dtype, a, s));
   else SF_HIP(launch_conv_gemm(dtype, a, s));
+  return SF_OK;
+  SF_API_END
+}
+
+int sf_bench_conv1d(int dtype, int B, int L, int C, int N, int taps, int upsample, int path, int tile, int sk, int iters, float *ms_out) {
+  SF_API_BEGIN
+  if (!ms_out || iters < 1) fail(SF_ERR_INVALID, "bad argument");
+  const size_t es = dsize(dtype);
+  const int K = taps * C, Lout = L * upsample, M = B * Lout;
+  void *x = nullptr, *w = nullptr, *out = nullptr, *res = nullptr;
+  float *bias = nullptr, *slab = nullptr;
+  int *cnt = nullptr;
+  SF_HIP(hipMalloc(&x, (size_t)B * L * C * es));
+  SF_HIP(hipMalloc(&w, (size_t)N * K * es));
+  SF_HIP(hipMalloc(&out, (size_t)M * N * es));
+  SF_HIP(hipMalloc(&res, (size_t)M * N * es));
+  SF_HIP(hipMalloc(&bias, N * sizeof(float)));
+  const size_t slab_bytes = std::min<size_t>((size_t)16 * M * N * 4, (size_t)1 << 28);
+  SF_HIP(hipMalloc(&slab, slab_bytes));
+  SF_HIP(hipMalloc(&cnt, 4096 * sizeof(int)));
+  SF_HIP(hipMemset(cnt, 0, 4096 * sizeof(int)));
+  // non-trivial bit patterns (zero operands clock higher): bf16/f32 values around +-1
+  SF_HIP(hipMemset(x, 0x3c, (size_t)B * L * C * es));
+  SF_HIP(hipMemset(w, 0xbc, (size_t)N * K * es));
+  SF_HIP(hipMemset(res, 0x3d, (size_t)M * N * es));
+  SF_HIP(hipMemset(bias, 0, N * sizeof(float)));
+  ConvGemmArgs a;
+  a.src = x;
+  a.src_ld = C;
+  a.w = w;
+  a.bias = bias;
+  a.N = N;
+  a.K = K;
+  a.cin = C;
+  a.taps = taps;
+  a.pad = taps / 2;
+  while ((1 << a.up_shift) < upsample) ++a.up_shift;
+  a.Lsrc = L;
+  a.Lout = Lout;
+  a.M = M;
+  a.out = out;
+  a.out_ld = N;
+  a.n_store = N;
+  a.res = res;
+  a.res_ld = N;
+  a.sk_slab = slab;
+  a.sk_slab_bytes = slab_bytes;
+  a.sk_cnt = cnt;
+  a.sk_cnt_ints = 4096;
+  g_conv_gemm_force.path = path;
+  g_conv_gemm_force.tile = tile;
+  g_conv_gemm_force.sk = sk;
+  hipEvent_t e0, e1;
+  SF_HIP(hipEventCreate(&e0));
+  SF_HIP(hipEventCreate(&e1));
+  hipError_t err = hipSuccess;
+  for (int i = 0; i < 3 && err == hipSuccess; ++i) err = launch_conv_gemm(dtype, a, nullptr);
+  if (err == hipSuccess) {
+    SF_HIP(hipDeviceSynchronize());
+    SF_HIP(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters && err == hipSuccess; ++i) err = launch_conv_gemm(dtype, a, nullptr);
+    SF_HIP(hipEventRecord(e1, nullptr));
+    SF_HIP(hipEventSynchronize(e1));
+    SF_HIP(hipEventElapsedTime(ms_out, e0, e1));
+    *ms_out /= (float)iters;
+  }
+  g_conv_gemm_force = ConvGemmForce();
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  for (void *p : {x, w, out, res, (void *)bias, (void *)slab, (void *)cnt}) (void)hipFree(p);
+  if (err != hipSuccess) fail(SF_ERR_UNSUPPORTED, "variant not applicable: %s", hipGetErrorString(err));
   return SF_OK;
   SF_API_END
 }

@@ -358,7 +358,9 @@ hipError_t launch_cfg(const ConvGemmArgs &a, hipStream_t s) {
 }
 
 // tile variants: 0 scalar-A 64x64, 1 128x32, 2 128x64, 3 64x64, 4 128x128
+int pick_variant(const ConvGemmArgs &a);
 int pick_variant(const ConvGemmArgs &a) {
+  if (g_conv_gemm_force.path == 1 && g_conv_gemm_force.tile >= 1 && g_conv_gemm_force.tile <= 4) return g_conv_gemm_force.tile;
   const bool scalar_a = (a.cin % BK) != 0 || (a.cin2 % BK) != 0;
   if (scalar_a) return (a.cin2 != 0 || a.pro != 0) ? -1 : 0;
   const long M = a.M, N = a.n_store;
@@ -414,14 +416,30 @@ const char *conv_gemm_variant_name(int dt, const ConvGemmArgs &a) {
                                        {"conv_gemm_sk<bf16,64x64>", "conv_gemm_sk<bf16,64x32>", "conv_gemm_sk<bf16,32x32>"}};
   static const char *fast_names[2][3] = {{"conv_gemm_fast<f32,64x64>", "conv_gemm_fast<f32,64x32>", "conv_gemm_fast<f32,32x32>"},
                                          {"conv_gemm_fast<bf16,64x64>", "conv_gemm_fast<bf16,64x32>", "conv_gemm_fast<bf16,32x32>"}};
-  if (use_sk(a)) return (conv_gemm_fast_ok(dt, a) ? fast_names : sk_names)[dt == F32 ? 0 : 1][conv_gemm_sk_variant(a)];
+  const long t64 = (long)((a.M + 63) / 64) * ((a.n_store + 63) / 64);
+  const bool short_act = t64 < 500 && a.K >= 256 && (a.K % 32) == 0 && (a.cin % 32) == 0 && (a.cin2 % 32) == 0;
+  if (!short_act) {
+    V2Plan pl;
+    if (conv_gemm_v2_plan(dt, a, pl)) return conv_gemm_v2_name(dt, pl);
+  }
+  if (short_act || use_sk(a)) return (conv_gemm_fast_ok(dt, a) ? fast_names : sk_names)[dt == F32 ? 0 : 1][conv_gemm_sk_variant(a)];
   int v = pick_variant(a);
   return v < 0 ? "conv_gemm<invalid>" : names[dt == F32 ? 0 : 1][v];
 }
 
+ConvGemmForce g_conv_gemm_force;
+
 hipError_t launch_conv_gemm(int dt, const ConvGemmArgs &a, hipStream_t s) {
   if (!conv_gemm_supported(dt, a)) return hipErrorInvalidValue;
-  if (use_sk(a)) return launch_conv_gemm_sk(dt, a, s);
+  const ConvGemmForce &f = g_conv_gemm_force;
+  const long t64 = (long)((a.M + 63) / 64) * ((a.n_store + 63) / 64);
+  const bool short_act = t64 < 500 && a.K >= 256 && (a.K % 32) == 0 && (a.cin % 32) == 0 && (a.cin2 % 32) == 0;
+  if (f.path == 4 || (f.path == 0 && !short_act)) {
+    V2Plan pl;   // long activations: classic 2x2-wave tiles, channel counts that are multiples of 64, no prologue
+    if (conv_gemm_v2_plan(dt, a, pl)) return launch_conv_gemm_v2(dt, a, pl, s);
+    if (f.path == 4) return hipErrorInvalidValue;
+  }
+  if (f.path == 2 || (f.path == 0 && (short_act || use_sk(a)))) return launch_conv_gemm_sk(dt, a, s);
   return dt == F32 ? dispatch<float>(a, s) : dispatch<bf16>(a, s);
 }
 

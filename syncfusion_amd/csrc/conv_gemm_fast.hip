@@ -14,7 +14,6 @@
 namespace sf {
 namespace {
 
-constexpr int BKT = 128;
 constexpr unsigned OOB = 0x80000000u;   // beyond every buffer: the load returns zero
 
 template <typename T> __device__ __forceinline__ Vec16<T> buf_ld16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
@@ -24,9 +23,11 @@ template <typename T> __device__ __forceinline__ Vec16<T> buf_ld16(__amdgpu_buff
   return v;
 }
 
-template <typename T, int BM, int BN, bool CAT>
+// KW = K elements one wave multiplies per iteration (32 or 64); the workgroup stages BKT = 4*KW per iteration.
+template <typename T, int BM, int BN, bool CAT, int KW>
 __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(const ConvGemmArgs a, const int mtiles, const int ntiles, const int swz,
                                                              const unsigned bytesA, const unsigned bytesA2, const unsigned bytesW) {
+  constexpr int BKT = 4 * KW;
   constexpr int VEC = Vec16<T>::N;
   constexpr int ES = (int)sizeof(T);
   constexpr int VPR = BKT / VEC;
@@ -139,11 +140,11 @@ __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(const ConvGemmArgs 
   };
 
   const int fr = lane & 31, fh = lane >> 5;
-  const int kw0 = 32 * wave;
+  const int kw0 = KW * wave;
   auto compute = [&]() {
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
+      for (int s = 0; s < KW / 16; ++s) {
         bf16x8 af[TM], bfr[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8 *>(As + (i * 32 + fr) * LD + kw0 + 16 * s + 8 * fh);
@@ -156,12 +157,12 @@ __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(const ConvGemmArgs 
       }
     } else {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < KW / 8; ++q) {
         f32x4 af[TM], bfr[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4 *>(As + (i * 32 + fr) * LD + kw0 + 16 * fh + 4 * q);
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4 *>(As + (i * 32 + fr) * LD + kw0 + (KW / 2) * fh + 4 * q);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const f32x4 *>(Bs + (j * 32 + fr) * LD + kw0 + 16 * fh + 4 * q);
+        for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const f32x4 *>(Bs + (j * 32 + fr) * LD + kw0 + (KW / 2) * fh + 4 * q);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -243,7 +244,8 @@ __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(const ConvGemmArgs 
   }
 }
 
-template <typename T, int BM, int BN, bool CAT> hipError_t launch_fast2(const ConvGemmArgs &a, hipStream_t s) {
+template <typename T, int BM, int BN, bool CAT, int KW> hipError_t launch_fast2(const ConvGemmArgs &a, hipStream_t s) {
+  constexpr int BKT = 4 * KW;
   constexpr int LD = BKT + 16 / (int)sizeof(T);
   constexpr size_t stage_bytes = (size_t)(BM + BN) * LD * sizeof(T);
   constexpr size_t red_bytes = (size_t)4 * BM * (BN + 4) * sizeof(float);
@@ -254,7 +256,7 @@ template <typename T, int BM, int BN, bool CAT> hipError_t launch_fast2(const Co
   const size_t bA = (size_t)(a.M / a.Lout + (a.M % a.Lout ? 1 : 0)) * a.Lsrc * a.src_ld * es;
   const size_t bA2 = CAT ? (size_t)a.M * a.src2_ld * es : 0;
   const size_t bW = (size_t)a.N * a.K * es;
-  auto kern = conv_gemm_fast_kernel<T, BM, BN, CAT>;
+  auto kern = conv_gemm_fast_kernel<T, BM, BN, CAT, KW>;
   static bool en = false;
   if (!en) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
@@ -270,7 +272,7 @@ template <typename T, int BM, int BN, bool CAT> hipError_t launch_fast2(const Co
 // eligibility: 1-D, <= 3 taps, no prologue, channel count a multiple of the K chunk, every buffer < 2 GiB
 bool conv_gemm_fast_ok(int dt, const ConvGemmArgs &a) {
   if (a.geom != 0 || a.pro != 0 || a.taps > 3 || a.taps < 1) return false;
-  if ((a.cin % BKT) || (a.cin2 % 32) || (a.K % 32)) return false;
+  if ((a.cin % 128) || (a.cin2 % 32) || (a.K % 32)) return false;
   const size_t es = dsize(dt);
   const size_t lim = 0x7FFFFFF0ull;
   const size_t clips = (size_t)(a.M / a.Lout + 1);
@@ -281,7 +283,11 @@ bool conv_gemm_fast_ok(int dt, const ConvGemmArgs &a) {
 }
 
 hipError_t launch_conv_gemm_fast(int dt, const ConvGemmArgs &a, int variant, hipStream_t s) {
-#define SF_FAST(T, BM, BN) (a.cin2 ? launch_fast2<T, BM, BN, true>(a, s) : launch_fast2<T, BM, BN, false>(a, s))
+  // 256-wide chunks (64 K per wave and iteration: half the barriers) when the channel count allows it
+  const bool wide = (a.cin % 256) == 0 && g_conv_gemm_force.sk == 64;   // measured: no gain over 128-wide chunks
+#define SF_FAST(T, BM, BN)                                                                                              \
+  (wide ? (a.cin2 ? launch_fast2<T, BM, BN, true, 64>(a, s) : launch_fast2<T, BM, BN, false, 64>(a, s))                 \
+        : (a.cin2 ? launch_fast2<T, BM, BN, true, 32>(a, s) : launch_fast2<T, BM, BN, false, 32>(a, s)))
   if (dt == F32) {
     switch (variant) {
       case 0: return SF_FAST(float, 64, 64);

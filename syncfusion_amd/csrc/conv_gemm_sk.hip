@@ -353,10 +353,13 @@ template <typename T, int BM, int BN> hipError_t launch_sk(const ConvGemmArgs &a
 
 // tile choice: the largest of 64x64 / 64x32 / 32x32 that still yields >= 224 workgroups
 int conv_gemm_sk_variant(const ConvGemmArgs &a) {
+  if (g_conv_gemm_force.path == 2 && g_conv_gemm_force.tile >= 0 && g_conv_gemm_force.tile <= 2) return g_conv_gemm_force.tile;
+  // measured (tools/gemm_sweep.py): on short activations the smallest tile wins at every U-Net shape -- more
+  // workgroups in flight matter more than operand reuse
   auto blocks = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.n_store + bn - 1) / bn); };
-  if (blocks(64, 64) >= 224) return 0;
-  if (blocks(64, 32) >= 224) return 1;
-  return 2;
+  if (blocks(32, 32) <= 4096) return 2;
+  if (blocks(64, 32) <= 4096) return 1;
+  return 0;
 }
 
 bool conv_gemm_fast_ok(int dt, const ConvGemmArgs &a);

@@ -1,0 +1,401 @@
+// Main MFMA implicit-GEMM convolution ("v2"): 1-D and video geometry, channel counts that are multiples of 64.
+//
+//   * 256 threads = 4 waves as 2x2; block tile BM x BN (128x128, 128x64, 64x64), wave tile (BM/2)x(BN/2) of
+//     32x32 MFMA tiles; K walked in 64-wide chunks (4 MFMA k-steps per tile per chunk for bf16).
+//   * A and W chunks are fetched with `buffer_load_dwordx4` (wave-uniform descriptors, 32-bit per-lane offsets,
+//     out-of-range offsets return zero: padding rows, M/N tails and K tails need no predication), issued for
+//     chunk t+1 BEFORE the MFMAs of chunk t and written to the OTHER LDS buffer after them: one barrier per chunk.
+//   * optional GRID split-K for short activations (few output rows, long K): `sk` workgroups share an output
+//     tile, each writes its fp32 partial tile to a slab, takes a ticket (agent-scope release -> relaxed
+//     fetch_add), and the last arriver (agent-scope acquire) sums the slabs IN FIXED ORDER and runs the epilogue.
+//     No float atomics: results are bit-reproducible and independent of arrival order.
+//   * epilogue through LDS: row-major 16-byte stores, operand loads (bias / residual / per-clip scale+add)
+//     batched and unconditional.
+#include "common.h"
+#include "kernels.h"
+
+namespace sf {
+namespace {
+
+constexpr int BK = 64;
+constexpr unsigned OOB = 0x80000000u;
+
+template <typename T> __device__ __forceinline__ Vec16<T> buf_ld16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  Vec16<T> v;
+  u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+  v.v = __builtin_bit_cast(decltype(v.v), raw);
+  return v;
+}
+
+struct V2Extra {
+  int mtiles, ntiles, sk, chunks_per_split, swz;
+  unsigned bytesA, bytesA2, bytesW;
+  float *slab;   // [sk][M][N] fp32 partial tiles (sk > 1)
+  int *cnt;      // [mtiles * ntiles] arrival tickets, zero between launches
+};
+
+template <typename T, int BM, int BN, int GEOM, bool CAT>
+__global__ __launch_bounds__(256) void conv_gemm_v2_kernel(const ConvGemmArgs a, const V2Extra x) {
+  constexpr int VEC = Vec16<T>::N;
+  constexpr int ES = (int)sizeof(T);
+  constexpr int VPR = BK / VEC;        // 16-byte vectors per staged row: bf16 8, fp32 16
+  constexpr int RPP = 256 / VPR;       // rows per pass: 32 / 16
+  constexpr int PA = BM / RPP, PB = BN / RPP;
+  constexpr int LD = BK + 16 / ES;     // padded LDS row (144 B bf16 / 272 B fp32): conflict-free b128 fragment reads
+  constexpr int WTM = BM / 2, WTN = BN / 2;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int LDR = BN + 4;
+  constexpr int STAGE = (BM + BN) * LD;   // elements per LDS buffer
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T *lds = reinterpret_cast<T *>(smem);
+  float *red = reinterpret_cast<float *>(smem);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  // ---- block -> (row tile, column tile, K slice): all users of one W panel on one XCD -----------------
+  int mt, nt, ks;
+  {
+    const int bid = blockIdx.x;
+    if (x.swz) {
+      const int xcd = bid & 7, j = bid >> 3;
+      mt = j % x.mtiles;
+      const int r = j / x.mtiles;
+      ks = r % x.sk;
+      nt = xcd + 8 * (r / x.sk);
+    } else {
+      mt = bid % x.mtiles;
+      const int r = bid / x.mtiles;
+      ks = r % x.sk;
+      nt = r / x.sk;
+    }
+  }
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int srow = tid / VPR, svec = tid % VPR;
+
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.src), 0, x.bytesA, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(CAT ? a.src2 : a.src), 0, CAT ? x.bytesA2 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.w), 0, x.bytesW, 0x00020000);
+
+  // ---- per staged row: source coordinates (once) ---------------------------------------------------------
+  int rbase[PA], rp0[PA], rh[PA], rw_[PA];
+  unsigned roff2[PA], woff[PB];
+  unsigned vmask[PA];   // 0 for a live output row, OOB for rows beyond M
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int m = m0 + i * RPP + srow;
+    const bool vm = m < a.M;
+    const int mm = vm ? m : 0;
+    vmask[i] = vm ? 0u : OOB;
+    if constexpr (GEOM == 0) {
+      const int b = mm / a.Lout, l = mm - b * a.Lout;
+      rbase[i] = b * a.Lsrc;
+      rp0[i] = l * a.stride - a.pad;
+      rh[i] = rw_[i] = 0;
+    } else {
+      const int w_ = mm % a.Wo;
+      int r = mm / a.Wo;
+      const int h_ = r % a.Ho;
+      r /= a.Ho;
+      const int t_ = r % a.To, n_ = r / a.To;
+      rbase[i] = n_ * a.Ti;
+      rp0[i] = t_ * a.st - a.pt;
+      rh[i] = h_ * a.sh - a.ph;
+      rw_[i] = w_ * a.sw - a.pw;
+    }
+    roff2[i] = CAT ? ((unsigned)((mm * a.src2_ld + svec * VEC) * ES) | vmask[i]) : OOB;
+  }
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    const int n = n0 + i * RPP + srow;
+    woff[i] = n < a.N ? (unsigned)((n * a.K + svec * VEC) * ES) : OOB;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int k_taps = a.taps * a.cin;
+  const int nk_total = (a.K + BK - 1) / BK;
+  const int kt0 = ks * x.chunks_per_split;
+  const int nkt = min(x.chunks_per_split, nk_total - kt0);
+  const unsigned lane_k = (unsigned)(svec * VEC);
+  const int pmax = (a.Lsrc << a.up_shift) - 1;
+
+  Vec16<T> ra[PA], rb[PB];
+  auto prefetch = [&](int kt) {
+    const int k0 = (kt0 + kt) * BK;                                   // wave-uniform
+    const unsigned tmask = (k0 + lane_k >= (unsigned)a.K) ? OOB : 0u;  // K tail of the last chunk
+#pragma unroll
+    for (int i = 0; i < PB; ++i) rb[i] = buf_ld16<T>(rW, (woff[i] + (unsigned)(k0 * ES)) | tmask);
+    if (!CAT || k0 < k_taps) {
+      const int tap = k0 / a.cin;                                      // scalar: cin % 64 == 0
+      const int cb = k0 - tap * a.cin;
+      if constexpr (GEOM == 0) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+          const int p = rp0[i] + tap;
+          const unsigned bad = ((unsigned)p > (unsigned)pmax) ? OOB : 0u;
+          const unsigned off = (unsigned)(((rbase[i] + (max(p, 0) >> a.up_shift)) * a.src_ld + cb + (int)lane_k) * ES);
+          ra[i] = buf_ld16<T>(rA, off | bad | vmask[i] | tmask);
+        }
+      } else {
+        const int dw = tap % a.kw;
+        const int r = tap / a.kw;
+        const int dh = r % a.kh, dt = r / a.kh;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+          const int ti = rp0[i] + dt, hi = rh[i] + dh, wi = rw_[i] + dw;
+          const bool ok = (unsigned)ti < (unsigned)a.Ti && (unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi;
+          const unsigned off = (unsigned)(((((rbase[i] + max(ti, 0)) * a.Hi + max(hi, 0)) * a.Wi + max(wi, 0)) * a.src_ld + cb + (int)lane_k) * ES);
+          ra[i] = buf_ld16<T>(rA, off | (ok ? 0u : OOB) | vmask[i] | tmask);
+        }
+      }
+    } else {
+      const unsigned cb = (unsigned)((k0 - k_taps) * ES);
+#pragma unroll
+      for (int i = 0; i < PA; ++i) ra[i] = buf_ld16<T>(rA2, (roff2[i] + cb) | tmask);
+    }
+  };
+  auto stage = [&](int buf) {
+    T *As = lds + buf * STAGE, *Bs = As + BM * LD;
+#pragma unroll
+    for (int i = 0; i < PB; ++i) st16<T>(Bs + (i * RPP + srow) * LD + svec * VEC, rb[i]);
+#pragma unroll
+    for (int i = 0; i < PA; ++i) st16<T>(As + (i * RPP + srow) * LD + svec * VEC, ra[i]);
+  };
+
+  const int fr = lane & 31, fh = lane >> 5;
+  auto compute = [&](int buf) {
+    const T *As = lds + buf * STAGE + (wr * WTM) * LD, *Bs = lds + buf * STAGE + (BM + wc * WTN) * LD;
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int s = 0; s < BK / 16; ++s) {
+        bf16x8 af[TM], bfr[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8 *>(As + (i * 32 + fr) * LD + 16 * s + 8 * fh);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8 *>(Bs + (j * 32 + fr) * LD + 16 * s + 8 * fh);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+      // fp32: v_mfma_f32_32x32x2_f32; the two k of a step are {s, 32 + s} of the chunk (same permutation for A and W)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        f32x4 af[TM], bfr[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4 *>(As + (i * 32 + fr) * LD + 32 * fh + 4 * q);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const f32x4 *>(Bs + (j * 32 + fr) * LD + 32 * fh + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bfr[j][e], acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+
+  // ---- K loop: loads of chunk t+1 in flight under the MFMAs of chunk t; one barrier per chunk ---------------
+  prefetch(0);
+  stage(0);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const bool more = kt + 1 < nkt;
+    if (more) prefetch(kt + 1);
+    compute(kt & 1);
+    if (more) stage((kt + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- accumulators -> LDS (fp32, row-major) --------------------------------------------------------------
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        red[(wr * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LDR + wc * WTN + j * 32 + fr] = acc[i][j][r];
+  __syncthreads();
+
+  constexpr int QN = BN / 4;
+  constexpr int ITER = (BM * QN) / 256;
+  const bool split = x.sk > 1;
+  if (split) {
+    // partial tile -> slab[ks]; ticket; only the last arriver continues
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int idx = tid + it * 256;
+      const int ml = idx / QN, nq = idx - ml * QN;
+      const int m = m0 + ml, nb = n0 + nq * 4;
+      if (m < a.M && nb < a.N)
+        *reinterpret_cast<f32x4 *>(x.slab + ((size_t)ks * a.M + m) * a.N + nb) = *reinterpret_cast<const f32x4 *>(red + (size_t)ml * LDR + nq * 4);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int *flag = reinterpret_cast<int *>(smem + (size_t)BM * LDR * sizeof(float));
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int t = __hip_atomic_fetch_add(x.cnt + (mt * x.ntiles + nt), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = (t == x.sk - 1);
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(x.cnt + (mt * x.ntiles + nt), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next launch
+      }
+      *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+  }
+
+  T *out = static_cast<T *>(a.out);
+  const T *res = static_cast<const T *>(a.res);
+  const bool has_res = res != nullptr, has_bs = a.bscale != nullptr, has_ba = a.badd != nullptr;
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const int idx = tid + it * 256;
+    const int ml = idx / QN, nq = idx - ml * QN;
+    const int m = m0 + ml, nb = n0 + nq * 4;
+    const bool live = m < a.M && nb < a.n_store;
+    const int mc = min(m, a.M - 1);
+    float bi[4], rv[4], sv[4], av[4];
+    const int b = (has_bs || has_ba) ? mc / a.Lout : 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int nc = min(nb + e, a.N - 1);
+      bi[e] = a.bias ? a.bias[nc] : 0.f;
+      rv[e] = has_res ? to_f(res[(size_t)mc * a.res_ld + nc]) : 0.f;
+      sv[e] = has_bs ? a.bscale[(size_t)b * a.bscale_ld + nc] : 1.f;
+      av[e] = has_ba ? a.badd[(size_t)b * a.badd_ld + nc] : 0.f;
+    }
+    f32x4 v;
+    if (split) {
+      const int nbc = min(nb, a.N - 4);
+      v = *reinterpret_cast<const f32x4 *>(x.slab + (size_t)mc * a.N + nbc);
+      for (int s = 1; s < x.sk; ++s) {   // fixed order: slab 0, 1, ... -> independent of which block arrived last
+        f32x4 t = *reinterpret_cast<const f32x4 *>(x.slab + ((size_t)s * a.M + mc) * a.N + nbc);
+        v[0] += t[0];
+        v[1] += t[1];
+        v[2] += t[2];
+        v[3] += t[3];
+      }
+    } else {
+      v = *reinterpret_cast<const f32x4 *>(red + (size_t)ml * LDR + nq * 4);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int n = nb + e;
+      float xv = (v[e] + bi[e]) * sv[e] + rv[e] + av[e];
+      xv = n < a.N ? apply_act(xv, a.act) : 0.f;
+      if (live && n < a.n_store) {
+        if (a.out_f32) static_cast<float *>(a.out)[(size_t)m * a.out_ld + n] = xv;
+        else out[(size_t)m * a.out_ld + n] = from_f<T>(xv);
+      }
+    }
+  }
+}
+
+template <typename T, int BM, int BN, int GEOM, bool CAT> hipError_t launch_v2_t(const ConvGemmArgs &a, const V2Plan &pl, hipStream_t s) {
+  constexpr int LD = BK + 16 / (int)sizeof(T);
+  constexpr size_t stage_bytes = (size_t)2 * (BM + BN) * LD * sizeof(T);
+  constexpr size_t red_bytes = (size_t)BM * (BN + 4) * sizeof(float) + 16;
+  const size_t lds = stage_bytes > red_bytes ? stage_bytes : red_bytes;
+  V2Extra x;
+  x.mtiles = (a.M + BM - 1) / BM;
+  x.ntiles = (a.n_store + BN - 1) / BN;
+  x.sk = pl.sk;
+  x.chunks_per_split = pl.chunks_per_split;
+  x.swz = (x.ntiles % 8 == 0) ? 1 : 0;
+  const size_t es = sizeof(T);
+  if (a.geom == 0) x.bytesA = (unsigned)((size_t)(a.M / a.Lout + (a.M % a.Lout ? 1 : 0)) * a.Lsrc * a.src_ld * es);
+  else x.bytesA = (unsigned)((size_t)(a.M / (a.To * a.Ho * a.Wo)) * a.Ti * a.Hi * a.Wi * a.src_ld * es);
+  x.bytesA2 = CAT ? (unsigned)((size_t)a.M * a.src2_ld * es) : 0u;
+  x.bytesW = (unsigned)((size_t)a.N * a.K * es);
+  x.slab = a.sk_slab;
+  x.cnt = a.sk_cnt;
+  auto kern = conv_gemm_v2_kernel<T, BM, BN, GEOM, CAT>;
+  static bool en = false;
+  if (!en) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e != hipSuccess) return e;
+    en = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(x.mtiles * x.ntiles * x.sk), dim3(256), lds, s, a, x);
+  return hipGetLastError();
+}
+
+template <typename T, int BM, int BN> hipError_t launch_v2_g(const ConvGemmArgs &a, const V2Plan &pl, hipStream_t s) {
+  if (a.geom == 1) return a.cin2 ? hipErrorInvalidValue : launch_v2_t<T, BM, BN, 1, false>(a, pl, s);
+  return a.cin2 ? launch_v2_t<T, BM, BN, 0, true>(a, pl, s) : launch_v2_t<T, BM, BN, 0, false>(a, pl, s);
+}
+
+}  // namespace
+
+// eligibility + tile / split-K choice
+bool conv_gemm_v2_plan(int dt, const ConvGemmArgs &a, V2Plan &pl) {
+  if (a.pro != 0 || (a.cin % BK) || (a.cin2 % 32) || (a.K % 32) || a.N % 4) return false;
+  if (a.geom == 1 && a.cin2) return false;
+  const size_t es = dsize(dt), lim = 0x7FFFFFF0ull;
+  size_t bA;
+  if (a.geom == 0) bA = (size_t)(a.M / a.Lout + 1) * a.Lsrc * a.src_ld * es;
+  else bA = (size_t)(a.M / (a.To * a.Ho * a.Wo) + 1) * a.Ti * a.Hi * a.Wi * a.src_ld * es;
+  if (bA >= lim || (size_t)a.M * (a.src2_ld > 0 ? a.src2_ld : 1) * es >= lim || (size_t)a.N * a.K * es >= lim) return false;
+  auto tiles = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.n_store + bn - 1) / bn); };
+  const int nk = (a.K + BK - 1) / BK;
+  // Measured on MI355X (tools/gemm_sweep.py, bf16): 128x128 wins once it yields >= ~300 workgroups, 64x64 otherwise;
+  // below ~500 64x64-tiles the wave-split-K kernel with 32x32 tiles is faster (see launch_conv_gemm).
+  static const int bms[3] = {128, 128, 64}, bns[3] = {128, 64, 64};
+  pl.variant = (a.n_store >= 128 && tiles(128, 128) >= 300) ? 0 : 2;
+  const ConvGemmForce &f = g_conv_gemm_force;
+  if (f.path == 4 && f.tile >= 0 && f.tile <= 2) pl.variant = f.tile;
+  const long t = tiles(bms[pl.variant], bns[pl.variant]);
+  pl.sk = 1;
+  if (false && t < 224 && a.sk_slab && a.sk_cnt && a.n_store == a.N) {   // measured slower than wave-split-K: fences ~2-7 us per block
+    // split K so that tiles*sk ~ 256..512 workgroups, at least 4 chunks (256 K) per slice
+    int sk = (int)((320 + t - 1) / t);
+    const int max_sk = nk / 4 > 0 ? nk / 4 : 1;
+    if (sk > max_sk) sk = max_sk;
+    if (sk > 16) sk = 16;
+    while (sk > 1 && ((size_t)sk * a.M * a.N * sizeof(float) > a.sk_slab_bytes || t > a.sk_cnt_ints)) --sk;
+    pl.sk = sk < 1 ? 1 : sk;
+  }
+  if (f.path == 4 && f.sk >= 1 && a.sk_slab && (size_t)f.sk * a.M * a.N * sizeof(float) <= a.sk_slab_bytes) pl.sk = f.sk;
+  pl.chunks_per_split = (nk + pl.sk - 1) / pl.sk;
+  pl.sk = (nk + pl.chunks_per_split - 1) / pl.chunks_per_split;   // no empty slices
+  return true;
+}
+
+const char *conv_gemm_v2_name(int dt, const V2Plan &pl) {
+  static const char *n[2][2][3] = {{{"conv_gemm_v2<f32,128x128>", "conv_gemm_v2<f32,128x64>", "conv_gemm_v2<f32,64x64>"},
+                                    {"conv_gemm_v2<f32,128x128,splitK>", "conv_gemm_v2<f32,128x64,splitK>", "conv_gemm_v2<f32,64x64,splitK>"}},
+                                   {{"conv_gemm_v2<bf16,128x128>", "conv_gemm_v2<bf16,128x64>", "conv_gemm_v2<bf16,64x64>"},
+                                    {"conv_gemm_v2<bf16,128x128,splitK>", "conv_gemm_v2<bf16,128x64,splitK>", "conv_gemm_v2<bf16,64x64,splitK>"}}};
+  return n[dt == F32 ? 0 : 1][pl.sk > 1 ? 1 : 0][pl.variant];
+}
+
+hipError_t launch_conv_gemm_v2(int dt, const ConvGemmArgs &a, const V2Plan &pl, hipStream_t s) {
+  if (dt == F32) {
+    switch (pl.variant) {
+      case 0: return launch_v2_g<float, 128, 128>(a, pl, s);
+      case 1: return launch_v2_g<float, 128, 64>(a, pl, s);
+      default: return launch_v2_g<float, 64, 64>(a, pl, s);
+    }
+  }
+  switch (pl.variant) {
+    case 0: return launch_v2_g<bf16, 128, 128>(a, pl, s);
+    case 1: return launch_v2_g<bf16, 128, 64>(a, pl, s);
+    default: return launch_v2_g<bf16, 64, 64>(a, pl, s);
+  }
+}
+
+}  // namespace sf

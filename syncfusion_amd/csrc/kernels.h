@@ -33,8 +33,28 @@ struct ConvGemmArgs {
   // epilogue: v = acc + bias; v *= bscale[b][n]; v += res[m][n]; v += badd[b][n]; v = act(v)
   //   act: 0 none, 1 relu, 2 gelu(erf), 3 silu(gelu(v))   out_f32: store fp32 whatever the compute type
   int badd_ld = 0, bscale_ld = 0, act = 0, out_f32 = 0;
+  // optional scratch for grid split-K (conv_gemm_v2): fp32 partial-tile slab and per-tile arrival tickets
+  // (the tickets must be zero before the launch; the kernel re-arms them)
+  float *sk_slab = nullptr;
+  size_t sk_slab_bytes = 0;
+  int *sk_cnt = nullptr;
+  int sk_cnt_ints = 0;
 };
+struct V2Plan {
+  int variant = 2;  // 0: 128x128, 1: 128x64, 2: 64x64
+  int sk = 1, chunks_per_split = 0;
+};
+bool conv_gemm_v2_plan(int dt, const ConvGemmArgs &a, V2Plan &pl);
+const char *conv_gemm_v2_name(int dt, const V2Plan &pl);
+hipError_t launch_conv_gemm_v2(int dt, const ConvGemmArgs &a, const V2Plan &pl, hipStream_t s);
 hipError_t launch_conv_gemm(int dt, const ConvGemmArgs &a, hipStream_t s);
+// Tuning hook (sf_bench_conv1d only; not thread-safe): force the kernel family / tile / split-K of launch_conv_gemm.
+//   path: 0 automatic, 1 classic (conv_gemm), 2 wave-split-K (sk / fast), 4 v2;  tile: -1 automatic else variant index;
+//   sk: -1 automatic else the grid split-K factor of v2.
+struct ConvGemmForce {
+  int path = 0, tile = -1, sk = -1;
+};
+extern ConvGemmForce g_conv_gemm_force;
 // name of the tile variant launch_conv_gemm picks for these arguments (profiling labels)
 const char *conv_gemm_variant_name(int dt, const ConvGemmArgs &a);
 // bytes of dynamic LDS the GN table needs is bounded; returns false when the shape is unsupported.

@@ -12,6 +12,7 @@
 //     exactly 1), computed once per sample() call and added in the preceding conv's epilogue;
 //   * LayerNorm affines of the attention pre-norms are folded into the q/kv projection weights;
 //   * with classifier-free guidance the conditional and unconditional evaluations run as one 2B batch.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <exception>
@@ -57,7 +58,11 @@ struct Plan {  // everything carved out of the caller's workspace for one (B, L0
   int *step = nullptr;
   int nbr = 1;                 // clip-parallel branches
   int64_t slab_stride = 0;     // floats of GroupNorm scratch per branch
+  float *sk_slab = nullptr;    // grid split-K partial tiles (per branch: sk_stride floats)
+  int *sk_cnt = nullptr;       // arrival tickets (per branch: kSkCnt ints), zeroed once per call
+  int64_t sk_stride = 0;
 };
+constexpr int kSkCnt = 1024;
 
 }  // namespace
 
@@ -420,6 +425,17 @@ Plan make_plan(const sf_unet &u, Workspace &ws, int B, int L0, bool two, int num
   p.mod_all = ws.alloc_n<float>((int64_t)p.Bt * u.mod_ld);
   p.ca_all = ws.alloc_n<float>((int64_t)p.Bt * u.ca_ld);
   p.slab = ws.alloc_n<float>(slab_floats);
+  {
+    // split-K scratch: up to 16 partial tiles of the largest short-activation GEMM output per branch
+    int64_t mx = 0;
+    for (int d = 0; d < c.n_layers; ++d) {
+      const int64_t rows = p.lv[d].rows / p.nbr;
+      if (rows <= 8192) mx = std::max<int64_t>(mx, rows * std::max(p.lv[d].C, 3 * u.hd));
+    }
+    p.sk_stride = align_up(8 * mx, 64);
+    p.sk_slab = ws.alloc_n<float>(p.sk_stride * p.nbr);
+    p.sk_cnt = ws.alloc_n<int>((int64_t)kSkCnt * sf_unet::kMaxBranches);
+  }
   p.four = ws.alloc((int64_t)p.Bt * u.four_ld * es);
   p.f1 = ws.alloc((int64_t)p.Bt * u.mf * es);
   p.f2 = ws.alloc((int64_t)p.Bt * u.mf * es);
@@ -465,6 +481,12 @@ struct Exec {
     a.cin2 = w.cin2;
     a.taps = w.taps;
     if (a.n_store == 0) a.n_store = w.N;
+    if (!w.direct && p.sk_slab) {
+      a.sk_slab = p.sk_slab;
+      a.sk_slab_bytes = (size_t)p.sk_stride * sizeof(float);
+      a.sk_cnt = p.sk_cnt;
+      a.sk_cnt_ints = kSkCnt;
+    }
     // algorithmic work of this launch: 2*M*N*K_real FLOPs; bytes = activations in + out (+ residual) + weights
     const double kreal = w.kreal > 0 ? w.kreal : w.K;
     const double es_in = dsize(dt_in), es_out = a.out_f32 ? 4.0 : (double)dsize(dt_out);
@@ -689,6 +711,7 @@ struct Exec {
   // per-call conditioning: context pyramids to channels-last, cross-attention collapse
   void conditioning(const float *const *ctx, const float *emb) {
     const sf_unet_config &c = u.cfg;
+    SF_HIP(hipMemsetAsync(p.sk_cnt, 0, sizeof(int) * kSkCnt * sf_unet::kMaxBranches, s));   // split-K tickets start at zero
     const size_t es = dsize(u.dt);
     for (int d = 0; d < c.n_layers; ++d) {
       const Level &l = p.lv[d];
@@ -743,6 +766,8 @@ struct Exec {
     v.mod_all = p.mod_all + (int64_t)br * bt * u.mod_ld;
     v.ca_all = p.ca_all + (int64_t)br * bt * u.ca_ld;
     v.slab = p.slab + (int64_t)br * p.slab_stride;
+    v.sk_slab = p.sk_slab + (int64_t)br * p.sk_stride;
+    v.sk_cnt = p.sk_cnt + (int64_t)br * kSkCnt;
     return v;
   }
 
