@@ -177,6 +177,7 @@ int sf_bench_conv1d(int dtype, int B, int L, int C, int N, int taps, int upsampl
 int sf_op_ln_modulate(int dtype, const void *x, const float *scale_shift, float eps, int B, int L, int C, void *out, void *stream) {
   SF_API_BEGIN
   if (!x || !out) fail(SF_ERR_INVALID, "null argument");
+  if (scale_shift && (C % 2)) fail(SF_ERR_UNSUPPORTED, "C must be even");
   SF_HIP(launch_ln_modulate(dtype, x, C, scale_shift, 2 * C, eps, B, L, C, out, C, static_cast<hipStream_t>(stream)));
   return SF_OK;
   SF_API_END

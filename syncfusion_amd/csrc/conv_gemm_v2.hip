@@ -126,42 +126,80 @@ __global__ __launch_bounds__(256) void conv_gemm_v2_kernel(const ConvGemmArgs a,
   const unsigned lane_k = (unsigned)(svec * VEC);
   const int pmax = (a.Lsrc << a.up_shift) - 1;
 
-  Vec16<T> ra[PA], rb[PB];
-  auto prefetch = [&](int kt) {
-    const int k0 = (kt0 + kt) * BK;                                   // wave-uniform
-    const unsigned tmask = (k0 + lane_k >= (unsigned)a.K) ? OOB : 0u;  // K tail of the last chunk
+  // two register sets: the loads of chunk t+2 are issued under the MFMAs of chunk t and written to LDS after the
+  // MFMAs of chunk t+1 -- two compute phases of latency cover (named sets: static register indexing)
+  struct RegSet {
+    Vec16<T> ra[PA], rb[PB];
+  };
+  RegSet s0, s1;
+
+  // Streaming gather state (chunks are requested in K order).  The expensive per-row arithmetic (clamps, shifts,
+  // multiplies, range checks) runs only when the TAP changes -- once every cin/64 chunks; inside a tap a chunk costs
+  // one add + one or per staged vector.  Measured before this: 206 VALU instructions per 16 MFMAs (issue-bound).
+  unsigned cur[PA];      // byte offset of staged row i at channel 0 of the current tap (OOB bit set when out of range)
+  unsigned cb, kb;       // byte offset of the chunk inside the tap's channels / inside a W row
+  int tap;
+  bool second = false;   // reading the concatenated second source
+  const unsigned tap_bytes = (unsigned)(a.cin * ES), kbytes = (unsigned)(a.K * ES), lane_b = lane_k * ES;
+  auto retap = [&](int t) {
+    if constexpr (GEOM == 0) {
 #pragma unroll
-    for (int i = 0; i < PB; ++i) rb[i] = buf_ld16<T>(rW, (woff[i] + (unsigned)(k0 * ES)) | tmask);
-    if (!CAT || k0 < k_taps) {
-      const int tap = k0 / a.cin;                                      // scalar: cin % 64 == 0
-      const int cb = k0 - tap * a.cin;
-      if constexpr (GEOM == 0) {
-#pragma unroll
-        for (int i = 0; i < PA; ++i) {
-          const int p = rp0[i] + tap;
-          const unsigned bad = ((unsigned)p > (unsigned)pmax) ? OOB : 0u;
-          const unsigned off = (unsigned)(((rbase[i] + (max(p, 0) >> a.up_shift)) * a.src_ld + cb + (int)lane_k) * ES);
-          ra[i] = buf_ld16<T>(rA, off | bad | vmask[i] | tmask);
-        }
-      } else {
-        const int dw = tap % a.kw;
-        const int r = tap / a.kw;
-        const int dh = r % a.kh, dt = r / a.kh;
-#pragma unroll
-        for (int i = 0; i < PA; ++i) {
-          const int ti = rp0[i] + dt, hi = rh[i] + dh, wi = rw_[i] + dw;
-          const bool ok = (unsigned)ti < (unsigned)a.Ti && (unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi;
-          const unsigned off = (unsigned)(((((rbase[i] + max(ti, 0)) * a.Hi + max(hi, 0)) * a.Wi + max(wi, 0)) * a.src_ld + cb + (int)lane_k) * ES);
-          ra[i] = buf_ld16<T>(rA, off | (ok ? 0u : OOB) | vmask[i] | tmask);
-        }
+      for (int i = 0; i < PA; ++i) {
+        const int p = rp0[i] + t;
+        const unsigned bad = ((unsigned)p > (unsigned)pmax) ? OOB : 0u;
+        cur[i] = ((unsigned)(((rbase[i] + (max(p, 0) >> a.up_shift)) * a.src_ld) * ES) + lane_b) | bad | vmask[i];
       }
     } else {
-      const unsigned cb = (unsigned)((k0 - k_taps) * ES);
+      const int dw = t % a.kw;
+      const int r = t / a.kw;
+      const int dh = r % a.kh, dt = r / a.kh;
 #pragma unroll
-      for (int i = 0; i < PA; ++i) ra[i] = buf_ld16<T>(rA2, (roff2[i] + cb) | tmask);
+      for (int i = 0; i < PA; ++i) {
+        const int ti = rp0[i] + dt, hi = rh[i] + dh, wi = rw_[i] + dw;
+        const bool ok = (unsigned)ti < (unsigned)a.Ti && (unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi;
+        cur[i] = ((unsigned)(((((rbase[i] + max(ti, 0)) * a.Hi + max(hi, 0)) * a.Wi + max(wi, 0)) * a.src_ld) * ES) + lane_b) |
+                 (ok ? 0u : OOB) | vmask[i];
+      }
     }
   };
-  auto stage = [&](int buf) {
+  {   // position the stream at this block's first chunk (grid split-K slices start mid-way)
+    const int k0 = kt0 * BK;
+    kb = (unsigned)(k0 * ES);
+    if (CAT && k0 >= k_taps) {
+      second = true;
+      tap = a.taps;
+      cb = (unsigned)((k0 - k_taps) * ES);
+#pragma unroll
+      for (int i = 0; i < PA; ++i) cur[i] = roff2[i];
+    } else {
+      tap = k0 / a.cin;
+      cb = (unsigned)((k0 - tap * a.cin) * ES);
+      retap(tap);
+    }
+  }
+  auto prefetch = [&](RegSet &R) {
+    const unsigned tmask = (kb + lane_b >= kbytes) ? OOB : 0u;   // K tail of the last chunk
+#pragma unroll
+    for (int i = 0; i < PB; ++i) R.rb[i] = buf_ld16<T>(rW, (woff[i] + kb) | tmask);
+    const __amdgpu_buffer_rsrc_t rs = (CAT && second) ? rA2 : rA;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) R.ra[i] = buf_ld16<T>(rs, (cur[i] + cb) | tmask);
+    kb += (unsigned)(BK * ES);
+    cb += (unsigned)(BK * ES);
+    if (!second && cb >= tap_bytes) {   // wave-uniform; no memory operation inside
+      cb = 0;
+      ++tap;
+      if (tap < a.taps) retap(tap);
+      else {
+        second = true;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) cur[i] = roff2[i];
+      }
+    }
+  };
+  auto stage = [&](int buf, RegSet &R) {
+    Vec16<T>(&ra)[PA] = R.ra;
+    Vec16<T>(&rb)[PB] = R.rb;
     T *As = lds + buf * STAGE, *Bs = As + BM * LD;
 #pragma unroll
     for (int i = 0; i < PB; ++i) st16<T>(Bs + (i * RPP + srow) * LD + svec * VEC, rb[i]);
@@ -205,15 +243,21 @@ __global__ __launch_bounds__(256) void conv_gemm_v2_kernel(const ConvGemmArgs a,
   };
 
   // ---- K loop: loads of chunk t+1 in flight under the MFMAs of chunk t; one barrier per chunk ---------------
-  prefetch(0);
-  stage(0);
+  prefetch(s0);
+  if (nkt > 1) prefetch(s1);
+  stage(0, s0);
   __syncthreads();
-  for (int kt = 0; kt < nkt; ++kt) {
-    const bool more = kt + 1 < nkt;
-    if (more) prefetch(kt + 1);
-    compute(kt & 1);
-    if (more) stage((kt + 1) & 1);
+  for (int kt = 0; kt < nkt; kt += 2) {
+    if (kt + 2 < nkt) prefetch(s0);
+    compute(0);
+    if (kt + 1 < nkt) stage(1, s1);
     __syncthreads();
+    if (kt + 1 < nkt) {
+      if (kt + 3 < nkt) prefetch(s1);
+      compute(1);
+      if (kt + 2 < nkt) stage(0, s0);
+      __syncthreads();
+    }
   }
 
   // ---- accumulators -> LDS (fp32, row-major) --------------------------------------------------------------

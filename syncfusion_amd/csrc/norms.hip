@@ -165,11 +165,25 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const T *__restrict__ 
   Vec16<T> v[VPT];
   float sum = 0.f;
 #pragma unroll
-  for (int i = 0; i < VPT; ++i) {
-    v[i] = ld16<T>(x + (size_t)rr * ld + (size_t)(i * tpr + sub) * V);
+  for (int i = 0; i < VPT; ++i) v[i] = ld16<T>(x + (size_t)rr * ld + (size_t)(i * tpr + sub) * V);
+  // the per-clip scale / shift do not depend on the statistics: issue their loads now, next to the row's, so the
+  // kernel pays ONE memory round trip instead of two (16-byte loads; the engine keeps every offset 16-byte aligned)
+  const int b = rr / L;
+  f32x4 sc[VPT][V / 4], sh[VPT][V / 4];
+  if (ss) {
+#pragma unroll
+    for (int i = 0; i < VPT; ++i)
+#pragma unroll
+      for (int q = 0; q < V / 4; ++q) {
+        const int c0 = (i * tpr + sub) * V + 4 * q;
+        sc[i][q] = *reinterpret_cast<const f32x4 *>(ss + (size_t)b * ss_ld + c0);
+        sh[i][q] = *reinterpret_cast<const f32x4 *>(ss + (size_t)b * ss_ld + C + c0);
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < VPT; ++i)
 #pragma unroll
     for (int j = 0; j < V; ++j) sum += v[i].get(j);
-  }
   for (int o = tpr >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
   const float mean = sum / (float)C;
   float sq = 0.f;
@@ -183,7 +197,6 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const T *__restrict__ 
   for (int o = tpr >> 1; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
   const float rstd = rsqrtf(sq / (float)C + eps);
   if (!active) return;
-  const int b = row / L;
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {
     const int c0 = (i * tpr + sub) * V;
@@ -191,7 +204,7 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const T *__restrict__ 
 #pragma unroll
     for (int j = 0; j < V; ++j) {
       float y = (v[i].get(j) - mean) * rstd;
-      if (ss) y = fmaf(y, 1.0f + ss[(size_t)b * ss_ld + c0 + j], ss[(size_t)b * ss_ld + C + c0 + j]);
+      if (ss) y = fmaf(y, 1.0f + sc[i][j >> 2][j & 3], sh[i][j >> 2][j & 3]);
       o.set(j, y);
     }
     st16<T>(out + (size_t)row * out_ld + c0, o);
@@ -288,6 +301,7 @@ hipError_t ln_go(const void *x, int ld, const float *ss, int ss_ld, float eps, i
                  hipStream_t s) {
   constexpr int V = Vec16<T>::N;
   if (C % V) return hipErrorInvalidValue;
+  if (ss && ((ss_ld % 4) || (reinterpret_cast<uintptr_t>(ss) % 16))) return hipErrorInvalidValue;   // 16-byte scale/shift loads
   int vpr = C / V;
   int tpr = 1;
   while (tpr < 64 && tpr * 2 <= vpr) tpr *= 2;

@@ -6,7 +6,7 @@
 // 1x1x1 strided shortcut -- is the same MFMA implicit GEMM over channels-last activations
 // (rows = ((n*T + t)*H + h)*W + w), with the eval-mode BatchNorm folded into the weights/bias at build
 // time and ReLU / residual add fused in the epilogue.  Odd channel counts (45, 144, 230, 460, 921) are
-// zero-padded to multiples of 32 so that K slices never straddle taps.
+// zero-padded to multiples of 64 so that K slices never straddle taps.
 #include <algorithm>
 #include <exception>
 #include <memory>
@@ -52,8 +52,9 @@ Conv3 make_conv(sf_onsetnet &o, Packer &pk, const std::string &conv_name, const 
   Conv3 c;
   c.cin_real = cin;
   c.cout = cout;
-  c.cin_ld = cin < 32 ? pad_to(cin, 4) : pad_to(cin, 32);
-  c.cout_ld = pad_to(cout, 32);
+  // multiples of 64 so that every layer but the RGB stem runs on the main (v2) MFMA kernel
+  c.cin_ld = cin < 32 ? pad_to(cin, 4) : pad_to(cin, 64);
+  c.cout_ld = pad_to(cout, 64);
   c.kt = kt;
   c.kh = kh;
   c.kw = kw;

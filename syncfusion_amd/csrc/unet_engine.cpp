@@ -235,7 +235,7 @@ void build_group(Builder &bd, Group &g, const std::string &pre, int d, int &mod_
   g.conv2 = bd.conv(pre + ".resnet.conv2", C, C, 3, 0, true, thin, C, 0);
   // Modulation Linear -> rows of the shared per-step GEMM (filled by build())
   g.mod_off = mod_cols;
-  mod_cols += 2 * C;
+  mod_cols = pad_to(mod_cols + 2 * C, 4);
   const int ctx = c.context_channels[d];
   g.inject = bd.conv(pre + ".inject.conv", C, C, 1, ctx, true, thin, C, pad_to(ctx, 32));
   g.attn = c.attentions[d] != 0;
@@ -336,7 +336,7 @@ void build(sf_unet &u, const WeightMap *wm, hipStream_t s) {
     if (thin && cin > 32) fail(SF_ERR_UNSUPPORTED, "up conv at depth %d unsupported (%d -> %d)", d, b.C, cin);
     b.up = bd.conv(pre + ".up", cin, b.C, 3, 0, true, thin, b.C, 0);
     b.skip_off = mod_cols;
-    mod_cols += cin;
+    mod_cols = pad_to(mod_cols + cin, 4);   // every entry of the shared modulation vector starts 16-byte aligned
     b.down_items.assign(c.items[d], Group());
     b.up_items.assign(c.items[d], Group());
     for (int j = 0; j < c.items[d]; ++j) build_group(bd, b.down_items[j], pre + ".items_down." + std::to_string(j), d, mod_cols, ca_cols, n_ca);

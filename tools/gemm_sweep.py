@@ -14,6 +14,7 @@ def run(dt, B, L, Cc, N, taps, up, path, tile, sk, iters=50):
     return ms.value * 1e3 if rc == 0 else None
 
 shapes = [  # (name, B, L, C, N, taps)
+    ("onset-like 128ch", 8, 11264, 128, 256, 9), ("big square", 64, 704, 512, 512, 3),
     ("d7 conv3 B8", 8, 44, 1024, 1024, 3), ("d6 conv3 B8", 8, 88, 1024, 1024, 3), ("d5 conv3 B8", 8, 176, 512, 512, 3),
     ("d4 conv3 B8", 8, 352, 256, 256, 3), ("d3 conv3 B8", 8, 704, 128, 128, 3), ("d6 qkv B8", 8, 88, 1024, 1536, 1),
     ("d6 conv3 B32", 32, 88, 1024, 1024, 3), ("d4 conv3 B32", 32, 352, 256, 256, 3), ("d6 conv3 B64", 64, 88, 1024, 1024, 3),
