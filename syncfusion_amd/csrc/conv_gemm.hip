@@ -400,6 +400,7 @@ bool conv_gemm_supported(int dt, const ConvGemmArgs &a) {
 hipError_t launch_conv_gemm_sk(int dt, const ConvGemmArgs &a, hipStream_t s);
 int conv_gemm_sk_variant(const ConvGemmArgs &a);
 bool conv_gemm_fast_ok(int dt, const ConvGemmArgs &a);
+bool conv_gemm_wp_ok(int dt, const ConvGemmArgs &a);
 
 static bool use_sk(const ConvGemmArgs &a) {
   const int v = pick_variant(a);
@@ -422,6 +423,9 @@ const char *conv_gemm_variant_name(int dt, const ConvGemmArgs &a) {
     V2Plan pl;
     if (conv_gemm_v2_plan(dt, a, pl)) return conv_gemm_v2_name(dt, pl);
   }
+  static const char *wp_names[2][3] = {{"conv_gemm_wp<f32,32x32>", "conv_gemm_wp<f32,32x32>", "conv_gemm_wp<f32,32x32>"},
+                                       {"conv_gemm_wp<bf16,64x64>", "conv_gemm_wp<bf16,64x32>", "conv_gemm_wp<bf16,32x32>"}};
+  if ((short_act || use_sk(a)) && a.M <= 512 && a.K >= 2048 && conv_gemm_wp_ok(dt, a)) return wp_names[dt == F32 ? 0 : 1][conv_gemm_sk_variant(a)];
   if (short_act || use_sk(a)) return (conv_gemm_fast_ok(dt, a) ? fast_names : sk_names)[dt == F32 ? 0 : 1][conv_gemm_sk_variant(a)];
   int v = pick_variant(a);
   return v < 0 ? "conv_gemm<invalid>" : names[dt == F32 ? 0 : 1][v];
@@ -439,7 +443,7 @@ hipError_t launch_conv_gemm(int dt, const ConvGemmArgs &a, hipStream_t s) {
     if (conv_gemm_v2_plan(dt, a, pl)) return launch_conv_gemm_v2(dt, a, pl, s);
     if (f.path == 4) return hipErrorInvalidValue;
   }
-  if (f.path == 2 || (f.path == 0 && (short_act || use_sk(a)))) return launch_conv_gemm_sk(dt, a, s);
+  if (f.path == 2 || f.path == 5 || (f.path == 0 && (short_act || use_sk(a)))) return launch_conv_gemm_sk(dt, a, s);
   return dt == F32 ? dispatch<float>(a, s) : dispatch<bf16>(a, s);
 }
 

@@ -353,7 +353,8 @@ template <typename T, int BM, int BN> hipError_t launch_sk(const ConvGemmArgs &a
 
 // tile choice: the largest of 64x64 / 64x32 / 32x32 that still yields >= 224 workgroups
 int conv_gemm_sk_variant(const ConvGemmArgs &a) {
-  if (g_conv_gemm_force.path == 2 && g_conv_gemm_force.tile >= 0 && g_conv_gemm_force.tile <= 2) return g_conv_gemm_force.tile;
+  if ((g_conv_gemm_force.path == 2 || g_conv_gemm_force.path == 5) && g_conv_gemm_force.tile >= 0 && g_conv_gemm_force.tile <= 2)
+    return g_conv_gemm_force.tile;
   // measured (tools/gemm_sweep.py): on short activations the smallest tile wins at every U-Net shape -- more
   // workgroups in flight matter more than operand reuse
   auto blocks = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.n_store + bn - 1) / bn); };
@@ -364,10 +365,19 @@ int conv_gemm_sk_variant(const ConvGemmArgs &a) {
 
 bool conv_gemm_fast_ok(int dt, const ConvGemmArgs &a);
 hipError_t launch_conv_gemm_fast(int dt, const ConvGemmArgs &a, int variant, hipStream_t s);
+bool conv_gemm_wp_ok(int dt, const ConvGemmArgs &a);
+hipError_t launch_conv_gemm_wp(int dt, const ConvGemmArgs &a, int variant, hipStream_t s);
 
 hipError_t launch_conv_gemm_sk(int dt, const ConvGemmArgs &a, hipStream_t s) {
   if ((a.cin % 32) || (a.cin2 % 32) || (a.K % 32)) return hipErrorInvalidValue;
   const int v = conv_gemm_sk_variant(a);
+  // barrier-free wave-private pipelines: measured faster only on the shortest activations (M <= 512, long K);
+  // elsewhere the staged kernel wins because its loads are shared by more MFMA work per byte
+  const bool prefer_wp = g_conv_gemm_force.path == 5 || (g_conv_gemm_force.path == 0 && a.M <= 512 && a.K >= 2048);
+  if (prefer_wp && conv_gemm_wp_ok(dt, a)) {
+    hipError_t e = launch_conv_gemm_wp(dt, a, dt == F32 ? 2 : v, s);
+    if (e != hipErrorInvalidValue) return e;
+  }
   if (conv_gemm_fast_ok(dt, a)) return launch_conv_gemm_fast(dt, a, v, s);   // lean path (conv_gemm_fast.hip)
   if (dt == F32) {
     switch (v) {

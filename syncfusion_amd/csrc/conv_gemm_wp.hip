@@ -1,0 +1,325 @@
+// Wave-private split-K implicit GEMM ("wp") for SHORT activations: the deep U-Net levels at small batch
+// (M = B*L_d = 352..5632 rows, N <= 1536, K = 384..3072).
+//
+// Measured on the staged wave-split-K kernel (conv_gemm_fast.hip, rocprofv3 PMC, M=352 N=1024 K=3072): each wave
+// lives 32 k cycles for 24 K-chunks -- 1330 cycles per chunk for ~75 instructions and 2 MFMAs; 49 % of the wave
+// cycles are spent parked at s_waitcnt / s_barrier.  The four waves of a workgroup multiply DIFFERENT K slices, so
+// they share no operand: the two workgroup barriers per chunk only coupled four independent streams.
+//
+// Here every wave runs its own pipeline over its own quarter of K, with NO barrier in the loop:
+//   * full-line loads: one buffer_load_dwordx4 covers 8 rows x 128 B (a 64-wide K chunk of bf16 is exactly a line),
+//     offsets hoisted (streaming state as in conv_gemm_v2), out-of-range rows / K tails return zero;
+//   * two register sets keep the loads of chunks t+1 and t+2 in flight under the MFMAs of chunk t;
+//   * the chunk is transposed into MFMA fragment order through a WAVE-PRIVATE LDS region (same-wave LDS operations
+//     execute in order: only lgkmcnt waits, no s_barrier);
+//   * the four partial tiles meet once, in the epilogue (fixed-order sum through LDS -> deterministic).
+#include "common.h"
+#include "kernels.h"
+
+namespace sf {
+namespace {
+
+constexpr int BK = 64;
+constexpr unsigned OOB = 0x80000000u;
+
+template <typename T> __device__ __forceinline__ Vec16<T> buf_ld16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  Vec16<T> v;
+  u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+  v.v = __builtin_bit_cast(decltype(v.v), raw);
+  return v;
+}
+
+template <typename T, int BM, int BN, bool CAT>
+__global__ __launch_bounds__(256) void conv_gemm_wp_kernel(const ConvGemmArgs a, const int mtiles, const int ntiles, const int swz,
+                                                           const unsigned bytesA, const unsigned bytesA2, const unsigned bytesW) {
+  constexpr int VEC = Vec16<T>::N;
+  constexpr int ES = (int)sizeof(T);
+  constexpr int VPR = BK / VEC;          // vectors per 64-wide row: bf16 8, fp32 16
+  constexpr int RPI = 64 / VPR;          // rows one wave-instruction covers: 8 / 4
+  constexpr int PA = BM / RPI, PB = BN / RPI;
+  constexpr int LD = BK + 16 / ES;       // 144 B / 272 B rows: conflict-free b128 fragment reads
+  constexpr int TM = BM / 32, TN = BN / 32;
+  constexpr int LDR = BN + 4;
+  constexpr int WSTAGE = (BM + BN) * LD; // elements of one wave-private staging buffer
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  T *wlds = reinterpret_cast<T *>(smem) + (size_t)wave * 2 * WSTAGE;   // [2 buffers][A rows | W rows]
+  float *red = reinterpret_cast<float *>(smem);
+
+  int bid = blockIdx.x, mt, nt;
+  if (swz) {
+    const int xcd = bid & 7, j = bid >> 3;
+    nt = xcd + 8 * (j / mtiles);
+    mt = j % mtiles;
+  } else {
+    nt = bid / mtiles;
+    mt = bid % mtiles;
+  }
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int lrow = lane / VPR, lvec = lane % VPR;
+
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.src), 0, bytesA, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(CAT ? a.src2 : a.src), 0, CAT ? bytesA2 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.w), 0, bytesW, 0x00020000);
+
+  // ---- per staged row (once): clip base, first tap position, validity ------------------------------------------
+  int rbase[PA], rp0[PA];
+  unsigned roff2[PA], woff[PB], vmask[PA];
+  const int pmax = (a.Lsrc << a.up_shift) - 1;
+  const unsigned lane_b = (unsigned)(lvec * VEC * ES);
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int m = m0 + i * RPI + lrow;
+    const bool vm = m < a.M;
+    const int mm = vm ? m : 0;
+    vmask[i] = vm ? 0u : OOB;
+    const int b = mm / a.Lout, l = mm - b * a.Lout;
+    rbase[i] = b * a.Lsrc;
+    rp0[i] = l * a.stride - a.pad;
+    roff2[i] = CAT ? (((unsigned)(mm * a.src2_ld * ES) + lane_b) | vmask[i]) : OOB;
+  }
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    const int n = n0 + i * RPI + lrow;
+    woff[i] = n < a.N ? ((unsigned)(n * a.K * ES) + lane_b) : OOB;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- this wave's K range: a contiguous quarter of the 64-wide chunks ----------------------------------------
+  const int k_taps = a.taps * a.cin;
+  const int nk = (a.K + BK - 1) / BK;
+  const int per = (nk + 3) / 4;
+  const int c0 = wave * per;
+  const int nkt = max(0, min(per, nk - c0));
+
+  unsigned cur[PA], cb, kb;
+  int tap;
+  bool second = false;
+  const unsigned tap_bytes = (unsigned)(a.cin * ES), kbytes = (unsigned)(a.K * ES);
+  auto retap = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const int p = rp0[i] + t;
+      const unsigned bad = ((unsigned)p > (unsigned)pmax) ? OOB : 0u;
+      cur[i] = ((unsigned)(((rbase[i] + (max(p, 0) >> a.up_shift)) * a.src_ld) * ES) + lane_b) | bad | vmask[i];
+    }
+  };
+  {
+    const int k0 = c0 * BK;
+    kb = (unsigned)(k0 * ES);
+    if (CAT && k0 >= k_taps) {
+      second = true;
+      tap = a.taps;
+      cb = (unsigned)((k0 - k_taps) * ES);
+#pragma unroll
+      for (int i = 0; i < PA; ++i) cur[i] = roff2[i];
+    } else {
+      tap = min(k0 / a.cin, a.taps - 1);
+      cb = (unsigned)((k0 - tap * a.cin) * ES);
+      retap(tap);
+    }
+  }
+
+  struct RegSet {
+    Vec16<T> ra[PA], rb[PB];
+  };
+  RegSet s0, s1;
+  auto prefetch = [&](RegSet &R) {
+    const unsigned tmask = (kb + lane_b >= kbytes) ? OOB : 0u;
+#pragma unroll
+    for (int i = 0; i < PB; ++i) R.rb[i] = buf_ld16<T>(rW, (woff[i] + kb) | tmask);
+    const __amdgpu_buffer_rsrc_t rs = (CAT && second) ? rA2 : rA;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) R.ra[i] = buf_ld16<T>(rs, (cur[i] + cb) | tmask);
+    kb += (unsigned)(BK * ES);
+    cb += (unsigned)(BK * ES);
+    if (!second && cb >= tap_bytes) {
+      cb = 0;
+      ++tap;
+      if (tap < a.taps) retap(tap);
+      else {
+        second = true;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) cur[i] = roff2[i];
+      }
+    }
+  };
+  auto stage = [&](int buf, RegSet &R) {
+    T *As = wlds + buf * WSTAGE, *Bs = As + BM * LD;
+#pragma unroll
+    for (int i = 0; i < PB; ++i) st16<T>(Bs + (i * RPI + lrow) * LD + lvec * VEC, R.rb[i]);
+#pragma unroll
+    for (int i = 0; i < PA; ++i) st16<T>(As + (i * RPI + lrow) * LD + lvec * VEC, R.ra[i]);
+  };
+  const int fr = lane & 31, fh = lane >> 5;
+  auto compute = [&](int buf) {
+    const T *As = wlds + buf * WSTAGE, *Bs = As + BM * LD;
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int s = 0; s < BK / 16; ++s) {
+        bf16x8 af[TM], bfr[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8 *>(As + (i * 32 + fr) * LD + 16 * s + 8 * fh);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8 *>(Bs + (j * 32 + fr) * LD + 16 * s + 8 * fh);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        f32x4 af[TM], bfr[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4 *>(As + (i * 32 + fr) * LD + 32 * fh + 4 * q);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const f32x4 *>(Bs + (j * 32 + fr) * LD + 32 * fh + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bfr[j][e], acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+
+  // ---- the wave's own pipeline: no workgroup barrier --------------------------------------------------------
+  if (nkt > 0) prefetch(s0);
+  if (nkt > 1) prefetch(s1);
+  // Same-wave LDS operations execute in program order, so "write the chunk, then read the fragments" needs no
+  // s_barrier; the wave_barrier()s only stop the COMPILER from moving LDS accesses of different lanes across the
+  // stage/compute boundaries.
+  for (int kt = 0; kt < nkt; kt += 2) {
+    stage(0, s0);
+    __builtin_amdgcn_wave_barrier();
+    if (kt + 2 < nkt) prefetch(s0);
+    compute(0);
+    __builtin_amdgcn_wave_barrier();
+    if (kt + 1 < nkt) {
+      stage(1, s1);
+      __builtin_amdgcn_wave_barrier();
+      if (kt + 3 < nkt) prefetch(s1);
+      compute(1);
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+
+  // ---- the four partial tiles meet here --------------------------------------------------------------------
+  __syncthreads();   // every wave is done with its staging buffers (red aliases them)
+  float *myred = red + (size_t)wave * BM * LDR;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) myred[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LDR + j * 32 + fr] = acc[i][j][r];
+  __syncthreads();
+
+  T *out = static_cast<T *>(a.out);
+  const T *res = static_cast<const T *>(a.res);
+  const bool has_res = res != nullptr, has_bs = a.bscale != nullptr, has_ba = a.badd != nullptr;
+  constexpr int QN = BN / 4;
+#pragma unroll
+  for (int it = 0; it < (BM * QN + 255) / 256; ++it) {
+    const int idx = tid + it * 256;
+    const int ml = idx / QN, nq = idx - ml * QN;
+    const int m = m0 + ml, nb = n0 + nq * 4;
+    const bool live = idx < BM * QN && m < a.M && nb < a.n_store;
+    const int mc = min(m, a.M - 1);
+    float bi[4], rv[4], sv[4], av[4];
+    const int b = (has_bs || has_ba) ? mc / a.Lout : 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int nc = min(nb + e, a.N - 1);
+      bi[e] = a.bias ? a.bias[nc] : 0.f;
+      rv[e] = has_res ? to_f(res[(size_t)mc * a.res_ld + nc]) : 0.f;
+      sv[e] = has_bs ? a.bscale[(size_t)b * a.bscale_ld + nc] : 1.f;
+      av[e] = has_ba ? a.badd[(size_t)b * a.badd_ld + nc] : 0.f;
+    }
+    const int mlc = min(ml, BM - 1);
+    f32x4 v = *reinterpret_cast<const f32x4 *>(red + (size_t)mlc * LDR + nq * 4);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      f32x4 t = *reinterpret_cast<const f32x4 *>(red + ((size_t)w * BM + mlc) * LDR + nq * 4);
+      v[0] += t[0];
+      v[1] += t[1];
+      v[2] += t[2];
+      v[3] += t[3];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int n = nb + e;
+      float x = (v[e] + bi[e]) * sv[e] + rv[e] + av[e];
+      x = n < a.N ? apply_act(x, a.act) : 0.f;
+      if (live && n < a.n_store) {
+        if (a.out_f32) static_cast<float *>(a.out)[(size_t)m * a.out_ld + n] = x;
+        else out[(size_t)m * a.out_ld + n] = from_f<T>(x);
+      }
+    }
+  }
+}
+
+template <typename T, int BM, int BN, bool CAT> hipError_t launch_wp2(const ConvGemmArgs &a, hipStream_t s) {
+  constexpr int LD = BK + 16 / (int)sizeof(T);
+  constexpr size_t stage_bytes = (size_t)4 * 2 * (BM + BN) * LD * sizeof(T);
+  constexpr size_t red_bytes = (size_t)4 * BM * (BN + 4) * sizeof(float);
+  const size_t lds = stage_bytes > red_bytes ? stage_bytes : red_bytes;
+  if (lds > 150 * 1024) return hipErrorInvalidValue;   // fp32 64-row tiles do not fit: the caller falls back
+  const int mtiles = (a.M + BM - 1) / BM, ntiles = (a.n_store + BN - 1) / BN;
+  const int swz = (ntiles % 8 == 0) ? 1 : 0;
+  const size_t es = sizeof(T);
+  const size_t bA = (size_t)(a.M / a.Lout + (a.M % a.Lout ? 1 : 0)) * a.Lsrc * a.src_ld * es;
+  const size_t bA2 = CAT ? (size_t)a.M * a.src2_ld * es : 0;
+  const size_t bW = (size_t)a.N * a.K * es;
+  auto kern = conv_gemm_wp_kernel<T, BM, BN, CAT>;
+  static bool en = false;
+  if (!en) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e != hipSuccess) return e;
+    en = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(mtiles * ntiles), dim3(256), lds, s, a, mtiles, ntiles, swz, (unsigned)bA, (unsigned)bA2, (unsigned)bW);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+bool conv_gemm_wp_ok(int dt, const ConvGemmArgs &a) {
+  if (a.geom != 0 || a.pro != 0 || a.taps < 1) return false;
+  if ((a.cin % BK) || (a.cin2 % 32) || (a.K % 32)) return false;
+  const size_t es = dsize(dt), lim = 0x7FFFFFF0ull;
+  if ((size_t)(a.M / a.Lout + 1) * a.Lsrc * a.src_ld * es >= lim) return false;
+  if ((size_t)a.M * (a.src2_ld > 0 ? a.src2_ld : 1) * es >= lim) return false;
+  if ((size_t)a.N * a.K * es >= lim) return false;
+  return true;
+}
+
+// variant: 0 = 64x64, 1 = 64x32, 2 = 32x32
+hipError_t launch_conv_gemm_wp(int dt, const ConvGemmArgs &a, int variant, hipStream_t s) {
+#define SF_WP(T, BM, BN) (a.cin2 ? launch_wp2<T, BM, BN, true>(a, s) : launch_wp2<T, BM, BN, false>(a, s))
+  if (dt == F32) {
+    switch (variant) {
+      case 0: return SF_WP(float, 64, 64);
+      case 1: return SF_WP(float, 64, 32);
+      default: return SF_WP(float, 32, 32);
+    }
+  }
+  switch (variant) {
+    case 0: return SF_WP(bf16, 64, 64);
+    case 1: return SF_WP(bf16, 64, 32);
+    default: return SF_WP(bf16, 32, 32);
+  }
+#undef SF_WP
+}
+
+}  // namespace sf

@@ -21,7 +21,7 @@ shapes = [  # (name, B, L, C, N, taps)
 ]
 variants = [("auto", 0, -1, -1),
             ("wsk 64x64", 2, 0, -1), ("wsk 64x32", 2, 1, -1), ("wsk 32x32", 2, 2, -1),
-            ("wsk 64x64 kw32", 2, 0, 32), ("wsk 64x32 kw32", 2, 1, 32), ("wsk 32x32 kw32", 2, 2, 32),
+            ("wp 64x64", 5, 0, -1), ("wp 64x32", 5, 1, -1), ("wp 32x32", 5, 2, -1),
             ("v2 128x128", 4, 0, 1), ("v2 128x64", 4, 1, 1), ("v2 64x64", 4, 2, 1)]
 dt = 1 if (len(sys.argv) < 2 or sys.argv[1] == "bf16") else 0
 for name, B, L, Cc, N, taps in shapes:
