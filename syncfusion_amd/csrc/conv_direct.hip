@@ -62,19 +62,41 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvGemmArgs a) 
   for (int n = 0; n < NT; ++n) acc[n] = 0.f;
 
   const float2 *tb = tab + (size_t)(b - b_first) * a.cin;
+  constexpr int VI = Vec16<TI>::N;
+  const bool vec_ok = (a.cin % VI) == 0 && (a.src_ld % VI) == 0;
+  const int pmax = (a.Lsrc << a.up_shift) - 1;
   for (int tap = 0; tap < a.taps; ++tap) {
-    int p = l * a.stride + tap - a.pad;
-    if (p < 0 || p >= (a.Lsrc << a.up_shift)) continue;
-    const TI *row = src + (size_t)(b * a.Lsrc + (p >> a.up_shift)) * a.src_ld;
+    // unconditional loads from a clamped row; rows in the zero padding contribute through `live` = 0
+    const int p = l * a.stride + tap - a.pad;
+    const float live = (p >= 0 && p <= pmax) ? 1.f : 0.f;
+    const TI *row = src + (size_t)(b * a.Lsrc + (min(max(p, 0), pmax) >> a.up_shift)) * a.src_ld;
     const float *wk = wl + (size_t)tap * a.cin * NT;
-    for (int ci = 0; ci < a.cin; ++ci) {
-      float x = to_f(row[ci]);
-      if (a.pro == 1) {
-        float2 sd = tb[ci];
-        x = silu_t<FAST>(fmaf(x, sd.x, sd.y));
-      }
+    if (vec_ok) {
+      for (int c0 = 0; c0 < a.cin; c0 += VI) {
+        const Vec16<TI> v = ld16<TI>(row + c0);
 #pragma unroll
-      for (int n = 0; n < NT; ++n) acc[n] = fmaf(x, wk[ci * NT + n], acc[n]);
+        for (int j = 0; j < VI; ++j) {
+          float x = v.get(j);
+          if (a.pro == 1) {
+            const float2 sd = tb[c0 + j];
+            x = silu_t<FAST>(fmaf(x, sd.x, sd.y));
+          }
+          x *= live;
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[n] = fmaf(x, wk[(c0 + j) * NT + n], acc[n]);
+        }
+      }
+    } else {
+      for (int ci = 0; ci < a.cin; ++ci) {
+        float x = to_f(row[ci]);
+        if (a.pro == 1) {
+          const float2 sd = tb[ci];
+          x = silu_t<FAST>(fmaf(x, sd.x, sd.y));
+        }
+        x *= live;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[n] = fmaf(x, wk[ci * NT + n], acc[n]);
+      }
     }
   }
   if (a.cin2 > 0) {
@@ -87,21 +109,24 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvGemmArgs a) 
     }
   }
 
+  // epilogue: operand loads batched and unconditional, one predicated store pass
   TO *out = static_cast<TO *>(a.out) + (size_t)m * a.out_ld;
-  const TO *res = a.res ? static_cast<const TO *>(a.res) + (size_t)m * a.res_ld : nullptr;
+  const TO *res = static_cast<const TO *>(a.res);
+  const bool has_res = res != nullptr, has_bs = a.bscale != nullptr, has_ba = a.badd != nullptr;
+  float bi[NT], rv[NT], sv[NT], av[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
-    if (n < a.n_store) {
-      float v = 0.f;
-      if (n < a.N) {
-        v = acc[n] + (a.bias ? a.bias[n] : 0.f);
-        if (a.bscale) v *= a.bscale[(size_t)b * a.bscale_ld + n];
-        if (res) v += to_f(res[n]);
-        if (a.badd) v += a.badd[(size_t)b * a.badd_ld + n];
-        v = apply_act(v, a.act);
-      }
-      out[n] = from_f<TO>(v);
-    }
+    const int nc = min(n, a.N - 1);
+    bi[n] = a.bias ? a.bias[nc] : 0.f;
+    rv[n] = has_res ? to_f(res[(size_t)m * a.res_ld + nc]) : 0.f;
+    sv[n] = has_bs ? a.bscale[(size_t)b * a.bscale_ld + nc] : 1.f;
+    av[n] = has_ba ? a.badd[(size_t)b * a.badd_ld + nc] : 0.f;
+  }
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    float v = (acc[n] + bi[n]) * sv[n] + rv[n] + av[n];
+    v = n < a.N ? apply_act(v, a.act) : 0.f;
+    if (n < a.n_store) out[n] = from_f<TO>(v);
   }
 }
 

@@ -898,6 +898,12 @@ int sf_unet_forward(sf_unet *h, const float *x, const float *sigma, const float 
   if (two) SF_HIP(hipMemcpyAsync(sig2 + B, sigma, B * sizeof(float), hipMemcpyDeviceToDevice, s));
   h->prof.clear();
   h->ev_used = 0;
+  if (h->prof_on) {
+    // calibration record: the same event pair around an (almost) empty kernel = the fixed cost the HIP-event method
+    // adds to every launch (event processing + dispatch latency); bench.py subtracts it
+    int *scratch = p.step + 1;
+    for (int i = 0; i < 4; ++i) ex.timed("calib_empty", 0.0, 0.0, [&] { SF_HIP(launch_step_advance(scratch, s)); });
+  }
   ex.eval(x, sig2, nullptr);
   if (h->prof_on) {
     SF_HIP(hipStreamSynchronize(s));
