@@ -173,6 +173,18 @@ int sf_onsets_to_track(const float *logits, int N, int T, const int32_t *start_f
                        float frame_rate, float sample_rate, float threshold, float *track, int L, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Post-sampling resampler
+ *   replaces: torchaudio.functional.resample(gen[i, :, :cut_length].cpu(), orig_freq=sample_rate,
+ *   new_freq=downsample_rate) at main/generation.py:91-98 (torchaudio==0.13.1 defaults: windowed-sinc, Hann,
+ *   lowpass_filter_width 6, rolloff 0.99).  x: (R, L) fp32 rows; out: (R, ceil(new*L/orig)).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct sf_resampler sf_resampler;
+int sf_resampler_create(int orig_freq, int new_freq, int lowpass_filter_width, float rolloff, sf_resampler **out);
+void sf_resampler_destroy(sf_resampler *h);
+int sf_resampler_out_length(const sf_resampler *h, int L);
+int sf_resampler_forward(sf_resampler *h, const float *x, int R, int L, float *out, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Op-level entry points (channels-last, used by tests/ to localise kernel bugs).
  *   dtype selects the storage type of x / w / out (fp32 or bf16 bit patterns).
  * ---------------------------------------------------------------------------------------- */

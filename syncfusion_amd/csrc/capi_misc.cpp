@@ -1,5 +1,6 @@
 // Version / error / device probes, the onset glue and the op-level test entry points of the C ABI.
 #include <algorithm>
+#include <cmath>
 #include <exception>
 
 #include "engine_common.h"
@@ -38,6 +39,55 @@ int sf_onsets_to_track(const float *logits, int N, int T, const int32_t *start_f
   SF_API_BEGIN
   if (!logits || !track || N < 1 || T < 1 || L < 1 || frame_rate <= 0.f) fail(SF_ERR_INVALID, "bad argument");
   SF_HIP(launch_onsets_to_track(logits, N, T, start_frame, frame_rate, sample_rate, threshold, track, L, static_cast<hipStream_t>(stream)));
+  return SF_OK;
+  SF_API_END
+}
+
+}  // extern "C"
+
+#include <vector>
+namespace sf {
+void resample_bank(int orig_freq, int new_freq, int lowpass_filter_width, double rolloff, std::vector<float> &bank, int &orig,
+                   int &nnew, int &width);
+}
+struct sf_resampler {
+  int orig = 1, nnew = 1, width = 0;
+  float *bank = nullptr;
+  ~sf_resampler() {
+    if (bank) (void)hipFree(bank);
+  }
+};
+
+extern "C" {
+
+int sf_resampler_create(int orig_freq, int new_freq, int lowpass_filter_width, float rolloff, sf_resampler **out) {
+  SF_API_BEGIN
+  if (!out || orig_freq < 1 || new_freq < 1 || lowpass_filter_width < 1 || !(rolloff > 0.f && rolloff <= 1.f)) fail(SF_ERR_INVALID, "bad argument");
+  *out = nullptr;
+  std::vector<float> bank;
+  auto *h = new sf_resampler();
+  // rolloff arrives as a C float; the reference passes the Python double 0.99 -- use the nearest double of the decimal
+  const double ro = std::round((double)rolloff * 1e6) / 1e6;
+  resample_bank(orig_freq, new_freq, lowpass_filter_width, ro, bank, h->orig, h->nnew, h->width);
+  hipError_t e = hipMalloc(&h->bank, bank.size() * sizeof(float));
+  if (e == hipSuccess) e = hipMemcpy(h->bank, bank.data(), bank.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    delete h;
+    fail(SF_ERR_HIP, "resampler bank upload: %s", hipGetErrorString(e));
+  }
+  *out = h;
+  return SF_OK;
+  SF_API_END
+}
+void sf_resampler_destroy(sf_resampler *h) { delete h; }
+int sf_resampler_out_length(const sf_resampler *h, int L) {
+  if (!h || L < 0) return -1;
+  return (int)(((int64_t)h->nnew * L + h->orig - 1) / h->orig);   // ceil(new * L / orig)
+}
+int sf_resampler_forward(sf_resampler *h, const float *x, int R, int L, float *out, void *stream) {
+  SF_API_BEGIN
+  if (!h || !x || !out || R < 1 || L < 1) fail(SF_ERR_INVALID, "bad argument");
+  SF_HIP(launch_resample(x, R, L, h->bank, h->orig, h->nnew, h->width, out, sf_resampler_out_length(h, L), static_cast<hipStream_t>(stream)));
   return SF_OK;
   SF_API_END
 }

@@ -116,6 +116,10 @@ hipError_t launch_cfg_combine(const float *v_c, const float *v_u, float scale, f
 // mean over the spatial rows of a video activation: x:(N*T*HW, ld) -> out:(N*T, C) fp32
 hipError_t launch_spatial_mean(int dt, const void *x, int ld, int NT, int HW, int C, float *out, hipStream_t s);
 
+// polyphase sinc resampler (resample.hip): bank [nnew][2*width+orig] fp32 on the device; x:(R,L) -> out:(R,Lout)
+hipError_t launch_resample(const float *x, int R, int L, const float *bank, int orig, int nnew, int width, float *out, int Lout,
+                           hipStream_t s);
+
 // onset glue (sf_onsets_to_track)
 hipError_t launch_onsets_to_track(const float *logits, int N, int T, const int32_t *start_frame, float frame_rate,
                                   float sample_rate, float threshold, float *track, int L, hipStream_t s);

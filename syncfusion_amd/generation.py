@@ -17,6 +17,7 @@ from typing import Iterable, List, Optional, Sequence, Union
 import torch
 
 from . import _lib
+from .resample import resample
 
 Tensor = torch.Tensor
 
@@ -67,9 +68,6 @@ def generate_dataset(experiment_path: Union[str, Path], model, dataset: Iterable
                      cond_text: bool = False, one_chunk_per_track: bool = False, cut_length: Optional[int] = None,
                      downsample_rate: Optional[int] = None, save_cond: bool = False) -> List[Path]:
     """Same signature as main/generation.py:12-30.  ``dataset`` yields already-collated batches."""
-    if downsample_rate:
-        raise NotImplementedError("48 kHz -> 22.05 kHz polyphase resampling is the next row of the scope table (SURVEY 8f-2); "
-                                  "files are written at sample_rate")
     experiment_path = Path(experiment_path)
     experiment_path.mkdir(exist_ok=True, parents=True)
     if model_path:
@@ -88,9 +86,13 @@ def generate_dataset(experiment_path: Union[str, Path], model, dataset: Iterable
                 continue
         gen = generate_batch(model, y, z, text, num_steps=num_steps, length=length, embedding_scale=embedding_scale,
                              cut_prefix=cut_prefix, cond_text=cond_text, cut_length=cut_length)
+        out_sr = sample_rate
+        if downsample_rate:                                                       # :90-98, on the device instead of the CPU
+            gen = resample(gen, orig_freq=sample_rate, new_freq=downsample_rate)
+            out_sr = downsample_rate
         for i in range(B):
             name = f"{chunk_id}.wav" if not one_chunk_per_track else f"{str(filenames[i]).split('/')[-1]}.wav"
-            save_wav(experiment_path / name, gen[i], sample_rate)
+            save_wav(experiment_path / name, gen[i], out_sr)
             written.append(experiment_path / name)
             chunk_id += 1
     return written

@@ -321,3 +321,31 @@ def test_e2e_frames_to_audio_shapes(cuda, full_model):
     assert gen.shape == (B, 1, 44100) and torch.isfinite(gen).all()
     first = int(torch.nonzero(track[0, 0])[0])
     assert float(gen[0, :, :first].abs().max()) == 0.0
+
+
+def test_generate_dataset_writes_resampled_wavs(cuda, tmp_path):
+    """main/generation.py:49-122 end to end on a small model: resume-skip, cut_prefix, crop, device resample, wav files."""
+    import wave
+
+    from syncfusion_amd import Model, RandomEmbedder
+    from syncfusion_amd.generation import generate_dataset
+
+    dm = _small_diffusion(cuda)
+    enc = small_encoder_module().to(cuda)
+    model = Model(1e-4, 0.95, 0.999, 1e-6, 1e-3, dm, enc, RandomEmbedder(SMALL_UNET["embedding_features"]), None).to(cuda)
+    L = 16 * 60
+    g = torch.Generator().manual_seed(0)
+
+    def batches():
+        for _ in range(2):
+            y = torch.zeros(2, 1, L)
+            y[:, 0, 100] = 1.0
+            yield torch.zeros(2, 1, L), y, torch.randn(2, 1, L, generator=g) * 0.1, ["a", "b"], ["f0", "f1"]
+
+    kw = dict(num_steps=3, length=L, embedding_scale=2.0, cut_prefix=True, cut_length=800, sample_rate=48000, downsample_rate=22050)
+    files = generate_dataset(tmp_path, model, batches(), **kw)
+    assert [f.name for f in files] == ["0.wav", "1.wav", "2.wav", "3.wav"]
+    with wave.open(str(files[0])) as w:
+        assert w.getframerate() == 22050 and w.getnframes() == -(-147 * 800 // 320) and w.getnchannels() == 1
+    # second call: every batch's last file exists -> everything is skipped (the reference's crude resume, :52-59)
+    assert generate_dataset(tmp_path, model, batches(), **kw) == []

@@ -157,3 +157,16 @@ def test_onsets_to_track_matches_reference_formatting(cuda):
                 want[i, 0, pos] = 1.0
     got = onsets_to_track(logits.to(cuda), L, fps, sr, 0.5, start.to(cuda)).cpu()
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("orig,new,L", [(48000, 22050, 96000), (48000, 22050, 1001), (16000, 48000, 777), (44100, 44100, 100)])
+def test_resample_matches_oracle(cuda, orig, new, L):
+    """sf_resampler_forward vs the CPU restatement of torchaudio.functional.resample (main/generation.py:91-98)."""
+    from oracle import resample_ref
+    from syncfusion_amd.resample import resample
+
+    x = torch.randn(3, 1, L, generator=torch.Generator().manual_seed(L))
+    ref = resample_ref.resample(x, orig, new)
+    got = resample(x.to(cuda), orig, new)
+    assert got.shape == ref.shape
+    assert float((got.cpu() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))

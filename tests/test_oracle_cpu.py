@@ -142,3 +142,26 @@ def test_oracle_rejects_bad_context():
         unet_ref.unet_forward(P, cfg, x, sigma, embedding=emb, channels=chans)
     with pytest.raises(AssertionError):
         unet_ref.unet_forward(P, cfg, x, sigma, embedding=None, channels=chans)
+
+
+def test_resample_oracle_properties():
+    """Analytic anchors of the restated torchaudio resampler (main/generation.py:91-98):
+    output length ceil(new*L/orig) (96000 @ 48 kHz -> 44100 @ 22.05 kHz), DC gain ~ 1, a 1 kHz tone stays a 1 kHz
+    tone at the new rate, and content above the new Nyquist is removed."""
+    from oracle import resample_ref
+
+    sr, new, L = 48000, 22050, 96000
+    k, width, orig, nn = resample_ref.sinc_resample_kernel(sr, new)
+    assert (orig, nn, width) == (320, 147, 14) and tuple(k.shape) == (147, 1, 348)
+    t = torch.arange(L, dtype=torch.float64) / sr
+    tone = torch.sin(2 * math.pi * 1000.0 * t).float()[None]
+    out = resample_ref.resample(tone, sr, new)
+    assert out.shape == (1, 44100)
+    t2 = torch.arange(44100, dtype=torch.float64) / new
+    want = torch.sin(2 * math.pi * 1000.0 * t2).float()
+    assert float((out[0, 200:-200] - want[200:-200]).abs().max()) < 2e-3
+    dc = resample_ref.resample(torch.ones(1, L), sr, new)
+    assert float((dc[0, 200:-200] - 1).abs().max()) < 2e-3
+    hf = torch.sin(2 * math.pi * 15000.0 * t).float()[None]          # above the 11.025 kHz Nyquist of the output
+    assert float(resample_ref.resample(hf, sr, new)[0, 200:-200].abs().max()) < 5e-3
+    assert resample_ref.resample(tone, sr, sr) is tone
