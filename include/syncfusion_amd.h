@@ -87,6 +87,8 @@ int sf_unet_param_name(const sf_unet_config *cfg, int index, char *name_out, int
 /* Bytes of caller-allocated workspace needed for batch B and length L0 (two_pass != 0 when
  * embedding_scale != 1: cond and uncond evaluations run as one 2B batch). */
 int64_t sf_unet_workspace_bytes(const sf_unet *h, int B, int L0, int two_pass);
+/* Same for sf_vsample with `num_steps` steps (adds the sigma schedule and the per-step modulation table). */
+int64_t sf_vsample_workspace_bytes(const sf_unet *h, int B, int L0, int two_pass, int num_steps);
 
 /* One denoiser evaluation  v = net(x, sigma; channels, embedding, embedding_scale)
  *   (replaces UNetV0.forward, reached from main/module_diffusion.py:77 through VDiffusion).

@@ -101,8 +101,11 @@ class UNetEngine(_Base):
             if tuple(c.shape) != want:
                 raise AssertionError(f"context channels at depth {d}: expected {want}, got {tuple(c.shape)}")
 
-    def _ws_for(self, B: int, L0: int, two: bool) -> torch.Tensor:
-        n = self.lib.sf_unet_workspace_bytes(self.handle, B, L0, int(two))
+    def _ws_for(self, B: int, L0: int, two: bool, num_steps: int = 0) -> torch.Tensor:
+        if num_steps:
+            n = self.lib.sf_vsample_workspace_bytes(self.handle, B, L0, int(two), int(num_steps))
+        else:
+            n = self.lib.sf_unet_workspace_bytes(self.handle, B, L0, int(two))
         if n < 0:
             raise _lib.SyncFusionAmdError(f"unsupported shape B={B}, L0={L0}: {self.lib.sf_last_error().decode()}")
         return self._workspace(n, self.device)
@@ -135,7 +138,7 @@ class UNetEngine(_Base):
             x = _lib.f32c(x_noisy).clone()  # the caller's noise is not mutated (main/generation.py:69,77-83)
             ctx = [_lib.f32c(c) for c in channels]
             emb = _lib.f32c(embedding)
-            ws = self._ws_for(B, L0, float(embedding_scale) != 1.0)
+            ws = self._ws_for(B, L0, float(embedding_scale) != 1.0, int(num_steps))
             check(self.lib.sf_vsample(self.handle, x.data_ptr(), _lib.ptr_array(ctx), emb.data_ptr(), B, L0, int(num_steps),
                                       float(embedding_scale), int(bool(use_graph)), ws.data_ptr(), ws.numel(),
                                       _lib.stream_ptr(self.device)), "sf_vsample")

@@ -55,6 +55,7 @@ SYMBOLS = {
     "sf_unet_param_count": (_I, [C.POINTER(UnetConfig)]),
     "sf_unet_param_name": (_I, [C.POINTER(UnetConfig), _I, C.c_char_p, _I, C.POINTER(_L)]),
     "sf_unet_workspace_bytes": (_L, [_P, _I, _I, _I]),
+    "sf_vsample_workspace_bytes": (_L, [_P, _I, _I, _I, _I]),
     "sf_unet_forward": (_I, [_P, _P, _P, C.POINTER(_P), _P, _I, _I, _F, _P, _P, _L, _P]),
     "sf_vsample": (_I, [_P, _P, C.POINTER(_P), _P, _I, _I, _I, _F, _I, _P, _L, _P]),
     "sf_unet_debug_enable": (_I, [_P, _P, _L]),

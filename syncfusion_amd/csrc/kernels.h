@@ -108,6 +108,8 @@ hipError_t launch_time_fourier(int dt, const float *sig, const int *sig_idx, con
 //   x <- a1*(a0*x - b0*v) + b1*(b0*x + a0*v),  (a0,b0,a1,b1) = sched[*step_idx][0..3].
 hipError_t launch_vsampler_update(float *x, const float *v, const float *v_uncond, float scale, const float *sched,
                                   const int *step_idx, int64_t n, hipStream_t s);
+// cur[0..ld) = table[*step_idx][0..ld), then (*step_idx)++  (single workgroup; first kernel of a sampling step)
+hipError_t launch_step_select(const float *table, int ld, int *step_idx, float *cur, hipStream_t s);
 // (*step_idx)++ -- its own 1-thread launch so that no kernel of a step races with the increment
 hipError_t launch_step_advance(int *step_idx, hipStream_t s);
 // out = v_u + (v_c - v_u) * scale   (single forward with CFG)

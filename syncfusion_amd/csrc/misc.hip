@@ -82,6 +82,20 @@ __global__ void vsampler_update_kernel(float *__restrict__ x, const float *__res
     x[i] = a1 * x_pred + b1 * n_pred;
   }
 }
+// First kernel of a sampling step: row (*step) of the per-step table -> cur, then (*step)++.  Thread 0 reads the
+// counter before anyone writes it and publishes the row index through LDS; every later kernel of the step sees the
+// incremented counter (they index with *step - 1), so nothing races with the increment.
+__global__ void step_select_kernel(const float *__restrict__ table, int ld, int *step_idx, float *__restrict__ cur) {
+  __shared__ int row;
+  if (threadIdx.x == 0) {
+    row = *step_idx;
+    *step_idx = row + 1;
+  }
+  __syncthreads();
+  const float4 *src = reinterpret_cast<const float4 *>(table + (size_t)row * ld);   // ld % 4 == 0, 16-byte aligned rows
+  float4 *dst = reinterpret_cast<float4 *>(cur);
+  for (int i = threadIdx.x; i < ld / 4; i += blockDim.x) dst[i] = src[i];
+}
 __global__ void step_advance_kernel(int *step_idx) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *step_idx = *step_idx + 1;
 }
@@ -193,6 +207,10 @@ hipError_t launch_time_fourier(int dt, const float *sig, const int *sig_idx, con
 hipError_t launch_vsampler_update(float *x, const float *v, const float *v_uncond, float scale, const float *sched,
                                   const int *step_idx, int64_t n, hipStream_t s) {
   hipLaunchKernelGGL(vsampler_update_kernel, grid_for(n), dim3(TPB), 0, s, x, v, v_uncond, scale, sched, step_idx, n);
+  return hipGetLastError();
+}
+hipError_t launch_step_select(const float *table, int ld, int *step_idx, float *cur, hipStream_t s) {
+  hipLaunchKernelGGL(step_select_kernel, dim3(1), dim3(1024), 0, s, table, ld, step_idx, cur);
   return hipGetLastError();
 }
 hipError_t launch_step_advance(int *step_idx, hipStream_t s) {

@@ -58,6 +58,12 @@ struct Plan {  // everything carved out of the caller's workspace for one (B, L0
   int *step = nullptr;
   int nbr = 1;                 // clip-parallel branches
   int64_t slab_stride = 0;     // floats of GroupNorm scratch per branch
+  // modulation vectors: per clip ([Bt][mod_ld], mod_stride = mod_ld) for a single forward, or ONE row shared by all
+  // clips (mod_stride = 0) inside the sampler, where sigma is the same for every clip and the rows of all steps are
+  // computed once per call (mod_steps [steps][mod_ld])
+  int mod_stride = 0;
+  float *mod_steps = nullptr;
+  int steps_cap = 0;
   float *sk_slab = nullptr;    // grid split-K partial tiles (per branch: sk_stride floats)
   int *sk_cnt = nullptr;       // arrival tickets (per branch: kSkCnt ints), zeroed once per call
   int64_t sk_stride = 0;
@@ -423,6 +429,9 @@ Plan make_plan(const sf_unet &u, Workspace &ws, int B, int L0, bool two, int num
   p.x2 = ws.alloc_n<float>(n0);
   p.vout = ws.alloc_n<float>(n0);
   p.mod_all = ws.alloc_n<float>((int64_t)p.Bt * u.mod_ld);
+  p.mod_stride = u.mod_ld;
+  p.steps_cap = num_steps > 1 ? num_steps : 0;
+  if (p.steps_cap) p.mod_steps = ws.alloc_n<float>((int64_t)p.steps_cap * u.mod_ld);
   p.ca_all = ws.alloc_n<float>((int64_t)p.Bt * u.ca_ld);
   p.slab = ws.alloc_n<float>(slab_floats);
   {
@@ -436,10 +445,11 @@ Plan make_plan(const sf_unet &u, Workspace &ws, int B, int L0, bool two, int num
     p.sk_slab = ws.alloc_n<float>(p.sk_stride * p.nbr);
     p.sk_cnt = ws.alloc_n<int>((int64_t)kSkCnt * sf_unet::kMaxBranches);
   }
-  p.four = ws.alloc((int64_t)p.Bt * u.four_ld * es);
-  p.f1 = ws.alloc((int64_t)p.Bt * u.mf * es);
-  p.f2 = ws.alloc((int64_t)p.Bt * u.mf * es);
-  p.sf = ws.alloc((int64_t)p.Bt * u.mf * es);
+  const int64_t frows = std::max<int64_t>(p.Bt, p.steps_cap);
+  p.four = ws.alloc(frows * u.four_ld * es);
+  p.f1 = ws.alloc(frows * u.mf * es);
+  p.f2 = ws.alloc(frows * u.mf * es);
+  p.sf = ws.alloc(frows * u.mf * es);
   p.emb2 = ws.alloc_n<float>((int64_t)p.Bt * c.embedding_features);
   p.emb_t = ws.alloc((int64_t)p.Bt * c.embedding_features * es);
   p.xhat_e = ws.alloc((int64_t)p.Bt * c.embedding_features * es);
@@ -571,7 +581,7 @@ struct Exec {
     conv3(g.conv2, tA, tB, g.gn2_g, g.gn2_b, cur);
     // Modulation: LN_C(x; eps 1e-6) * (1 + scale) + shift
     timed("ln_modulate", 8.0 * l.rows * C, 2.0 * l.rows * C * dsize(u.dt),
-          [&] { SF_HIP(launch_ln_modulate(u.dt, tB, C, p.mod_all + g.mod_off, u.mod_ld, 1e-6f, p.Bt, l.L, C, tA, C, s)); });
+          [&] { SF_HIP(launch_ln_modulate(u.dt, tB, C, p.mod_all + g.mod_off, p.mod_stride, 1e-6f, p.Bt, l.L, C, tA, C, s)); });
     // InjectChannels: Conv1x1(cat[x, ctx]) + x   (+ collapsed cross-attention bias when no self-attention follows)
     {
       ConvGemmArgs a;
@@ -691,7 +701,7 @@ struct Exec {
       a.res = xin;
       a.res_ld = b.cin;
       a.bscale = p.mod_all + b.skip_off;
-      a.bscale_ld = u.mod_ld;
+      a.bscale_ld = p.mod_stride;
       if (xout_dt != u.dt && !b.up.direct) fail(SF_ERR_UNSUPPORTED, "depth 0 must be a thin level (channels[0] %% 32 != 0)");
       conv(b.up, a, u.dt, xout_dt);
     }
@@ -699,13 +709,15 @@ struct Exec {
   }
 
   // features + modulation vectors of one step; sigma from sig[b] (sig_idx == nullptr) or sig[*sig_idx]
-  void features(const float *sig, const int *sig_idx) {
-    timed("time_fourier", 0.0, (double)p.Bt * u.four_ld * dsize(u.dt),
-          [&] { SF_HIP(launch_time_fourier(u.dt, sig, sig_idx, u.fourier_w, p.Bt, u.half, p.four, u.four_ld, s)); });
-    dense(u.lin0, p.four, u.four_ld, p.Bt, p.f1, u.mf, /*gelu*/ 2, false);
-    dense(u.mlp0, p.f1, u.mf, p.Bt, p.f2, u.mf, 2, false);
-    dense(u.mlp1, p.f2, u.mf, p.Bt, p.sf, u.mf, /*silu(gelu)*/ 3, false);
-    dense(u.mod, p.sf, u.mf, p.Bt, p.mod_all, u.mod_ld, 0, true);
+  void features(const float *sig, const int *sig_idx) { features_rows(sig, sig_idx, p.Bt, p.mod_all); }
+  // rows x (time MLP -> all Modulation / SkipModulate vectors); row r uses sigma sig[r] (or sig[*sig_idx])
+  void features_rows(const float *sig, const int *sig_idx, int rows, float *mod_out) {
+    timed("time_fourier", 0.0, (double)rows * u.four_ld * dsize(u.dt),
+          [&] { SF_HIP(launch_time_fourier(u.dt, sig, sig_idx, u.fourier_w, rows, u.half, p.four, u.four_ld, s)); });
+    dense(u.lin0, p.four, u.four_ld, rows, p.f1, u.mf, /*gelu*/ 2, false);
+    dense(u.mlp0, p.f1, u.mf, rows, p.f2, u.mf, 2, false);
+    dense(u.mlp1, p.f2, u.mf, rows, p.sf, u.mf, /*silu(gelu)*/ 3, false);
+    dense(u.mod, p.sf, u.mf, rows, mod_out, u.mod_ld, 0, true);
   }
 
   // per-call conditioning: context pyramids to channels-last, cross-attention collapse
@@ -763,7 +775,7 @@ struct Exec {
     const int64_t n0 = (int64_t)br * bt * p.L0 * u.cfg.in_channels;
     v.x2 = p.x2 + n0;
     v.vout = p.vout + n0;
-    v.mod_all = p.mod_all + (int64_t)br * bt * u.mod_ld;
+    v.mod_all = p.mod_all + (int64_t)br * bt * p.mod_stride;
     v.ca_all = p.ca_all + (int64_t)br * bt * u.ca_ld;
     v.slab = p.slab + (int64_t)br * p.slab_stride;
     v.sk_slab = p.sk_slab + (int64_t)br * p.sk_stride;
@@ -772,13 +784,18 @@ struct Exec {
   }
 
   // one U-Net evaluation of the (possibly doubled) batch: x (B rows) -> p.vout (Bt rows)
-  void eval(const float *x, const float *sig, const int *sig_idx) {
+  void eval(const float *x, const float *sig, const int *sig_idx, bool features_ready = false) {
     const int64_t n = (int64_t)p.B * p.L0 * u.cfg.in_channels;
-    SF_HIP(hipMemcpyAsync(p.x2, x, n * sizeof(float), hipMemcpyDeviceToDevice, s));
-    if (p.two) SF_HIP(hipMemcpyAsync(p.x2 + n, x, n * sizeof(float), hipMemcpyDeviceToDevice, s));
-    features(sig, sig_idx);
+    // classifier-free guidance evaluates [x ; x] as one 2B batch; a single pass reads the caller's x in place
+    float *xin = const_cast<float *>(x);
+    if (p.two) {
+      SF_HIP(hipMemcpyAsync(p.x2, x, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+      SF_HIP(hipMemcpyAsync(p.x2 + n, x, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+      xin = p.x2;
+    }
+    if (!features_ready) features(sig, sig_idx);
     if (p.nbr <= 1) {
-      block(0, p.x2, F32, p.vout, F32);
+      block(0, xin, F32, p.vout, F32);
       return;
     }
     const bool serial = u.prof_on;   // instrumented pass: same kernel shapes, one after another on the launch stream
@@ -791,7 +808,7 @@ struct Exec {
       hipStream_t sb = (serial || br == 0) ? s : u.bstream[br];
       if (sb != s) SF_HIP(hipStreamWaitEvent(sb, u.ev_fork, 0));
       Exec eb{u, v, sb};
-      eb.block(0, v.x2, F32, v.vout, F32);
+      eb.block(0, xin + (v.x2 - p.x2), F32, v.vout, F32);
       if (sb != s) SF_HIP(hipEventRecord(u.ev_join[br], sb));
     }
     if (!serial)
@@ -871,7 +888,19 @@ int64_t sf_unet_workspace_bytes(const sf_unet *h, int B, int L0, int two_pass) {
   try {
     if (!h) fail(SF_ERR_INVALID, "null handle");
     Workspace dry(nullptr, 0);
-    make_plan(*h, dry, B, L0, two_pass != 0, 4096);
+    make_plan(*h, dry, B, L0, two_pass != 0, 1);
+    return dry.used();
+  } catch (const EngineError &) {
+    return -1;
+  }
+}
+
+int64_t sf_vsample_workspace_bytes(const sf_unet *h, int B, int L0, int two_pass, int num_steps) {
+  try {
+    if (!h) fail(SF_ERR_INVALID, "null handle");
+    if (num_steps < 1) fail(SF_ERR_INVALID, "num_steps must be >= 1");
+    Workspace dry(nullptr, 0);
+    make_plan(*h, dry, B, L0, two_pass != 0, num_steps);
     return dry.used();
   } catch (const EngineError &) {
     return -1;
@@ -970,10 +999,25 @@ int sf_vsample(sf_unet *h, float *x, const float *const *ctx, const float *emb, 
   SF_HIP(hipStreamSynchronize(s));  // `host` goes out of scope; pageable H2D copies are staged, but be explicit
 
   const int64_t n = (int64_t)B * L0 * h->cfg.in_channels;
+  // sigma_i is the same for every clip, so the time MLP and the 42 Modulation / SkipModulate projections of ALL steps
+  // are one set of GEMMs with M = num_steps, once per call (instead of five launches inside every step); a step then
+  // starts by selecting its row (which also advances the device step counter) and every consumer reads that one row
+  // for all clips (clip stride 0).
+  const bool pre = T > 1 && p.mod_steps != nullptr;
+  if (pre) {
+    ex.features_rows(sigs, nullptr, T, p.mod_steps);
+    p.mod_stride = 0;
+  }
   auto one_step = [&]() {
-    ex.eval(x, sigs, p.step);
-    SF_HIP(launch_vsampler_update(x, p.vout, two ? p.vout + n : nullptr, embedding_scale, sched, p.step, n, s));
-    SF_HIP(launch_step_advance(p.step, s));
+    if (pre) {
+      SF_HIP(launch_step_select(p.mod_steps, h->mod_ld, p.step, p.mod_all, s));
+      ex.eval(x, nullptr, nullptr, /*features_ready=*/true);
+      SF_HIP(launch_vsampler_update(x, p.vout, two ? p.vout + n : nullptr, embedding_scale, sched - 4, p.step, n, s));   // *step == i + 1 here
+    } else {
+      ex.eval(x, sigs, p.step);
+      SF_HIP(launch_vsampler_update(x, p.vout, two ? p.vout + n : nullptr, embedding_scale, sched, p.step, n, s));
+      SF_HIP(launch_step_advance(p.step, s));
+    }
   };
 
   h->launches = 0;
