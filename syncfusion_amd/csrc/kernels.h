@@ -61,6 +61,33 @@ const char *conv_gemm_variant_name(int dt, const ConvGemmArgs &a);
 bool conv_gemm_supported(int dt, const ConvGemmArgs &a);
 
 // ---------------------------------------------------------------------------------------
+// Thin-level convolution (conv_thin.hip): C = 32 / 64 channels on long sequences, one workgroup per `rw` consecutive
+// positions of a clip.  out[b,l,:] = W . [pro(src)[b, l-1..l+1, :]  |  src2[b,l,:]] + bias (+ res) (+ badd[b])
+//   pro 1: SiLU(GroupNorm(src))  with statistics merged from stats_in [B][nch_in][G][2] (mean, M2 per chunk_in rows)
+//   pro 2: LayerNorm_C(src; eps) * (1 + ss[b][c]) + ss[b][C + c]   (ss == nullptr: plain normalisation)
+//   res_self: the residual is pro(src) itself (InjectChannels after Modulation);  stats_out (optional): (mean, M2) of the
+//   stored output per (clip, workgroup, group) = a slab with nch = nchw, chunk_rows = rw for the next GroupNorm.
+// Weights: the packed [N = C][K = taps*C + C2] matrix of the implicit-GEMM path (compute type).
+// ---------------------------------------------------------------------------------------
+struct ConvThinArgs {
+  const void *src = nullptr, *src2 = nullptr, *w = nullptr, *res = nullptr;
+  void *out = nullptr;
+  const float *bias = nullptr, *gamma = nullptr, *beta = nullptr, *stats_in = nullptr, *ss = nullptr, *badd = nullptr;
+  float *stats_out = nullptr;
+  int B = 0, L = 0, C = 0, C2 = 0, taps = 1;
+  int src_ld = 0, src2_ld = 0, out_ld = 0, res_ld = 0, ss_ld = 0, badd_ld = 0;
+  int pro = 0, res_self = 0, G = 1, nch_in = 1, chunk_in = 1;
+  float eps = 1e-5f;
+  int rw = 32, nchw = 1;
+};
+struct ThinPlan {
+  int rw = 32, nchw = 1;
+};
+ThinPlan conv_thin_plan(int B, int L);
+bool conv_thin_supported(int dt, const ConvThinArgs &a);
+hipError_t launch_conv_thin(int dt, const ConvThinArgs &a, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------
 // Direct (VALU) convolution for thin layers (Cin*taps small, N <= 32): one output row per thread.
 // Same A/epilogue semantics as ConvGemmArgs (1-D geometry only); weights fp32 [N][taps*cin + cin2].
 // ---------------------------------------------------------------------------------------

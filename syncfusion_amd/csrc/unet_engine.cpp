@@ -58,6 +58,7 @@ struct Plan {  // everything carved out of the caller's workspace for one (B, L0
   int *step = nullptr;
   int nbr = 1;                 // clip-parallel branches
   int64_t slab_stride = 0;     // floats of GroupNorm scratch per branch
+  int64_t slab_half = 0;       // second statistics slab of a branch starts here
   // modulation vectors: per clip ([Bt][mod_ld], mod_stride = mod_ld) for a single forward, or ONE row shared by all
   // clips (mod_stride = 0) inside the sampler, where sigma is the same for every clip and the rows of all steps are
   // computed once per call (mod_steps [steps][mod_ld])
@@ -422,7 +423,15 @@ Plan make_plan(const sf_unet &u, Workspace &ws, int B, int L0, bool two, int num
     if (want > sf_unet::kMaxBranches) want = sf_unet::kMaxBranches;
     while (want > 1 && p.Bt % want) --want;
     p.nbr = u.dbg.buf ? 1 : want;
-    p.slab_stride = (int64_t)(p.Bt / p.nbr) * 32 * c.resnet_groups * 2;
+    // GroupNorm partial-statistics scratch per branch: two slabs (statistics of x and of the hidden activation),
+    // each [clips][chunks][groups][2]; the thin levels chunk by their workgroup tile (conv_thin_plan)
+    int64_t one = (int64_t)(p.Bt / p.nbr) * 32 * c.resnet_groups * 2;
+    for (int d = 0; d < c.n_layers; ++d) {
+      const ThinPlan tp = conv_thin_plan(p.Bt / p.nbr, p.lv[d].L);
+      one = std::max<int64_t>(one, (int64_t)(p.Bt / p.nbr) * tp.nchw * c.resnet_groups * 2);
+    }
+    p.slab_half = align_up(one, 64);
+    p.slab_stride = 2 * p.slab_half;
     slab_floats = p.slab_stride * p.nbr;
   }
   const int64_t n0 = (int64_t)p.Bt * L0 * c.in_channels;
@@ -468,6 +477,7 @@ struct Exec {
   sf_unet &u;
   Plan &p;
   hipStream_t s;
+  const void *stats_of = nullptr;   // thin levels: the activation whose GroupNorm partials currently sit in p.slab
 
   template <class F> void timed(const char *label, double flops, double bytes, F &&f) {
     ++u.launches;
@@ -546,6 +556,12 @@ struct Exec {
     // column tile and tap of the wide layers.
     // Thin levels (C <= 64: at most two column tiles) keep the activation in the conv's A-load instead
     // (statistics from gn_stats): their tensors are long and the extra activated copy would cost more.
+    if (group_thin(g, d, cur, tA, tB)) {
+      if (!g.attn) {
+        u.dbg.tap(tapname, u.dt, cur, C, l.rows, C, s);
+        return;
+      }
+    } else {
     const bool fuse_act = C <= 64;
     GnPlan gp = gn_plan(p.Bt, l.L, C);
     auto conv3 = [&](const ConvW &w, const void *in, void *out, const float *gam, const float *bet, const void *res) {
@@ -601,6 +617,7 @@ struct Exec {
       }
       conv(g.inject, a, u.dt, u.dt);
     }
+    }   // generic (non-thin) resnet / modulation / inject
     if (g.attn) {
       // x + W_o MHA(W_q LN_a(x), W_kv LN_b(x)): the two LayerNorms share (mean, rstd); their affines are folded.
       timed("ln_modulate", 6.0 * l.rows * C, 2.0 * l.rows * C * dsize(u.dt),
@@ -646,6 +663,94 @@ struct Exec {
     u.dbg.tap(tapname, u.dt, cur, C, l.rows, C, s);
   }
 
+  // Thin level (C = 32 / 64): the item is three conv_thin launches -- conv1 [GN+SiLU in, statistics of h out],
+  // conv2 [GN+SiLU in, + x], inject [LayerNorm-modulate in, + itself, (+ cross-attention bias), statistics out] --
+  // instead of gn_stats, conv, gn_stats, conv, ln_modulate, conv.  Returns false when the shape is not covered.
+  // On return: no attention -> result in cur; attention -> inject output in tB (what the attention code expects).
+  bool group_thin(const Group &g, int d, void *&cur, void *&tA, void *&tB) {
+    const Level &l = p.lv[d];
+    const Block &b = u.blocks[d];
+    const int C = l.C, G = u.cfg.resnet_groups;
+    if (g.conv1.direct || g.inject.direct || g.conv1.cin != C || g.inject.cin != C) return false;
+    const ThinPlan tp = conv_thin_plan(p.Bt, l.L);
+    ConvThinArgs base;
+    base.B = p.Bt;
+    base.L = l.L;
+    base.C = C;
+    base.G = G;
+    base.rw = tp.rw;
+    base.nchw = tp.nchw;
+    base.nch_in = tp.nchw;
+    base.chunk_in = tp.rw;
+    base.src_ld = base.out_ld = base.res_ld = C;
+    ConvThinArgs a1 = base, a3 = base;
+    a1.taps = 3;
+    a1.pro = 1;
+    a3.taps = 1;
+    a3.pro = 2;
+    a3.C2 = g.inject.cin2;
+    if (!conv_thin_supported(u.dt, a1) || !conv_thin_supported(u.dt, a3)) return false;
+    float *sA = p.slab, *sB = p.slab + p.slab_half;
+    const double es = dsize(u.dt), rc = (double)l.rows * C;
+    if (stats_of != cur)
+      timed("gn_stats", 3.0 * rc, rc * es, [&] { SF_HIP(launch_gn_stats(u.dt, cur, C, p.Bt, l.L, C, G, tp.nchw, tp.rw, sA, s)); });
+    {
+      ConvThinArgs a = a1;
+      a.src = cur;
+      a.w = g.conv1.w;
+      a.bias = g.conv1.bias;
+      a.gamma = g.gn1_g;
+      a.beta = g.gn1_b;
+      a.stats_in = sA;
+      a.stats_out = sB;
+      a.out = tA;
+      timed("conv_thin", 2.0 * rc * 3 * C, 2.0 * rc * es + 3.0 * C * C * es, [&] { SF_HIP(launch_conv_thin(u.dt, a, s)); });
+    }
+    {
+      ConvThinArgs a = a1;
+      a.src = tA;
+      a.w = g.conv2.w;
+      a.bias = g.conv2.bias;
+      a.gamma = g.gn2_g;
+      a.beta = g.gn2_b;
+      a.stats_in = sB;
+      a.res = cur;
+      a.out = tB;
+      timed("conv_thin", 2.0 * rc * 3 * C, 3.0 * rc * es + 3.0 * C * C * es, [&] { SF_HIP(launch_conv_thin(u.dt, a, s)); });
+    }
+    {
+      ConvThinArgs a = a3;
+      a.src = tB;
+      a.src2 = l.ctx;
+      a.src2_ld = b.ctx_ld;
+      a.w = g.inject.w;
+      a.bias = g.inject.bias;
+      a.ss = p.mod_all + g.mod_off;
+      a.ss_ld = p.mod_stride;
+      a.eps = 1e-6f;
+      a.res_self = 1;
+      if (g.cross && !g.attn) {
+        a.badd = p.ca_all + g.ca_off;
+        a.badd_ld = u.ca_ld;
+      }
+      a.stats_out = g.attn ? nullptr : sA;
+      a.out = tA;
+      const double kin = g.inject.kreal > 0 ? g.inject.kreal : g.inject.K;
+      timed("conv_thin", 2.0 * rc * kin + 8.0 * rc, 2.0 * rc * es + (double)l.rows * (kin - C) * es + kin * C * es,
+            [&] { SF_HIP(launch_conv_thin(u.dt, a, s)); });
+    }
+    if (g.attn) {
+      std::swap(tA, tB);   // inject output -> tB, tA free
+      stats_of = nullptr;
+    } else {
+      void *o = cur;
+      cur = tA;
+      tA = o;
+      stats_of = cur;
+    }
+    return true;
+  }
+
   // Block d: skip + scale * Up(items_up(inner(items_down(Down(x)))))
   void block(int d, const void *xin, int xin_dt, void *xout, int xout_dt) {
     const sf_unet_config &c = u.cfg;
@@ -678,12 +783,14 @@ struct Exec {
     }
     const std::string pre = "d" + std::to_string(d);
     u.dbg.tap(pre + ".down", u.dt, cur, l.C, l.rows, l.C, s);
+    stats_of = nullptr;
     for (size_t j = 0; j < b.down_items.size(); ++j) group(b.down_items[j], d, cur, tA, tB, pre + ".items_down." + std::to_string(j));
     if (d + 1 < c.n_layers) {
       block(d + 1, cur, u.dt, tA, u.dt);
       void *o = cur;
       cur = tA;
       tA = o;
+      stats_of = nullptr;   // deeper levels share the statistics slabs
     }
     for (size_t j = 0; j < b.up_items.size(); ++j) group(b.up_items[j], d, cur, tA, tB, pre + ".items_up." + std::to_string(j));
     {
