@@ -20,6 +20,7 @@
 // K is cut in slots of 8 channels: slot -> (tap, channel octet) for the convolution input, then the octets of the
 // second source (InjectChannels concatenates [x, context]).  MFMA step s takes slot 2s on lanes 0-31 and slot 2s+1 on
 // lanes 32-63 (bf16: one 32x32x16; fp32 parity path: eight 32x32x2).
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -98,23 +99,58 @@ __device__ __forceinline__ float2 gn_merge_n(const float *__restrict__ sl, int G
   return make_float2(mu, rsqrtf(var + eps));
 }
 
+// four consecutive channels of one position (epilogue granularity)
+template <typename T> struct K4;
+template <> struct K4<bf16> {
+  uint2 raw;
+  __device__ __forceinline__ float get(int i) const {
+    const unsigned int w = i < 2 ? raw.x : raw.y;
+    return __uint_as_float((i & 1) ? (w & 0xffff0000u) : (w << 16));
+  }
+  __device__ __forceinline__ static K4 load(const bf16 *p) {
+    K4 r;
+    r.raw = *reinterpret_cast<const uint2 *>(p);
+    return r;
+  }
+  __device__ __forceinline__ static K4 zero() {
+    K4 r;
+    r.raw = make_uint2(0u, 0u);
+    return r;
+  }
+};
+template <> struct K4<float> {
+  f32x4 v;
+  __device__ __forceinline__ float get(int i) const { return v[i]; }
+  __device__ __forceinline__ static K4 load(const float *p) {
+    K4 r;
+    r.v = *reinterpret_cast<const f32x4 *>(p);
+    return r;
+  }
+  __device__ __forceinline__ static K4 zero() {
+    K4 r;
+    r.v = f32x4{0.f, 0.f, 0.f, 0.f};
+    return r;
+  }
+};
+
 template <typename T, int C, int TAPS, int C2, int PRO>
 __global__ __launch_bounds__(1024) void conv_thin_kernel(const ConvThinArgs a) {
   constexpr int E = 8;
   constexpr int QC = C / E;                 // channel octets of the first source
-  constexpr int S1 = TAPS * QC, S2 = C2 / E, S = S1 + S2, NSTEP = S / 2;
-  static_assert(S % 2 == 0, "slot count must be even");
+  constexpr int S1 = TAPS * QC, S2 = C2 / E, S = S1 + S2, NSTEP = S / 2, NSTEP1 = S1 / 2, NSTEP2 = S2 / 2;
+  static_assert(S1 % 2 == 0 && S2 % 2 == 0, "slot counts must be even");
   constexpr int NCB = C / 32;               // 32-wide blocks of output channels
   constexpr int SROW = C + E;               // LDS row pitch in elements (16-byte skew against bank conflicts)
   constexpr int HALO = TAPS / 2;
+  constexpr int NV = 6;                     // staged 8-channel vectors per thread (upper bound, see thin_go)
   constexpr bool FAST = !std::is_same<T, float>::value;
   constexpr bool KEEP_W = sizeof(T) == 2;   // bf16: the wave's weight fragments stay in registers
 
   extern __shared__ __align__(16) unsigned char smem[];
   float *sc = reinterpret_cast<float *>(smem);
   float *sh = sc + C;
-  float *part = sh + C;   // [tile][G][3]
-  T *tile = reinterpret_cast<T *>(part + kThinMaxTiles * kThinMaxG * 3);
+  float *part = sh + C;   // [tile][G][2]
+  T *tile = reinterpret_cast<T *>(part + kThinMaxTiles * kThinMaxG * 2);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = blockDim.x >> 6;
   const int half = lane >> 5, l32 = lane & 31;
@@ -123,21 +159,50 @@ __global__ __launch_bounds__(1024) void conv_thin_kernel(const ConvThinArgs a) {
   const int rows = min(a.rw, a.L - r0);
   const int ntile = (rows + 31) >> 5;
   const int K = S * E;
+  const int cpg = C / a.G;
   const T *src = static_cast<const T *>(a.src);
   const T *wgt = static_cast<const T *>(a.w);
   const int cb = wave % NCB;   // launch guarantees NW % NCB == 0: a wave keeps one block of output channels
 
-  // ---- weights of this wave (issued first: they do not depend on anything) ----------------------------------
+  // ---- every global read of the workgroup is issued up front: ONE memory round trip ---------------------------
+  // (a) rows [r0 - HALO, r0 + rows + HALO) of the first source
+  const int total = (rows + 2 * HALO) * QC;
+  K8<T> xin[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int idx = tid + i * blockDim.x;
+    const int rr = idx / QC, q = idx - rr * QC;
+    const int pos = r0 - HALO + rr;
+    const bool ok = idx < total && pos >= 0 && pos < a.L;
+    xin[i] = ok ? K8<T>::load(src + ((size_t)b * a.L + pos) * a.src_ld + q * E) : K8<T>::zero();
+  }
+  // (b) the wave's weights
   K8<T> wf[KEEP_W ? NSTEP : 1];
   const T *wrow = wgt + (size_t)(cb * 32 + l32) * K + half * E;
   if constexpr (KEEP_W) {
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) wf[s] = K8<T>::load(wrow + s * 2 * E);
   }
+  // (c) second source and residual of the wave's first tile
+  const int t_first = wave / NCB;
+  const int rowl_first = t_first * 32 + l32;
+  const bool rv_first = t_first < ntile && rowl_first < rows;
+  const size_t grow_first = (size_t)b * a.L + r0 + (rv_first ? rowl_first : 0);
+  K8<T> s2f[NSTEP2 > 0 ? NSTEP2 : 1];
+  if constexpr (NSTEP2 > 0) {
+#pragma unroll
+    for (int s = 0; s < NSTEP2; ++s)
+      s2f[s] = rv_first ? K8<T>::load(static_cast<const T *>(a.src2) + grow_first * a.src2_ld + (2 * s + half) * E) : K8<T>::zero();
+  }
+  K4<T> resf[4];
+  const bool res_g = a.res != nullptr && !a.res_self;
+#pragma unroll
+  for (int v = 0; v < 4; ++v)
+    resf[v] = (res_g && rv_first) ? K4<T>::load(static_cast<const T *>(a.res) + grow_first * a.res_ld + cb * 32 + half * 4 + 8 * v)
+                                  : K4<T>::zero();
 
   // ---- prologue parameters -> LDS ----------------------------------------------------------------------------
   if constexpr (PRO == 1) {
-    const int cpg = C / a.G;
     for (int g = tid >> 5; g < a.G; g += blockDim.x >> 5) {
       const float2 st = gn_merge_n(a.stats_in + ((size_t)b * a.nch_in * a.G + g) * 2, a.G, a.nch_in, a.chunk_in, a.L, cpg, a.eps, l32);
       if (l32 < cpg) {
@@ -156,15 +221,16 @@ __global__ __launch_bounds__(1024) void conv_thin_kernel(const ConvThinArgs a) {
     __syncthreads();
   }
 
-  // ---- stage rows [r0 - HALO, r0 + rows + HALO) with the prologue applied once --------------------------------
-  {
-    const int total = (rows + 2 * HALO) * QC;
-    for (int idx = tid; idx < total; idx += blockDim.x) {
+  // ---- prologue applied once per element, staged in LDS ---------------------------------------------------------
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int idx = tid + i * blockDim.x;
+    if (idx < total) {
       const int rr = idx / QC, q = idx - rr * QC;
-      const int pos = r0 - HALO + rr;
-      const bool ok = pos >= 0 && pos < a.L;
-      K8<T> v = ok ? K8<T>::load(src + ((size_t)b * a.L + pos) * a.src_ld + q * E) : K8<T>::zero();
+      K8<T> v = xin[i];
       if constexpr (PRO == 1) {
+        const int pos = r0 - HALO + rr;
+        const bool ok = pos >= 0 && pos < a.L;   // the convolution pads the ACTIVATED tensor with zeros
 #pragma unroll
         for (int j = 0; j < E; ++j) {
           const float y = fmaf(v.get(j), sc[q * E + j], sh[q * E + j]);
@@ -199,34 +265,42 @@ __global__ __launch_bounds__(1024) void conv_thin_kernel(const ConvThinArgs a) {
   __syncthreads();
 
   // ---- tiles ---------------------------------------------------------------------------------------------------
-  const int cpg = C / a.G;
   for (int item = wave; item < ntile * NCB; item += NW) {
     const int t = item / NCB;
     const int row_l = t * 32 + l32;
     const bool rvalid = row_l < rows;
     const size_t grow = (size_t)b * a.L + r0 + (rvalid ? row_l : 0);
+    if (item != wave) {   // later tiles of this wave: fetch their second source / residual now
+      if constexpr (NSTEP2 > 0) {
+#pragma unroll
+        for (int s = 0; s < NSTEP2; ++s)
+          s2f[s] = rvalid ? K8<T>::load(static_cast<const T *>(a.src2) + grow * a.src2_ld + (2 * s + half) * E) : K8<T>::zero();
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        resf[v] = (res_g && rvalid) ? K4<T>::load(static_cast<const T *>(a.res) + grow * a.res_ld + cb * 32 + half * 4 + 8 * v)
+                                    : K4<T>::zero();
+    }
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) {
       K8<T> bf;
-      const int slot = 2 * s + half;   // S1 is even: both halves of a step read the same source
-      if (2 * s + 1 < S1) {   // both halves read the staged first source
+      if (s < NSTEP1) {   // staged first source: slot = 2s + half -> (tap, octet)
+        const int slot = 2 * s + half;
         const int tap = slot / QC, q = slot - tap * QC;
         bf = K8<T>::load(tile + (row_l + tap) * SROW + q * E);
-      } else if (2 * s >= S1) {   // both halves read the second source from global memory
-        const int q2 = slot - S1;
-        bf = rvalid ? K8<T>::load(static_cast<const T *>(a.src2) + grow * a.src2_ld + q2 * E) : K8<T>::zero();
-      } else {   // S1 odd: cannot happen for the instantiated shapes (S1 even)
-        bf = K8<T>::zero();
+      } else {
+        bf = s2f[NSTEP2 > 0 ? s - NSTEP1 : 0];
       }
       if constexpr (KEEP_W) mma_step(acc, wf[s], bf);
       else mma_step(acc, K8<T>::load(wrow + s * 2 * E), bf);
     }
 
     // ---- epilogue: lane = position row_l, registers 4v..4v+3 = channels cb*32 + half*4 + 8v + {0..3} -----------
-    float pn[4], pm[4], pq[4];
+    float gs[4], gq[4];
+    float xs[4][4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       const int c0 = cb * 32 + half * 4 + 8 * v;
@@ -235,13 +309,12 @@ __global__ __launch_bounds__(1024) void conv_thin_kernel(const ConvThinArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) val[e] = acc[4 * v + e] + bias[e];
       if (a.res_self) {   // residual = the staged (modulated) input itself
-        const T *rp = tile + (row_l + HALO) * SROW + c0;
+        const K4<T> rp = K4<T>::load(tile + (row_l + HALO) * SROW + c0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) val[e] += to_f(rp[e]);
-      } else if (a.res && rvalid) {
-        const T *rp = static_cast<const T *>(a.res) + grow * a.res_ld + c0;
+        for (int e = 0; e < 4; ++e) val[e] += rp.get(e);
+      } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) val[e] += to_f(rp[e]);
+        for (int e = 0; e < 4; ++e) val[e] += resf[v].get(e);
       }
       if (a.badd) {
         const f32x4 ba = *reinterpret_cast<const f32x4 *>(a.badd + (size_t)b * a.badd_ld + c0);
@@ -256,34 +329,44 @@ __global__ __launch_bounds__(1024) void conv_thin_kernel(const ConvThinArgs a) {
         if constexpr (sizeof(T) == 2) *reinterpret_cast<uint2 *>(op) = *reinterpret_cast<const uint2 *>(o);
         else *reinterpret_cast<f32x4 *>(op) = *reinterpret_cast<const f32x4 *>(o);
       }
-      // GroupNorm partial of the STORED values of this lane's four channels (one group: cpg is 4 or 8)
-      if (a.stats_out) {
-        const float x0 = to_f(o[0]), x1 = to_f(o[1]), x2 = to_f(o[2]), x3 = to_f(o[3]);
-        const float m = 0.25f * ((x0 + x1) + (x2 + x3));
-        const float d0 = x0 - m, d1 = x1 - m, d2 = x2 - m, d3 = x3 - m;
-        pn[v] = rvalid ? 4.f : 0.f;
-        pm[v] = rvalid ? m : 0.f;
-        pq[v] = rvalid ? (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) : 0.f;
-      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) xs[v][e] = rvalid ? to_f(o[e]) : 0.f;   // statistics see the STORED values
     }
+    // GroupNorm partial of this tile: two passes over registers (sum -> mean, then centred squares), shuffle sums
+    // over the 32 positions (and the other half-wave when a group spans both: cpg == 8).  Fixed order: deterministic.
     if (a.stats_out) {
+      const int vrows = min(32, rows - t * 32);
+      const float cnt = (float)vrows * (float)cpg;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) gs[v] = (xs[v][0] + xs[v][1]) + (xs[v][2] + xs[v][3]);
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
 #pragma unroll
-        for (int off = 16; off > 0; off >>= 1) {
-          const float nb = __shfl_down(pn[v], off, 32), mb = __shfl_down(pm[v], off, 32), qb = __shfl_down(pq[v], off, 32);
-          welford_merge(pn[v], pm[v], pq[v], nb, mb, qb);
+        for (int off = 16; off > 0; off >>= 1) gs[v] += __shfl_xor(gs[v], off, 64);
+        if (cpg == 8) gs[v] += __shfl_xor(gs[v], 32, 64);
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const float m = gs[v] / cnt;
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = rvalid ? xs[v][e] - m : 0.f;
+          q = fmaf(d, d, q);
         }
-        if (cpg == 8) {   // the two half-waves hold the two halves of the same group
-          const float nb = __shfl(pn[v], 32, 64), mb = __shfl(pm[v], 32, 64), qb = __shfl(pq[v], 32, 64);
-          if (lane == 0) welford_merge(pn[v], pm[v], pq[v], nb, mb, qb);
-        }
-        const int g = (cb * 32 + half * 4 + 8 * v) / cpg;
-        if (l32 == 0 && (cpg == 4 || half == 0)) {
-          float *pp = part + ((size_t)t * a.G + g) * 3;
-          pp[0] = pn[v];
-          pp[1] = pm[v];
-          pp[2] = pq[v];
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
+        if (cpg == 8) q += __shfl_xor(q, 32, 64);
+        gs[v] = m;
+        gq[v] = q;
+      }
+      if (l32 == 0 && (cpg == 4 || half == 0)) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int g = (cb * 32 + half * 4 + 8 * v) / cpg;
+          float *pp = part + ((size_t)t * a.G + g) * 2;
+          pp[0] = gs[v];
+          pp[1] = gq[v];
         }
       }
     }
@@ -295,8 +378,8 @@ __global__ __launch_bounds__(1024) void conv_thin_kernel(const ConvThinArgs a) {
     if (tid < a.G) {
       float n = 0.f, mean = 0.f, m2 = 0.f;
       for (int t = 0; t < ntile; ++t) {
-        const float *pp = part + ((size_t)t * a.G + tid) * 3;
-        welford_merge(n, mean, m2, pp[0], pp[1], pp[2]);
+        const float *pp = part + ((size_t)t * a.G + tid) * 2;
+        welford_merge(n, mean, m2, (float)min(32, rows - t * 32) * (float)cpg, pp[0], pp[1]);
       }
       float *so = a.stats_out + (((size_t)b * a.nchw + ch) * a.G + tid) * 2;
       so[0] = mean;
@@ -308,7 +391,7 @@ __global__ __launch_bounds__(1024) void conv_thin_kernel(const ConvThinArgs a) {
 template <typename T> size_t thin_lds_bytes(int C, int taps, int rw) {
   const int halo = taps / 2;
   const size_t rows = (size_t)((rw + 31) / 32) * 32 + 2 * halo + 1;
-  return (size_t)(2 * C + kThinMaxTiles * kThinMaxG * 3) * sizeof(float) + rows * (C + 8) * sizeof(T);
+  return (size_t)(2 * C + kThinMaxTiles * kThinMaxG * 2) * sizeof(float) + rows * (C + 8) * sizeof(T);
 }
 
 template <typename T, int C, int TAPS, int C2, int PRO> hipError_t thin_go(const ConvThinArgs &a, hipStream_t s) {
@@ -326,6 +409,8 @@ template <typename T, int C, int TAPS, int C2, int PRO> hipError_t thin_go(const
   int nw = ((a.rw + 31) / 32) * NCB;
   if (nw > 16) nw = 16;
   nw = (nw / NCB) * NCB;
+  // staging registers: (rw + 2) * C/8 vectors over nw*64 threads must fit the kernel's NV = 6 per thread
+  if ((a.rw + 2) * (C / 8) > 6 * nw * 64) return hipErrorInvalidValue;
   hipLaunchKernelGGL(kern, dim3(a.B * a.nchw), dim3(nw * 64), lds, s, a);
   return hipGetLastError();
 }
@@ -346,7 +431,12 @@ template <typename T> hipError_t thin_dispatch(const ConvThinArgs &a, hipStream_
 
 ThinPlan conv_thin_plan(int B, int L) {
   ThinPlan p;
-  long target = ((long)B * L + 255) / 256;   // positions per workgroup for ~256 workgroups
+  static const int wgs = [] {   // tuning hook: workgroups a launch aims for
+    const char *e = getenv("SF_THIN_WGS");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 256;
+  }();
+  long target = ((long)B * L + wgs - 1) / wgs;   // positions per workgroup
   int rw = (int)((target + 31) / 32) * 32;
   if (rw < 32) rw = 32;
   if (rw > 32 * kThinMaxTiles) rw = 32 * kThinMaxTiles;
