@@ -133,73 +133,89 @@ template <> struct K4<float> {
   }
 };
 
-template <typename T, int C, int TAPS, int C2, int PRO>
+// CIN: channels of a staged source row; NOUT: output channels (8, 32, 64); C2: channels of the concatenated second source
+template <typename T, int CIN, int TAPS, int C2, int PRO, int NOUT>
 __global__ __launch_bounds__(1024) void conv_thin_kernel(const ConvThinArgs a) {
   constexpr int E = 8;
-  constexpr int QC = C / E;                 // channel octets of the first source
-  constexpr int S1 = TAPS * QC, S2 = C2 / E, S = S1 + S2, NSTEP = S / 2, NSTEP1 = S1 / 2, NSTEP2 = S2 / 2;
-  static_assert(S1 % 2 == 0 && S2 % 2 == 0, "slot counts must be even");
-  constexpr int NCB = C / 32;               // 32-wide blocks of output channels
-  constexpr int SROW = C + E;               // LDS row pitch in elements (16-byte skew against bank conflicts)
+  constexpr int QC = CIN / E;               // channel octets of a staged row
+  constexpr int S1 = TAPS * QC, S2 = C2 / E, S = S1 + S2, NSTEP = (S + 1) / 2;
+  constexpr int NL = S1 / 2;                // steps whose two slots both come from the staged source
+  constexpr bool MIX = (S1 & 1) != 0;       // step NL: lanes 0-31 staged source, lanes 32-63 second source / nothing
+  constexpr int NS2 = NSTEP - NL;           // steps that touch the second source (incl. the mixed one)
+  constexpr int NCB = (NOUT + 31) / 32;     // 32-wide blocks of output channels
+  constexpr int SROW = CIN + E;             // LDS row pitch in elements (16-byte skew against bank conflicts)
   constexpr int HALO = TAPS / 2;
   constexpr int NV = 6;                     // staged 8-channel vectors per thread (upper bound, see thin_go)
   constexpr bool FAST = !std::is_same<T, float>::value;
   constexpr bool KEEP_W = sizeof(T) == 2;   // bf16: the wave's weight fragments stay in registers
+  static_assert(PRO == 0 || CIN == NOUT, "prologues belong to the item convolutions (C -> C)");
 
   extern __shared__ __align__(16) unsigned char smem[];
   float *sc = reinterpret_cast<float *>(smem);
-  float *sh = sc + C;
-  float *part = sh + C;   // [tile][G][2]
+  float *sh = sc + CIN;
+  float *part = sh + CIN;   // [tile][G][2]
   T *tile = reinterpret_cast<T *>(part + kThinMaxTiles * kThinMaxG * 2);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = blockDim.x >> 6;
   const int half = lane >> 5, l32 = lane & 31;
   const int b = blockIdx.x / a.nchw, ch = blockIdx.x - b * a.nchw;
-  const int r0 = ch * a.rw;
+  const int r0 = ch * a.rw;                       // first output position of the workgroup
   const int rows = min(a.rw, a.L - r0);
   const int ntile = (rows + 31) >> 5;
   const int K = S * E;
-  const int cpg = C / a.G;
+  const int cpg = NOUT / a.G;
   const T *src = static_cast<const T *>(a.src);
   const T *wgt = static_cast<const T *>(a.w);
   const int cb = wave % NCB;   // launch guarantees NW % NCB == 0: a wave keeps one block of output channels
+  // source rows feeding positions [r0 - HALO, r0 + rows + HALO): nearest-neighbour upsampling reads row p >> up_shift
+  const int j0 = (r0 - HALO) >> a.up_shift;       // arithmetic shift: -1 stays -1 (the zero padding row)
+  const int nsrc = ((r0 + rows - 1 + HALO) >> a.up_shift) - j0 + 1;
 
   // ---- every global read of the workgroup is issued up front: ONE memory round trip ---------------------------
-  // (a) rows [r0 - HALO, r0 + rows + HALO) of the first source
-  const int total = (rows + 2 * HALO) * QC;
+  // (a) the staged source rows
+  const int total = nsrc * QC;
   K8<T> xin[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int idx = tid + i * blockDim.x;
     const int rr = idx / QC, q = idx - rr * QC;
-    const int pos = r0 - HALO + rr;
-    const bool ok = idx < total && pos >= 0 && pos < a.L;
-    xin[i] = ok ? K8<T>::load(src + ((size_t)b * a.L + pos) * a.src_ld + q * E) : K8<T>::zero();
+    const int j = j0 + rr;
+    const bool ok = idx < total && j >= 0 && j < a.Ls;
+    xin[i] = ok ? K8<T>::load(src + ((size_t)b * a.Ls + j) * a.src_ld + q * E) : K8<T>::zero();
   }
-  // (b) the wave's weights
+  // (b) the wave's weights: lane = output channel cb*32 + l32, slot 2s + half
   K8<T> wf[KEEP_W ? NSTEP : 1];
-  const T *wrow = wgt + (size_t)(cb * 32 + l32) * K + half * E;
+  const int wc = cb * 32 + l32;
+  const T *wrow = wgt + (size_t)(wc < NOUT ? wc : 0) * K + half * E;
+  auto wload = [&](int s) { return (wc < NOUT && 2 * s + half < S) ? K8<T>::load(wrow + s * 2 * E) : K8<T>::zero(); };
   if constexpr (KEEP_W) {
 #pragma unroll
-    for (int s = 0; s < NSTEP; ++s) wf[s] = K8<T>::load(wrow + s * 2 * E);
+    for (int s = 0; s < NSTEP; ++s) wf[s] = wload(s);
   }
   // (c) second source and residual of the wave's first tile
   const int t_first = wave / NCB;
   const int rowl_first = t_first * 32 + l32;
   const bool rv_first = t_first < ntile && rowl_first < rows;
   const size_t grow_first = (size_t)b * a.L + r0 + (rv_first ? rowl_first : 0);
-  K8<T> s2f[NSTEP2 > 0 ? NSTEP2 : 1];
-  if constexpr (NSTEP2 > 0) {
+  K8<T> s2f[NS2 > 0 ? NS2 : 1];
+  auto s2load = [&](int i, bool rv, size_t grow) {
+    const int q2 = 2 * (NL + i) + half - S1;
+    return (rv && q2 >= 0 && q2 < S2) ? K8<T>::load(static_cast<const T *>(a.src2) + grow * a.src2_ld + q2 * E) : K8<T>::zero();
+  };
+  if constexpr (S2 > 0) {
 #pragma unroll
-    for (int s = 0; s < NSTEP2; ++s)
-      s2f[s] = rv_first ? K8<T>::load(static_cast<const T *>(a.src2) + grow_first * a.src2_ld + (2 * s + half) * E) : K8<T>::zero();
+    for (int i = 0; i < NS2; ++i) s2f[i] = s2load(i, rv_first, grow_first);
+  } else if constexpr (NS2 > 0) {
+    s2f[0] = K8<T>::zero();
   }
   K4<T> resf[4];
   const bool res_g = a.res != nullptr && !a.res_self;
 #pragma unroll
-  for (int v = 0; v < 4; ++v)
-    resf[v] = (res_g && rv_first) ? K4<T>::load(static_cast<const T *>(a.res) + grow_first * a.res_ld + cb * 32 + half * 4 + 8 * v)
-                                  : K4<T>::zero();
+  for (int v = 0; v < 4; ++v) {
+    const bool vv = NOUT >= 32 || 8 * v < NOUT;
+    resf[v] = (vv && res_g && rv_first) ? K4<T>::load(static_cast<const T *>(a.res) + grow_first * a.res_ld + cb * 32 + half * 4 + 8 * v)
+                                        : K4<T>::zero();
+  }
 
   // ---- prologue parameters -> LDS ----------------------------------------------------------------------------
   if constexpr (PRO == 1) {
@@ -214,9 +230,9 @@ __global__ __launch_bounds__(1024) void conv_thin_kernel(const ConvThinArgs a) {
     }
     __syncthreads();
   } else if constexpr (PRO == 2) {
-    if (tid < C) {
+    if (tid < CIN) {
       sc[tid] = a.ss ? 1.0f + a.ss[(size_t)b * a.ss_ld + tid] : 1.0f;
-      sh[tid] = a.ss ? a.ss[(size_t)b * a.ss_ld + C + tid] : 0.0f;
+      sh[tid] = a.ss ? a.ss[(size_t)b * a.ss_ld + CIN + tid] : 0.0f;
     }
     __syncthreads();
   }
@@ -229,34 +245,34 @@ __global__ __launch_bounds__(1024) void conv_thin_kernel(const ConvThinArgs a) {
       const int rr = idx / QC, q = idx - rr * QC;
       K8<T> v = xin[i];
       if constexpr (PRO == 1) {
-        const int pos = r0 - HALO + rr;
-        const bool ok = pos >= 0 && pos < a.L;   // the convolution pads the ACTIVATED tensor with zeros
+        const int j = j0 + rr;
+        const bool ok = j >= 0 && j < a.Ls;   // the convolution pads the ACTIVATED tensor with zeros
 #pragma unroll
-        for (int j = 0; j < E; ++j) {
-          const float y = fmaf(v.get(j), sc[q * E + j], sh[q * E + j]);
-          v.set(j, ok ? silu_t<FAST>(y) : 0.f);
+        for (int e = 0; e < E; ++e) {
+          const float y = fmaf(v.get(e), sc[q * E + e], sh[q * E + e]);
+          v.set(e, ok ? silu_t<FAST>(y) : 0.f);
         }
       } else if constexpr (PRO == 2) {
-        // LayerNorm over the C channels of the row: its QC octets sit on QC consecutive lanes
+        // LayerNorm over the channels of the row: its QC octets sit on QC consecutive lanes
         float sum = 0.f;
 #pragma unroll
-        for (int j = 0; j < E; ++j) sum += v.get(j);
+        for (int e = 0; e < E; ++e) sum += v.get(e);
 #pragma unroll
         for (int o = QC >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-        const float mean = sum / (float)C;
+        const float mean = sum / (float)CIN;
         float sq = 0.f;
 #pragma unroll
-        for (int j = 0; j < E; ++j) {
-          const float d = v.get(j) - mean;
+        for (int e = 0; e < E; ++e) {
+          const float d = v.get(e) - mean;
           sq = fmaf(d, d, sq);
         }
 #pragma unroll
         for (int o = QC >> 1; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
-        const float rstd = rsqrtf(sq / (float)C + a.eps);
+        const float rstd = rsqrtf(sq / (float)CIN + a.eps);
 #pragma unroll
-        for (int j = 0; j < E; ++j) {
-          const float y = (v.get(j) - mean) * rstd;
-          v.set(j, fmaf(y, sc[q * E + j], sh[q * E + j]));
+        for (int e = 0; e < E; ++e) {
+          const float y = (v.get(e) - mean) * rstd;
+          v.set(e, fmaf(y, sc[q * E + e], sh[q * E + e]));
         }
       }
       v.store(tile + rr * SROW + q * E);
@@ -271,44 +287,55 @@ __global__ __launch_bounds__(1024) void conv_thin_kernel(const ConvThinArgs a) {
     const bool rvalid = row_l < rows;
     const size_t grow = (size_t)b * a.L + r0 + (rvalid ? row_l : 0);
     if (item != wave) {   // later tiles of this wave: fetch their second source / residual now
-      if constexpr (NSTEP2 > 0) {
+      if constexpr (S2 > 0) {
 #pragma unroll
-        for (int s = 0; s < NSTEP2; ++s)
-          s2f[s] = rvalid ? K8<T>::load(static_cast<const T *>(a.src2) + grow * a.src2_ld + (2 * s + half) * E) : K8<T>::zero();
+        for (int i = 0; i < NS2; ++i) s2f[i] = s2load(i, rvalid, grow);
       }
 #pragma unroll
-      for (int v = 0; v < 4; ++v)
-        resf[v] = (res_g && rvalid) ? K4<T>::load(static_cast<const T *>(a.res) + grow * a.res_ld + cb * 32 + half * 4 + 8 * v)
-                                    : K4<T>::zero();
+      for (int v = 0; v < 4; ++v) {
+        const bool vv = NOUT >= 32 || 8 * v < NOUT;
+        resf[v] = (vv && res_g && rvalid) ? K4<T>::load(static_cast<const T *>(a.res) + grow * a.res_ld + cb * 32 + half * 4 + 8 * v)
+                                          : K4<T>::zero();
+      }
     }
+    const int prow = r0 + (rvalid ? row_l : 0) - HALO;   // upsampled position of tap 0
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) {
       K8<T> bf;
-      if (s < NSTEP1) {   // staged first source: slot = 2s + half -> (tap, octet)
-        const int slot = 2 * s + half;
+      if (s < NL || (MIX && s == NL)) {   // staged source: slot -> (tap, octet); row = (position + tap) >> up_shift
+        const int slot = min(2 * s + half, S1 - 1);
         const int tap = slot / QC, q = slot - tap * QC;
-        bf = K8<T>::load(tile + (row_l + tap) * SROW + q * E);
+        const int jj = ((prow + tap) >> a.up_shift) - j0;
+        bf = K8<T>::load(tile + jj * SROW + q * E);
+        if (MIX && s == NL) {
+          if (half) bf = s2f[0];
+        }
       } else {
-        bf = s2f[NSTEP2 > 0 ? s - NSTEP1 : 0];
+        bf = s2f[NS2 > 0 ? s - NL : 0];
       }
       if constexpr (KEEP_W) mma_step(acc, wf[s], bf);
-      else mma_step(acc, K8<T>::load(wrow + s * 2 * E), bf);
+      else mma_step(acc, wload(s), bf);
     }
 
     // ---- epilogue: lane = position row_l, registers 4v..4v+3 = channels cb*32 + half*4 + 8v + {0..3} -----------
-    float gs[4], gq[4];
     float xs[4][4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
+      if (!(NOUT >= 32 || 8 * v < NOUT)) continue;
       const int c0 = cb * 32 + half * 4 + 8 * v;
       float val[4];
       const f32x4 bias = a.bias ? *reinterpret_cast<const f32x4 *>(a.bias + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int e = 0; e < 4; ++e) val[e] = acc[4 * v + e] + bias[e];
-      if (a.res_self) {   // residual = the staged (modulated) input itself
+      if (a.bscale) {
+        const f32x4 bs = *reinterpret_cast<const f32x4 *>(a.bscale + (size_t)b * a.bscale_ld + c0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) val[e] *= bs[e];
+      }
+      if (a.res_self) {   // residual = the staged (modulated) input itself (CIN == NOUT, no upsampling)
         const K4<T> rp = K4<T>::load(tile + (row_l + HALO) * SROW + c0);
 #pragma unroll
         for (int e = 0; e < 4; ++e) val[e] += rp.get(e);
@@ -336,37 +363,63 @@ __global__ __launch_bounds__(1024) void conv_thin_kernel(const ConvThinArgs a) {
     // over the 32 positions (and the other half-wave when a group spans both: cpg == 8).  Fixed order: deterministic.
     if (a.stats_out) {
       const int vrows = min(32, rows - t * 32);
-      const float cnt = (float)vrows * (float)cpg;
-#pragma unroll
-      for (int v = 0; v < 4; ++v) gs[v] = (xs[v][0] + xs[v][1]) + (xs[v][2] + xs[v][3]);
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-#pragma unroll
-        for (int off = 16; off > 0; off >>= 1) gs[v] += __shfl_xor(gs[v], off, 64);
-        if (cpg == 8) gs[v] += __shfl_xor(gs[v], 32, 64);
-      }
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const float m = gs[v] / cnt;
-        float q = 0.f;
+      if constexpr (NOUT == 8) {   // one channel per group (G == 8): this lane's four channels are four groups
+        const float cnt = (float)vrows;
+        float m[4], q[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float d = rvalid ? xs[v][e] - m : 0.f;
-          q = fmaf(d, d, q);
-        }
+          float sum = xs[0][e];
 #pragma unroll
-        for (int off = 16; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
-        if (cpg == 8) q += __shfl_xor(q, 32, 64);
-        gs[v] = m;
-        gq[v] = q;
-      }
-      if (l32 == 0 && (cpg == 4 || half == 0)) {
+          for (int off = 16; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+          m[e] = sum / cnt;
+          const float d = rvalid ? xs[0][e] - m[e] : 0.f;
+          float qq = d * d;
+#pragma unroll
+          for (int off = 16; off > 0; off >>= 1) qq += __shfl_xor(qq, off, 64);
+          q[e] = qq;
+        }
+        if (l32 == 0) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float *pp = part + ((size_t)t * a.G + half * 4 + e) * 2;
+            pp[0] = m[e];
+            pp[1] = q[e];
+          }
+        }
+      } else {
+        const float cnt = (float)vrows * (float)cpg;
+        float gs[4], gq[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) gs[v] = (xs[v][0] + xs[v][1]) + (xs[v][2] + xs[v][3]);
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-          const int g = (cb * 32 + half * 4 + 8 * v) / cpg;
-          float *pp = part + ((size_t)t * a.G + g) * 2;
-          pp[0] = gs[v];
-          pp[1] = gq[v];
+#pragma unroll
+          for (int off = 16; off > 0; off >>= 1) gs[v] += __shfl_xor(gs[v], off, 64);
+          if (cpg == 8) gs[v] += __shfl_xor(gs[v], 32, 64);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const float m = gs[v] / cnt;
+          float q = 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float d = rvalid ? xs[v][e] - m : 0.f;
+            q = fmaf(d, d, q);
+          }
+#pragma unroll
+          for (int off = 16; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
+          if (cpg == 8) q += __shfl_xor(q, 32, 64);
+          gs[v] = m;
+          gq[v] = q;
+        }
+        if (l32 == 0 && (cpg == 4 || half == 0)) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int g = (cb * 32 + half * 4 + 8 * v) / cpg;
+            float *pp = part + ((size_t)t * a.G + g) * 2;
+            pp[0] = gs[v];
+            pp[1] = gq[v];
+          }
         }
       }
     }
@@ -388,15 +441,15 @@ __global__ __launch_bounds__(1024) void conv_thin_kernel(const ConvThinArgs a) {
   }
 }
 
-template <typename T> size_t thin_lds_bytes(int C, int taps, int rw) {
+template <typename T> size_t thin_lds_bytes(int cin, int taps, int rw) {
   const int halo = taps / 2;
   const size_t rows = (size_t)((rw + 31) / 32) * 32 + 2 * halo + 1;
-  return (size_t)(2 * C + kThinMaxTiles * kThinMaxG * 2) * sizeof(float) + rows * (C + 8) * sizeof(T);
+  return (size_t)(2 * cin + kThinMaxTiles * kThinMaxG * 2) * sizeof(float) + rows * (cin + 8) * sizeof(T);
 }
 
-template <typename T, int C, int TAPS, int C2, int PRO> hipError_t thin_go(const ConvThinArgs &a, hipStream_t s) {
-  const size_t lds = thin_lds_bytes<T>(C, TAPS, a.rw);
-  auto kern = conv_thin_kernel<T, C, TAPS, C2, PRO>;
+template <typename T, int CIN, int TAPS, int C2, int PRO, int NOUT> hipError_t thin_go(const ConvThinArgs &a, hipStream_t s) {
+  const size_t lds = thin_lds_bytes<T>(CIN, TAPS, a.rw);
+  auto kern = conv_thin_kernel<T, CIN, TAPS, C2, PRO, NOUT>;
   if (lds > 64 * 1024) {
     static bool raised = false;   // per instantiation
     if (!raised) {
@@ -405,24 +458,46 @@ template <typename T, int C, int TAPS, int C2, int PRO> hipError_t thin_go(const
       raised = true;
     }
   }
-  constexpr int NCB = C / 32;
+  constexpr int NCB = (NOUT + 31) / 32;
   int nw = ((a.rw + 31) / 32) * NCB;
   if (nw > 16) nw = 16;
   nw = (nw / NCB) * NCB;
-  // staging registers: (rw + 2) * C/8 vectors over nw*64 threads must fit the kernel's NV = 6 per thread
-  if ((a.rw + 2) * (C / 8) > 6 * nw * 64) return hipErrorInvalidValue;
+  // staging registers: the source rows of a workgroup (<= rw + 2) * CIN/8 vectors must fit NV = 6 per thread
+  if ((a.rw + 2) * (CIN / 8) > 6 * nw * 64) return hipErrorInvalidValue;
   hipLaunchKernelGGL(kern, dim3(a.B * a.nchw), dim3(nw * 64), lds, s, a);
   return hipGetLastError();
 }
 
+// the instantiated shapes: (CIN, taps, C2, pro, NOUT)
+struct ThinShape {
+  int cin, taps, c2, pro, nout;
+};
+constexpr ThinShape kThinShapes[] = {
+    // ResnetItem convolutions (GroupNorm+SiLU in) and Modulation+InjectChannels (LayerNorm-modulate in)
+    {8, 3, 0, 1, 8},   {32, 3, 0, 1, 32},  {64, 3, 0, 1, 64},
+    {8, 1, 8, 2, 8},   {32, 1, 32, 2, 32}, {64, 1, 32, 2, 64}, {64, 1, 64, 2, 64},
+    // patchify down convolutions on the (rows/f, f*cin) view
+    {32, 1, 0, 0, 32}, {64, 1, 0, 0, 64},  {128, 1, 0, 0, 64},
+    // nearest-upsample + conv3 up convolutions
+    {32, 3, 0, 0, 8},  {64, 3, 0, 0, 32},  {64, 3, 0, 0, 64},
+};
+
 template <typename T> hipError_t thin_dispatch(const ConvThinArgs &a, hipStream_t s) {
-#define SF_THIN(CC, TT, C22, PP) \
-  if (a.C == CC && a.taps == TT && a.C2 == C22 && a.pro == PP) return thin_go<T, CC, TT, C22, PP>(a, s)
-  SF_THIN(32, 3, 0, 1);
-  SF_THIN(64, 3, 0, 1);
-  SF_THIN(32, 1, 32, 2);
-  SF_THIN(64, 1, 32, 2);
-  SF_THIN(64, 1, 64, 2);
+#define SF_THIN(CC, TT, C22, PP, NN) \
+  if (a.C == CC && a.taps == TT && a.C2 == C22 && a.pro == PP && a.N == NN) return thin_go<T, CC, TT, C22, PP, NN>(a, s)
+  SF_THIN(8, 3, 0, 1, 8);
+  SF_THIN(32, 3, 0, 1, 32);
+  SF_THIN(64, 3, 0, 1, 64);
+  SF_THIN(8, 1, 8, 2, 8);
+  SF_THIN(32, 1, 32, 2, 32);
+  SF_THIN(64, 1, 32, 2, 64);
+  SF_THIN(64, 1, 64, 2, 64);
+  SF_THIN(32, 1, 0, 0, 32);
+  SF_THIN(64, 1, 0, 0, 64);
+  SF_THIN(128, 1, 0, 0, 64);
+  SF_THIN(32, 3, 0, 0, 8);
+  SF_THIN(64, 3, 0, 0, 32);
+  SF_THIN(64, 3, 0, 0, 64);
 #undef SF_THIN
   return hipErrorInvalidValue;
 }
@@ -446,13 +521,17 @@ ThinPlan conv_thin_plan(int B, int L) {
 }
 
 bool conv_thin_supported(int dt, const ConvThinArgs &a) {
-  if (a.G < 1 || a.G > kThinMaxG || a.C % a.G) return false;
-  const int cpg = a.C / a.G;
-  if (cpg != 4 && cpg != 8) return false;
-  if (a.rw < 32 || a.rw % 32 || a.rw > 32 * kThinMaxTiles) return false;
-  const bool shape = (a.taps == 3 && a.C2 == 0 && a.pro == 1 && (a.C == 32 || a.C == 64)) ||
-                     (a.taps == 1 && a.pro == 2 && ((a.C == 32 && a.C2 == 32) || (a.C == 64 && (a.C2 == 32 || a.C2 == 64))));
+  bool shape = false;
+  for (const ThinShape &t : kThinShapes) shape = shape || (a.C == t.cin && a.taps == t.taps && a.C2 == t.c2 && a.pro == t.pro && a.N == t.nout);
   if (!shape) return false;
+  if (a.rw < 32 || a.rw % 32 || a.rw > 32 * kThinMaxTiles) return false;
+  if (a.up_shift < 0 || a.up_shift > 4 || (a.Ls << a.up_shift) != a.L) return false;
+  if (a.up_shift && (a.C2 || a.pro || a.res_self)) return false;
+  if (a.pro == 1 || a.stats_out) {   // GroupNorm bookkeeping: a lane's four channels must sit in one group (or be four groups)
+    if (a.G < 1 || a.G > kThinMaxG || a.N % a.G) return false;
+    const int cpg = a.N / a.G;
+    if (a.N == 8 ? cpg != 1 : (cpg != 4 && cpg != 8)) return false;
+  }
   const size_t lds = dt == F32 ? thin_lds_bytes<float>(a.C, a.taps, a.rw) : thin_lds_bytes<bf16>(a.C, a.taps, a.rw);
   return lds <= 160 * 1024;
 }

@@ -103,6 +103,7 @@ struct ConvW {
   int N = 0, K = 0, cin = 0, cin2 = 0, taps = 1;
   int kreal = 0;           // un-padded reduction length (algorithmic FLOP accounting)
   bool direct = false;     // thin layer -> conv_direct (fp32 weights)
+  void *wt = nullptr;      // direct layers only: the same [N][K] matrix in the compute type (conv_thin's MFMA operand)
 };
 
 // Name lookup + packing helper shared by the Encoder1d and VideoOnsetNet engines.

@@ -61,8 +61,8 @@ const char *conv_gemm_variant_name(int dt, const ConvGemmArgs &a);
 bool conv_gemm_supported(int dt, const ConvGemmArgs &a);
 
 // ---------------------------------------------------------------------------------------
-// Thin-level convolution (conv_thin.hip): C = 32 / 64 channels on long sequences, one workgroup per `rw` consecutive
-// positions of a clip.  out[b,l,:] = W . [pro(src)[b, l-1..l+1, :]  |  src2[b,l,:]] + bias (+ res) (+ badd[b])
+// Thin-level convolution (conv_thin.hip): <= 64 output channels on long sequences, one workgroup per `rw` consecutive
+// positions of a clip.  out[b,l,:] = (W . [pro(src)[b, (l-1..l+1) >> up_shift, :]  |  src2[b,l,:]] + bias) * bscale[b] (+ res) (+ badd[b])
 //   pro 1: SiLU(GroupNorm(src))  with statistics merged from stats_in [B][nch_in][G][2] (mean, M2 per chunk_in rows)
 //   pro 2: LayerNorm_C(src; eps) * (1 + ss[b][c]) + ss[b][C + c]   (ss == nullptr: plain normalisation)
 //   res_self: the residual is pro(src) itself (InjectChannels after Modulation);  stats_out (optional): (mean, M2) of the
@@ -72,10 +72,12 @@ bool conv_gemm_supported(int dt, const ConvGemmArgs &a);
 struct ConvThinArgs {
   const void *src = nullptr, *src2 = nullptr, *w = nullptr, *res = nullptr;
   void *out = nullptr;
-  const float *bias = nullptr, *gamma = nullptr, *beta = nullptr, *stats_in = nullptr, *ss = nullptr, *badd = nullptr;
+  const float *bias = nullptr, *gamma = nullptr, *beta = nullptr, *stats_in = nullptr, *ss = nullptr, *badd = nullptr, *bscale = nullptr;
   float *stats_out = nullptr;
-  int B = 0, L = 0, C = 0, C2 = 0, taps = 1;
-  int src_ld = 0, src2_ld = 0, out_ld = 0, res_ld = 0, ss_ld = 0, badd_ld = 0;
+  // L output positions per clip, read from Ls = L >> up_shift source rows (nearest-neighbour upsampling when up_shift > 0);
+  // C channels per source row, N output channels, C2 channels of the concatenated second source; weights [N][taps*C + C2]
+  int B = 0, L = 0, Ls = 0, up_shift = 0, C = 0, N = 0, C2 = 0, taps = 1;
+  int src_ld = 0, src2_ld = 0, out_ld = 0, res_ld = 0, ss_ld = 0, badd_ld = 0, bscale_ld = 0;
   int pro = 0, res_self = 0, G = 1, nch_in = 1, chunk_in = 1;
   float eps = 1e-5f;
   int rw = 32, nchw = 1;

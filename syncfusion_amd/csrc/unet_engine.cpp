@@ -190,6 +190,11 @@ struct Builder {
     c.w = u.arena.alloc((int64_t)N * c.K * dsize(wdt));
     SF_HIP(launch_pack_conv(wdt, w, N, Ctot, 0, C1, taps, c.cin, nullptr, c.w, c.K, 0, s));
     if (C2) SF_HIP(launch_pack_conv(wdt, w, N, Ctot, C1, C2, 1, c.cin2, nullptr, c.w, c.K, (int64_t)taps * c.cin, s));
+    if (direct && N % 8 == 0 && C1 % 8 == 0 && C2 % 8 == 0) {   // 8-channel levels can also run on conv_thin (MFMA, compute type)
+      c.wt = u.arena.alloc((int64_t)N * c.K * dsize(u.dt));
+      SF_HIP(launch_pack_conv(u.dt, w, N, Ctot, 0, C1, taps, c.cin, nullptr, c.wt, c.K, 0, s));
+      if (C2) SF_HIP(launch_pack_conv(u.dt, w, N, Ctot, C1, C2, 1, c.cin2, nullptr, c.wt, c.K, (int64_t)taps * c.cin, s));
+    }
     if (b) {
       c.bias = u.arena.alloc_n<float>(N);
       SF_HIP(hipMemcpyAsync(c.bias, b, N * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -671,12 +676,15 @@ struct Exec {
     const Level &l = p.lv[d];
     const Block &b = u.blocks[d];
     const int C = l.C, G = u.cfg.resnet_groups;
-    if (g.conv1.direct || g.inject.direct || g.conv1.cin != C || g.inject.cin != C) return false;
+    if (g.conv1.cin != C || g.inject.cin != C) return false;
+    const void *w1 = g.conv1.direct ? g.conv1.wt : g.conv1.w, *w2 = g.conv2.direct ? g.conv2.wt : g.conv2.w;
+    const void *w3 = g.inject.direct ? g.inject.wt : g.inject.w;
+    if (!w1 || !w2 || !w3) return false;
     const ThinPlan tp = conv_thin_plan(p.Bt, l.L);
     ConvThinArgs base;
     base.B = p.Bt;
-    base.L = l.L;
-    base.C = C;
+    base.L = base.Ls = l.L;
+    base.C = base.N = C;
     base.G = G;
     base.rw = tp.rw;
     base.nchw = tp.nchw;
@@ -697,7 +705,7 @@ struct Exec {
     {
       ConvThinArgs a = a1;
       a.src = cur;
-      a.w = g.conv1.w;
+      a.w = w1;
       a.bias = g.conv1.bias;
       a.gamma = g.gn1_g;
       a.beta = g.gn1_b;
@@ -709,7 +717,7 @@ struct Exec {
     {
       ConvThinArgs a = a1;
       a.src = tA;
-      a.w = g.conv2.w;
+      a.w = w2;
       a.bias = g.conv2.bias;
       a.gamma = g.gn2_g;
       a.beta = g.gn2_b;
@@ -723,7 +731,7 @@ struct Exec {
       a.src = tB;
       a.src2 = l.ctx;
       a.src2_ld = b.ctx_ld;
-      a.w = g.inject.w;
+      a.w = w3;
       a.bias = g.inject.bias;
       a.ss = p.mod_all + g.mod_off;
       a.ss_ld = p.mod_stride;
@@ -752,13 +760,43 @@ struct Exec {
   }
 
   // Block d: skip + scale * Up(items_up(inner(items_down(Down(x)))))
-  void block(int d, const void *xin, int xin_dt, void *xout, int xout_dt) {
+  // Returns true when the GroupNorm partials of xout were left in p.slab (thin up convolution).
+  bool block(int d, const void *xin, int xin_dt, void *xout, int xout_dt) {
     const sf_unet_config &c = u.cfg;
     const Block &b = u.blocks[d];
     Level &l = p.lv[d];
     const int Lprev = l.L * b.factor;
     void *cur = l.buf[0], *tA = l.buf[1], *tB = l.buf[2];
-    {
+    stats_of = nullptr;
+    bool down_done = false;
+    if (!b.down.direct && xin_dt == u.dt) {   // patchify conv on the (rows/f, f*cin) view as a thin-level kernel
+      const ThinPlan tp = conv_thin_plan(p.Bt, l.L);
+      ConvThinArgs a;
+      a.B = p.Bt;
+      a.L = a.Ls = l.L;
+      a.C = b.factor * b.cin;
+      a.N = l.C;
+      a.taps = 1;
+      a.G = c.resnet_groups;
+      a.rw = tp.rw;
+      a.nchw = tp.nchw;
+      a.src = xin;
+      a.src_ld = a.C;
+      a.w = b.down.w;
+      a.bias = b.down.bias;
+      a.out = cur;
+      a.out_ld = l.C;
+      a.stats_out = p.slab;
+      if (!conv_thin_supported(u.dt, a)) a.stats_out = nullptr;
+      if (conv_thin_supported(u.dt, a)) {
+        const double es = dsize(u.dt), kin = b.down.kreal > 0 ? b.down.kreal : b.down.K;
+        timed("conv_thin", 2.0 * l.rows * l.C * kin, (double)l.rows * (kin + l.C) * es + kin * l.C * es,
+              [&] { SF_HIP(launch_conv_thin(u.dt, a, s)); });
+        if (a.stats_out) stats_of = cur;
+        down_done = true;
+      }
+    }
+    if (!down_done) {
       ConvGemmArgs a;
       a.src = xin;
       a.M = (int)l.rows;
@@ -783,17 +821,50 @@ struct Exec {
     }
     const std::string pre = "d" + std::to_string(d);
     u.dbg.tap(pre + ".down", u.dt, cur, l.C, l.rows, l.C, s);
-    stats_of = nullptr;
     for (size_t j = 0; j < b.down_items.size(); ++j) group(b.down_items[j], d, cur, tA, tB, pre + ".items_down." + std::to_string(j));
     if (d + 1 < c.n_layers) {
-      block(d + 1, cur, u.dt, tA, u.dt);
+      const bool have = block(d + 1, cur, u.dt, tA, u.dt);
       void *o = cur;
       cur = tA;
       tA = o;
-      stats_of = nullptr;   // deeper levels share the statistics slabs
+      stats_of = have ? cur : nullptr;   // deeper levels share the statistics slabs
     }
     for (size_t j = 0; j < b.up_items.size(); ++j) group(b.up_items[j], d, cur, tA, tB, pre + ".items_up." + std::to_string(j));
-    {
+    bool up_stats = false, up_done = false;
+    if (!b.up.direct && xout_dt == u.dt && xin_dt == u.dt) {   // nearest-upsample + conv3 + SkipModulate as a thin-level kernel
+      const ThinPlan tp = conv_thin_plan(p.Bt, Lprev);
+      ConvThinArgs a;
+      a.B = p.Bt;
+      a.L = Lprev;
+      a.Ls = l.L;
+      a.up_shift = b.up_shift;
+      a.C = l.C;
+      a.N = b.cin;
+      a.taps = 3;
+      a.G = c.resnet_groups;
+      a.rw = tp.rw;
+      a.nchw = tp.nchw;
+      a.src = cur;
+      a.src_ld = l.C;
+      a.w = b.up.w;
+      a.bias = b.up.bias;
+      a.bscale = p.mod_all + b.skip_off;
+      a.bscale_ld = p.mod_stride;
+      a.res = xin;
+      a.res_ld = b.cin;
+      a.out = xout;
+      a.out_ld = b.cin;
+      a.stats_out = p.slab;
+      if (!conv_thin_supported(u.dt, a)) a.stats_out = nullptr;
+      if ((1 << b.up_shift) == b.factor && conv_thin_supported(u.dt, a)) {
+        const double es = dsize(u.dt), rows_out = (double)l.rows * b.factor;
+        timed("conv_thin", 2.0 * rows_out * b.cin * 3 * l.C, ((double)l.rows * l.C + 2.0 * rows_out * b.cin) * es + 3.0 * l.C * b.cin * es,
+              [&] { SF_HIP(launch_conv_thin(u.dt, a, s)); });
+        up_stats = a.stats_out != nullptr;
+        up_done = true;
+      }
+    }
+    if (!up_done) {
       ConvGemmArgs a;
       a.src = cur;
       a.src_ld = l.C;
@@ -813,6 +884,7 @@ struct Exec {
       conv(b.up, a, u.dt, xout_dt);
     }
     u.dbg.tap(pre + ".out", xout_dt, xout, b.cin, l.rows * b.factor, b.cin, s);
+    return up_stats;
   }
 
   // features + modulation vectors of one step; sigma from sig[b] (sig_idx == nullptr) or sig[*sig_idx]
