@@ -190,10 +190,12 @@ struct Builder {
     c.w = u.arena.alloc((int64_t)N * c.K * dsize(wdt));
     SF_HIP(launch_pack_conv(wdt, w, N, Ctot, 0, C1, taps, c.cin, nullptr, c.w, c.K, 0, s));
     if (C2) SF_HIP(launch_pack_conv(wdt, w, N, Ctot, C1, C2, 1, c.cin2, nullptr, c.w, c.K, (int64_t)taps * c.cin, s));
-    if (direct && N % 8 == 0 && C1 % 8 == 0 && C2 % 8 == 0) {   // 8-channel levels can also run on conv_thin (MFMA, compute type)
-      c.wt = u.arena.alloc((int64_t)N * c.K * dsize(u.dt));
-      SF_HIP(launch_pack_conv(u.dt, w, N, Ctot, 0, C1, taps, c.cin, nullptr, c.wt, c.K, 0, s));
-      if (C2) SF_HIP(launch_pack_conv(u.dt, w, N, Ctot, C1, C2, 1, c.cin2, nullptr, c.wt, c.K, (int64_t)taps * c.cin, s));
+    if (direct && N % 8 == 0 && C1 % 8 == 0) {   // 8-channel levels can also run on conv_thin (MFMA, compute type):
+      const int c2p = pad_to(C2, 8);                // second source padded to whole octets (the context buffer is, too)
+      const int64_t kt = (int64_t)taps * C1 + c2p;
+      c.wt = u.arena.alloc(N * kt * dsize(u.dt));
+      SF_HIP(launch_pack_conv(u.dt, w, N, Ctot, 0, C1, taps, C1, nullptr, c.wt, kt, 0, s));
+      if (C2) SF_HIP(launch_pack_conv(u.dt, w, N, Ctot, C1, C2, 1, c2p, nullptr, c.wt, kt, (int64_t)taps * C1, s));
     }
     if (b) {
       c.bias = u.arena.alloc_n<float>(N);
@@ -337,7 +339,7 @@ void build(sf_unet &u, const WeightMap *wm, hipStream_t s) {
     b.ctx = c.context_channels[d];
     while ((1 << b.up_shift) < b.factor) ++b.up_shift;
     const bool thin = (b.C % 32) != 0;
-    b.ctx_ld = thin ? b.ctx : pad_to(b.ctx, 32);
+    b.ctx_ld = thin ? pad_to(b.ctx, 8) : pad_to(b.ctx, 32);   // pad columns are zero-filled by the layout conversion
     const std::string pre = "net.blocks." + std::to_string(d);
     // Downsample: Conv1d(cin, C, kernel=f, stride=f).  As a GEMM it is a plain matrix product over the
     // (rows/f, f*cin) view of the input when that width is MFMA-friendly; else the direct kernel.
@@ -696,7 +698,8 @@ struct Exec {
     a1.pro = 1;
     a3.taps = 1;
     a3.pro = 2;
-    a3.C2 = g.inject.cin2;
+    a3.C2 = g.inject.direct ? pad_to(g.inject.cin2, 8) : g.inject.cin2;
+    if (a3.C2 > b.ctx_ld) return false;
     if (!conv_thin_supported(u.dt, a1) || !conv_thin_supported(u.dt, a3)) return false;
     float *sA = p.slab, *sB = p.slab + p.slab_half;
     const double es = dsize(u.dt), rc = (double)l.rows * C;
