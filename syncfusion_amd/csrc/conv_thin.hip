@@ -29,7 +29,7 @@
 namespace sf {
 namespace {
 
-constexpr int kThinMaxTiles = 16;   // 32-position tiles per workgroup (RW <= 512)
+constexpr int kThinMaxTiles = 64;   // 32-position tiles per workgroup (RW <= 2048; 512 above 8 channels)
 constexpr int kThinMaxG = 16;
 
 // eight consecutive channels of one position
@@ -79,6 +79,31 @@ __device__ __forceinline__ void mma_step(f32x16 &acc, const K8<bf16> &a, const K
 __device__ __forceinline__ void mma_step(f32x16 &acc, const K8<float> &a, const K8<float> &b) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.get(j), b.get(j), acc, 0, 0, 0);
+}
+
+// Sum over the 32 lanes of each half-wave with DPP row operations (VALU only: no LDS crossbar traffic, unlike
+// __shfl_xor = ds_bpermute); every lane receives the total of its own half.  Fixed order -> deterministic.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float2 half_sums(float v) {   // (total of lanes 0-31, total of lanes 32-63), on every lane
+  v += dpp_mov<0xb1, 0xf>(v);
+  v += dpp_mov<0x4e, 0xf>(v);
+  v += dpp_mov<0x124, 0xf>(v);
+  v += dpp_mov<0x128, 0xf>(v);
+  v += dpp_mov<0x142, 0xa>(v);
+  return make_float2(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31)),
+                     __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)));
+}
+__device__ __forceinline__ float half_sum32(float v, int half) {
+  v += dpp_mov<0xb1, 0xf>(v);    // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4e, 0xf>(v);    // quad_perm [2,3,0,1]
+  v += dpp_mov<0x124, 0xf>(v);   // row_ror:4
+  v += dpp_mov<0x128, 0xf>(v);   // row_ror:8      -> every lane holds the sum of its row of 16
+  v += dpp_mov<0x142, 0xa>(v);   // row_bcast:15   -> rows 1 and 3 add the total of the row before
+  const float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+  const float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+  return half ? hi : lo;
 }
 
 // (mean, rstd) of one (clip, group) from its nch chunk partials, any nch: lane j of the half-wave folds partials
@@ -359,24 +384,19 @@ __global__ __launch_bounds__(1024) void conv_thin_kernel(const ConvThinArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) xs[v][e] = rvalid ? to_f(o[e]) : 0.f;   // statistics see the STORED values
     }
-    // GroupNorm partial of this tile: two passes over registers (sum -> mean, then centred squares), shuffle sums
-    // over the 32 positions (and the other half-wave when a group spans both: cpg == 8).  Fixed order: deterministic.
+    // GroupNorm partial of this tile: two passes over registers (sum -> mean, then centred squares); the sums over
+    // the 32 positions are DPP reductions (plus the other half-wave when a group spans both: cpg == 8).
     if (a.stats_out) {
       const int vrows = min(32, rows - t * 32);
       if constexpr (NOUT == 8) {   // one channel per group (G == 8): this lane's four channels are four groups
         const float cnt = (float)vrows;
         float m[4], q[4];
 #pragma unroll
+        for (int e = 0; e < 4; ++e) m[e] = half_sum32(xs[0][e], half) / cnt;
+#pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float sum = xs[0][e];
-#pragma unroll
-          for (int off = 16; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
-          m[e] = sum / cnt;
           const float d = rvalid ? xs[0][e] - m[e] : 0.f;
-          float qq = d * d;
-#pragma unroll
-          for (int off = 16; off > 0; off >>= 1) qq += __shfl_xor(qq, off, 64);
-          q[e] = qq;
+          q[e] = half_sum32(d * d, half);
         }
         if (l32 == 0) {
 #pragma unroll
@@ -390,27 +410,21 @@ __global__ __launch_bounds__(1024) void conv_thin_kernel(const ConvThinArgs a) {
         const float cnt = (float)vrows * (float)cpg;
         float gs[4], gq[4];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) gs[v] = (xs[v][0] + xs[v][1]) + (xs[v][2] + xs[v][3]);
-#pragma unroll
         for (int v = 0; v < 4; ++v) {
-#pragma unroll
-          for (int off = 16; off > 0; off >>= 1) gs[v] += __shfl_xor(gs[v], off, 64);
-          if (cpg == 8) gs[v] += __shfl_xor(gs[v], 32, 64);
+          const float2 hs = half_sums((xs[v][0] + xs[v][1]) + (xs[v][2] + xs[v][3]));
+          const float sum = cpg == 8 ? hs.x + hs.y : (half ? hs.y : hs.x);
+          gs[v] = sum / cnt;
         }
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-          const float m = gs[v] / cnt;
           float q = 0.f;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float d = rvalid ? xs[v][e] - m : 0.f;
+            const float d = rvalid ? xs[v][e] - gs[v] : 0.f;
             q = fmaf(d, d, q);
           }
-#pragma unroll
-          for (int off = 16; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
-          if (cpg == 8) q += __shfl_xor(q, 32, 64);
-          gs[v] = m;
-          gq[v] = q;
+          const float2 hq = half_sums(q);
+          gq[v] = cpg == 8 ? hq.x + hq.y : (half ? hq.y : hq.x);
         }
         if (l32 == 0 && (cpg == 4 || half == 0)) {
 #pragma unroll
@@ -428,27 +442,33 @@ __global__ __launch_bounds__(1024) void conv_thin_kernel(const ConvThinArgs a) {
   // ---- (mean, M2) of this workgroup's output per group, tiles folded in order ------------------------------------
   if (a.stats_out) {
     __syncthreads();
-    if (tid < a.G) {
-      float n = 0.f, mean = 0.f, m2 = 0.f;
-      for (int t = 0; t < ntile; ++t) {
-        const float *pp = part + ((size_t)t * a.G + tid) * 2;
-        welford_merge(n, mean, m2, (float)min(32, rows - t * 32) * (float)cpg, pp[0], pp[1]);
+    // one wave per group: lane t holds tile t's (count, mean, M2); exact pooled statistics in two DPP-reduced passes
+    for (int g = wave; g < a.G; g += NW) {
+      const bool on = lane < ntile;
+      const float *pp = part + ((size_t)(on ? lane : 0) * a.G + g) * 2;
+      const float n_t = on ? (float)min(32, rows - lane * 32) * (float)cpg : 0.f;
+      const float m_t = on ? pp[0] : 0.f, q_t = on ? pp[1] : 0.f;
+      const float2 sn = half_sums(n_t), sm = half_sums(n_t * m_t);
+      const float n = sn.x + sn.y, mean = (sm.x + sm.y) / n;
+      const float d = m_t - mean;
+      const float2 sq = half_sums(fmaf(n_t * d, d, q_t));
+      if (lane == 0) {
+        float *so = a.stats_out + (((size_t)b * a.nchw + ch) * a.G + g) * 2;
+        so[0] = mean;
+        so[1] = sq.x + sq.y;
       }
-      float *so = a.stats_out + (((size_t)b * a.nchw + ch) * a.G + tid) * 2;
-      so[0] = mean;
-      so[1] = m2;
     }
   }
 }
 
-template <typename T> size_t thin_lds_bytes(int cin, int taps, int rw) {
+template <typename T> size_t thin_lds_bytes(int cin, int taps, int rw, int up_shift) {
   const int halo = taps / 2;
-  const size_t rows = (size_t)((rw + 31) / 32) * 32 + 2 * halo + 1;
+  const size_t rows = (size_t)(rw >> up_shift) + 2 * halo + 2;   // source rows a workgroup stages (+ slack)
   return (size_t)(2 * cin + kThinMaxTiles * kThinMaxG * 2) * sizeof(float) + rows * (cin + 8) * sizeof(T);
 }
 
 template <typename T, int CIN, int TAPS, int C2, int PRO, int NOUT> hipError_t thin_go(const ConvThinArgs &a, hipStream_t s) {
-  const size_t lds = thin_lds_bytes<T>(CIN, TAPS, a.rw);
+  const size_t lds = thin_lds_bytes<T>(CIN, TAPS, a.rw, a.up_shift);
   auto kern = conv_thin_kernel<T, CIN, TAPS, C2, PRO, NOUT>;
   if (lds > 64 * 1024) {
     static bool raised = false;   // per instantiation
@@ -463,7 +483,7 @@ template <typename T, int CIN, int TAPS, int C2, int PRO, int NOUT> hipError_t t
   if (nw > 16) nw = 16;
   nw = (nw / NCB) * NCB;
   // staging registers: the source rows of a workgroup (<= rw + 2) * CIN/8 vectors must fit NV = 6 per thread
-  if ((a.rw + 2) * (CIN / 8) > 6 * nw * 64) return hipErrorInvalidValue;
+  if (((a.rw >> a.up_shift) + 3) * (CIN / 8) > 6 * nw * 64) return hipErrorInvalidValue;
   hipLaunchKernelGGL(kern, dim3(a.B * a.nchw), dim3(nw * 64), lds, s, a);
   return hipGetLastError();
 }
@@ -504,8 +524,16 @@ template <typename T> hipError_t thin_dispatch(const ConvThinArgs &a, hipStream_
 
 }  // namespace
 
-ThinPlan conv_thin_plan(int B, int L) {
+ThinPlan conv_thin_plan(int B, int L, int C) {
   ThinPlan p;
+  static const int rows8 = [] {   // tuning hook: positions per workgroup on the 8-channel level
+    const char *e = getenv("SF_THIN_ROWS8");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 1024;
+  }();
+  // a wave's fixed cost (weights, prologue table, epilogue bookkeeping) is amortised over 32 positions x C channels
+  // per tile: the 8-channel level gives each wave several tiles
+  const int max_rows = C <= 8 ? rows8 : 512;
   static const int wgs = [] {   // tuning hook: workgroups a launch aims for
     const char *e = getenv("SF_THIN_WGS");
     const int v = e ? atoi(e) : 0;
@@ -514,7 +542,7 @@ ThinPlan conv_thin_plan(int B, int L) {
   long target = ((long)B * L + wgs - 1) / wgs;   // positions per workgroup
   int rw = (int)((target + 31) / 32) * 32;
   if (rw < 32) rw = 32;
-  if (rw > 32 * kThinMaxTiles) rw = 32 * kThinMaxTiles;
+  if (rw > max_rows) rw = max_rows;
   p.rw = rw;
   p.nchw = (L + rw - 1) / rw;
   return p;
@@ -532,7 +560,7 @@ bool conv_thin_supported(int dt, const ConvThinArgs &a) {
     const int cpg = a.N / a.G;
     if (a.N == 8 ? cpg != 1 : (cpg != 4 && cpg != 8)) return false;
   }
-  const size_t lds = dt == F32 ? thin_lds_bytes<float>(a.C, a.taps, a.rw) : thin_lds_bytes<bf16>(a.C, a.taps, a.rw);
+  const size_t lds = dt == F32 ? thin_lds_bytes<float>(a.C, a.taps, a.rw, a.up_shift) : thin_lds_bytes<bf16>(a.C, a.taps, a.rw, a.up_shift);
   return lds <= 160 * 1024;
 }
 

@@ -85,7 +85,8 @@ struct ConvThinArgs {
 struct ThinPlan {
   int rw = 32, nchw = 1;
 };
-ThinPlan conv_thin_plan(int B, int L);
+// C = channels of the level whose positions are tiled (the OUTPUT level of a down / up convolution)
+ThinPlan conv_thin_plan(int B, int L, int C);
 bool conv_thin_supported(int dt, const ConvThinArgs &a);
 hipError_t launch_conv_thin(int dt, const ConvThinArgs &a, hipStream_t s);
 

@@ -434,7 +434,7 @@ Plan make_plan(const sf_unet &u, Workspace &ws, int B, int L0, bool two, int num
     // each [clips][chunks][groups][2]; the thin levels chunk by their workgroup tile (conv_thin_plan)
     int64_t one = (int64_t)(p.Bt / p.nbr) * 32 * c.resnet_groups * 2;
     for (int d = 0; d < c.n_layers; ++d) {
-      const ThinPlan tp = conv_thin_plan(p.Bt / p.nbr, p.lv[d].L);
+      const ThinPlan tp = conv_thin_plan(p.Bt / p.nbr, p.lv[d].L, p.lv[d].C);
       one = std::max<int64_t>(one, (int64_t)(p.Bt / p.nbr) * tp.nchw * c.resnet_groups * 2);
     }
     p.slab_half = align_up(one, 64);
@@ -682,7 +682,7 @@ struct Exec {
     const void *w1 = g.conv1.direct ? g.conv1.wt : g.conv1.w, *w2 = g.conv2.direct ? g.conv2.wt : g.conv2.w;
     const void *w3 = g.inject.direct ? g.inject.wt : g.inject.w;
     if (!w1 || !w2 || !w3) return false;
-    const ThinPlan tp = conv_thin_plan(p.Bt, l.L);
+    const ThinPlan tp = conv_thin_plan(p.Bt, l.L, C);
     ConvThinArgs base;
     base.B = p.Bt;
     base.L = base.Ls = l.L;
@@ -773,7 +773,7 @@ struct Exec {
     stats_of = nullptr;
     bool down_done = false;
     if (!b.down.direct && xin_dt == u.dt) {   // patchify conv on the (rows/f, f*cin) view as a thin-level kernel
-      const ThinPlan tp = conv_thin_plan(p.Bt, l.L);
+      const ThinPlan tp = conv_thin_plan(p.Bt, l.L, l.C);
       ConvThinArgs a;
       a.B = p.Bt;
       a.L = a.Ls = l.L;
@@ -835,7 +835,7 @@ struct Exec {
     for (size_t j = 0; j < b.up_items.size(); ++j) group(b.up_items[j], d, cur, tA, tB, pre + ".items_up." + std::to_string(j));
     bool up_stats = false, up_done = false;
     if (!b.up.direct && xout_dt == u.dt && xin_dt == u.dt) {   // nearest-upsample + conv3 + SkipModulate as a thin-level kernel
-      const ThinPlan tp = conv_thin_plan(p.Bt, Lprev);
+      const ThinPlan tp = conv_thin_plan(p.Bt, Lprev, b.cin);
       ConvThinArgs a;
       a.B = p.Bt;
       a.L = Lprev;
