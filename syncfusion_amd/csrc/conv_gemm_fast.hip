@@ -24,7 +24,9 @@ template <typename T> __device__ __forceinline__ Vec16<T> buf_ld16(__amdgpu_buff
 }
 
 // KW = K elements one wave multiplies per iteration (32 or 64); the workgroup stages BKT = 4*KW per iteration.
-template <typename T, int BM, int BN, bool CAT, int KW>
+// NSET = K chunks in flight per workgroup.  The weights of a denoising step stream from HBM (they do not fit the
+// Infinity Cache), so a workgroup needs latency x bandwidth bytes outstanding: 2 chunks (32 KB) cap a CU at ~45 GB/s.
+template <typename T, int BM, int BN, bool CAT, int KW, int NSET>
 __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(const ConvGemmArgs a, const int mtiles, const int ntiles, const int swz,
                                                              const unsigned bytesA, const unsigned bytesA2, const unsigned bytesW) {
   constexpr int BKT = 4 * KW;
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(const ConvGemmArgs 
   struct RegSet {
     Vec16<T> ra[PA], rb[PB];
   };
-  RegSet s0, s1;
+  RegSet rs[NSET];
   const int nkt = (a.K + BKT - 1) / BKT;
 
   // Streaming state of the gather, advanced once per prefetched chunk (chunks are requested in K order):
@@ -173,20 +175,50 @@ __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(const ConvGemmArgs 
     }
   };
 
-  prefetch(s0);
-  if (nkt > 1) prefetch(s1);
-  for (int kt = 0; kt < nkt; kt += 2) {
-    stage(s0);
-    __syncthreads();
-    if (kt + 2 < nkt) prefetch(s0);
-    compute();
-    __syncthreads();
-    if (kt + 1 < nkt) {
-      stage(s1);
-      __syncthreads();
-      if (kt + 3 < nkt) prefetch(s1);
-      compute();
-      __syncthreads();
+  // ---- epilogue operands (bias, residual, per-clip scale / add): they depend on nothing the K loop computes, so with
+  // one epilogue pass per thread (32x32 tiles) their loads are issued HERE and overlap the whole reduction instead of
+  // costing a memory round trip after it ----------------------------------------------------------------------------
+  const T *res = static_cast<const T *>(a.res);
+  const bool has_res = res != nullptr, has_bs = a.bscale != nullptr, has_ba = a.badd != nullptr;
+  constexpr int QN = BN / 4;
+  constexpr int EIT = (BM * QN + 255) / 256;
+  constexpr bool HOIST = EIT == 1;
+  struct EpiOps {
+    float bi[4], rv[4], sv[4], av[4];
+  };
+  auto epi_load = [&](int it) {
+    EpiOps o;
+    const int idx = tid + it * 256;
+    const int ml = idx / QN, nq = idx - ml * QN;
+    const int m = m0 + ml, nb = n0 + nq * 4;
+    const int mc = min(m, a.M - 1);
+    const int b = (has_bs || has_ba) ? mc / a.Lout : 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int nc = min(nb + e, a.N - 1);
+      o.bi[e] = a.bias ? a.bias[nc] : 0.f;
+      o.rv[e] = has_res ? to_f(res[(size_t)mc * a.res_ld + nc]) : 0.f;
+      o.sv[e] = has_bs ? a.bscale[(size_t)b * a.bscale_ld + nc] : 1.f;
+      o.av[e] = has_ba ? a.badd[(size_t)b * a.badd_ld + nc] : 0.f;
+    }
+    return o;
+  };
+  EpiOps eo0;
+  if constexpr (HOIST) eo0 = epi_load(0);
+
+#pragma unroll
+  for (int j = 0; j < NSET; ++j)
+    if (j < nkt) prefetch(rs[j]);
+  for (int kt = 0; kt < nkt; kt += NSET) {
+#pragma unroll
+    for (int j = 0; j < NSET; ++j) {
+      if (kt + j < nkt) {
+        stage(rs[j]);
+        __syncthreads();
+        if (kt + j + NSET < nkt) prefetch(rs[j]);
+        compute();
+        __syncthreads();
+      }
     }
   }
 
@@ -201,26 +233,16 @@ __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(const ConvGemmArgs 
   __syncthreads();
 
   T *out = static_cast<T *>(a.out);
-  const T *res = static_cast<const T *>(a.res);
-  const bool has_res = res != nullptr, has_bs = a.bscale != nullptr, has_ba = a.badd != nullptr;
-  constexpr int QN = BN / 4;
 #pragma unroll
-  for (int it = 0; it < (BM * QN + 255) / 256; ++it) {
+  for (int it = 0; it < EIT; ++it) {
     const int idx = tid + it * 256;
     const int ml = idx / QN, nq = idx - ml * QN;
     const int m = m0 + ml, nb = n0 + nq * 4;
     const bool live = idx < BM * QN && m < a.M && nb < a.n_store;
-    const int mc = min(m, a.M - 1);
-    float bi[4], rv[4], sv[4], av[4];
-    const int b = (has_bs || has_ba) ? mc / a.Lout : 0;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int nc = min(nb + e, a.N - 1);
-      bi[e] = a.bias ? a.bias[nc] : 0.f;
-      rv[e] = has_res ? to_f(res[(size_t)mc * a.res_ld + nc]) : 0.f;
-      sv[e] = has_bs ? a.bscale[(size_t)b * a.bscale_ld + nc] : 1.f;
-      av[e] = has_ba ? a.badd[(size_t)b * a.badd_ld + nc] : 0.f;
-    }
+    EpiOps eo;
+    if constexpr (HOIST) eo = eo0;
+    else eo = epi_load(it);
+    const float *bi = eo.bi, *rv = eo.rv, *sv = eo.sv, *av = eo.av;
     const int mlc = min(ml, BM - 1);
     f32x4 v = *reinterpret_cast<const f32x4 *>(red + (size_t)mlc * LDR + nq * 4);
 #pragma unroll
@@ -244,7 +266,7 @@ __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(const ConvGemmArgs 
   }
 }
 
-template <typename T, int BM, int BN, bool CAT, int KW> hipError_t launch_fast2(const ConvGemmArgs &a, hipStream_t s) {
+template <typename T, int BM, int BN, bool CAT, int KW, int NSET> hipError_t launch_fast3(const ConvGemmArgs &a, hipStream_t s) {
   constexpr int BKT = 4 * KW;
   constexpr int LD = BKT + 16 / (int)sizeof(T);
   constexpr size_t stage_bytes = (size_t)(BM + BN) * LD * sizeof(T);
@@ -256,7 +278,7 @@ template <typename T, int BM, int BN, bool CAT, int KW> hipError_t launch_fast2(
   const size_t bA = (size_t)(a.M / a.Lout + (a.M % a.Lout ? 1 : 0)) * a.Lsrc * a.src_ld * es;
   const size_t bA2 = CAT ? (size_t)a.M * a.src2_ld * es : 0;
   const size_t bW = (size_t)a.N * a.K * es;
-  auto kern = conv_gemm_fast_kernel<T, BM, BN, CAT, KW>;
+  auto kern = conv_gemm_fast_kernel<T, BM, BN, CAT, KW, NSET>;
   static bool en = false;
   if (!en) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
@@ -265,6 +287,12 @@ template <typename T, int BM, int BN, bool CAT, int KW> hipError_t launch_fast2(
   }
   hipLaunchKernelGGL(kern, dim3(mtiles * ntiles), dim3(256), lds, s, a, mtiles, ntiles, swz, (unsigned)bA, (unsigned)bA2, (unsigned)bW);
   return hipGetLastError();
+}
+
+// Two chunks in flight: measured with HBM-cold weights (tools/gemm_cold.py), 4 or 6 chunks in flight are no faster
+// (the limit is the L2 -> CU fill rate, ~25 B/clk/CU here, not latency) and 6 cost occupancy.
+template <typename T, int BM, int BN, bool CAT, int KW> hipError_t launch_fast2(const ConvGemmArgs &a, hipStream_t s) {
+  return launch_fast3<T, BM, BN, CAT, KW, 2>(a, s);
 }
 
 }  // namespace

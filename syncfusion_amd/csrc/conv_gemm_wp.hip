@@ -193,6 +193,35 @@ __global__ __launch_bounds__(256) void conv_gemm_wp_kernel(const ConvGemmArgs a,
     }
   };
 
+  // ---- epilogue operands: loaded up front when one epilogue pass per thread suffices (see conv_gemm_fast.hip) ------
+  const T *res = static_cast<const T *>(a.res);
+  const bool has_res = res != nullptr, has_bs = a.bscale != nullptr, has_ba = a.badd != nullptr;
+  constexpr int QN = BN / 4;
+  constexpr int EIT = (BM * QN + 255) / 256;
+  constexpr bool HOIST = EIT == 1;
+  struct EpiOps {
+    float bi[4], rv[4], sv[4], av[4];
+  };
+  auto epi_load = [&](int it) {
+    EpiOps o;
+    const int idx = tid + it * 256;
+    const int ml = idx / QN, nq = idx - ml * QN;
+    const int m = m0 + ml, nb = n0 + nq * 4;
+    const int mc = min(m, a.M - 1);
+    const int b = (has_bs || has_ba) ? mc / a.Lout : 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int nc = min(nb + e, a.N - 1);
+      o.bi[e] = a.bias ? a.bias[nc] : 0.f;
+      o.rv[e] = has_res ? to_f(res[(size_t)mc * a.res_ld + nc]) : 0.f;
+      o.sv[e] = has_bs ? a.bscale[(size_t)b * a.bscale_ld + nc] : 1.f;
+      o.av[e] = has_ba ? a.badd[(size_t)b * a.badd_ld + nc] : 0.f;
+    }
+    return o;
+  };
+  EpiOps eo0;
+  if constexpr (HOIST) eo0 = epi_load(0);
+
   // ---- the wave's own pipeline: no workgroup barrier --------------------------------------------------------
   if (nkt > 0) prefetch(s0);
   if (nkt > 1) prefetch(s1);
@@ -226,26 +255,16 @@ __global__ __launch_bounds__(256) void conv_gemm_wp_kernel(const ConvGemmArgs a,
   __syncthreads();
 
   T *out = static_cast<T *>(a.out);
-  const T *res = static_cast<const T *>(a.res);
-  const bool has_res = res != nullptr, has_bs = a.bscale != nullptr, has_ba = a.badd != nullptr;
-  constexpr int QN = BN / 4;
 #pragma unroll
-  for (int it = 0; it < (BM * QN + 255) / 256; ++it) {
+  for (int it = 0; it < EIT; ++it) {
     const int idx = tid + it * 256;
     const int ml = idx / QN, nq = idx - ml * QN;
     const int m = m0 + ml, nb = n0 + nq * 4;
     const bool live = idx < BM * QN && m < a.M && nb < a.n_store;
-    const int mc = min(m, a.M - 1);
-    float bi[4], rv[4], sv[4], av[4];
-    const int b = (has_bs || has_ba) ? mc / a.Lout : 0;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int nc = min(nb + e, a.N - 1);
-      bi[e] = a.bias ? a.bias[nc] : 0.f;
-      rv[e] = has_res ? to_f(res[(size_t)mc * a.res_ld + nc]) : 0.f;
-      sv[e] = has_bs ? a.bscale[(size_t)b * a.bscale_ld + nc] : 1.f;
-      av[e] = has_ba ? a.badd[(size_t)b * a.badd_ld + nc] : 0.f;
-    }
+    EpiOps eo;
+    if constexpr (HOIST) eo = eo0;
+    else eo = epi_load(it);
+    const float *bi = eo.bi, *rv = eo.rv, *sv = eo.sv, *av = eo.av;
     const int mlc = min(ml, BM - 1);
     f32x4 v = *reinterpret_cast<const f32x4 *>(red + (size_t)mlc * LDR + nq * 4);
 #pragma unroll
