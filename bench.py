@@ -163,7 +163,25 @@ def main():
     else:
         achieved = d_by / (d_ms * 1e-3) / 1e9
         roof = dict(bound="hbm", achieved=round(achieved, 2), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(achieved / PEAK_HBM_GBS, 5))
-    roof.update(traffic=None, kernel=dom, launches_per_eval=d_n, avg_launch_us=round(d_ms / d_n * 1e3, 3),
+    # HBM-side bytes per launch of the dominant kernel: PMC passes cannot run inside this process (they serialise the
+    # device and need rocprofv3), so the number comes from the committed summary of separate rocprofv3 --pmc passes over
+    # THIS command (tools/pmc_traffic.py; FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as is); null when the
+    # summary has no entry for the kernel or the workload is not the profiled one.
+    traffic, traffic_src = None, None
+    if args.batch == 8 and args.dtype == "bf16" and args.scale == 1.0:
+        import glob
+
+        for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))[::-1]:
+            try:
+                with open(path) as f:
+                    kern = json.load(f).get("kernels", {})
+            except (OSError, ValueError):
+                continue
+            ent = kern.get(dom.split("<")[0])
+            if ent:
+                traffic, traffic_src = ent["traffic_bytes_per_launch"], os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))
+                break
+    roof.update(traffic=traffic, traffic_source=traffic_src, algorithmic_bytes_per_launch=round(d_by / d_n), kernel=dom, launches_per_eval=d_n, avg_launch_us=round(d_ms / d_n * 1e3, 3),
                 share_of_eval_time=round(d_ms / total_ms, 4),
                 per_kernel={k: dict(ms=round(v[0], 4), launches=v[3], tflops=round(v[1] / max(v[0], 1e-9) / 1e9, 3),
                                     gbs=round(v[2] / max(v[0], 1e-9) / 1e6, 1)) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])},
