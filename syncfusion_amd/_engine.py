@@ -103,7 +103,9 @@ class UNetEngine(_Base):
 
     def _ws_for(self, B: int, L0: int, two: bool, num_steps: int = 0) -> torch.Tensor:
         if num_steps:
-            n = self.lib.sf_vsample_workspace_bytes(self.handle, B, L0, int(two), int(num_steps))
+            # sized for at least 256 steps: a later call with more steps then finds the same buffer (and the engine its
+            # cached step graph, whose kernel nodes hold workspace addresses)
+            n = self.lib.sf_vsample_workspace_bytes(self.handle, B, L0, int(two), max(int(num_steps), 256))
         else:
             n = self.lib.sf_unet_workspace_bytes(self.handle, B, L0, int(two))
         if n < 0:

@@ -51,6 +51,7 @@ struct Plan {  // everything carved out of the caller's workspace for one (B, L0
   int B = 0, Bt = 0, L0 = 0;
   bool two = false;
   std::vector<Level> lv;
+  float *xs = nullptr;         // sampler state (B, L0, in_channels) the step graph works on
   float *x2 = nullptr, *vout = nullptr, *mod_all = nullptr, *ca_all = nullptr, *slab = nullptr, *emb2 = nullptr;
   float *sched = nullptr;  // [steps][4] = (alpha_i, beta_i, alpha_{i+1}, beta_{i+1})
   float *sigs = nullptr;   // [steps] schedule sigmas, then [Bt] per-row sigmas of a single forward
@@ -108,10 +109,17 @@ struct sf_unet {
   std::vector<std::pair<std::string, int64_t>> names;
   // graph cache for sf_vsample
   hipGraphExec_t gexec = nullptr;
-  struct {
-    const void *x = nullptr, *ws = nullptr;
-    int B = 0, L0 = 0;
+  // the instantiated step graph is reused by later sf_vsample calls with the same shape / workspace / guidance scale
+  // (every pointer baked into its kernel nodes lives in the workspace or in the engine; the sampler state is an
+  // internal workspace buffer, the caller's x is copied in and out)
+  struct GraphKey {
+    int B = 0, L0 = 0, T = 0, nbr = 0;
+    bool two = false, valid = false;
     float scale = 0.f;
+    const void *ws = nullptr;
+    bool operator==(const GraphKey &o) const {
+      return valid && o.valid && B == o.B && L0 == o.L0 && T == o.T && nbr == o.nbr && two == o.two && scale == o.scale && ws == o.ws;
+    }
   } gkey;
 
   // stream capture is illegal on the legacy null stream (torch's default): the sampling loop runs on an
@@ -395,6 +403,8 @@ void build(sf_unet &u, const WeightMap *wm, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------------
 // workspace plan
 // ---------------------------------------------------------------------------------------------------
+constexpr int kSchedSteps = 1024;   // schedule capacity that keeps the workspace layout independent of num_steps
+
 Plan make_plan(const sf_unet &u, Workspace &ws, int B, int L0, bool two, int num_steps) {
   const sf_unet_config &c = u.cfg;
   Plan p;
@@ -444,10 +454,10 @@ Plan make_plan(const sf_unet &u, Workspace &ws, int B, int L0, bool two, int num
   const int64_t n0 = (int64_t)p.Bt * L0 * c.in_channels;
   p.x2 = ws.alloc_n<float>(n0);
   p.vout = ws.alloc_n<float>(n0);
+  p.xs = ws.alloc_n<float>(n0);
   p.mod_all = ws.alloc_n<float>((int64_t)p.Bt * u.mod_ld);
   p.mod_stride = u.mod_ld;
   p.steps_cap = num_steps > 1 ? num_steps : 0;
-  if (p.steps_cap) p.mod_steps = ws.alloc_n<float>((int64_t)p.steps_cap * u.mod_ld);
   p.ca_all = ws.alloc_n<float>((int64_t)p.Bt * u.ca_ld);
   p.slab = ws.alloc_n<float>(slab_floats);
   {
@@ -461,19 +471,23 @@ Plan make_plan(const sf_unet &u, Workspace &ws, int B, int L0, bool two, int num
     p.sk_slab = ws.alloc_n<float>(p.sk_stride * p.nbr);
     p.sk_cnt = ws.alloc_n<int>((int64_t)kSkCnt * sf_unet::kMaxBranches);
   }
-  const int64_t frows = std::max<int64_t>(p.Bt, p.steps_cap);
-  p.four = ws.alloc(frows * u.four_ld * es);
-  p.f1 = ws.alloc(frows * u.mf * es);
-  p.f2 = ws.alloc(frows * u.mf * es);
-  p.sf = ws.alloc(frows * u.mf * es);
   p.emb2 = ws.alloc_n<float>((int64_t)p.Bt * c.embedding_features);
   p.emb_t = ws.alloc((int64_t)p.Bt * c.embedding_features * es);
   p.xhat_e = ws.alloc((int64_t)p.Bt * c.embedding_features * es);
   p.v_all = ws.alloc((int64_t)p.Bt * (u.n_ca > 0 ? u.n_ca : 1) * u.hd * es);
-  const int64_t ns = num_steps > 0 ? num_steps : 1;
+  // Everything whose SIZE depends on the number of steps comes last, so that no other address does: a step graph
+  // instantiated for one num_steps stays valid for another (up to kSchedSteps; the tables are indexed by the device
+  // step counter).  Order: step counter, schedule (fixed capacity), sigmas, modulation table, time-MLP rows.
+  const int64_t ns = std::max<int64_t>(num_steps > 0 ? num_steps : 1, kSchedSteps);
+  p.step = ws.alloc_n<int>(4);
   p.sched = ws.alloc_n<float>(4 * ns);
   p.sigs = ws.alloc_n<float>(ns + p.Bt);
-  p.step = ws.alloc_n<int>(4);
+  if (p.steps_cap) p.mod_steps = ws.alloc_n<float>((int64_t)p.steps_cap * u.mod_ld);   // base fixed, length ~ num_steps
+  const int64_t frows = std::max<int64_t>(p.Bt, p.steps_cap);   // time-MLP rows: only used outside the step graph
+  p.four = ws.alloc(frows * u.four_ld * es);
+  p.f1 = ws.alloc(frows * u.mf * es);
+  p.f2 = ws.alloc(frows * u.mf * es);
+  p.sf = ws.alloc(frows * u.mf * es);
   return p;
 }
 
@@ -1190,23 +1204,38 @@ int sf_vsample(sf_unet *h, float *x, const float *const *ctx, const float *emb, 
     ex.features_rows(sigs, nullptr, T, p.mod_steps);
     p.mod_stride = 0;
   }
+  float *xs = p.xs;
+  SF_HIP(hipMemcpyAsync(xs, x, n * sizeof(float), hipMemcpyDeviceToDevice, s));
   auto one_step = [&]() {
     if (pre) {
       SF_HIP(launch_step_select(p.mod_steps, h->mod_ld, p.step, p.mod_all, s));
-      ex.eval(x, nullptr, nullptr, /*features_ready=*/true);
-      SF_HIP(launch_vsampler_update(x, p.vout, two ? p.vout + n : nullptr, embedding_scale, sched - 4, p.step, n, s));   // *step == i + 1 here
+      ex.eval(xs, nullptr, nullptr, /*features_ready=*/true);
+      SF_HIP(launch_vsampler_update(xs, p.vout, two ? p.vout + n : nullptr, embedding_scale, sched - 4, p.step, n, s));   // *step == i + 1 here
     } else {
-      ex.eval(x, sigs, p.step);
-      SF_HIP(launch_vsampler_update(x, p.vout, two ? p.vout + n : nullptr, embedding_scale, sched, p.step, n, s));
+      ex.eval(xs, sigs, p.step);
+      SF_HIP(launch_vsampler_update(xs, p.vout, two ? p.vout + n : nullptr, embedding_scale, sched, p.step, n, s));
       SF_HIP(launch_step_advance(p.step, s));
     }
   };
 
+  sf_unet::GraphKey key;
+  key.B = B;
+  key.L0 = L0;
+  key.T = T > kSchedSteps ? T : 0;   // the layout (hence the graph) depends on num_steps only beyond the fixed schedule capacity
+  key.nbr = p.nbr;
+  key.two = two;
+  key.scale = embedding_scale;
+  key.ws = ws;
+  key.valid = true;
+  if (use_graph && T > 1 && h->gexec && !h->prof_on && h->gkey == key) {
+    for (int i = 0; i < T; ++i) SF_HIP(hipGraphLaunch(h->gexec, s));   // steady state: no eager step, no capture
+  } else {
   h->launches = 0;
   one_step();  // step 0 eagerly (also performs every one-time kernel attribute setup outside capture)
   h->launches += 2;
   if (T > 1) {
     if (use_graph) {
+      h->gkey.valid = false;
       hipGraph_t graph = nullptr;
       SF_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
       try {
@@ -1225,11 +1254,14 @@ int sf_vsample(sf_unet *h, float *x, const float *const *ctx, const float *emb, 
       hipError_t e = hipGraphInstantiate(&h->gexec, graph, nullptr, nullptr, 0);
       (void)hipGraphDestroy(graph);
       if (e != hipSuccess) fail(SF_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+      h->gkey = key;
       for (int i = 1; i < T; ++i) SF_HIP(hipGraphLaunch(h->gexec, s));
     } else {
       for (int i = 1; i < T; ++i) one_step();
     }
   }
+  }
+  SF_HIP(hipMemcpyAsync(x, xs, n * sizeof(float), hipMemcpyDeviceToDevice, s));
   if (s != user) {
     SF_HIP(hipEventRecord(h->ev_out, s));
     SF_HIP(hipStreamWaitEvent(user, h->ev_out, 0));

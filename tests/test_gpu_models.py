@@ -123,6 +123,26 @@ def test_sample_graph_equals_eager_bitwise(cuda):
     assert torch.equal(a, b) and torch.equal(b, c), "the path has no atomics: results must be bit-reproducible"
 
 
+def test_sample_reuses_cached_step_graph(cuda):
+    """A second sample() call of the same shape replays the step graph instantiated by the first (no eager step, no
+    capture): new noise / new conditioning must still give exactly the eager result, and a different num_steps or
+    guidance scale must not hit the stale graph."""
+    m = _small_diffusion(cuda)
+    B, L0 = 2, 16 * 44
+    outs = {}
+    for graph in (True, False):
+        m.sampler.use_graph = graph
+        res = []
+        for seed, steps, scale in ((1, 6, 2.0), (2, 6, 2.0), (3, 6, 2.0), (4, 4, 2.0), (5, 4, 1.0), (6, 4, 1.0)):
+            _, _, emb, chans = synth_inputs(SMALL_UNET, B, L0, seed=seed)
+            noise = torch.randn(B, 1, L0, generator=torch.Generator().manual_seed(100 + seed)).to(cuda)
+            res.append(m.sample(x_noisy=noise, num_steps=steps, channels=[c.to(cuda) for c in chans], embedding=emb.to(cuda),
+                                embedding_scale=scale).cpu())
+        outs[graph] = res
+    for a, b in zip(outs[True], outs[False]):
+        assert torch.equal(a, b)
+
+
 def test_sampler_zero_net_identity(cuda):
     """Analytic identity: with v == 0 every step multiplies x by cos(pi/2T) -> x_T = x_0 cos(pi/2T)^T.
     A net whose output convs are zero returns v == 0 exactly (skip + scale * 0 at depth 0 gives v = x; so instead
