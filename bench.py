@@ -64,21 +64,26 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--dump-launches", default=None, help="write the per-launch event timings of one evaluation to this file")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank: exercises the N > 1 code path on a 1-GPU box")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
     from syncfusion_amd import dist as sfd
+
+    sfd.FORCE_COLLECTIVES = bool(args.force_dist)
     import syncfusion_amd as sa
 
     B = args.batch
@@ -100,7 +105,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if dist_on:
             import torch.distributed as dist
 
             dist.barrier()
@@ -113,7 +118,7 @@ def main():
     out = run(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
 
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -245,7 +250,7 @@ def main():
         "cpu_baseline": cpu,
     }
     print(json.dumps(line))
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
 
         dist.destroy_process_group()

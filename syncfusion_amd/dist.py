@@ -27,10 +27,18 @@ def rank_seed(base_seed: int, rank: int) -> int:
     return base_seed + rank
 
 
+# test hook (bench.py --force-dist): run the collectives even when the group has a single rank
+FORCE_COLLECTIVES = False
+
+
+def _single() -> bool:
+    return (not (dist.is_available() and dist.is_initialized())) or (dist.get_world_size() == 1 and not FORCE_COLLECTIVES)
+
+
 @torch.no_grad()
 def broadcast_module(module: torch.nn.Module, src: int = 0) -> int:
     """Flat-buffer broadcast of every parameter and buffer from ``src``.  Returns bytes moved per rank."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if _single():
         return 0
     tensors = [t for t in list(module.parameters()) + list(module.buffers()) if t.is_floating_point()]
     if not tensors:
@@ -48,7 +56,7 @@ def broadcast_module(module: torch.nn.Module, src: int = 0) -> int:
 @torch.no_grad()
 def gather_clips(local: torch.Tensor, total: int, dst: int = 0) -> Optional[torch.Tensor]:
     """Gather per-rank ``(b_r, ...)`` clip tensors into ``(total, ...)`` on ``dst`` (None elsewhere)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if _single():
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
     sizes = [shard_range(total, r, world) for r in range(world)]
