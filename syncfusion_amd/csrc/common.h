@@ -77,6 +77,21 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Wave-wide sum with DPP row operations (VALU only -- __shfl_xor is ds_bpermute, i.e. LDS crossbar traffic); every lane
+// receives the total.  Fixed order: deterministic.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_mov_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += dpp_mov_f<0xb1, 0xf>(v);    // quad_perm [1,0,3,2]
+  v += dpp_mov_f<0x4e, 0xf>(v);    // quad_perm [2,3,0,1]
+  v += dpp_mov_f<0x124, 0xf>(v);   // row_ror:4
+  v += dpp_mov_f<0x128, 0xf>(v);   // row_ror:8      -> every lane holds the sum of its row of 16
+  v += dpp_mov_f<0x142, 0xa>(v);   // row_bcast:15   -> rows 1 and 3 add the total of the row before
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31)) +
+         __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 // Chan/Welford merge of (n, mean, M2) partials.
 __device__ __forceinline__ void welford_merge(float &n, float &mean, float &m2, float nb, float mb, float m2b) {
   if (nb <= 0.f) return;

@@ -277,6 +277,85 @@ __global__ __launch_bounds__(512) void gn_silu_kernel(const T *__restrict__ x, i
   }
 }
 
+// Same operation when the (clip, group) slab fits the workgroup's registers (<= RV 16-byte vectors per thread: every level
+// of the reference U-Net at 2 s clips): x, gamma and beta are fetched in ONE memory round trip, the statistics are
+// two in-register passes (sum -> mean, centred squares -> variance) with a DPP wave reduction and one barrier each.
+template <typename T, int RV>
+__global__ __launch_bounds__(512) void gn_silu_reg_kernel(const T *__restrict__ x, int ld, int L, int C, int G,
+                                                          const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                                                          T *__restrict__ out, int out_ld) {
+  constexpr bool FAST = sizeof(T) == 2;
+  constexpr int V = Vec16<T>::N;
+  __shared__ float red[2][8];
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+  const int cpg = C / G;
+  const int vr = cpg / V;                  // vectors per row
+  const int nv = L * vr;
+  const T *base = x + (size_t)b * L * ld + (size_t)g * cpg;
+  T *obase = out + (size_t)b * L * out_ld + (size_t)g * cpg;
+  Vec16<T> v[RV];
+  f32x4 ga[RV][V / 4], be[RV][V / 4];
+  int rr[RV], cc[RV];
+#pragma unroll
+  for (int i = 0; i < RV; ++i) {
+    const int idx = tid + i * 512;
+    const bool on = idx < nv;
+    const int r = on ? idx / vr : 0, cv = on ? idx - r * vr : 0;
+    rr[i] = r;
+    cc[i] = cv;
+    v[i] = on ? ld16<T>(base + (size_t)r * ld + cv * V) : zero16<T>();
+#pragma unroll
+    for (int q = 0; q < V / 4; ++q) {
+      ga[i][q] = *reinterpret_cast<const f32x4 *>(gamma + g * cpg + cv * V + 4 * q);
+      be[i][q] = *reinterpret_cast<const f32x4 *>(beta + g * cpg + cv * V + 4 * q);
+    }
+  }
+  const float n = (float)L * (float)cpg;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < RV; ++i)
+#pragma unroll
+    for (int j = 0; j < V; ++j) s += v[i].get(j);   // padding vectors are zero
+  s = wave_sum_dpp(s);
+  if ((tid & 63) == 0) red[0][wave] = s;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) tot += red[0][w];
+  const float mean = tot / n;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < RV; ++i) {
+    if (tid + i * 512 < nv) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const float d = v[i].get(j) - mean;
+        q = fmaf(d, d, q);
+      }
+    }
+  }
+  q = wave_sum_dpp(q);
+  if ((tid & 63) == 0) red[1][wave] = q;
+  __syncthreads();
+  float tq = 0.f;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) tq += red[1][w];
+  const float rstd = rsqrtf(tq / n + eps);
+#pragma unroll
+  for (int i = 0; i < RV; ++i) {
+    if (tid + i * 512 < nv) {
+      Vec16<T> o;
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const float sc = rstd * ga[i][j >> 2][j & 3];
+        o.set(j, silu_t<FAST>(fmaf(v[i].get(j) - mean, sc, be[i][j >> 2][j & 3])));
+      }
+      st16<T>(obase + (size_t)rr[i] * out_ld + cc[i] * V, o);
+    }
+  }
+}
+
 template <typename T>
 hipError_t gn_silu_go(const void *x, int ld, int B, int L, int C, int G, const float *gamma, const float *beta, float eps, void *out,
                       int out_ld, hipStream_t s) {
@@ -288,6 +367,12 @@ hipError_t gn_silu_go(const void *x, int ld, int B, int L, int C, int G, const f
   dim3 grid(B * G);
 #define SF_GNS(VW) hipLaunchKernelGGL((gn_silu_kernel<T, VW>), grid, dim3(512), 0, s, xp, ld, L, C, G, gamma, beta, eps, op, out_ld)
   const bool al = (ld % V == 0) && (out_ld % V == 0);
+  if (al && cpg % V == 0 && (int64_t)L * (cpg / V) <= 4 * 512) {   // slab fits the registers of one workgroup
+    const int64_t nv = (int64_t)L * (cpg / V);
+    if (nv <= 2 * 512) hipLaunchKernelGGL((gn_silu_reg_kernel<T, 2>), grid, dim3(512), 0, s, xp, ld, L, C, G, gamma, beta, eps, op, out_ld);
+    else hipLaunchKernelGGL((gn_silu_reg_kernel<T, 4>), grid, dim3(512), 0, s, xp, ld, L, C, G, gamma, beta, eps, op, out_ld);
+    return hipGetLastError();
+  }
   if (al && cpg % V == 0) SF_GNS(V);
   else if (ld % 4 == 0 && out_ld % 4 == 0 && cpg % 4 == 0) SF_GNS(4);
   else if (ld % 2 == 0 && out_ld % 2 == 0 && cpg % 2 == 0) SF_GNS(2);
