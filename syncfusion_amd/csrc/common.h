@@ -92,6 +92,14 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
          __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// sum over aligned groups of 8 consecutive lanes (every lane of the group receives it): two quad permutes + half-row mirror
+__device__ __forceinline__ float sum8_dpp(float v) {
+  v += dpp_mov_f<0xb1, 0xf>(v);    // quad_perm [1,0,3,2]
+  v += dpp_mov_f<0x4e, 0xf>(v);    // quad_perm [2,3,0,1]
+  v += dpp_mov_f<0x141, 0xf>(v);   // row_half_mirror: lane i <-> 7 - i inside each 8
+  return v;
+}
+
 // Chan/Welford merge of (n, mean, M2) partials.
 __device__ __forceinline__ void welford_merge(float &n, float &mean, float &m2, float nb, float mb, float m2b) {
   if (nb <= 0.f) return;

@@ -433,6 +433,19 @@ const char *conv_gemm_variant_name(int dt, const ConvGemmArgs &a) {
 
 ConvGemmForce g_conv_gemm_force;
 
+bool conv_gemm_emits_rowpart(int dt, const ConvGemmArgs &a) {
+  if (g_conv_gemm_force.path != 0 || !conv_gemm_supported(dt, a)) return false;
+  if ((a.n_store % 32) || a.n_store != a.N) return false;
+  const long t64 = (long)((a.M + 63) / 64) * ((a.n_store + 63) / 64);
+  const bool short_act = t64 < 500 && a.K >= 256 && (a.K % 32) == 0 && (a.cin % 32) == 0 && (a.cin2 % 32) == 0;
+  if (!(short_act || use_sk(a))) return false;                 // would go to v2 / the classic tiles
+  if ((a.cin % 32) || (a.cin2 % 32) || (a.K % 32)) return false;
+  if (conv_gemm_sk_variant(a) != 2) return false;              // 32x32 tiles only
+  const bool prefer_wp = a.M <= 512 && a.K >= 2048;
+  if (prefer_wp && conv_gemm_wp_ok(dt, a)) return true;        // wp 32x32 (its LDS footprint fits in both types)
+  return conv_gemm_fast_ok(dt, a);
+}
+
 hipError_t launch_conv_gemm(int dt, const ConvGemmArgs &a, hipStream_t s) {
   if (!conv_gemm_supported(dt, a)) return hipErrorInvalidValue;
   const ConvGemmForce &f = g_conv_gemm_force;

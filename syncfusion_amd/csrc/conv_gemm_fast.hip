@@ -26,7 +26,8 @@ template <typename T> __device__ __forceinline__ Vec16<T> buf_ld16(__amdgpu_buff
 // KW = K elements one wave multiplies per iteration (32 or 64); the workgroup stages BKT = 4*KW per iteration.
 // NSET = K chunks in flight per workgroup.  The weights of a denoising step stream from HBM (they do not fit the
 // Infinity Cache), so a workgroup needs latency x bandwidth bytes outstanding: 2 chunks (32 KB) cap a CU at ~45 GB/s.
-template <typename T, int BM, int BN, bool CAT, int KW, int NSET>
+// LN: the first source is LayerNorm-modulated on the fly (ConvGemmArgs::ln_*; 32x32 tiles, one tap, Lout >= 32).
+template <typename T, int BM, int BN, bool CAT, int KW, int NSET, bool LN>
 __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(const ConvGemmArgs a, const int mtiles, const int ntiles, const int swz,
                                                              const unsigned bytesA, const unsigned bytesA2, const unsigned bytesW) {
   constexpr int BKT = 4 * KW;
@@ -43,6 +44,11 @@ __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(const ConvGemmArgs 
   T *As = reinterpret_cast<T *>(smem);
   T *Bs = As + BM * LD;
   float *red = reinterpret_cast<float *>(smem);
+  // LN: behind the staging / reduction area: rowstat[BM][2] = (mean, rstd), tab[2 clips][2][cin] = (1 + scale | shift)
+  constexpr size_t kStageBytes = (size_t)(BM + BN) * LD * sizeof(T), kRedBytes = (size_t)4 * BM * LDR * sizeof(float);
+  constexpr size_t kLnOff = ((kStageBytes > kRedBytes ? kStageBytes : kRedBytes) + 15) / 16 * 16;
+  float *rowstat = reinterpret_cast<float *>(smem + kLnOff);
+  float *lntab = rowstat + 2 * BM;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int bid = blockIdx.x, mt, nt;
@@ -92,8 +98,16 @@ __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(const ConvGemmArgs 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // LN: per staged row (mean, rstd, clip selector) -- filled after the first chunks are in flight
+  float ln_mu[PA], ln_rs[PA];
+  int ln_cs[PA];
+  const int ln_b0 = m0 / a.Lout;
+  const bool has_ss = LN && a.ln_ss != nullptr;
+  const bool ln_epi = LN && a.ln_colsum != nullptr;   // normalise the accumulator instead of the operand
   struct RegSet {
     Vec16<T> ra[PA], rb[PB];
+    unsigned c0;   // LN: first channel of the chunk inside the first source
+    bool first;    // LN: the chunk belongs to the first source
   };
   RegSet rs[NSET];
   const int nkt = (a.K + BKT - 1) / BKT;
@@ -113,6 +127,10 @@ __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(const ConvGemmArgs 
     // per lane, only in the last chunk of a ragged K: OR-ing the top bit makes the offset out of range (-> zeros)
     // without giving the compiler a select it could turn into a branch around the load
     const unsigned tmask = (kb + lane_kb >= kbytes) ? OOB : 0u;
+    if constexpr (LN) {
+      R.c0 = cb / (unsigned)ES;
+      R.first = !second;
+    }
 #pragma unroll
     for (int i = 0; i < PB; ++i) R.rb[i] = buf_ld16<T>(rW, (offW[i] + kb) | tmask);
     const __amdgpu_buffer_rsrc_t rs = (CAT && second) ? rA2 : rA;
@@ -137,6 +155,34 @@ __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(const ConvGemmArgs 
   auto stage = [&](RegSet &R) {
 #pragma unroll
     for (int i = 0; i < PB; ++i) st16<T>(Bs + (i * RPP + srow) * LD + svec * VEC, R.rb[i]);
+    if constexpr (LN) {
+      if (R.first && !ln_epi) {   // wave-uniform: y = x * (rstd * sc) + (sh - mean * rstd * sc), table rows read as 16-byte vectors
+        const int c = (int)R.c0 + svec * VEC;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+          Vec16<T> v = R.ra[i];
+          if (has_ss) {
+            const f32x4 *tsc = reinterpret_cast<const f32x4 *>(lntab + (ln_cs[i] * 2 + 0) * a.cin + c);
+            const f32x4 *tsh = reinterpret_cast<const f32x4 *>(lntab + (ln_cs[i] * 2 + 1) * a.cin + c);
+#pragma unroll
+            for (int q = 0; q < VEC / 4; ++q) {
+              const f32x4 sc4 = tsc[q], sh4 = tsh[q];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float A = ln_rs[i] * sc4[e];
+                v.set(4 * q + e, fmaf(v.get(4 * q + e), A, fmaf(-ln_mu[i], A, sh4[e])));
+              }
+            }
+          } else {
+            const float B = -ln_mu[i] * ln_rs[i];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) v.set(j, fmaf(v.get(j), ln_rs[i], B));
+          }
+          st16<T>(As + (i * RPP + srow) * LD + svec * VEC, v);
+        }
+        return;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < PA; ++i) st16<T>(As + (i * RPP + srow) * LD + svec * VEC, R.ra[i]);
   };
@@ -182,9 +228,9 @@ __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(const ConvGemmArgs 
   const bool has_res = res != nullptr, has_bs = a.bscale != nullptr, has_ba = a.badd != nullptr;
   constexpr int QN = BN / 4;
   constexpr int EIT = (BM * QN + 255) / 256;
-  constexpr bool HOIST = EIT == 1;
+  constexpr bool HOIST = EIT == 1 && !LN;   // (the LN variant would pass 128 registers and lose a workgroup per CU)
   struct EpiOps {
-    float bi[4], rv[4], sv[4], av[4];
+    float bi[4], rv[4], sv[4], av[4], cu[4];
   };
   auto epi_load = [&](int it) {
     EpiOps o;
@@ -200,6 +246,7 @@ __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(const ConvGemmArgs 
       o.rv[e] = has_res ? to_f(res[(size_t)mc * a.res_ld + nc]) : 0.f;
       o.sv[e] = has_bs ? a.bscale[(size_t)b * a.bscale_ld + nc] : 1.f;
       o.av[e] = has_ba ? a.badd[(size_t)b * a.badd_ld + nc] : 0.f;
+      o.cu[e] = ln_epi ? a.ln_colsum[nc] : 0.f;
     }
     return o;
   };
@@ -209,6 +256,56 @@ __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(const ConvGemmArgs 
 #pragma unroll
   for (int j = 0; j < NSET; ++j)
     if (j < nkt) prefetch(rs[j]);
+  // ---- LN: pooled row statistics from the producer's per-tile partials, modulation table -> LDS --------------------
+  if constexpr (LN) {
+    {
+      const int r = tid >> 3, t8 = tid & 7;           // 8 threads per row, 32 rows
+      const int m = min(m0 + r, a.M - 1);
+      float mp[4], qp[4];
+      float sm = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int pidx = t8 + 8 * j;
+        const bool on = pidx < a.ln_nt;
+        const float2 pv = on ? *reinterpret_cast<const float2 *>(a.ln_part + ((size_t)m * a.ln_nt + pidx) * 2) : make_float2(0.f, 0.f);
+        mp[j] = pv.x;
+        qp[j] = pv.y;
+        sm += pv.x;
+      }
+      const float mean = sum8_dpp(sm) / (float)a.ln_nt;   // every partial covers 32 channels
+      float dq = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (t8 + 8 * j < a.ln_nt) {
+          const float d = mp[j] - mean;
+          dq += fmaf(32.f * d, d, qp[j]);
+        }
+      }
+      const float m2 = sum8_dpp(dq);
+      if (t8 == 0) {
+        rowstat[2 * r] = mean;
+        rowstat[2 * r + 1] = rsqrtf(m2 / (float)a.cin + a.ln_eps);
+      }
+    }
+    if (a.ln_ss) {
+      const int nclip = (a.M + a.Lout - 1) / a.Lout;
+      for (int i = tid; i < 2 * a.cin; i += 256) {
+        const int cs = i >= a.cin, c = i - cs * a.cin;
+        const int b = min(ln_b0 + cs, nclip - 1);
+        lntab[(cs * 2 + 0) * a.cin + c] = 1.0f + a.ln_ss[(size_t)b * a.ln_ss_ld + c];
+        lntab[(cs * 2 + 1) * a.cin + c] = a.ln_ss[(size_t)b * a.ln_ss_ld + a.cin + c];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const int ml = i * RPP + srow;
+      ln_mu[i] = rowstat[2 * ml];
+      ln_rs[i] = rowstat[2 * ml + 1];
+      ln_cs[i] = (min(m0 + ml, a.M - 1) / a.Lout != ln_b0) ? 1 : 0;
+    }
+  }
+
   for (int kt = 0; kt < nkt; kt += NSET) {
 #pragma unroll
     for (int j = 0; j < NSET; ++j) {
@@ -253,32 +350,69 @@ __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(const ConvGemmArgs 
       v[2] += t[2];
       v[3] += t[3];
     }
+    float rvt[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) rvt[e] = rv[e];
+    if constexpr (LN) {
+      if (ln_epi) {   // LayerNorm of the raw source folded into the accumulator
+        const float mu = rowstat[2 * mlc], rstd = rowstat[2 * mlc + 1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = rstd * (v[e] - mu * eo.cu[e]);
+      }
+    }
+    if constexpr (LN) {
+      if (a.res_ln) {   // the residual is the LayerNorm-modulated source row itself
+        const float mu = rowstat[2 * mlc], rstd = rowstat[2 * mlc + 1];
+        const int cs = (min(m, a.M - 1) / a.Lout != ln_b0) ? 1 : 0;
+        const int nbc = min(nb, a.N - 4);   // res_ln implies N == cin, a multiple of 32
+        const f32x4 sc4 = has_ss ? *reinterpret_cast<const f32x4 *>(lntab + (cs * 2 + 0) * a.cin + nbc) : f32x4{1.f, 1.f, 1.f, 1.f};
+        const f32x4 sh4 = has_ss ? *reinterpret_cast<const f32x4 *>(lntab + (cs * 2 + 1) * a.cin + nbc) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rvt[e] = fmaf((rv[e] - mu) * rstd, sc4[e], sh4[e]);
+      }
+    }
+    float xo[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int n = nb + e;
-      float x = (v[e] + bi[e]) * sv[e] + rv[e] + av[e];
+      float x = (v[e] + bi[e]) * sv[e] + rvt[e] + av[e];
       x = n < a.N ? apply_act(x, a.act) : 0.f;
+      xo[e] = a.out_f32 ? x : to_f(from_f<T>(x));
       if (live && n < a.n_store) {
         if (a.out_f32) static_cast<float *>(a.out)[(size_t)m * a.out_ld + n] = x;
         else out[(size_t)m * a.out_ld + n] = from_f<T>(x);
       }
     }
+    if constexpr (EIT == 1 && BN == 32) {
+      if (a.rowpart_out) {   // (mean, M2) of this row's 32 stored values: 8 consecutive lanes hold them, 4 each
+        const float mean = sum8_dpp((xo[0] + xo[1]) + (xo[2] + xo[3])) * (1.0f / 32.0f);
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = xo[e] - mean;
+          q = fmaf(d, d, q);
+        }
+        q = sum8_dpp(q);
+        if (nq == 0 && live) *reinterpret_cast<float2 *>(a.rowpart_out + ((size_t)m * a.rowpart_nt + nt) * 2) = make_float2(mean, q);
+      }
+    }
   }
 }
 
-template <typename T, int BM, int BN, bool CAT, int KW, int NSET> hipError_t launch_fast3(const ConvGemmArgs &a, hipStream_t s) {
+template <typename T, int BM, int BN, bool CAT, int KW, int NSET, bool LN = false> hipError_t launch_fast3(const ConvGemmArgs &a, hipStream_t s) {
   constexpr int BKT = 4 * KW;
   constexpr int LD = BKT + 16 / (int)sizeof(T);
   constexpr size_t stage_bytes = (size_t)(BM + BN) * LD * sizeof(T);
   constexpr size_t red_bytes = (size_t)4 * BM * (BN + 4) * sizeof(float);
-  const size_t lds = stage_bytes > red_bytes ? stage_bytes : red_bytes;
+  size_t lds = stage_bytes > red_bytes ? stage_bytes : red_bytes;
+  if (LN) lds = (lds + 15) / 16 * 16 + (size_t)(2 * BM + (a.ln_ss ? 4 * a.cin : 0)) * sizeof(float);   // rowstat (+ modulation table)
   const int mtiles = (a.M + BM - 1) / BM, ntiles = (a.n_store + BN - 1) / BN;
   const int swz = (ntiles % 8 == 0) ? 1 : 0;
   const size_t es = sizeof(T);
   const size_t bA = (size_t)(a.M / a.Lout + (a.M % a.Lout ? 1 : 0)) * a.Lsrc * a.src_ld * es;
   const size_t bA2 = CAT ? (size_t)a.M * a.src2_ld * es : 0;
   const size_t bW = (size_t)a.N * a.K * es;
-  auto kern = conv_gemm_fast_kernel<T, BM, BN, CAT, KW, NSET>;
+  auto kern = conv_gemm_fast_kernel<T, BM, BN, CAT, KW, NSET, LN>;
   static bool en = false;
   if (!en) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
@@ -308,6 +442,22 @@ bool conv_gemm_fast_ok(int dt, const ConvGemmArgs &a) {
   if ((size_t)a.M * (a.src2_ld > 0 ? a.src2_ld : 1) * es >= lim) return false;
   if ((size_t)a.N * a.K * es >= lim) return false;
   return true;
+}
+
+bool conv_gemm_ln_ok(int dt, const ConvGemmArgs &a) {
+  if (!conv_gemm_fast_ok(dt, a)) return false;
+  if (a.taps != 1 || a.stride != 1 || a.up_shift != 0 || a.Lout != a.Lsrc || a.Lout < 32) return false;
+  if (!a.ln_part || a.ln_nt * 32 != a.cin || a.ln_nt > 32) return false;
+  if (a.res_ln && (a.N != a.cin || !a.res)) return false;
+  if (a.ln_colsum && (a.cin2 || a.ln_ss || a.res_ln)) return false;
+  if (a.rowpart_out && ((a.n_store % 32) || a.rowpart_nt * 32 != a.n_store)) return false;
+  return true;
+}
+
+hipError_t launch_conv_gemm_ln(int dt, const ConvGemmArgs &a, hipStream_t s) {
+  if (!conv_gemm_ln_ok(dt, a)) return hipErrorInvalidValue;
+  if (dt == F32) return a.cin2 ? launch_fast3<float, 32, 32, true, 32, 2, true>(a, s) : launch_fast3<float, 32, 32, false, 32, 2, true>(a, s);
+  return a.cin2 ? launch_fast3<bf16, 32, 32, true, 32, 2, true>(a, s) : launch_fast3<bf16, 32, 32, false, 32, 2, true>(a, s);
 }
 
 hipError_t launch_conv_gemm_fast(int dt, const ConvGemmArgs &a, int variant, hipStream_t s) {

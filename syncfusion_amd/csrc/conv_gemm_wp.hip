@@ -275,14 +275,29 @@ __global__ __launch_bounds__(256) void conv_gemm_wp_kernel(const ConvGemmArgs a,
       v[2] += t[2];
       v[3] += t[3];
     }
+    float xo[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int n = nb + e;
       float x = (v[e] + bi[e]) * sv[e] + rv[e] + av[e];
       x = n < a.N ? apply_act(x, a.act) : 0.f;
+      xo[e] = a.out_f32 ? x : to_f(from_f<T>(x));
       if (live && n < a.n_store) {
         if (a.out_f32) static_cast<float *>(a.out)[(size_t)m * a.out_ld + n] = x;
         else out[(size_t)m * a.out_ld + n] = from_f<T>(x);
+      }
+    }
+    if constexpr (HOIST && BN == 32) {
+      if (a.rowpart_out) {   // row-LayerNorm partial of the stored values (see ConvGemmArgs, conv_gemm_fast.hip)
+        const float mean = sum8_dpp((xo[0] + xo[1]) + (xo[2] + xo[3])) * (1.0f / 32.0f);
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = xo[e] - mean;
+          q = fmaf(d, d, q);
+        }
+        q = sum8_dpp(q);
+        if (nq == 0 && live) *reinterpret_cast<float2 *>(a.rowpart_out + ((size_t)m * a.rowpart_nt + nt) * 2) = make_float2(mean, q);
       }
     }
   }

@@ -33,6 +33,20 @@ struct ConvGemmArgs {
   // epilogue: v = acc + bias; v *= bscale[b][n]; v += res[m][n]; v += badd[b][n]; v = act(v)
   //   act: 0 none, 1 relu, 2 gelu(erf), 3 silu(gelu(v))   out_f32: store fp32 whatever the compute type
   int badd_ld = 0, bscale_ld = 0, act = 0, out_f32 = 0;
+  // Row-LayerNorm fusion (conv_gemm_fast / conv_gemm_wp, 32x32 tiles only):
+  //   producer side: rowpart_out != nullptr -> the epilogue also writes, per output row and 32-column tile, the (mean, M2)
+  //     of the STORED values: rowpart_out[(m * rowpart_nt + n_tile) * 2 + {0,1}]   (rowpart_nt = n_store / 32);
+  //   consumer side (launch_conv_gemm_ln): the first source (cin channels, one tap) is read as
+  //     LayerNorm_cin(src; ln_eps) * (1 + ln_ss[b][c]) + ln_ss[b][cin + c]  (ln_ss == nullptr: plain normalisation), the row
+  //     statistics pooled from ln_part (ln_nt = cin / 32 partials per row); res_ln: the residual rows get the same transform.
+  float *rowpart_out = nullptr;
+  int rowpart_nt = 0;
+  //     ln_colsum != nullptr (plain normalisation, no second source): the source is multiplied RAW and the LayerNorm is
+  //     applied to the accumulator instead,  rstd_m * (acc[m][n] - mean_m * ln_colsum[n]),  ln_colsum[n] = sum_k w[n][k].
+  const float *ln_colsum = nullptr;
+  const float *ln_part = nullptr, *ln_ss = nullptr;
+  int ln_nt = 0, ln_ss_ld = 0, res_ln = 0;
+  float ln_eps = 1e-5f;
   // optional scratch for grid split-K (conv_gemm_v2): fp32 partial-tile slab and per-tile arrival tickets
   // (the tickets must be zero before the launch; the kernel re-arms them)
   float *sk_slab = nullptr;
@@ -48,6 +62,11 @@ bool conv_gemm_v2_plan(int dt, const ConvGemmArgs &a, V2Plan &pl);
 const char *conv_gemm_v2_name(int dt, const V2Plan &pl);
 hipError_t launch_conv_gemm_v2(int dt, const ConvGemmArgs &a, const V2Plan &pl, hipStream_t s);
 hipError_t launch_conv_gemm(int dt, const ConvGemmArgs &a, hipStream_t s);
+// true when launch_conv_gemm would run `a` on a kernel that honours rowpart_out (fast / wp, 32x32 tiles)
+bool conv_gemm_emits_rowpart(int dt, const ConvGemmArgs &a);
+// GEMM whose first source is LayerNorm-modulated on the fly from producer-side row partials (see ConvGemmArgs)
+bool conv_gemm_ln_ok(int dt, const ConvGemmArgs &a);
+hipError_t launch_conv_gemm_ln(int dt, const ConvGemmArgs &a, hipStream_t s);
 // Tuning hook (sf_bench_conv1d only; not thread-safe): force the kernel family / tile / split-K of launch_conv_gemm.
 //   path: 0 automatic, 1 classic (conv_gemm), 2 wave-split-K (sk / fast), 4 v2;  tile: -1 automatic else variant index;
 //   sk: -1 automatic else the grid split-K factor of v2.
@@ -159,6 +178,8 @@ hipError_t launch_onsets_to_track(const float *logits, int N, int T, const int32
 // ---------------------------------------------------------------------------------------
 // Weight packing (run once at engine creation)
 // ---------------------------------------------------------------------------------------
+// out[n] = sum_k w[n][k] of a packed [N][K] matrix (as stored, i.e. of the rounded compute-type values)
+hipError_t launch_row_sums(int dt, const void *w, int N, int K, float *out, hipStream_t s);
 // conv weight (N, Ctot, taps) fp32, channels [c_off, c_off+Cin) -> out[n*out_row + col0 + tap*cin_pad + ci] as DT,
 // zero for ci in [Cin, cin_pad)  (+ optional per-N scale = folded BatchNorm)
 hipError_t launch_pack_conv(int dt, const float *w, int N, int Ctot, int c_off, int Cin, int taps, int cin_pad, const float *nscale,

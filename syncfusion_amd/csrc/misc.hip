@@ -209,6 +209,18 @@ hipError_t launch_vsampler_update(float *x, const float *v, const float *v_uncon
   hipLaunchKernelGGL(vsampler_update_kernel, grid_for(n), dim3(TPB), 0, s, x, v, v_uncond, scale, sched, step_idx, n);
   return hipGetLastError();
 }
+template <typename T> __global__ void row_sums_kernel(const T *__restrict__ w, int K, float *__restrict__ out) {
+  const T *row = w + (size_t)blockIdx.x * K;
+  float acc = 0.f;
+  for (int k = threadIdx.x; k < K; k += 64) acc += to_f(row[k]);
+  acc = wave_sum(acc);
+  if (threadIdx.x == 0) out[blockIdx.x] = acc;
+}
+hipError_t launch_row_sums(int dt, const void *w, int N, int K, float *out, hipStream_t s) {
+  SF_DT(dt, hipLaunchKernelGGL(row_sums_kernel<float>, dim3(N), dim3(64), 0, s, (const float *)w, K, out),
+        hipLaunchKernelGGL(row_sums_kernel<bf16>, dim3(N), dim3(64), 0, s, (const bf16 *)w, K, out));
+  return hipGetLastError();
+}
 hipError_t launch_step_select(const float *table, int ld, int *step_idx, float *cur, hipStream_t s) {
   hipLaunchKernelGGL(step_select_kernel, dim3(1), dim3(1024), 0, s, table, ld, step_idx, cur);
   return hipGetLastError();

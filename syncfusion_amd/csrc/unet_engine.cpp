@@ -13,6 +13,7 @@
 //   * LayerNorm affines of the attention pre-norms are folded into the q/kv projection weights;
 //   * with classifier-free guidance the conditional and unconditional evaluations run as one 2B batch.
 #include <algorithm>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <exception>
@@ -27,6 +28,7 @@ namespace {
 struct Group {
   float *gn1_g = nullptr, *gn1_b = nullptr, *gn2_g = nullptr, *gn2_b = nullptr;
   ConvW conv1, conv2, inject, qkv, attn_out, cross_out;
+  float *qkv_colsum = nullptr;   // sum_k of every packed qkv row: LayerNorm of the raw input applied to the accumulator
   int mod_off = 0;  // column of [scale | shift] inside mod_all
   bool attn = false, cross = false;
   int ca_off = 0;   // column of the collapsed cross-attention bias inside ca_all
@@ -60,6 +62,8 @@ struct Plan {  // everything carved out of the caller's workspace for one (B, L0
   int nbr = 1;                 // clip-parallel branches
   int64_t slab_stride = 0;     // floats of GroupNorm scratch per branch
   int64_t slab_half = 0;       // second statistics slab of a branch starts here
+  float *rowpart = nullptr;    // per-row LayerNorm partials of the wide levels: two buffers per branch (y and z of an item)
+  int64_t rowpart_half = 0, rowpart_stride = 0;
   // modulation vectors: per clip ([Bt][mod_ld], mod_stride = mod_ld) for a single forward, or ONE row shared by all
   // clips (mod_stride = 0) inside the sampler, where sigma is the same for every clip and the rows of all steps are
   // computed once per call (mod_steps [steps][mod_ld])
@@ -108,6 +112,7 @@ struct sf_unet {
   }
   std::vector<std::pair<std::string, int64_t>> names;
   // graph cache for sf_vsample
+  bool no_ln_fusion = getenv("SF_NO_LN_FUSION") != nullptr;   // debugging aid: launch every LayerNorm separately
   hipGraphExec_t gexec = nullptr;
   // the instantiated step graph is reused by later sf_vsample calls with the same shape / workspace / guidance scale
   // (every pointer baked into its kernel nodes lives in the workspace or in the engine; the sampler state is an
@@ -280,6 +285,8 @@ void build_group(Builder &bd, Group &g, const std::string &pre, int d, int &mod_
       SF_HIP(launch_fold_bias(wq, hd, C, nb, nullptr, g.qkv.bias, bd.s));
       SF_HIP(launch_fold_bias(wkv, 2 * hd, C, cb, nullptr, g.qkv.bias + hd, bd.s));
       bd.linear_into(g.attn_out, 0, wo, C, hd, nullptr);
+      g.qkv_colsum = u.arena.alloc_n<float>(3 * hd);
+      SF_HIP(launch_row_sums(u.dt, g.qkv.w, 3 * hd, g.qkv.K, g.qkv_colsum, bd.s));
     }
   }
   if (g.cross) {
@@ -461,6 +468,14 @@ Plan make_plan(const sf_unet &u, Workspace &ws, int B, int L0, bool two, int num
   p.ca_all = ws.alloc_n<float>((int64_t)p.Bt * u.ca_ld);
   p.slab = ws.alloc_n<float>(slab_floats);
   {
+    int64_t one = 64;
+    for (int d = 0; d < c.n_layers; ++d)
+      if (p.lv[d].C % 32 == 0) one = std::max<int64_t>(one, p.lv[d].rows / p.nbr * (p.lv[d].C / 32) * 2);
+    p.rowpart_half = align_up(one, 64);
+    p.rowpart_stride = 2 * p.rowpart_half;
+    p.rowpart = ws.alloc_n<float>(p.rowpart_stride * p.nbr);
+  }
+  {
     // split-K scratch: up to 16 partial tiles of the largest short-activation GEMM output per branch
     int64_t mx = 0;
     for (int d = 0; d < c.n_layers; ++d) {
@@ -513,7 +528,7 @@ struct Exec {
     u.prof.push_back({label, flops, bytes, e0, e1, 0.f});
   }
 
-  void conv(const ConvW &w, ConvGemmArgs a, int dt_in, int dt_out) {
+  ConvGemmArgs filled(const ConvW &w, ConvGemmArgs a) const {
     a.w = w.w;
     a.bias = w.bias;
     a.N = w.N;
@@ -528,6 +543,12 @@ struct Exec {
       a.sk_cnt = p.sk_cnt;
       a.sk_cnt_ints = kSkCnt;
     }
+    return a;
+  }
+
+  // ln: the GEMM normalises (and modulates) its first source on the fly from the producer's row partials
+  void conv(const ConvW &w, ConvGemmArgs a0, int dt_in, int dt_out, bool ln = false) {
+    ConvGemmArgs a = filled(w, a0);
     // algorithmic work of this launch: 2*M*N*K_real FLOPs; bytes = activations in + out (+ residual) + weights
     const double kreal = w.kreal > 0 ? w.kreal : w.K;
     const double es_in = dsize(dt_in), es_out = a.out_f32 ? 4.0 : (double)dsize(dt_out);
@@ -538,7 +559,9 @@ struct Exec {
     if (w.direct) timed("conv_direct", flops, bytes, [&] { SF_HIP(launch_conv_direct(dt_in, dt_out, a, s)); });
     else {
       if (dt_in != u.dt || (dt_out != u.dt && !a.out_f32)) fail(SF_ERR_INVALID, "internal: dtype mismatch on the MFMA path");
-      timed(conv_gemm_variant_name(u.dt, a), flops, bytes, [&] { SF_HIP(launch_conv_gemm(u.dt, a, s)); });
+      if (ln) timed(u.dt == F32 ? "conv_gemm_fast<f32,32x32>" : "conv_gemm_fast<bf16,32x32>", flops + 8.0 * a.M * a.cin, bytes,
+                    [&] { SF_HIP(launch_conv_gemm_ln(u.dt, a, s)); });
+      else timed(conv_gemm_variant_name(u.dt, a), flops, bytes, [&] { SF_HIP(launch_conv_gemm(u.dt, a, s)); });
     }
   }
 
@@ -585,8 +608,12 @@ struct Exec {
     } else {
     const bool fuse_act = C <= 64;
     GnPlan gp = gn_plan(p.Bt, l.L, C);
-    auto conv3 = [&](const ConvW &w, const void *in, void *out, const float *gam, const float *bet, const void *res) {
+    auto conv3 = [&](const ConvW &w, const void *in, void *out, const float *gam, const float *bet, const void *res, float *rowpart) {
       ConvGemmArgs a;
+      if (rowpart) {
+        a.rowpart_out = rowpart;
+        a.rowpart_nt = C / 32;
+      }
       if (fuse_act) {
         gn(in, d, C);
         a.src = in;
@@ -614,33 +641,129 @@ struct Exec {
       a.res_ld = C;
       conv(w, a, u.dt, u.dt);
     };
-    conv3(g.conv1, cur, tA, g.gn1_g, g.gn1_b, nullptr);
-    conv3(g.conv2, tA, tB, g.gn2_g, g.gn2_b, cur);
-    // Modulation: LN_C(x; eps 1e-6) * (1 + scale) + shift
-    timed("ln_modulate", 8.0 * l.rows * C, 2.0 * l.rows * C * dsize(u.dt),
-          [&] { SF_HIP(launch_ln_modulate(u.dt, tB, C, p.mod_all + g.mod_off, p.mod_stride, 1e-6f, p.Bt, l.L, C, tA, C, s)); });
-    // InjectChannels: Conv1x1(cat[x, ctx]) + x   (+ collapsed cross-attention bias when no self-attention follows)
-    {
+    // Wide levels: the two LayerNorms of an item (Modulation before InjectChannels, the attention pre-norm) are not
+    // launched: the producing GEMM's epilogue leaves per-row (mean, M2) partials per 32-column tile, the consuming GEMM
+    // pools them and normalises (and modulates) its A operand while staging it.  Falls back to ln_modulate launches
+    // whenever a shape is outside what conv_gemm_fast / conv_gemm_wp cover.
+    float *rp_y = p.rowpart, *rp_z = p.rowpart + p.rowpart_half;
+    auto inject_args = [&](const void *src, void *out) {
       ConvGemmArgs a;
-      a.src = tA;
+      a.src = src;
       a.src_ld = C;
       a.src2 = l.ctx;
       a.src2_ld = b.ctx_ld;
       a.M = (int)l.rows;
       a.Lout = a.Lsrc = l.L;
-      a.out = tB;
+      a.out = out;
       a.out_ld = C;
-      a.res = tA;
+      a.res = src;
       a.res_ld = C;
       if (g.cross && !g.attn) {
         a.badd = p.ca_all + g.ca_off;
         a.badd_ld = u.ca_ld;
       }
+      return a;
+    };
+    auto qkv_args = [&](const void *src) {
+      ConvGemmArgs a;
+      a.src = src;
+      a.src_ld = C;
+      a.M = (int)l.rows;
+      a.Lout = a.Lsrc = l.L;
+      a.out = l.qkv;
+      a.out_ld = 3 * u.hd;
+      return a;
+    };
+    bool fuse_mod = false;
+    // (measured: normalising the operand while staging costs more than the separate launch once the row is 1024 wide)
+    if (!fuse_act && C % 32 == 0 && C <= 512 && !u.no_ln_fusion) {
+      ConvGemmArgs pc;   // conv2 as it will be launched
+      pc.src = l.act;
+      pc.src_ld = C;
+      pc.M = (int)l.rows;
+      pc.Lout = pc.Lsrc = l.L;
+      pc.pad = 1;
+      pc.out = tB;
+      pc.out_ld = C;
+      pc.res = cur;
+      pc.res_ld = C;
+      ConvGemmArgs pi = inject_args(tB, tA);
+      pi.ln_part = rp_y;
+      pi.ln_nt = C / 32;
+      pi.ln_ss = p.mod_all + g.mod_off;
+      pi.ln_ss_ld = p.mod_stride;
+      pi.ln_eps = 1e-6f;
+      pi.res_ln = 1;
+      fuse_mod = conv_gemm_emits_rowpart(u.dt, filled(g.conv2, pc)) && conv_gemm_ln_ok(u.dt, filled(g.inject, pi));
+    }
+    bool fuse_attn = false;
+    if (g.attn && C % 32 == 0 && !u.no_ln_fusion) {
+      ConvGemmArgs pq = qkv_args(tB);
+      pq.ln_part = rp_z;
+      pq.ln_nt = C / 32;
+      pq.ln_eps = 1e-5f;
+      pq.ln_colsum = g.qkv_colsum;
+      ConvGemmArgs pi = inject_args(tA, tB);
+      const bool inj_emits = fuse_mod ? true : conv_gemm_emits_rowpart(u.dt, filled(g.inject, pi));
+      fuse_attn = inj_emits && conv_gemm_ln_ok(u.dt, filled(g.qkv, pq));
+    }
+    conv3(g.conv1, cur, tA, g.gn1_g, g.gn1_b, nullptr, nullptr);
+    conv3(g.conv2, tA, tB, g.gn2_g, g.gn2_b, cur, fuse_mod ? rp_y : nullptr);
+    if (fuse_mod) {
+      // Modulation + InjectChannels in one GEMM: m = LN_C(y; 1e-6) * (1 + scale) + shift;  z = m + Conv1x1(cat[m, ctx]) (+ bias)
+      ConvGemmArgs a = inject_args(tB, tA);
+      a.ln_part = rp_y;
+      a.ln_nt = C / 32;
+      a.ln_ss = p.mod_all + g.mod_off;
+      a.ln_ss_ld = p.mod_stride;
+      a.ln_eps = 1e-6f;
+      a.res_ln = 1;
+      if (fuse_attn) {
+        a.rowpart_out = rp_z;
+        a.rowpart_nt = C / 32;
+      }
+      conv(g.inject, a, u.dt, u.dt, /*ln=*/true);
+      std::swap(tA, tB);   // z -> tB, as the code below expects
+    } else {
+      // Modulation: LN_C(x; eps 1e-6) * (1 + scale) + shift
+      timed("ln_modulate", 8.0 * l.rows * C, 2.0 * l.rows * C * dsize(u.dt),
+            [&] { SF_HIP(launch_ln_modulate(u.dt, tB, C, p.mod_all + g.mod_off, p.mod_stride, 1e-6f, p.Bt, l.L, C, tA, C, s)); });
+      // InjectChannels: Conv1x1(cat[x, ctx]) + x   (+ collapsed cross-attention bias when no self-attention follows)
+      ConvGemmArgs a = inject_args(tA, tB);
+      if (fuse_attn) {
+        a.rowpart_out = rp_z;
+        a.rowpart_nt = C / 32;
+      }
       conv(g.inject, a, u.dt, u.dt);
+    }
+    if (g.attn) {
+      // x + W_o MHA(W_q LN_a(x), W_kv LN_b(x)): the two LayerNorms share (mean, rstd); their affines are folded.
+      if (fuse_attn) {
+        ConvGemmArgs a = qkv_args(tB);
+        a.ln_part = rp_z;
+        a.ln_nt = C / 32;
+        a.ln_eps = 1e-5f;
+        a.ln_colsum = g.qkv_colsum;   // raw z through the MFMAs, rstd * (acc - mean * colsum) in the epilogue
+        conv(g.qkv, a, u.dt, u.dt, /*ln=*/true);
+      } else {
+        timed("ln_modulate", 6.0 * l.rows * C, 2.0 * l.rows * C * dsize(u.dt),
+              [&] { SF_HIP(launch_ln_modulate(u.dt, tB, C, nullptr, 0, 1e-5f, p.Bt, l.L, C, tA, C, s)); });
+        conv(g.qkv, qkv_args(tA), u.dt, u.dt);
+      }
+      attention_tail(g, d, cur, tB);
+      u.dbg.tap(tapname, u.dt, cur, C, l.rows, C, s);
+      return;
+    } else {
+      void *o = cur;
+      cur = tB;
+      tB = tA;
+      tA = o;
+      u.dbg.tap(tapname, u.dt, cur, C, l.rows, C, s);
+      return;
     }
     }   // generic (non-thin) resnet / modulation / inject
     if (g.attn) {
-      // x + W_o MHA(W_q LN_a(x), W_kv LN_b(x)): the two LayerNorms share (mean, rstd); their affines are folded.
+      // thin level followed by self-attention: plain pre-norm launch
       timed("ln_modulate", 6.0 * l.rows * C, 2.0 * l.rows * C * dsize(u.dt),
             [&] { SF_HIP(launch_ln_modulate(u.dt, tB, C, nullptr, 0, 1e-5f, p.Bt, l.L, C, tA, C, s)); });
       {
@@ -653,27 +776,7 @@ struct Exec {
         a.out_ld = 3 * u.hd;
         conv(g.qkv, a, u.dt, u.dt);
       }
-      const size_t es = dsize(u.dt);
-      timed("attention", 4.0 * p.Bt * (double)l.L * l.L * u.hd, 4.0 * l.rows * u.hd * es, [&] {
-        SF_HIP(launch_attention(u.dt, l.qkv, 3 * u.hd, static_cast<char *>(l.qkv) + (size_t)u.hd * es, 3 * u.hd, p.Bt, l.L,
-                                u.cfg.attention_heads, u.cfg.attention_features, l.ao, u.hd, s));
-      });
-      {
-        ConvGemmArgs a;
-        a.src = l.ao;
-        a.src_ld = u.hd;
-        a.M = (int)l.rows;
-        a.Lout = a.Lsrc = l.L;
-        a.out = cur;
-        a.out_ld = C;
-        a.res = tB;
-        a.res_ld = C;
-        if (g.cross) {
-          a.badd = p.ca_all + g.ca_off;
-          a.badd_ld = u.ca_ld;
-        }
-        conv(g.attn_out, a, u.dt, u.dt);
-      }
+      attention_tail(g, d, cur, tB);
       // result in cur's buffer; tA, tB free again
     } else {
       void *o = cur;
@@ -682,6 +785,31 @@ struct Exec {
       tA = o;
     }
     u.dbg.tap(tapname, u.dt, cur, C, l.rows, C, s);
+  }
+
+  // softmax attention on the packed q | k | v projections, then x' = z + W_o ao (+ collapsed cross-attention bias) -> `out`
+  void attention_tail(const Group &g, int d, void *out, const void *z) {
+    const Level &l = p.lv[d];
+    const int C = l.C;
+    const size_t es = dsize(u.dt);
+    timed("attention", 4.0 * p.Bt * (double)l.L * l.L * u.hd, 4.0 * l.rows * u.hd * es, [&] {
+      SF_HIP(launch_attention(u.dt, l.qkv, 3 * u.hd, static_cast<char *>(l.qkv) + (size_t)u.hd * es, 3 * u.hd, p.Bt, l.L,
+                              u.cfg.attention_heads, u.cfg.attention_features, l.ao, u.hd, s));
+    });
+    ConvGemmArgs a;
+    a.src = l.ao;
+    a.src_ld = u.hd;
+    a.M = (int)l.rows;
+    a.Lout = a.Lsrc = l.L;
+    a.out = out;
+    a.out_ld = C;
+    a.res = z;
+    a.res_ld = C;
+    if (g.cross) {
+      a.badd = p.ca_all + g.ca_off;
+      a.badd_ld = u.ca_ld;
+    }
+    conv(g.attn_out, a, u.dt, u.dt);
   }
 
   // Thin level (C = 32 / 64): the item is three conv_thin launches -- conv1 [GN+SiLU in, statistics of h out],
@@ -974,6 +1102,7 @@ struct Exec {
     v.mod_all = p.mod_all + (int64_t)br * bt * p.mod_stride;
     v.ca_all = p.ca_all + (int64_t)br * bt * u.ca_ld;
     v.slab = p.slab + (int64_t)br * p.slab_stride;
+    v.rowpart = p.rowpart + (int64_t)br * p.rowpart_stride;
     v.sk_slab = p.sk_slab + (int64_t)br * p.sk_stride;
     v.sk_cnt = p.sk_cnt + (int64_t)br * kSkCnt;
     return v;
