@@ -167,11 +167,196 @@ __global__ __launch_bounds__(128) void attention_mfma_kernel(const bf16 *__restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Key-split variant for SHORT sequences (the U-Net's L = 44 ... 352 at batch 4-8: a few hundred 2-wave workgroups of
+// the kernel above leave most SIMDs empty and every latency exposed).  A 256-thread workgroup owns ONE 32-query tile;
+// its four waves take the 32-key tiles round-robin, each with wave-private LDS staging (no workgroup barrier in the
+// loop), and the four partial (max, sum, O) states are merged once through LDS (flash-decoding).  Same products,
+// layouts and operand permutation as above with TK = 32.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int KS = 4, TK2 = 32;
+constexpr int LDK2 = D + 8, LDV2 = TK2 + 8;
+constexpr int WSTG = TK2 * LDK2 + D * LDV2;   // bf16 elements of one wave's staging area (K tile | V^T tile)
+
+__global__ __launch_bounds__(256) void attention_ksplit_kernel(const bf16 *__restrict__ q, int ldq, const bf16 *__restrict__ kv, int ldkv,
+                                                               int L, int H, bf16 *__restrict__ out, int ldo, float scale) {
+  // staging: KS x WSTG bf16 (39 KB); merge (aliases it after a barrier): KS x 32 x (D + 1) floats + KS x 32 x 2
+  __shared__ __attribute__((aligned(16))) unsigned char smem[KS * WSTG * 2 > KS * 32 * (D + 4) * 4 ? KS * WSTG * 2 : KS * 32 * (D + 4) * 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const size_t rowbase = (size_t)b * L;
+  const int q0 = blockIdx.x * 32;
+  const int qi = q0 + fr;
+  const bool qvalid = qi < L;
+  bf16 *Ks = reinterpret_cast<bf16 *>(smem) + (size_t)wave * WSTG;
+  bf16 *Vt = Ks + TK2 * LDK2;
+
+  bf16x8 qf[4];
+  {
+    const bf16 *qp = q + (rowbase + (qvalid ? qi : 0)) * ldq + h * D;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      Vec16<bf16> v = ld16<bf16>(qp + 16 * s + 8 * fh);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[s][j] = (bf16)((float)v.v[j] * scale);
+    }
+  }
+  f32x16 o[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  float mrun = -INFINITY, lrun = 0.f;
+
+  const int koff = h * D, voff = H * D + h * D;
+  const int srow = lane >> 3, svec = lane & 7;   // one wave stages 8 rows x 64 d per pass, 4 passes per 32-key tile
+  const int ntk = (L + TK2 - 1) / TK2;
+  Vec16<bf16> rk[4], rv[4];
+  auto prefetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int kj = k0 + i * 8 + srow;
+      if (kj < L) {
+        const bf16 *kp = kv + (rowbase + kj) * ldkv;
+        rk[i] = ld16<bf16>(kp + koff + svec * 8);
+        rv[i] = ld16<bf16>(kp + voff + svec * 8);
+      } else {
+        rk[i] = zero16<bf16>();
+        rv[i] = zero16<bf16>();
+      }
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int kr = i * 8 + srow;
+      st16<bf16>(Ks + kr * LDK2 + svec * 8, rk[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) Vt[(svec * 8 + j) * LDV2 + kr] = rv[i].v[j];
+    }
+  };
+
+  if (wave < ntk) prefetch(wave * TK2);
+  for (int t = wave; t < ntk; t += KS) {
+    const int k0 = t * TK2;
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // this wave's LDS reads of the previous tile are done (lgkmcnt 0)
+    __builtin_amdgcn_wave_barrier();
+    stage();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    if (t + KS < ntk) prefetch((t + KS) * TK2);
+
+    f32x16 st;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      bf16x8 kf = *reinterpret_cast<const bf16x8 *>(Ks + fr * LDK2 + 16 * s + 8 * fh);
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st, 0, 0, 0);
+    }
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+      if (key >= L) st[r] = -INFINITY;
+      tmax = fmaxf(tmax, st[r]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float mnew = fmaxf(mrun, tmax);   // finite: a tile always holds at least one valid key
+    const float alpha = __expf(mrun - mnew);
+    float psum = 0.f;
+    bf16x8 pf[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pv = __expf(st[r] - mnew);
+      psum += pv;
+      pf[r >> 3][r & 7] = (bf16)pv;
+    }
+    lrun = lrun * alpha + psum;
+    mrun = mnew;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16 *vp = Vt + (32 * i + fr) * LDV2 + 16 * ks + 4 * fh;
+        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+        bf16x4 lo = *reinterpret_cast<const bf16x4 *>(vp);
+        bf16x4 hi = *reinterpret_cast<const bf16x4 *>(vp + 8);
+        bf16x8 vf;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          vf[j] = lo[j];
+          vf[4 + j] = hi[j];
+        }
+        o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], o[i], 0, 0, 0);
+      }
+  }
+  lrun += __shfl_xor(lrun, 32, 64);
+
+  // ---- merge the four key ranges: (m, l, O^T) per wave -> LDS [wave][q][d] fp32 ---------------------------------------
+  __syncthreads();   // every wave is done with its staging area (the merge buffers alias it)
+  float *mo = reinterpret_cast<float *>(smem);            // [KS][32][D + 1]
+  float *ml = mo + KS * 32 * (D + 1);                     // [KS][32][2] = (m, l)
+  {
+    float *om = mo + ((size_t)wave * 32 + fr) * (D + 1);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) om[32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh] = o[i][r];
+    if (fh == 0) {
+      ml[(wave * 32 + fr) * 2] = mrun;
+      ml[(wave * 32 + fr) * 2 + 1] = lrun;
+    }
+  }
+  __syncthreads();
+  {
+    const int qq = tid >> 3, c8 = tid & 7;   // 32 queries x 8 chunks of 8 d
+    float mw[KS], lw[KS], mstar = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < KS; ++w) {
+      mw[w] = ml[(w * 32 + qq) * 2];
+      lw[w] = ml[(w * 32 + qq) * 2 + 1];
+      mstar = fmaxf(mstar, mw[w]);
+    }
+    float lsum = 0.f, acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int w = 0; w < KS; ++w) {
+      const float sc = lw[w] > 0.f ? __expf(mw[w] - mstar) : 0.f;   // a wave without tiles contributes nothing
+      lsum += lw[w] * sc;
+      const float *ow = mo + ((size_t)w * 32 + qq) * (D + 1) + c8 * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = fmaf(ow[j], sc, acc[j]);
+    }
+    const float inv = 1.0f / lsum;
+    if (q0 + qq < L) {
+      Vec16<bf16> ov;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ov.v[j] = (bf16)(acc[j] * inv);
+      st16<bf16>(out + (rowbase + q0 + qq) * ldo + h * D + c8 * 8, ov);
+    }
+  }
+}
+
 }  // namespace
 
 hipError_t launch_attention_mfma(const void *q, int ldq, const void *kv, int ldkv, int B, int L, int H, int Dh, void *out, int ldo,
                                  hipStream_t s) {
   if (Dh != D || L <= 0) return hipErrorInvalidValue;
+  // short sequences: the 2-wave kernel would launch fewer waves than the chip has SIMDs -> split the keys across waves
+  const long waves_plain = (long)((L + WAVES * QW - 1) / (WAVES * QW)) * H * B * WAVES;
+  if (waves_plain < 2048 && L <= 4096) {
+    dim3 g2((L + 31) / 32, H, B);
+    hipLaunchKernelGGL(attention_ksplit_kernel, g2, dim3(256), 0, s, static_cast<const bf16 *>(q), ldq, static_cast<const bf16 *>(kv), ldkv,
+                       L, H, static_cast<bf16 *>(out), ldo, 1.0f / sqrtf((float)D));
+    return hipGetLastError();
+  }
   dim3 grid((L + WAVES * QW - 1) / (WAVES * QW), H, B);
   hipLaunchKernelGGL(attention_mfma_kernel, grid, dim3(128), 0, s, static_cast<const bf16 *>(q), ldq, static_cast<const bf16 *>(kv), ldkv,
                      L, H, static_cast<bf16 *>(out), ldo, 1.0f / sqrtf((float)D));
