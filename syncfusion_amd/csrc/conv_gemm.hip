@@ -401,6 +401,7 @@ hipError_t launch_conv_gemm_sk(int dt, const ConvGemmArgs &a, hipStream_t s);
 int conv_gemm_sk_variant(const ConvGemmArgs &a);
 bool conv_gemm_fast_ok(int dt, const ConvGemmArgs &a);
 bool conv_gemm_wp_ok(int dt, const ConvGemmArgs &a);
+bool conv_gemm_prefers_wp(const ConvGemmArgs &a);
 
 static bool use_sk(const ConvGemmArgs &a) {
   const int v = pick_variant(a);
@@ -425,7 +426,7 @@ const char *conv_gemm_variant_name(int dt, const ConvGemmArgs &a) {
   }
   static const char *wp_names[2][3] = {{"conv_gemm_wp<f32,32x32>", "conv_gemm_wp<f32,32x32>", "conv_gemm_wp<f32,32x32>"},
                                        {"conv_gemm_wp<bf16,64x64>", "conv_gemm_wp<bf16,64x32>", "conv_gemm_wp<bf16,32x32>"}};
-  if ((short_act || use_sk(a)) && a.M <= 512 && a.K >= 2048 && conv_gemm_wp_ok(dt, a)) return wp_names[dt == F32 ? 0 : 1][conv_gemm_sk_variant(a)];
+  if ((short_act || use_sk(a)) && conv_gemm_prefers_wp(a) && conv_gemm_wp_ok(dt, a)) return wp_names[dt == F32 ? 0 : 1][conv_gemm_sk_variant(a)];
   if (short_act || use_sk(a)) return (conv_gemm_fast_ok(dt, a) ? fast_names : sk_names)[dt == F32 ? 0 : 1][conv_gemm_sk_variant(a)];
   int v = pick_variant(a);
   return v < 0 ? "conv_gemm<invalid>" : names[dt == F32 ? 0 : 1][v];
@@ -441,7 +442,7 @@ bool conv_gemm_emits_rowpart(int dt, const ConvGemmArgs &a) {
   if (!(short_act || use_sk(a))) return false;                 // would go to v2 / the classic tiles
   if ((a.cin % 32) || (a.cin2 % 32) || (a.K % 32)) return false;
   if (conv_gemm_sk_variant(a) != 2) return false;              // 32x32 tiles only
-  const bool prefer_wp = a.M <= 512 && a.K >= 2048;
+  const bool prefer_wp = conv_gemm_prefers_wp(a);
   if (prefer_wp && conv_gemm_wp_ok(dt, a)) return true;        // wp 32x32 (its LDS footprint fits in both types)
   return conv_gemm_fast_ok(dt, a);
 }

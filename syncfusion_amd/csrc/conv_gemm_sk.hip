@@ -368,12 +368,19 @@ hipError_t launch_conv_gemm_fast(int dt, const ConvGemmArgs &a, int variant, hip
 bool conv_gemm_wp_ok(int dt, const ConvGemmArgs &a);
 hipError_t launch_conv_gemm_wp(int dt, const ConvGemmArgs &a, int variant, hipStream_t s);
 
+// Barrier-free wave-private pipelines (conv_gemm_wp.hip) win where few workgroups exist (cold weights, tools/gemm_cold.py):
+// every U-Net 3-tap convolution at <= 512 tiles of 32x32 (all of depths 3-7 at batch 4), and the shortest activations.
+bool conv_gemm_prefers_wp(const ConvGemmArgs &a) {
+  const long tiles = (long)((a.M + 31) / 32) * ((a.n_store + 31) / 32);
+  return (a.taps == 3 && tiles <= 512 && a.K >= 384) || (a.M <= 512 && a.K >= 2048);
+}
+
 hipError_t launch_conv_gemm_sk(int dt, const ConvGemmArgs &a, hipStream_t s) {
   if ((a.cin % 32) || (a.cin2 % 32) || (a.K % 32)) return hipErrorInvalidValue;
   const int v = conv_gemm_sk_variant(a);
   // barrier-free wave-private pipelines: measured faster only on the shortest activations (M <= 512, long K);
   // elsewhere the staged kernel wins because its loads are shared by more MFMA work per byte
-  const bool prefer_wp = g_conv_gemm_force.path == 5 || (g_conv_gemm_force.path == 0 && a.M <= 512 && a.K >= 2048);
+  const bool prefer_wp = g_conv_gemm_force.path == 5 || (g_conv_gemm_force.path == 0 && conv_gemm_prefers_wp(a));
   if (prefer_wp && conv_gemm_wp_ok(dt, a)) {
     hipError_t e = launch_conv_gemm_wp(dt, a, dt == F32 ? 2 : v, s);
     if (e != hipErrorInvalidValue) return e;
