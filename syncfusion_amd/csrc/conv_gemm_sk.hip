@@ -369,10 +369,11 @@ bool conv_gemm_wp_ok(int dt, const ConvGemmArgs &a);
 hipError_t launch_conv_gemm_wp(int dt, const ConvGemmArgs &a, int variant, hipStream_t s);
 
 // Barrier-free wave-private pipelines (conv_gemm_wp.hip) win where few workgroups exist (cold weights, tools/gemm_cold.py):
-// every U-Net 3-tap convolution at <= 512 tiles of 32x32 (all of depths 3-7 at batch 4), and the shortest activations.
+// at <= 512 tiles of 32x32 -- every GEMM of depths 3-7 at batch 4 except the widest qkv projections -- the staged
+// kernel's two barriers per chunk cost more than the operand sharing they buy.
 bool conv_gemm_prefers_wp(const ConvGemmArgs &a) {
   const long tiles = (long)((a.M + 31) / 32) * ((a.n_store + 31) / 32);
-  return (a.taps == 3 && tiles <= 512 && a.K >= 384) || (a.M <= 512 && a.K >= 2048);
+  return (tiles <= 512 && a.K >= 256) || (a.M <= 512 && a.K >= 2048);
 }
 
 hipError_t launch_conv_gemm_sk(int dt, const ConvGemmArgs &a, hipStream_t s) {
