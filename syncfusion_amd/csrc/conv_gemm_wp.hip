@@ -29,7 +29,9 @@ template <typename T> __device__ __forceinline__ Vec16<T> buf_ld16(__amdgpu_buff
   return v;
 }
 
-template <typename T, int BM, int BN, bool CAT>
+// NSET = K chunks a wave keeps in flight (register sets); ONE private LDS staging buffer per wave suffices because a
+// wave's LDS operations execute in program order (the next chunk's writes queue behind this chunk's fragment reads).
+template <typename T, int BM, int BN, bool CAT, int NSET>
 __global__ __launch_bounds__(256) void conv_gemm_wp_kernel(const ConvGemmArgs a, const int mtiles, const int ntiles, const int swz,
                                                            const unsigned bytesA, const unsigned bytesA2, const unsigned bytesW) {
   constexpr int VEC = Vec16<T>::N;
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(256) void conv_gemm_wp_kernel(const ConvGemmArgs a,
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  T *wlds = reinterpret_cast<T *>(smem) + (size_t)wave * 2 * WSTAGE;   // [2 buffers][A rows | W rows]
+  T *wlds = reinterpret_cast<T *>(smem) + (size_t)wave * WSTAGE;   // [A rows | W rows]
   float *red = reinterpret_cast<float *>(smem);
 
   int bid = blockIdx.x, mt, nt;
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(256) void conv_gemm_wp_kernel(const ConvGemmArgs a,
   struct RegSet {
     Vec16<T> ra[PA], rb[PB];
   };
-  RegSet s0, s1;
+  RegSet rs[NSET];
   auto prefetch = [&](RegSet &R) {
     const unsigned tmask = (kb + lane_b >= kbytes) ? OOB : 0u;
 #pragma unroll
@@ -152,16 +154,16 @@ __global__ __launch_bounds__(256) void conv_gemm_wp_kernel(const ConvGemmArgs a,
       }
     }
   };
-  auto stage = [&](int buf, RegSet &R) {
-    T *As = wlds + buf * WSTAGE, *Bs = As + BM * LD;
+  auto stage = [&](RegSet &R) {
+    T *As = wlds, *Bs = As + BM * LD;
 #pragma unroll
     for (int i = 0; i < PB; ++i) st16<T>(Bs + (i * RPI + lrow) * LD + lvec * VEC, R.rb[i]);
 #pragma unroll
     for (int i = 0; i < PA; ++i) st16<T>(As + (i * RPI + lrow) * LD + lvec * VEC, R.ra[i]);
   };
   const int fr = lane & 31, fh = lane >> 5;
-  auto compute = [&](int buf) {
-    const T *As = wlds + buf * WSTAGE, *Bs = As + BM * LD;
+  auto compute = [&]() {
+    const T *As = wlds, *Bs = As + BM * LD;
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
       for (int s = 0; s < BK / 16; ++s) {
@@ -223,23 +225,22 @@ __global__ __launch_bounds__(256) void conv_gemm_wp_kernel(const ConvGemmArgs a,
   if constexpr (HOIST) eo0 = epi_load(0);
 
   // ---- the wave's own pipeline: no workgroup barrier --------------------------------------------------------
-  if (nkt > 0) prefetch(s0);
-  if (nkt > 1) prefetch(s1);
+#pragma unroll
+  for (int j = 0; j < NSET; ++j)
+    if (j < nkt) prefetch(rs[j]);
   // Same-wave LDS operations execute in program order, so "write the chunk, then read the fragments" needs no
   // s_barrier; the wave_barrier()s only stop the COMPILER from moving LDS accesses of different lanes across the
   // stage/compute boundaries.
-  for (int kt = 0; kt < nkt; kt += 2) {
-    stage(0, s0);
-    __builtin_amdgcn_wave_barrier();
-    if (kt + 2 < nkt) prefetch(s0);
-    compute(0);
-    __builtin_amdgcn_wave_barrier();
-    if (kt + 1 < nkt) {
-      stage(1, s1);
-      __builtin_amdgcn_wave_barrier();
-      if (kt + 3 < nkt) prefetch(s1);
-      compute(1);
-      __builtin_amdgcn_wave_barrier();
+  for (int kt = 0; kt < nkt; kt += NSET) {
+#pragma unroll
+    for (int j = 0; j < NSET; ++j) {
+      if (kt + j < nkt) {
+        stage(rs[j]);
+        __builtin_amdgcn_wave_barrier();
+        if (kt + j + NSET < nkt) prefetch(rs[j]);
+        compute();
+        __builtin_amdgcn_wave_barrier();
+      }
     }
   }
 
@@ -303,9 +304,9 @@ __global__ __launch_bounds__(256) void conv_gemm_wp_kernel(const ConvGemmArgs a,
   }
 }
 
-template <typename T, int BM, int BN, bool CAT> hipError_t launch_wp2(const ConvGemmArgs &a, hipStream_t s) {
+template <typename T, int BM, int BN, bool CAT, int NSET> hipError_t launch_wp3(const ConvGemmArgs &a, hipStream_t s) {
   constexpr int LD = BK + 16 / (int)sizeof(T);
-  constexpr size_t stage_bytes = (size_t)4 * 2 * (BM + BN) * LD * sizeof(T);
+  constexpr size_t stage_bytes = (size_t)4 * (BM + BN) * LD * sizeof(T);
   constexpr size_t red_bytes = (size_t)4 * BM * (BN + 4) * sizeof(float);
   const size_t lds = stage_bytes > red_bytes ? stage_bytes : red_bytes;
   if (lds > 150 * 1024) return hipErrorInvalidValue;   // fp32 64-row tiles do not fit: the caller falls back
@@ -315,7 +316,7 @@ template <typename T, int BM, int BN, bool CAT> hipError_t launch_wp2(const Conv
   const size_t bA = (size_t)(a.M / a.Lout + (a.M % a.Lout ? 1 : 0)) * a.Lsrc * a.src_ld * es;
   const size_t bA2 = CAT ? (size_t)a.M * a.src2_ld * es : 0;
   const size_t bW = (size_t)a.N * a.K * es;
-  auto kern = conv_gemm_wp_kernel<T, BM, BN, CAT>;
+  auto kern = conv_gemm_wp_kernel<T, BM, BN, CAT, NSET>;
   static bool en = false;
   if (!en) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
@@ -324,6 +325,11 @@ template <typename T, int BM, int BN, bool CAT> hipError_t launch_wp2(const Conv
   }
   hipLaunchKernelGGL(kern, dim3(mtiles * ntiles), dim3(256), lds, s, a, mtiles, ntiles, swz, (unsigned)bA, (unsigned)bA2, (unsigned)bW);
   return hipGetLastError();
+}
+
+// two chunks in flight per wave: three or four measured slower (register pressure against 2.7 waves per SIMD)
+template <typename T, int BM, int BN, bool CAT> hipError_t launch_wp2(const ConvGemmArgs &a, hipStream_t s) {
+  return launch_wp3<T, BM, BN, CAT, 2>(a, s);
 }
 
 }  // namespace
