@@ -13,6 +13,8 @@
 //   * LayerNorm affines of the attention pre-norms are folded into the q/kv projection weights;
 //   * with classifier-free guidance the conditional and unconditional evaluations run as one 2B batch.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
@@ -1296,7 +1298,15 @@ int sf_vsample(sf_unet *h, float *x, const float *const *ctx, const float *emb, 
   h->dbg.reset();
   float *dbg_buf = h->dbg.buf;
   h->dbg.buf = nullptr;  // taps are a forward()-only facility
+  static const bool timing = getenv("SF_TIMING") != nullptr;   // debugging aid: host-side phase times on stderr
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms_since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(now() - t0).count(); };
+  const auto t_begin = now();
   ex.conditioning(ctx, emb);
+  if (timing) {
+    SF_HIP(hipStreamSynchronize(s));
+    fprintf(stderr, "[sf_vsample] conditioning %.3f ms\n", ms_since(t_begin));
+  }
 
   // LinearSchedule(1 -> 0) and (alpha, beta) = (cos, sin)(sigma*pi/2), exactly as VSampler builds them in fp32
   // (torch.linspace: start + i*step for the first half, end - (steps-1-i)*step for the second).
@@ -1356,8 +1366,18 @@ int sf_vsample(sf_unet *h, float *x, const float *const *ctx, const float *emb, 
   key.scale = embedding_scale;
   key.ws = ws;
   key.valid = true;
+  if (timing) {
+    SF_HIP(hipStreamSynchronize(s));
+    fprintf(stderr, "[sf_vsample] + schedule, per-step features: %.3f ms since entry\n", ms_since(t_begin));
+  }
   if (use_graph && T > 1 && h->gexec && !h->prof_on && h->gkey == key) {
+    const auto t_l = now();
     for (int i = 0; i < T; ++i) SF_HIP(hipGraphLaunch(h->gexec, s));   // steady state: no eager step, no capture
+    if (timing) {
+      const double enq = ms_since(t_l);
+      SF_HIP(hipStreamSynchronize(s));
+      fprintf(stderr, "[sf_vsample] %d graph launches: enqueue %.3f ms, done after %.3f ms\n", T, enq, ms_since(t_l));
+    }
   } else {
   h->launches = 0;
   one_step();  // step 0 eagerly (also performs every one-time kernel attribute setup outside capture)
