@@ -522,7 +522,356 @@ template <typename T> hipError_t thin_dispatch(const ConvThinArgs &a, hipStream_
   return hipErrorInvalidValue;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Item tail in ONE launch:  y = x + Conv3(SiLU(GN2(h)));  m = LN_C(y) * (1 + scale) + shift;  z = m + Conv1x1(cat[m, ctx]) (+ badd)
+// (the second half of a ResnetItem, the ModulationItem and the InjectChannelsItem).  y and m never leave the registers:
+// the conv2 accumulator of a wave holds ALL C channels of its 32 positions (channel 8v + 4*half + e of block cb in
+// register 4v + e), LayerNorm is a per-lane sum plus one exchange with the other half-wave, and the modulated tile is fed
+// straight back as the B operand of the 1x1 convolution -- an accumulator used as an operand carries its channels in
+// the order 16s + 8*(j >> 2) + 4*half + (j & 3), so the weight rows (A operand, staged in LDS) are read with the same
+// permutation.  The context channels follow as ordinary 8-channel slots.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int C, int C2>
+__global__ __launch_bounds__(1024) void thin_tail_kernel(const ThinTailArgs a) {
+  constexpr int E = 8;
+  constexpr int QC = C / E;
+  constexpr int S2 = 3 * QC, NST2 = (S2 + 1) / 2;     // conv2: slots / MFMA steps
+  constexpr int NSTM = (C + 15) / 16;                 // inject, modulated part: 16 channels per step
+  constexpr int SC = C2 / E, NSTC = (SC + 1) / 2;     // inject, context part
+  constexpr int NCB = (C + 31) / 32;
+  constexpr int K2 = 3 * C, K3 = C + C2;
+  constexpr int P2 = K2 + E, P3 = K3 + E;             // LDS row pitches of the staged weights (16-byte skew)
+  constexpr int SROW = C + E;
+  constexpr int NV = 6;
+  constexpr bool FAST = !std::is_same<T, float>::value;
+
+  extern __shared__ __align__(16) unsigned char smem[];
+  float *sc = reinterpret_cast<float *>(smem);        // GroupNorm scale / shift per channel
+  float *sh = sc + C;
+  float *lsc = sh + C;                                // 1 + modulation scale, modulation shift
+  float *lsh = lsc + C;
+  float *part = lsh + C;                              // [tile][G][2]
+  T *w2s = reinterpret_cast<T *>(part + kThinMaxTiles * kThinMaxG * 2);
+  T *w3s = w2s + C * P2;
+  T *tile = w3s + C * P3;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = blockDim.x >> 6;
+  const int half = lane >> 5, l32 = lane & 31;
+  const int b = blockIdx.x / a.nchw, ch = blockIdx.x - b * a.nchw;
+  const int r0 = ch * a.rw;
+  const int rows = min(a.rw, a.L - r0);
+  const int ntile = (rows + 31) >> 5;
+  const int cpg = C / a.G;
+  const T *src = static_cast<const T *>(a.h);
+
+  // ---- all global reads up front --------------------------------------------------------------------------------
+  const int total = (rows + 2) * QC;
+  K8<T> xin[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int idx = tid + i * blockDim.x;
+    const int rr = idx / QC, q = idx - rr * QC;
+    const int pos = r0 - 1 + rr;
+    const bool ok = idx < total && pos >= 0 && pos < a.L;
+    xin[i] = ok ? K8<T>::load(src + ((size_t)b * a.L + pos) * C + q * E) : K8<T>::zero();
+  }
+  // weights -> LDS (rows of the packed [C][K] matrices, 8 elements per thread and pass)
+  for (int i = tid; i < C * (K2 / E); i += blockDim.x) {
+    const int r = i / (K2 / E), v = i - r * (K2 / E);
+    K8<T>::load(static_cast<const T *>(a.w2) + (size_t)r * K2 + v * E).store(w2s + r * P2 + v * E);
+  }
+  for (int i = tid; i < C * (K3 / E); i += blockDim.x) {
+    const int r = i / (K3 / E), v = i - r * (K3 / E);
+    K8<T>::load(static_cast<const T *>(a.w3) + (size_t)r * K3 + v * E).store(w3s + r * P3 + v * E);
+  }
+  // GroupNorm statistics of h, modulation vectors
+  for (int g = tid >> 5; g < a.G; g += blockDim.x >> 5) {
+    const float2 st = gn_merge_n(a.stats_in + ((size_t)b * a.nch_in * a.G + g) * 2, a.G, a.nch_in, a.chunk_in, a.L, cpg, a.eps_gn, l32);
+    if (l32 < cpg) {
+      const int c = g * cpg + l32;
+      const float s = st.y * a.gamma[c];
+      sc[c] = s;
+      sh[c] = a.beta[c] - st.x * s;
+    }
+  }
+  if (tid < C) {
+    lsc[tid] = 1.0f + a.ss[(size_t)b * a.ss_ld + tid];
+    lsh[tid] = a.ss[(size_t)b * a.ss_ld + C + tid];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int idx = tid + i * blockDim.x;
+    if (idx < total) {
+      const int rr = idx / QC, q = idx - rr * QC;
+      const int pos = r0 - 1 + rr;
+      const bool ok = pos >= 0 && pos < a.L;
+      K8<T> v = xin[i];
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const float y = fmaf(v.get(e), sc[q * E + e], sh[q * E + e]);
+        v.set(e, ok ? silu_t<FAST>(y) : 0.f);
+      }
+      v.store(tile + rr * SROW + q * E);
+    }
+  }
+  __syncthreads();
+
+  for (int t = wave; t < ntile; t += NW) {
+    const int row_l = t * 32 + l32;
+    const bool rvalid = row_l < rows;
+    const size_t grow = (size_t)b * a.L + r0 + (rvalid ? row_l : 0);
+    // context fragments of this tile (second source of the 1x1 convolution): issue now, use last
+    K8<T> cf[NSTC > 0 ? NSTC : 1];
+#pragma unroll
+    for (int i = 0; i < NSTC; ++i) {
+      const int q2 = 2 * i + half;
+      cf[i] = (rvalid && q2 < SC) ? K8<T>::load(static_cast<const T *>(a.ctx) + grow * a.ctx_ld + q2 * E) : K8<T>::zero();
+    }
+    // ---- conv2 over the staged SiLU(GN2(h)) ----------------------------------------------------------------------
+    f32x16 acc[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[cb][i] = 0.f;
+    const int prow = rvalid ? row_l : 0;
+#pragma unroll
+    for (int s = 0; s < NST2; ++s) {
+      const int slot = min(2 * s + half, S2 - 1);
+      const bool sv = 2 * s + half < S2;
+      const int tap = slot / QC, q = slot - tap * QC;
+      K8<T> bf = K8<T>::load(tile + (prow + tap) * SROW + q * E);
+      if (!sv) bf = K8<T>::zero();
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const int c = cb * 32 + l32;
+        K8<T> af = K8<T>::load(w2s + min(c, C - 1) * P2 + slot * E);
+        if (c >= C || !sv) af = K8<T>::zero();
+        mma_step(acc[cb], af, bf);
+      }
+    }
+    // ---- y = conv2 + bias + x;  LayerNorm over the C channels of the position; modulate ------------------------------
+    float sum = 0.f;
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int c0 = cb * 32 + half * 4 + 8 * v;
+        if (c0 < C) {
+          const f32x4 bias = *reinterpret_cast<const f32x4 *>(a.bias2 + c0);
+          const K4<T> rx = rvalid ? K4<T>::load(static_cast<const T *>(a.x) + grow * C + c0) : K4<T>::zero();
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float y = to_f(from_f<T>(acc[cb][4 * v + e] + bias[e] + rx.get(e)));   // as stored by the unfused path
+            acc[cb][4 * v + e] = y;
+            sum += y;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[cb][4 * v + e] = 0.f;
+        }
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    const float mean = sum / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        if (cb * 32 + half * 4 + 8 * v < C) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float d = acc[cb][4 * v + e] - mean;
+            sq = fmaf(d, d, sq);
+          }
+        }
+    sq += __shfl_xor(sq, 32, 64);
+    const float rstd = rsqrtf(sq / (float)C + a.eps_ln);
+    // m, rounded to the compute type (it is both the operand and the residual of the 1x1 convolution)
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int c0 = cb * 32 + half * 4 + 8 * v;
+        if (c0 < C) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc[cb][4 * v + e] = to_f(from_f<T>(fmaf((acc[cb][4 * v + e] - mean) * rstd, lsc[c0 + e], lsh[c0 + e])));
+        }
+      }
+    // ---- z = m + W3 . [m | ctx] -------------------------------------------------------------------------------------
+    f32x16 zc[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) zc[cb][i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NSTM; ++s) {
+      // B operand: registers 8*(s&1) ... +7 of block s >> 1  <->  channels 16 s + 8 (j >> 2) + 4 half + (j & 3)
+      K8<T> bf;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bf.set(j, acc[s >> 1][8 * (s & 1) + j]);
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const int c = cb * 32 + l32;
+        const T *wr = w3s + min(c, C - 1) * P3 + 16 * s + 4 * half;
+        K8<T> af;
+        const K4<T> lo = K4<T>::load(wr), hi = K4<T>::load(wr + 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          af.set(j, (c < C && 16 * s + 4 * half + j < C) ? lo.get(j) : 0.f);
+          af.set(4 + j, (c < C && 16 * s + 8 + 4 * half + j < C) ? hi.get(j) : 0.f);
+        }
+        mma_step(zc[cb], af, bf);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NSTC; ++i) {
+      const int q2 = 2 * i + half;
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const int c = cb * 32 + l32;
+        K8<T> af = K8<T>::load(w3s + min(c, C - 1) * P3 + C + min(q2, SC - 1) * E);
+        if (c >= C || q2 >= SC) af = K8<T>::zero();
+        mma_step(zc[cb], af, cf[i]);
+      }
+    }
+    // ---- epilogue: + bias + m (+ per-clip bias), store, GroupNorm partial of the stored values ------------------------------
+    float xs[NCB][4][4];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int c0 = cb * 32 + half * 4 + 8 * v;
+        if (c0 >= C) continue;
+        const f32x4 bias = *reinterpret_cast<const f32x4 *>(a.bias3 + c0);
+        float val[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) val[e] = zc[cb][4 * v + e] + bias[e] + acc[cb][4 * v + e];
+        if (a.badd) {
+          const f32x4 ba = *reinterpret_cast<const f32x4 *>(a.badd + (size_t)b * a.badd_ld + c0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) val[e] += ba[e];
+        }
+        T o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = from_f<T>(val[e]);
+        if (rvalid) {
+          T *op = static_cast<T *>(a.out) + grow * C + c0;
+          if constexpr (sizeof(T) == 2) *reinterpret_cast<uint2 *>(op) = *reinterpret_cast<const uint2 *>(o);
+          else *reinterpret_cast<f32x4 *>(op) = *reinterpret_cast<const f32x4 *>(o);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xs[cb][v][e] = rvalid ? to_f(o[e]) : 0.f;
+      }
+    if (a.stats_out) {
+      const int vrows = min(32, rows - t * 32);
+      if constexpr (C == 8) {
+        const float cnt = (float)vrows;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float m = half_sum32(xs[0][0][e], half) / cnt;
+          const float d = rvalid ? xs[0][0][e] - m : 0.f;
+          const float q = half_sum32(d * d, half);
+          if (l32 == 0) {
+            float *pp = part + ((size_t)t * a.G + half * 4 + e) * 2;
+            pp[0] = m;
+            pp[1] = q;
+          }
+        }
+      } else {
+        const float cnt = (float)vrows * (float)cpg;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const float2 hs = half_sums((xs[cb][v][0] + xs[cb][v][1]) + (xs[cb][v][2] + xs[cb][v][3]));
+            const float m = (cpg == 8 ? hs.x + hs.y : (half ? hs.y : hs.x)) / cnt;
+            float q = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float d = rvalid ? xs[cb][v][e] - m : 0.f;
+              q = fmaf(d, d, q);
+            }
+            const float2 hq = half_sums(q);
+            const float qq = cpg == 8 ? hq.x + hq.y : (half ? hq.y : hq.x);
+            if (l32 == 0 && (cpg == 4 || half == 0)) {
+              float *pp = part + ((size_t)t * a.G + (cb * 32 + half * 4 + 8 * v) / cpg) * 2;
+              pp[0] = m;
+              pp[1] = qq;
+            }
+          }
+      }
+    }
+  }
+  if (a.stats_out) {
+    __syncthreads();
+    for (int g = wave; g < a.G; g += NW) {
+      const bool on = lane < ntile;
+      const float *pp = part + ((size_t)(on ? lane : 0) * a.G + g) * 2;
+      const float n_t = on ? (float)min(32, rows - lane * 32) * (float)cpg : 0.f;
+      const float m_t = on ? pp[0] : 0.f, q_t = on ? pp[1] : 0.f;
+      const float2 sn = half_sums(n_t), sm = half_sums(n_t * m_t);
+      const float n = sn.x + sn.y, mean = (sm.x + sm.y) / n;
+      const float d = m_t - mean;
+      const float2 sq2 = half_sums(fmaf(n_t * d, d, q_t));
+      if (lane == 0) {
+        float *so = a.stats_out + (((size_t)b * a.nchw + ch) * a.G + g) * 2;
+        so[0] = mean;
+        so[1] = sq2.x + sq2.y;
+      }
+    }
+  }
+}
+
+template <typename T> size_t tail_lds_bytes(int C, int C2, int rw) {
+  return (size_t)(4 * C + kThinMaxTiles * kThinMaxG * 2) * sizeof(float) +
+         ((size_t)C * (3 * C + 8) + (size_t)C * (C + C2 + 8) + (size_t)(rw + 4) * (C + 8)) * sizeof(T);
+}
+
+template <typename T, int C, int C2> hipError_t tail_go(const ThinTailArgs &a, hipStream_t s) {
+  const size_t lds = tail_lds_bytes<T>(C, C2, a.rw);
+  auto kern = thin_tail_kernel<T, C, C2>;
+  if (lds > 64 * 1024) {
+    static bool raised = false;
+    if (!raised) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return e;
+      raised = true;
+    }
+  }
+  int nw = (a.rw + 31) / 32;
+  if (nw > 16) nw = 16;
+  if ((a.rw + 2) * (C / 8) > 6 * nw * 64) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(kern, dim3(a.B * a.nchw), dim3(nw * 64), lds, s, a);
+  return hipGetLastError();
+}
+
+template <typename T> hipError_t tail_dispatch(const ThinTailArgs &a, hipStream_t s) {
+  if (a.C == 8 && a.C2 == 8) return tail_go<T, 8, 8>(a, s);
+  if (a.C == 32 && a.C2 == 32) return tail_go<T, 32, 32>(a, s);
+  if (a.C == 64 && a.C2 == 32) return tail_go<T, 64, 32>(a, s);
+  if (a.C == 64 && a.C2 == 64) return tail_go<T, 64, 64>(a, s);
+  return hipErrorInvalidValue;
+}
+
 }  // namespace
+
+bool thin_tail_supported(int dt, const ThinTailArgs &a) {
+  const bool shape = (a.C == 8 && a.C2 == 8) || (a.C == 32 && a.C2 == 32) || (a.C == 64 && (a.C2 == 32 || a.C2 == 64));
+  if (!shape || a.rw < 32 || a.rw % 32 || a.rw > 32 * kThinMaxTiles) return false;
+  if (a.G < 1 || a.G > kThinMaxG || a.C % a.G) return false;
+  const int cpg = a.C / a.G;
+  if (a.C == 8 ? cpg != 1 : (cpg != 4 && cpg != 8)) return false;
+  if (!a.ss || !a.stats_in) return false;
+  const size_t lds = dt == F32 ? tail_lds_bytes<float>(a.C, a.C2, a.rw) : tail_lds_bytes<bf16>(a.C, a.C2, a.rw);
+  return lds <= 160 * 1024;
+}
+
+hipError_t launch_thin_tail(int dt, const ThinTailArgs &a, hipStream_t s) {
+  if (!thin_tail_supported(dt, a)) return hipErrorInvalidValue;
+  return dt == F32 ? tail_dispatch<float>(a, s) : tail_dispatch<bf16>(a, s);
+}
 
 ThinPlan conv_thin_plan(int B, int L, int C) {
   ThinPlan p;

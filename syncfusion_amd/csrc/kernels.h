@@ -106,6 +106,19 @@ struct ThinPlan {
 };
 // C = channels of the level whose positions are tiled (the OUTPUT level of a down / up convolution)
 ThinPlan conv_thin_plan(int B, int L, int C);
+// Item tail of a thin level in one launch (conv_thin.hip):
+//   y = x + Conv3(SiLU(GroupNorm(h)));  m = LayerNorm_C(y; eps_ln) * (1 + ss[b][c]) + ss[b][C + c];  out = m + W3 . [m | ctx] + bias3 (+ badd[b])
+struct ThinTailArgs {
+  const void *h = nullptr, *x = nullptr, *ctx = nullptr, *w2 = nullptr, *w3 = nullptr;
+  void *out = nullptr;
+  const float *bias2 = nullptr, *bias3 = nullptr, *gamma = nullptr, *beta = nullptr, *stats_in = nullptr, *ss = nullptr, *badd = nullptr;
+  float *stats_out = nullptr;
+  int B = 0, L = 0, C = 0, C2 = 0, ctx_ld = 0, ss_ld = 0, badd_ld = 0, G = 1, nch_in = 1, chunk_in = 1;
+  float eps_gn = 1e-5f, eps_ln = 1e-6f;
+  int rw = 32, nchw = 1;
+};
+bool thin_tail_supported(int dt, const ThinTailArgs &a);
+hipError_t launch_thin_tail(int dt, const ThinTailArgs &a, hipStream_t s);
 bool conv_thin_supported(int dt, const ConvThinArgs &a);
 hipError_t launch_conv_thin(int dt, const ConvThinArgs &a, hipStream_t s);
 

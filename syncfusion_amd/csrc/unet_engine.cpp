@@ -115,6 +115,7 @@ struct sf_unet {
   std::vector<std::pair<std::string, int64_t>> names;
   // graph cache for sf_vsample
   bool no_ln_fusion = getenv("SF_NO_LN_FUSION") != nullptr;   // debugging aid: launch every LayerNorm separately
+  bool no_thin_tail = getenv("SF_NO_THIN_TAIL") != nullptr;   // debugging aid: conv2 / inject of the thin levels as two launches
   hipGraphExec_t gexec = nullptr;
   // the instantiated step graph is reused by later sf_vsample calls with the same shape / workspace / guidance scale
   // (every pointer baked into its kernel nodes lives in the workspace or in the engine; the sampler state is an
@@ -860,6 +861,52 @@ struct Exec {
       a.stats_out = sB;
       a.out = tA;
       timed("conv_thin", 2.0 * rc * 3 * C, 2.0 * rc * es + 3.0 * C * C * es, [&] { SF_HIP(launch_conv_thin(u.dt, a, s)); });
+    }
+    // conv2 + Modulation + InjectChannels in one launch when the fused tail covers the shape
+    {
+      ThinTailArgs t;
+      t.h = tA;
+      t.x = cur;
+      t.ctx = l.ctx;
+      t.ctx_ld = b.ctx_ld;
+      t.w2 = w2;
+      t.bias2 = g.conv2.bias;
+      t.gamma = g.gn2_g;
+      t.beta = g.gn2_b;
+      t.stats_in = sB;
+      t.w3 = w3;
+      t.bias3 = g.inject.bias;
+      t.ss = p.mod_all + g.mod_off;
+      t.ss_ld = p.mod_stride;
+      if (g.cross && !g.attn) {
+        t.badd = p.ca_all + g.ca_off;
+        t.badd_ld = u.ca_ld;
+      }
+      t.out = tB;
+      t.stats_out = g.attn ? nullptr : sA;
+      t.B = p.Bt;
+      t.L = l.L;
+      t.C = C;
+      t.C2 = a3.C2;
+      t.G = G;
+      t.nch_in = tp.nchw;
+      t.chunk_in = tp.rw;
+      t.rw = tp.rw;
+      t.nchw = tp.nchw;
+      if (!u.no_thin_tail && g.conv2.bias && g.inject.bias && thin_tail_supported(u.dt, t)) {
+        const double kin = g.inject.kreal > 0 ? g.inject.kreal : g.inject.K;
+        timed("conv_thin", 2.0 * rc * 3 * C + 2.0 * rc * kin + 8.0 * rc, 3.0 * rc * es + (double)l.rows * (kin - C) * es + (3.0 * C + kin) * C * es,
+              [&] { SF_HIP(launch_thin_tail(u.dt, t, s)); });
+        if (g.attn) {
+          stats_of = nullptr;   // z in tB, tA free: what the attention code expects
+        } else {
+          void *o = cur;
+          cur = tB;
+          tB = o;
+          stats_of = cur;
+        }
+        return true;
+      }
     }
     {
       ConvThinArgs a = a1;
