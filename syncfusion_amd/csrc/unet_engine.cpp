@@ -115,8 +115,11 @@ struct sf_unet {
   std::vector<std::pair<std::string, int64_t>> names;
   // graph cache for sf_vsample
   bool no_ln_fusion = getenv("SF_NO_LN_FUSION") != nullptr;   // debugging aid: launch every LayerNorm separately
+  bool no_indep_branches = getenv("SF_NO_INDEP_BRANCHES") != nullptr;   // debugging aid: fork / join the branches inside every step
   bool no_thin_tail = getenv("SF_NO_THIN_TAIL") != nullptr;   // debugging aid: conv2 / inject of the thin levels as two launches
   hipGraphExec_t gexec = nullptr;
+  hipGraphExec_t gexec_br[8] = {};   // independent-branch pipelines: one single-stream step graph per branch
+  bool gexec_indep = false;
   // the instantiated step graph is reused by later sf_vsample calls with the same shape / workspace / guidance scale
   // (every pointer baked into its kernel nodes lives in the workspace or in the engine; the sampler state is an
   // internal workspace buffer, the caller's x is copied in and out)
@@ -139,7 +142,7 @@ struct sf_unet {
   // (fork/join with events; captured into the step graph as parallel branches).
   static constexpr int kMaxBranches = 8;
   hipStream_t bstream[kMaxBranches] = {};
-  hipEvent_t ev_fork = nullptr, ev_join[kMaxBranches] = {};
+  hipEvent_t ev_fork = nullptr, ev_join[kMaxBranches] = {}, ev_step[kMaxBranches] = {};
   int branches_override = 0;
   void ensure_branch_streams(int n) {
     if (!ev_fork) SF_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
@@ -147,13 +150,18 @@ struct sf_unet {
       if (!bstream[i]) SF_HIP(hipStreamCreateWithFlags(&bstream[i], hipStreamNonBlocking));
       if (!ev_join[i]) SF_HIP(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
     }
+    for (int i = 0; i < n; ++i)
+      if (!ev_step[i]) SF_HIP(hipEventCreateWithFlags(&ev_step[i], hipEventDisableTiming));
   }
 
   ~sf_unet() {
     if (gexec) (void)hipGraphExecDestroy(gexec);
+    for (hipGraphExec_t g : gexec_br)
+      if (g) (void)hipGraphExecDestroy(g);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     for (int i = 0; i < kMaxBranches; ++i) {
       if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
+      if (ev_step[i]) (void)hipEventDestroy(ev_step[i]);
       if (bstream[i]) (void)hipStreamDestroy(bstream[i]);
     }
     for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
@@ -497,7 +505,7 @@ Plan make_plan(const sf_unet &u, Workspace &ws, int B, int L0, bool two, int num
   // instantiated for one num_steps stays valid for another (up to kSchedSteps; the tables are indexed by the device
   // step counter).  Order: step counter, schedule (fixed capacity), sigmas, modulation table, time-MLP rows.
   const int64_t ns = std::max<int64_t>(num_steps > 0 ? num_steps : 1, kSchedSteps);
-  p.step = ws.alloc_n<int>(4);
+  p.step = ws.alloc_n<int>(16);   // device step counters: one per independent branch pipeline
   p.sched = ws.alloc_n<float>(4 * ns);
   p.sigs = ws.alloc_n<float>(ns + p.Bt);
   if (p.steps_cap) p.mod_steps = ws.alloc_n<float>((int64_t)p.steps_cap * u.mod_ld);   // base fixed, length ~ num_steps
@@ -1377,8 +1385,7 @@ int sf_vsample(sf_unet *h, float *x, const float *const *ctx, const float *emb, 
   float *sigs = p.sigs;
   SF_HIP(hipMemcpyAsync(sched, host.data(), 4 * (size_t)T * sizeof(float), hipMemcpyHostToDevice, s));
   SF_HIP(hipMemcpyAsync(sigs, host.data() + 4 * (size_t)T, (size_t)T * sizeof(float), hipMemcpyHostToDevice, s));
-  SF_HIP(hipMemsetAsync(p.step, 0, 4 * sizeof(int), s));
-  SF_HIP(hipStreamSynchronize(s));  // `host` goes out of scope; pageable H2D copies are staged, but be explicit
+  SF_HIP(hipMemsetAsync(p.step, 0, 16 * sizeof(int), s));
 
   const int64_t n = (int64_t)B * L0 * h->cfg.in_channels;
   // sigma_i is the same for every clip, so the time MLP and the 42 Modulation / SkipModulate projections of ALL steps
@@ -1413,11 +1420,86 @@ int sf_vsample(sf_unet *h, float *x, const float *const *ctx, const float *emb, 
   key.scale = embedding_scale;
   key.ws = ws;
   key.valid = true;
-  if (timing) {
+  // One host synchronisation per call, placed HERE: the pageable H2D copies of the schedule above must have been staged
+  // before `host` dies, and the step graphs are measurably faster when their streams are idle at the first launch
+  // (449 vs 408 steps/s at 50 steps: launching onto busy streams leaves the two branch pipelines out of phase).
+  SF_HIP(hipStreamSynchronize(s));
+  if (timing) fprintf(stderr, "[sf_vsample] + schedule, per-step features: %.3f ms since entry\n", ms_since(t_begin));
+  // Independent branch pipelines.  Without guidance the clip slices never interact during the whole loop, so each
+  // branch owns a step counter, a modulation row and a SINGLE-STREAM step graph replayed on its own stream; the streams
+  // meet only at the end of the call.  (A two-stream graph with a fork/join per step costs ~1.7 ms of host time per launch
+  // on this runtime -- node by node -- against ~0.07 ms for a single-stream graph, and joins the branches 50 times.)
+  const bool indep = use_graph && pre && !two && p.nbr > 1 && !h->prof_on && !h->no_indep_branches;
+  if (indep) {
+    h->ensure_branch_streams(p.nbr);
+    const int64_t nb = n / p.nbr;
+    auto stream_of = [&](int br) { return br == 0 ? s : h->bstream[br]; };
+    auto branch_step = [&](int br) {
+      hipStream_t sb = stream_of(br);
+      Plan v = ex.branch_view(br);
+      v.mod_all = p.mod_all + (int64_t)br * h->mod_ld;   // the branch's own copy of the step's modulation row
+      SF_HIP(launch_step_select(p.mod_steps, h->mod_ld, p.step + br, v.mod_all, sb));
+      Exec eb{*h, v, sb};
+      float *xb = xs + (v.x2 - p.x2);
+      eb.block(0, xb, F32, v.vout, F32);
+      SF_HIP(launch_vsampler_update(xb, v.vout, nullptr, embedding_scale, sched - 4, p.step + br, nb, sb));
+    };
+    SF_HIP(hipEventRecord(h->ev_fork, s));
+    for (int br = 1; br < p.nbr; ++br) SF_HIP(hipStreamWaitEvent(h->bstream[br], h->ev_fork, 0));
+    const bool cached = h->gexec_indep && h->gkey == key;
+    const auto t_l = now();
+    if (!cached) {
+      h->gkey.valid = false;
+      h->launches = 0;
+      for (int br = 0; br < p.nbr; ++br) branch_step(br);   // step 0 eagerly (one-time kernel attribute setup outside capture)
+      for (int br = 0; br < p.nbr; ++br) {
+        hipStream_t sb = stream_of(br);
+        hipGraph_t graph = nullptr;
+        SF_HIP(hipStreamBeginCapture(sb, hipStreamCaptureModeThreadLocal));
+        try {
+          branch_step(br);
+        } catch (...) {
+          hipGraph_t g2 = nullptr;
+          (void)hipStreamEndCapture(sb, &g2);
+          if (g2) (void)hipGraphDestroy(g2);
+          throw;
+        }
+        SF_HIP(hipStreamEndCapture(sb, &graph));
+        if (h->gexec_br[br]) {
+          (void)hipGraphExecDestroy(h->gexec_br[br]);
+          h->gexec_br[br] = nullptr;
+        }
+        hipError_t e = hipGraphInstantiate(&h->gexec_br[br], graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) fail(SF_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+      }
+      h->gexec_indep = true;
+      h->gkey = key;
+    }
+    // (the capture above only records step 1; replay it for the remaining steps -- all of them when the graphs were cached)
+    // The branches are re-aligned after every step (two event edges, microseconds of host time): kept in lockstep they
+    // walk the same layers together and the second one finds the 430 MB of weights in L2 / Infinity Cache; left to drift
+    // they each stream the weights from HBM (measured: 2.40 vs 2.2 ms per step).
+    for (int i = cached ? 0 : 1; i < T; ++i) {
+      for (int br = 0; br < p.nbr; ++br) SF_HIP(hipGraphLaunch(h->gexec_br[br], stream_of(br)));
+      if (i + 1 < T) {
+        for (int br = 0; br < p.nbr; ++br) SF_HIP(hipEventRecord(h->ev_step[br], stream_of(br)));
+        for (int br = 0; br < p.nbr; ++br)
+          for (int o = 0; o < p.nbr; ++o)
+            if (o != br) SF_HIP(hipStreamWaitEvent(stream_of(br), h->ev_step[o], 0));
+      }
+    }
+    for (int br = 1; br < p.nbr; ++br) {
+      SF_HIP(hipEventRecord(h->ev_join[br], h->bstream[br]));
+      SF_HIP(hipStreamWaitEvent(s, h->ev_join[br], 0));
+    }
+    const double enq = ms_since(t_l);
+    // The call returns when the loop has finished.  Measured: with ~100 graph launches still queued on two streams, a
+    // caller that goes on to hipDeviceSynchronize (torch.cuda.synchronize) slows the GPU side by ~10 % (404-418 vs 448
+    // steps/s); waiting on the one stream that joins the branches does not.
     SF_HIP(hipStreamSynchronize(s));
-    fprintf(stderr, "[sf_vsample] + schedule, per-step features: %.3f ms since entry\n", ms_since(t_begin));
-  }
-  if (use_graph && T > 1 && h->gexec && !h->prof_on && h->gkey == key) {
+    if (timing) fprintf(stderr, "[sf_vsample] %d steps x %d independent branch graphs: enqueue %.3f ms, done after %.3f ms\n", T, p.nbr, enq, ms_since(t_l));
+  } else if (use_graph && T > 1 && h->gexec && !h->gexec_indep && !h->prof_on && h->gkey == key) {
     const auto t_l = now();
     for (int i = 0; i < T; ++i) SF_HIP(hipGraphLaunch(h->gexec, s));   // steady state: no eager step, no capture
     if (timing) {
@@ -1432,6 +1514,7 @@ int sf_vsample(sf_unet *h, float *x, const float *const *ctx, const float *emb, 
   if (T > 1) {
     if (use_graph) {
       h->gkey.valid = false;
+      h->gexec_indep = false;
       hipGraph_t graph = nullptr;
       SF_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
       try {
