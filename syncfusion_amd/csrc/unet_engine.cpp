@@ -142,7 +142,7 @@ struct sf_unet {
   // (fork/join with events; captured into the step graph as parallel branches).
   static constexpr int kMaxBranches = 8;
   hipStream_t bstream[kMaxBranches] = {};
-  hipEvent_t ev_fork = nullptr, ev_join[kMaxBranches] = {}, ev_step[kMaxBranches] = {};
+  hipEvent_t ev_fork = nullptr, ev_join[kMaxBranches] = {};
   int branches_override = 0;
   void ensure_branch_streams(int n) {
     if (!ev_fork) SF_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
@@ -150,8 +150,7 @@ struct sf_unet {
       if (!bstream[i]) SF_HIP(hipStreamCreateWithFlags(&bstream[i], hipStreamNonBlocking));
       if (!ev_join[i]) SF_HIP(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
     }
-    for (int i = 0; i < n; ++i)
-      if (!ev_step[i]) SF_HIP(hipEventCreateWithFlags(&ev_step[i], hipEventDisableTiming));
+
   }
 
   ~sf_unet() {
@@ -161,7 +160,6 @@ struct sf_unet {
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     for (int i = 0; i < kMaxBranches; ++i) {
       if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
-      if (ev_step[i]) (void)hipEventDestroy(ev_step[i]);
       if (bstream[i]) (void)hipStreamDestroy(bstream[i]);
     }
     for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
@@ -1477,18 +1475,8 @@ int sf_vsample(sf_unet *h, float *x, const float *const *ctx, const float *emb, 
       h->gkey = key;
     }
     // (the capture above only records step 1; replay it for the remaining steps -- all of them when the graphs were cached)
-    // The branches are re-aligned after every step (two event edges, microseconds of host time): kept in lockstep they
-    // walk the same layers together and the second one finds the 430 MB of weights in L2 / Infinity Cache; left to drift
-    // they each stream the weights from HBM (measured: 2.40 vs 2.2 ms per step).
-    for (int i = cached ? 0 : 1; i < T; ++i) {
+    for (int i = cached ? 0 : 1; i < T; ++i)
       for (int br = 0; br < p.nbr; ++br) SF_HIP(hipGraphLaunch(h->gexec_br[br], stream_of(br)));
-      if (i + 1 < T) {
-        for (int br = 0; br < p.nbr; ++br) SF_HIP(hipEventRecord(h->ev_step[br], stream_of(br)));
-        for (int br = 0; br < p.nbr; ++br)
-          for (int o = 0; o < p.nbr; ++o)
-            if (o != br) SF_HIP(hipStreamWaitEvent(stream_of(br), h->ev_step[o], 0));
-      }
-    }
     for (int br = 1; br < p.nbr; ++br) {
       SF_HIP(hipEventRecord(h->ev_join[br], h->bstream[br]));
       SF_HIP(hipStreamWaitEvent(s, h->ev_join[br], 0));
