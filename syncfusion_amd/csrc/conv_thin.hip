@@ -864,6 +864,11 @@ bool thin_tail_supported(int dt, const ThinTailArgs &a) {
   const int cpg = a.C / a.G;
   if (a.C == 8 ? cpg != 1 : (cpg != 4 && cpg != 8)) return false;
   if (!a.ss || !a.stats_in) return false;
+  {
+    int nw = (a.rw + 31) / 32;
+    if (nw > 16) nw = 16;
+    if ((a.rw + 2) * (a.C / 8) > 6 * nw * 64) return false;
+  }
   const size_t lds = dt == F32 ? tail_lds_bytes<float>(a.C, a.C2, a.rw) : tail_lds_bytes<bf16>(a.C, a.C2, a.rw);
   return lds <= 160 * 1024;
 }
@@ -908,6 +913,13 @@ bool conv_thin_supported(int dt, const ConvThinArgs &a) {
     if (a.G < 1 || a.G > kThinMaxG || a.N % a.G) return false;
     const int cpg = a.N / a.G;
     if (a.N == 8 ? cpg != 1 : (cpg != 4 && cpg != 8)) return false;
+  }
+  {   // staging registers: the source rows of a workgroup must fit 6 vectors per thread (see thin_go)
+    const int ncb = (a.N + 31) / 32;
+    int nw = ((a.rw + 31) / 32) * ncb;
+    if (nw > 16) nw = 16;
+    nw = (nw / ncb) * ncb;
+    if (((a.rw >> a.up_shift) + 3) * (a.C / 8) > 6 * nw * 64) return false;
   }
   const size_t lds = dt == F32 ? thin_lds_bytes<float>(a.C, a.taps, a.rw, a.up_shift) : thin_lds_bytes<bf16>(a.C, a.taps, a.rw, a.up_shift);
   return lds <= 160 * 1024;

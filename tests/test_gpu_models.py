@@ -321,6 +321,30 @@ def test_full_size_properties(cuda, full_model):
     assert rel_l2(s3.cpu(), s1.cpu()) < 1e-5
 
 
+@pytest.mark.parametrize("B,scale", [(1, 1.0), (3, 2.0), (16, 1.0), (32, 7.5)])
+def test_full_size_batch_and_branch_sweep(cuda, full_model, B, scale):
+    """Every batch size picks different tile plans (thin-level workgroup tiles, GEMM families, clip-parallel branches) and
+    BASELINE configs[2] doubles the batch for guidance: the result for a clip must not depend on any of it.  Compares
+    the automatic branch count with one branch and with the same clips evaluated two at a time."""
+    L0 = 45056
+    x, sigma, emb, chans = _full_inputs(full_model, B, L0, 90 + B)
+    net = full_model.model.net
+    gx, gs, ge, gc = x.to(cuda), sigma.to(cuda), emb.to(cuda), [c.to(cuda) for c in chans]
+    eng = net.engine()
+    try:
+        eng.set_branches(1)
+        one = net(gx, gs, embedding=ge, channels=gc, embedding_scale=scale)
+        eng.set_branches(0)
+        auto = net(gx, gs, embedding=ge, channels=gc, embedding_scale=scale)
+    finally:
+        eng.set_branches(0)
+    assert torch.isfinite(one).all() and torch.isfinite(auto).all()
+    assert rel_l2(auto.cpu(), one.cpu()) < 1e-5
+    k = min(B, 2)
+    part = net(gx[:k], gs[:k], embedding=ge[:k], channels=[c[:k] for c in gc], embedding_scale=scale)
+    assert rel_l2(part.cpu(), one[:k].cpu()) < 1e-5
+
+
 def test_e2e_frames_to_audio_shapes(cuda, full_model):
     """BASELINE configs[4] plumbing at a reduced step count: frames -> onset net -> glue -> Encoder1d -> sampler."""
     from syncfusion_amd.generation import generate_batch
