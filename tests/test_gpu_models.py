@@ -321,12 +321,12 @@ def test_full_size_properties(cuda, full_model):
     assert rel_l2(s3.cpu(), s1.cpu()) < 1e-5
 
 
-@pytest.mark.parametrize("B,scale", [(1, 1.0), (3, 2.0), (16, 1.0), (32, 7.5)])
-def test_full_size_batch_and_branch_sweep(cuda, full_model, B, scale):
+@pytest.mark.parametrize("B,scale,L0", [(1, 1.0, 45056), (3, 2.0, 45056), (16, 1.0, 45056), (32, 7.5, 45056), (2, 1.0, 262144), (4, 3.0, 262144)])
+def test_full_size_batch_and_branch_sweep(cuda, full_model, B, scale, L0):
     """Every batch size picks different tile plans (thin-level workgroup tiles, GEMM families, clip-parallel branches) and
     BASELINE configs[2] doubles the batch for guidance: the result for a clip must not depend on any of it.  Compares
-    the automatic branch count with one branch and with the same clips evaluated two at a time."""
-    L0 = 45056
+    the automatic branch count with one branch and with the same clips evaluated two at a time.  L0 = 2**18 is the
+    reference's default generation length (main/generation.py:23)."""
     x, sigma, emb, chans = _full_inputs(full_model, B, L0, 90 + B)
     net = full_model.model.net
     gx, gs, ge, gc = x.to(cuda), sigma.to(cuda), emb.to(cuda), [c.to(cuda) for c in chans]
