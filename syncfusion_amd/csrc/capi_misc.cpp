@@ -140,14 +140,6 @@ int sf_op_conv1d_cl(int dtype, const void *x, const float *w, const float *bias,
     a.beta = beta;
     a.eps = eps;
   }
-  if (!direct) {   // scratch for the grid split-K variant (short activations), as the engines provide it
-    const int64_t slab_floats = std::min<int64_t>((int64_t)8 * a.M * N, (int64_t)1 << 24);
-    a.sk_slab = wk.alloc_n<float>(slab_floats);
-    a.sk_slab_bytes = (size_t)slab_floats * sizeof(float);
-    a.sk_cnt = wk.alloc_n<int>(1024);
-    a.sk_cnt_ints = 1024;
-    SF_HIP(hipMemsetAsync(a.sk_cnt, 0, 1024 * sizeof(int), s));
-  }
   if (direct) SF_HIP(launch_conv_direct(dtype, dtype, a, s));
   else SF_HIP(launch_conv_gemm(dtype, a, s));
   return SF_OK;
@@ -160,8 +152,7 @@ int sf_bench_conv1d(int dtype, int B, int L, int C, int N, int taps, int upsampl
   const size_t es = dsize(dtype);
   const int K = taps * C, Lout = L * upsample, M = B * Lout;
   void *x = nullptr, *w = nullptr, *out = nullptr, *res = nullptr;
-  float *bias = nullptr, *slab = nullptr;
-  int *cnt = nullptr;
+  float *bias = nullptr;
   SF_HIP(hipMalloc(&x, (size_t)B * L * C * es));
   // SF_BENCH_COLD=1: rotate through enough weight copies (> 768 MB) that every launch streams its weights from HBM,
   // as inside a denoising step (430 MB of weights per step do not fit the 256 MB Infinity Cache)
@@ -174,10 +165,6 @@ int sf_bench_conv1d(int dtype, int B, int L, int C, int N, int taps, int upsampl
   SF_HIP(hipMalloc(&out, (size_t)M * N * es));
   SF_HIP(hipMalloc(&res, (size_t)M * N * es));
   SF_HIP(hipMalloc(&bias, N * sizeof(float)));
-  const size_t slab_bytes = std::min<size_t>((size_t)16 * M * N * 4, (size_t)1 << 28);
-  SF_HIP(hipMalloc(&slab, slab_bytes));
-  SF_HIP(hipMalloc(&cnt, 4096 * sizeof(int)));
-  SF_HIP(hipMemset(cnt, 0, 4096 * sizeof(int)));
   // non-trivial bit patterns (zero operands clock higher): bf16/f32 values around +-1
   SF_HIP(hipMemset(x, 0x3c, (size_t)B * L * C * es));
   SF_HIP(hipMemset(w, 0xbc, wbytes * ncopy));
@@ -202,10 +189,6 @@ int sf_bench_conv1d(int dtype, int B, int L, int C, int N, int taps, int upsampl
   a.n_store = N;
   a.res = res;
   a.res_ld = N;
-  a.sk_slab = slab;
-  a.sk_slab_bytes = slab_bytes;
-  a.sk_cnt = cnt;
-  a.sk_cnt_ints = 4096;
   g_conv_gemm_force.path = path;
   g_conv_gemm_force.tile = tile;
   g_conv_gemm_force.sk = sk;
@@ -229,7 +212,7 @@ int sf_bench_conv1d(int dtype, int B, int L, int C, int N, int taps, int upsampl
   g_conv_gemm_force = ConvGemmForce();
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
-  for (void *p : {x, w, out, res, (void *)bias, (void *)slab, (void *)cnt}) (void)hipFree(p);
+  for (void *p : {x, w, out, res, (void *)bias}) (void)hipFree(p);
   if (err != hipSuccess) fail(SF_ERR_UNSUPPORTED, "variant not applicable: %s", hipGetErrorString(err));
   return SF_OK;
   SF_API_END

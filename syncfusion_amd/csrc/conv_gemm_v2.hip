@@ -5,10 +5,9 @@
 //   * A and W chunks are fetched with `buffer_load_dwordx4` (wave-uniform descriptors, 32-bit per-lane offsets,
 //     out-of-range offsets return zero: padding rows, M/N tails and K tails need no predication), issued for
 //     chunk t+1 BEFORE the MFMAs of chunk t and written to the OTHER LDS buffer after them: one barrier per chunk.
-//   * optional GRID split-K for short activations (few output rows, long K): `sk` workgroups share an output
-//     tile, each writes its fp32 partial tile to a slab, takes a ticket (agent-scope release -> relaxed
-//     fetch_add), and the last arriver (agent-scope acquire) sums the slabs IN FIXED ORDER and runs the epilogue.
-//     No float atomics: results are bit-reproducible and independent of arrival order.
+//   * (a grid split-K variant -- partial tiles in a slab, arrival tickets with agent-scope release / acquire, last
+//     arriver reduces -- was measured slower than the wave-split-K kernels on every short-activation shape, 2-7 us of
+//     fences per workgroup, and removed.)
 //   * epilogue through LDS: row-major 16-byte stores, operand loads (bias / residual / per-clip scale+add)
 //     batched and unconditional.
 #include "common.h"
@@ -28,10 +27,8 @@ template <typename T> __device__ __forceinline__ Vec16<T> buf_ld16(__amdgpu_buff
 }
 
 struct V2Extra {
-  int mtiles, ntiles, sk, chunks_per_split, swz;
+  int mtiles, ntiles, swz;
   unsigned bytesA, bytesA2, bytesW;
-  float *slab;   // [sk][M][N] fp32 partial tiles (sk > 1)
-  int *cnt;      // [mtiles * ntiles] arrival tickets, zero between launches
 };
 
 template <typename T, int BM, int BN, int GEOM, bool CAT>
@@ -53,21 +50,17 @@ __global__ __launch_bounds__(256) void conv_gemm_v2_kernel(const ConvGemmArgs a,
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  // ---- block -> (row tile, column tile, K slice): all users of one W panel on one XCD -----------------
-  int mt, nt, ks;
+  // ---- block -> (row tile, column tile): all users of one W panel on one XCD ----------------------------
+  int mt, nt;
   {
     const int bid = blockIdx.x;
     if (x.swz) {
       const int xcd = bid & 7, j = bid >> 3;
       mt = j % x.mtiles;
-      const int r = j / x.mtiles;
-      ks = r % x.sk;
-      nt = xcd + 8 * (r / x.sk);
+      nt = xcd + 8 * (j / x.mtiles);
     } else {
       mt = bid % x.mtiles;
-      const int r = bid / x.mtiles;
-      ks = r % x.sk;
-      nt = r / x.sk;
+      nt = bid / x.mtiles;
     }
   }
   const int m0 = mt * BM, n0 = nt * BN;
@@ -121,8 +114,8 @@ __global__ __launch_bounds__(256) void conv_gemm_v2_kernel(const ConvGemmArgs a,
 
   const int k_taps = a.taps * a.cin;
   const int nk_total = (a.K + BK - 1) / BK;
-  const int kt0 = ks * x.chunks_per_split;
-  const int nkt = min(x.chunks_per_split, nk_total - kt0);
+  const int kt0 = 0;
+  const int nkt = nk_total;
   const unsigned lane_k = (unsigned)(svec * VEC);
   const int pmax = (a.Lsrc << a.up_shift) - 1;
 
@@ -162,7 +155,7 @@ __global__ __launch_bounds__(256) void conv_gemm_v2_kernel(const ConvGemmArgs a,
       }
     }
   };
-  {   // position the stream at this block's first chunk (grid split-K slices start mid-way)
+  {   // position the stream at the first chunk
     const int k0 = kt0 * BK;
     kb = (unsigned)(k0 * ES);
     if (CAT && k0 >= k_taps) {
@@ -272,36 +265,6 @@ __global__ __launch_bounds__(256) void conv_gemm_v2_kernel(const ConvGemmArgs a,
 
   constexpr int QN = BN / 4;
   constexpr int ITER = (BM * QN) / 256;
-  const bool split = x.sk > 1;
-  if (split) {
-    // partial tile -> slab[ks]; ticket; only the last arriver continues
-#pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-      const int idx = tid + it * 256;
-      const int ml = idx / QN, nq = idx - ml * QN;
-      const int m = m0 + ml, nb = n0 + nq * 4;
-      if (m < a.M && nb < a.N)
-        *reinterpret_cast<f32x4 *>(x.slab + ((size_t)ks * a.M + m) * a.N + nb) = *reinterpret_cast<const f32x4 *>(red + (size_t)ml * LDR + nq * 4);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int *flag = reinterpret_cast<int *>(smem + (size_t)BM * LDR * sizeof(float));
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const int t = __hip_atomic_fetch_add(x.cnt + (mt * x.ntiles + nt), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int last = (t == x.sk - 1);
-      if (last) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(x.cnt + (mt * x.ntiles + nt), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next launch
-      }
-      *flag = last;
-    }
-    __syncthreads();
-    if (!*flag) return;
-  }
-
   T *out = static_cast<T *>(a.out);
   const T *res = static_cast<const T *>(a.res);
   const bool has_res = res != nullptr, has_bs = a.bscale != nullptr, has_ba = a.badd != nullptr;
@@ -322,20 +285,7 @@ __global__ __launch_bounds__(256) void conv_gemm_v2_kernel(const ConvGemmArgs a,
       sv[e] = has_bs ? a.bscale[(size_t)b * a.bscale_ld + nc] : 1.f;
       av[e] = has_ba ? a.badd[(size_t)b * a.badd_ld + nc] : 0.f;
     }
-    f32x4 v;
-    if (split) {
-      const int nbc = min(nb, a.N - 4);
-      v = *reinterpret_cast<const f32x4 *>(x.slab + (size_t)mc * a.N + nbc);
-      for (int s = 1; s < x.sk; ++s) {   // fixed order: slab 0, 1, ... -> independent of which block arrived last
-        f32x4 t = *reinterpret_cast<const f32x4 *>(x.slab + ((size_t)s * a.M + mc) * a.N + nbc);
-        v[0] += t[0];
-        v[1] += t[1];
-        v[2] += t[2];
-        v[3] += t[3];
-      }
-    } else {
-      v = *reinterpret_cast<const f32x4 *>(red + (size_t)ml * LDR + nq * 4);
-    }
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(red + (size_t)ml * LDR + nq * 4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int n = nb + e;
@@ -357,16 +307,12 @@ template <typename T, int BM, int BN, int GEOM, bool CAT> hipError_t launch_v2_t
   V2Extra x;
   x.mtiles = (a.M + BM - 1) / BM;
   x.ntiles = (a.n_store + BN - 1) / BN;
-  x.sk = pl.sk;
-  x.chunks_per_split = pl.chunks_per_split;
   x.swz = (x.ntiles % 8 == 0) ? 1 : 0;
   const size_t es = sizeof(T);
   if (a.geom == 0) x.bytesA = (unsigned)((size_t)(a.M / a.Lout + (a.M % a.Lout ? 1 : 0)) * a.Lsrc * a.src_ld * es);
   else x.bytesA = (unsigned)((size_t)(a.M / (a.To * a.Ho * a.Wo)) * a.Ti * a.Hi * a.Wi * a.src_ld * es);
   x.bytesA2 = CAT ? (unsigned)((size_t)a.M * a.src2_ld * es) : 0u;
   x.bytesW = (unsigned)((size_t)a.N * a.K * es);
-  x.slab = a.sk_slab;
-  x.cnt = a.sk_cnt;
   auto kern = conv_gemm_v2_kernel<T, BM, BN, GEOM, CAT>;
   static bool en = false;
   if (!en) {
@@ -374,7 +320,7 @@ template <typename T, int BM, int BN, int GEOM, bool CAT> hipError_t launch_v2_t
     if (e != hipSuccess) return e;
     en = true;
   }
-  hipLaunchKernelGGL(kern, dim3(x.mtiles * x.ntiles * x.sk), dim3(256), lds, s, a, x);
+  hipLaunchKernelGGL(kern, dim3(x.mtiles * x.ntiles), dim3(256), lds, s, a, x);
   return hipGetLastError();
 }
 
@@ -385,7 +331,7 @@ template <typename T, int BM, int BN> hipError_t launch_v2_g(const ConvGemmArgs 
 
 }  // namespace
 
-// eligibility + tile / split-K choice
+// eligibility + tile choice
 bool conv_gemm_v2_plan(int dt, const ConvGemmArgs &a, V2Plan &pl) {
   if (a.pro != 0 || (a.cin % BK) || (a.cin2 % 32) || (a.K % 32) || a.N % 4) return false;
   if (a.geom == 1 && a.cin2) return false;
@@ -395,36 +341,18 @@ bool conv_gemm_v2_plan(int dt, const ConvGemmArgs &a, V2Plan &pl) {
   else bA = (size_t)(a.M / (a.To * a.Ho * a.Wo) + 1) * a.Ti * a.Hi * a.Wi * a.src_ld * es;
   if (bA >= lim || (size_t)a.M * (a.src2_ld > 0 ? a.src2_ld : 1) * es >= lim || (size_t)a.N * a.K * es >= lim) return false;
   auto tiles = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.n_store + bn - 1) / bn); };
-  const int nk = (a.K + BK - 1) / BK;
   // Measured on MI355X (tools/gemm_sweep.py, bf16): 128x128 wins once it yields >= ~300 workgroups, 64x64 otherwise;
   // below ~500 64x64-tiles the wave-split-K kernel with 32x32 tiles is faster (see launch_conv_gemm).
-  static const int bms[3] = {128, 128, 64}, bns[3] = {128, 64, 64};
   pl.variant = (a.n_store >= 128 && tiles(128, 128) >= 300) ? 0 : 2;
   const ConvGemmForce &f = g_conv_gemm_force;
   if (f.path == 4 && f.tile >= 0 && f.tile <= 2) pl.variant = f.tile;
-  const long t = tiles(bms[pl.variant], bns[pl.variant]);
-  pl.sk = 1;
-  if (false && t < 224 && a.sk_slab && a.sk_cnt && a.n_store == a.N) {   // measured slower than wave-split-K: fences ~2-7 us per block
-    // split K so that tiles*sk ~ 256..512 workgroups, at least 4 chunks (256 K) per slice
-    int sk = (int)((320 + t - 1) / t);
-    const int max_sk = nk / 4 > 0 ? nk / 4 : 1;
-    if (sk > max_sk) sk = max_sk;
-    if (sk > 16) sk = 16;
-    while (sk > 1 && ((size_t)sk * a.M * a.N * sizeof(float) > a.sk_slab_bytes || t > a.sk_cnt_ints)) --sk;
-    pl.sk = sk < 1 ? 1 : sk;
-  }
-  if (f.path == 4 && f.sk >= 1 && a.sk_slab && (size_t)f.sk * a.M * a.N * sizeof(float) <= a.sk_slab_bytes) pl.sk = f.sk;
-  pl.chunks_per_split = (nk + pl.sk - 1) / pl.sk;
-  pl.sk = (nk + pl.chunks_per_split - 1) / pl.chunks_per_split;   // no empty slices
   return true;
 }
 
 const char *conv_gemm_v2_name(int dt, const V2Plan &pl) {
-  static const char *n[2][2][3] = {{{"conv_gemm_v2<f32,128x128>", "conv_gemm_v2<f32,128x64>", "conv_gemm_v2<f32,64x64>"},
-                                    {"conv_gemm_v2<f32,128x128,splitK>", "conv_gemm_v2<f32,128x64,splitK>", "conv_gemm_v2<f32,64x64,splitK>"}},
-                                   {{"conv_gemm_v2<bf16,128x128>", "conv_gemm_v2<bf16,128x64>", "conv_gemm_v2<bf16,64x64>"},
-                                    {"conv_gemm_v2<bf16,128x128,splitK>", "conv_gemm_v2<bf16,128x64,splitK>", "conv_gemm_v2<bf16,64x64,splitK>"}}};
-  return n[dt == F32 ? 0 : 1][pl.sk > 1 ? 1 : 0][pl.variant];
+  static const char *n[2][3] = {{"conv_gemm_v2<f32,128x128>", "conv_gemm_v2<f32,128x64>", "conv_gemm_v2<f32,64x64>"},
+                                {"conv_gemm_v2<bf16,128x128>", "conv_gemm_v2<bf16,128x64>", "conv_gemm_v2<bf16,64x64>"}};
+  return n[dt == F32 ? 0 : 1][pl.variant];
 }
 
 hipError_t launch_conv_gemm_v2(int dt, const ConvGemmArgs &a, const V2Plan &pl, hipStream_t s) {

@@ -47,16 +47,9 @@ struct ConvGemmArgs {
   const float *ln_part = nullptr, *ln_ss = nullptr;
   int ln_nt = 0, ln_ss_ld = 0, res_ln = 0;
   float ln_eps = 1e-5f;
-  // optional scratch for grid split-K (conv_gemm_v2): fp32 partial-tile slab and per-tile arrival tickets
-  // (the tickets must be zero before the launch; the kernel re-arms them)
-  float *sk_slab = nullptr;
-  size_t sk_slab_bytes = 0;
-  int *sk_cnt = nullptr;
-  int sk_cnt_ints = 0;
 };
 struct V2Plan {
   int variant = 2;  // 0: 128x128, 1: 128x64, 2: 64x64
-  int sk = 1, chunks_per_split = 0;
 };
 bool conv_gemm_v2_plan(int dt, const ConvGemmArgs &a, V2Plan &pl);
 const char *conv_gemm_v2_name(int dt, const V2Plan &pl);
@@ -67,9 +60,9 @@ bool conv_gemm_emits_rowpart(int dt, const ConvGemmArgs &a);
 // GEMM whose first source is LayerNorm-modulated on the fly from producer-side row partials (see ConvGemmArgs)
 bool conv_gemm_ln_ok(int dt, const ConvGemmArgs &a);
 hipError_t launch_conv_gemm_ln(int dt, const ConvGemmArgs &a, hipStream_t s);
-// Tuning hook (sf_bench_conv1d only; not thread-safe): force the kernel family / tile / split-K of launch_conv_gemm.
+// Tuning hook (sf_bench_conv1d only; not thread-safe): force the kernel family / tile of launch_conv_gemm.
 //   path: 0 automatic, 1 classic (conv_gemm), 2 wave-split-K (sk / fast), 4 v2;  tile: -1 automatic else variant index;
-//   sk: -1 automatic else the grid split-K factor of v2.
+//   sk: reserved (was the grid split-K factor of v2; 64 selects the 256-wide chunk variant of conv_gemm_fast).
 struct ConvGemmForce {
   int path = 0, tile = -1, sk = -1;
 };

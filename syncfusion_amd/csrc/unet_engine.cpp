@@ -72,11 +72,7 @@ struct Plan {  // everything carved out of the caller's workspace for one (B, L0
   int mod_stride = 0;
   float *mod_steps = nullptr;
   int steps_cap = 0;
-  float *sk_slab = nullptr;    // grid split-K partial tiles (per branch: sk_stride floats)
-  int *sk_cnt = nullptr;       // arrival tickets (per branch: kSkCnt ints), zeroed once per call
-  int64_t sk_stride = 0;
 };
-constexpr int kSkCnt = 1024;
 
 }  // namespace
 
@@ -484,17 +480,6 @@ Plan make_plan(const sf_unet &u, Workspace &ws, int B, int L0, bool two, int num
     p.rowpart_stride = 2 * p.rowpart_half;
     p.rowpart = ws.alloc_n<float>(p.rowpart_stride * p.nbr);
   }
-  {
-    // split-K scratch: up to 16 partial tiles of the largest short-activation GEMM output per branch
-    int64_t mx = 0;
-    for (int d = 0; d < c.n_layers; ++d) {
-      const int64_t rows = p.lv[d].rows / p.nbr;
-      if (rows <= 8192) mx = std::max<int64_t>(mx, rows * std::max(p.lv[d].C, 3 * u.hd));
-    }
-    p.sk_stride = align_up(8 * mx, 64);
-    p.sk_slab = ws.alloc_n<float>(p.sk_stride * p.nbr);
-    p.sk_cnt = ws.alloc_n<int>((int64_t)kSkCnt * sf_unet::kMaxBranches);
-  }
   p.emb2 = ws.alloc_n<float>((int64_t)p.Bt * c.embedding_features);
   p.emb_t = ws.alloc((int64_t)p.Bt * c.embedding_features * es);
   p.xhat_e = ws.alloc((int64_t)p.Bt * c.embedding_features * es);
@@ -546,12 +531,6 @@ struct Exec {
     a.cin2 = w.cin2;
     a.taps = w.taps;
     if (a.n_store == 0) a.n_store = w.N;
-    if (!w.direct && p.sk_slab) {
-      a.sk_slab = p.sk_slab;
-      a.sk_slab_bytes = (size_t)p.sk_stride * sizeof(float);
-      a.sk_cnt = p.sk_cnt;
-      a.sk_cnt_ints = kSkCnt;
-    }
     return a;
   }
 
@@ -1102,7 +1081,6 @@ struct Exec {
   // per-call conditioning: context pyramids to channels-last, cross-attention collapse
   void conditioning(const float *const *ctx, const float *emb) {
     const sf_unet_config &c = u.cfg;
-    SF_HIP(hipMemsetAsync(p.sk_cnt, 0, sizeof(int) * kSkCnt * sf_unet::kMaxBranches, s));   // split-K tickets start at zero
     const size_t es = dsize(u.dt);
     for (int d = 0; d < c.n_layers; ++d) {
       const Level &l = p.lv[d];
@@ -1158,8 +1136,6 @@ struct Exec {
     v.ca_all = p.ca_all + (int64_t)br * bt * u.ca_ld;
     v.slab = p.slab + (int64_t)br * p.slab_stride;
     v.rowpart = p.rowpart + (int64_t)br * p.rowpart_stride;
-    v.sk_slab = p.sk_slab + (int64_t)br * p.sk_stride;
-    v.sk_cnt = p.sk_cnt + (int64_t)br * kSkCnt;
     return v;
   }
 

@@ -71,9 +71,9 @@ def _conv_case(cuda, dtype, B, L, C, N, taps, stride, pad, up, groups, residual,
     (2, 176, 128, 256, 1, 1, 0, 1, 0, False),   # 1x1 / Linear
     (2, 352, 32, 64, 5, 2, 2, 1, 0, False),     # Encoder1d strided conv k=2f+1
     (1, 1000, 64, 96, 3, 1, 1, 1, 4, False),    # ragged M, N not a tile multiple
-    (4, 88, 1024, 1024, 3, 1, 1, 1, 0, True),   # deep U-Net conv: few rows, K = 3072 -> grid split-K + ticket reduce
-    (8, 44, 512, 256, 3, 1, 1, 1, 0, True),     # split-K with clips shorter than a tile
-    (2, 100, 256, 320, 1, 1, 0, 1, 0, False),   # ragged M and N with split-K candidates
+    (4, 88, 1024, 1024, 3, 1, 1, 1, 0, True),   # deep U-Net conv: few rows, K = 3072 -> wave-private split-K kernel
+    (8, 44, 512, 256, 3, 1, 1, 1, 0, True),     # wave-split-K with clips shorter than a tile
+    (2, 100, 256, 320, 1, 1, 0, 1, 0, False),   # ragged M and N on the wave-split-K kernels
     (2, 352, 128, 128, 3, 1, 1, 2, 0, True),    # upsample x2 on the main (v2) path
 ])
 def test_conv_gemm(cuda, dtype, shape):
