@@ -175,6 +175,15 @@ int sf_onsets_to_track(const float *logits, int N, int T, const int32_t *start_f
                        float frame_rate, float sample_rate, float threshold, float *track, int L, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Post-sampling cut_prefix + crop on device
+ *   replaces: main/generation.py:86-89 (gen[i, :, :nonzero(y[i][0])[0]] = 0) and :100 (gen[..., :cut_length]).
+ *   gen: (B, C, L); y: (B, 1, L) impulse track; out: (B, C, cut_length); first_onset: (B) int32 device array that
+ *   receives the index of the first onset of every clip, L when the track is empty (the reference raises IndexError
+ *   there: the caller checks). */
+int sf_cut_prefix_crop(const float *gen, const float *y, int B, int C, int L, int cut_length, float *out, int32_t *first_onset,
+                       void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Post-sampling resampler
  *   replaces: torchaudio.functional.resample(gen[i, :, :cut_length].cpu(), orig_freq=sample_rate,
  *   new_freq=downsample_rate) at main/generation.py:91-98 (torchaudio==0.13.1 defaults: windowed-sinc, Hann,

@@ -12,9 +12,9 @@ from .encoder1d import Encoder1d
 from .generation import generate_batch, generate_dataset
 from .module import Model, RandomEmbedder
 from .onset_net import VideoOnsetNet
-from .onset_glue import onsets_to_track
+from .onset_glue import cut_prefix_crop, onsets_to_track
 from .resample import resample
 
 __all__ = ["DiffusionModel", "UNetV0", "VDiffusion", "VSampler", "LinearSchedule", "Encoder1d", "VideoOnsetNet", "Model",
-           "RandomEmbedder", "generate_batch", "generate_dataset", "instantiate", "instantiate_model_yaml", "onsets_to_track", "resample"]
+           "RandomEmbedder", "generate_batch", "generate_dataset", "instantiate", "instantiate_model_yaml", "onsets_to_track", "cut_prefix_crop", "resample"]
 __version__ = "0.1.0"

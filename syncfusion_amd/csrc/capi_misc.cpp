@@ -44,6 +44,14 @@ int sf_onsets_to_track(const float *logits, int N, int T, const int32_t *start_f
   SF_API_END
 }
 
+int sf_cut_prefix_crop(const float *gen, const float *y, int B, int C, int L, int cut_length, float *out, int32_t *first_onset, void *stream) {
+  SF_API_BEGIN
+  if (!gen || !y || !out || !first_onset || B < 1 || C < 1 || L < 1 || cut_length < 1 || cut_length > L) fail(SF_ERR_INVALID, "bad argument");
+  SF_HIP(launch_cut_prefix_crop(gen, y, B, C, L, cut_length, out, first_onset, static_cast<hipStream_t>(stream)));
+  return SF_OK;
+  SF_API_END
+}
+
 }  // extern "C"
 
 #include <vector>

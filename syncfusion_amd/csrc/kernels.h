@@ -177,6 +177,8 @@ hipError_t launch_spatial_mean(int dt, const void *x, int ld, int NT, int HW, in
 hipError_t launch_resample(const float *x, int R, int L, const float *bank, int orig, int nnew, int width, float *out, int Lout,
                            hipStream_t s);
 
+// cut_prefix + crop after sampling: first[b] = first non-zero of y[b,0,:] (L if none); out[b,c,l<Lc] = l < first[b] ? 0 : gen[b,c,l]
+hipError_t launch_cut_prefix_crop(const float *gen, const float *y, int B, int C, int L, int Lc, float *out, int *first, hipStream_t s);
 // onset glue (sf_onsets_to_track)
 hipError_t launch_onsets_to_track(const float *logits, int N, int T, const int32_t *start_frame, float frame_rate,
                                   float sample_rate, float threshold, float *track, int L, hipStream_t s);

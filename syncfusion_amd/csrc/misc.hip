@@ -221,6 +221,37 @@ hipError_t launch_row_sums(int dt, const void *w, int N, int K, float *out, hipS
         hipLaunchKernelGGL(row_sums_kernel<bf16>, dim3(N), dim3(64), 0, s, (const bf16 *)w, K, out));
   return hipGetLastError();
 }
+// first[b] = index of the first non-zero sample of y[b, 0, :] (L when there is none): strided scan, block-wide minimum
+__global__ __launch_bounds__(256) void first_nonzero_kernel(const float *__restrict__ y, int L, int ld, int *__restrict__ first) {
+  __shared__ int red[256];
+  const float *row = y + (size_t)blockIdx.x * ld;
+  int best = L;
+  for (int i = threadIdx.x; i < L && best == L; i += 256)
+    if (row[i] != 0.f) best = i;
+  red[threadIdx.x] = best;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] = min(red[threadIdx.x], red[threadIdx.x + off]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) first[blockIdx.x] = red[0];
+}
+// out[b, c, l] = l < first[b] ? 0 : gen[b, c, l]   for l < Lc   (cut_prefix zeroing + crop, main/generation.py:86-89,100)
+__global__ void cut_crop_kernel(const float *__restrict__ gen, const int *__restrict__ first, int C, int L, int Lc, float *__restrict__ out,
+                                int64_t n) {
+  SF_GRID_STRIDE(i, n) {
+    const int l = (int)(i % Lc);
+    const int64_t bc = i / Lc;
+    const int b = (int)(bc / C);
+    out[i] = l < first[b] ? 0.f : gen[bc * L + l];
+  }
+}
+hipError_t launch_cut_prefix_crop(const float *gen, const float *y, int B, int C, int L, int Lc, float *out, int *first, hipStream_t s) {
+  hipLaunchKernelGGL(first_nonzero_kernel, dim3(B), dim3(256), 0, s, y, L, L, first);
+  const int64_t n = (int64_t)B * C * Lc;
+  hipLaunchKernelGGL(cut_crop_kernel, grid_for(n), dim3(TPB), 0, s, gen, first, C, L, Lc, out, n);
+  return hipGetLastError();
+}
 hipError_t launch_step_select(const float *table, int ld, int *step_idx, float *cur, hipStream_t s) {
   hipLaunchKernelGGL(step_select_kernel, dim3(1), dim3(1024), 0, s, table, ld, step_idx, cur);
   return hipGetLastError();

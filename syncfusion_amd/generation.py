@@ -17,6 +17,7 @@ from typing import Iterable, List, Optional, Sequence, Union
 import torch
 
 from . import _lib
+from .onset_glue import cut_prefix_crop
 from .resample import resample
 
 Tensor = torch.Tensor
@@ -42,12 +43,8 @@ def generate_batch(model, y: Tensor, z: Optional[Tensor] = None, text: Optional[
     gen = model.model.sample(x_noisy=noise.to(device), num_steps=num_steps, channels=y_latent["xs"][2:-1],
                              embedding=z_latent.to(device), embedding_scale=embedding_scale)   # :77-83
     if cut_prefix:
-        for i in range(B):
-            nz = torch.nonzero(y[i][0]).squeeze(-1)
-            if nz.numel() == 0:
-                # the reference indexes [0] unconditionally and raises IndexError on a track without onsets (:88)
-                raise IndexError(f"clip {i}: cut_prefix=True needs at least one onset in y")
-            gen[i, :, : int(nz[0])] = 0.0                                          # :88-89
+        # one device pass for the batch (:86-89, :100); IndexError on a track without onsets, as the reference's [0] does
+        return cut_prefix_crop(gen, y[:, :1], cut_length or length)
     return gen[:, :, : (cut_length or length)]                                     # :91,100
 
 

@@ -32,3 +32,27 @@ def onsets_to_track(logits: torch.Tensor, length: int, frame_rate: float = 15.0,
                                           float(sample_rate), float(threshold), track.data_ptr(), int(length),
                                           _lib.stream_ptr(lg.device)), "sf_onsets_to_track")
     return track
+
+
+@torch.no_grad()
+def cut_prefix_crop(gen: torch.Tensor, y: torch.Tensor, cut_length: Optional[int] = None) -> torch.Tensor:
+    """``gen[i, :, :first_onset(y[i])] = 0`` then crop to ``cut_length`` (main/generation.py:86-89,100) in one device
+    pass for the whole batch; raises ``IndexError`` like the reference when a track has no onset."""
+    _lib.require_gpu_tensor(gen, "cut_prefix_crop")
+    lib = _lib.load()
+    g = _lib.f32c(gen)
+    B, C, L = g.shape
+    yt = _lib.f32c(y.to(g.device)).reshape(B, -1)
+    if yt.shape[1] < L:
+        raise ValueError("onset track shorter than the generated audio")
+    yt = yt[:, :L].contiguous() if yt.shape[1] != L else yt
+    Lc = int(cut_length or L)
+    out = torch.empty(B, C, Lc, dtype=torch.float32, device=g.device)
+    first = torch.empty(B, dtype=torch.int32, device=g.device)
+    with torch.cuda.device(g.device):
+        _lib.check(lib.sf_cut_prefix_crop(g.data_ptr(), yt.data_ptr(), B, C, L, Lc, out.data_ptr(), first.data_ptr(),
+                                          _lib.stream_ptr(g.device)), "sf_cut_prefix_crop")
+    empty = (first >= L).nonzero()
+    if empty.numel():
+        raise IndexError(f"clip {int(empty[0])}: cut_prefix=True needs at least one onset in y")
+    return out

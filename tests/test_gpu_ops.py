@@ -170,3 +170,27 @@ def test_resample_matches_oracle(cuda, orig, new, L):
     got = resample(x.to(cuda), orig, new)
     assert got.shape == ref.shape
     assert float((got.cpu() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_cut_prefix_crop_matches_reference_loop(cuda):
+    """sf_cut_prefix_crop vs the reference's per-clip loop (main/generation.py:86-89,100), incl. its IndexError."""
+    from syncfusion_amd.onset_glue import cut_prefix_crop
+
+    g = torch.Generator().manual_seed(11)
+    B, C, L, Lc = 5, 2, 5000, 4410
+    gen = torch.randn(B, C, L, generator=g)
+    y = torch.zeros(B, 1, L)
+    firsts = [0, 17, 2047, 4409, 4999]
+    for i, f in enumerate(firsts):
+        y[i, 0, f] = 1.0
+        y[i, 0, min(L - 1, f + 300)] = 1.0
+    ref = gen.clone()
+    for i in range(B):
+        idx = torch.nonzero(y[i][0]).squeeze(-1)
+        ref[i, :, : idx[0]] = 0.0
+    ref = ref[:, :, :Lc]
+    out = cut_prefix_crop(gen.to(cuda), y.to(cuda), Lc)
+    assert torch.equal(out.cpu(), ref)
+    y[3] = 0.0
+    with pytest.raises(IndexError):
+        cut_prefix_crop(gen.to(cuda), y.to(cuda), Lc)
