@@ -1,5 +1,6 @@
-import sys, time, torch
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import os, sys, time, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from syncfusion_amd import VideoOnsetNet
 from oracle.onsetnet_ref import onsetnet_flops
 dev = torch.device('cuda:0')
