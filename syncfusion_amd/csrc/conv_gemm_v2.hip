@@ -31,7 +31,8 @@ struct V2Extra {
   unsigned bytesA, bytesA2, bytesW;
 };
 
-template <typename T, int BM, int BN, int GEOM, bool CAT>
+// NSET (even) = K chunks in flight: register sets filled NSET chunks ahead of the MFMAs that consume them.
+template <typename T, int BM, int BN, int GEOM, bool CAT, int NSET>
 __global__ __launch_bounds__(256) void conv_gemm_v2_kernel(const ConvGemmArgs a, const V2Extra x) {
   constexpr int VEC = Vec16<T>::N;
   constexpr int ES = (int)sizeof(T);
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256) void conv_gemm_v2_kernel(const ConvGemmArgs a,
   struct RegSet {
     Vec16<T> ra[PA], rb[PB];
   };
-  RegSet s0, s1;
+  RegSet rs[NSET];
 
   // Streaming gather state (chunks are requested in K order).  The expensive per-row arithmetic (clamps, shifts,
   // multiplies, range checks) runs only when the TAP changes -- once every cin/64 chunks; inside a tap a chunk costs
@@ -236,20 +237,21 @@ __global__ __launch_bounds__(256) void conv_gemm_v2_kernel(const ConvGemmArgs a,
   };
 
   // ---- K loop: loads of chunk t+1 in flight under the MFMAs of chunk t; one barrier per chunk ---------------
-  prefetch(s0);
-  if (nkt > 1) prefetch(s1);
-  stage(0, s0);
+#pragma unroll
+  for (int j = 0; j < NSET; ++j)
+    if (j < nkt) prefetch(rs[j]);
+  stage(0, rs[0]);
   __syncthreads();
-  for (int kt = 0; kt < nkt; kt += 2) {
-    if (kt + 2 < nkt) prefetch(s0);
-    compute(0);
-    if (kt + 1 < nkt) stage(1, s1);
-    __syncthreads();
-    if (kt + 1 < nkt) {
-      if (kt + 3 < nkt) prefetch(s1);
-      compute(1);
-      if (kt + 2 < nkt) stage(0, s0);
-      __syncthreads();
+  for (int kt = 0; kt < nkt; kt += NSET) {
+#pragma unroll
+    for (int j = 0; j < NSET; ++j) {
+      const int c = kt + j;   // chunk c sits in LDS buffer j & 1; its register set is free again
+      if (c < nkt) {
+        if (c + NSET < nkt) prefetch(rs[j]);
+        compute(j & 1);
+        if (c + 1 < nkt) stage((j + 1) & 1, rs[(j + 1) % NSET]);
+        __syncthreads();
+      }
     }
   }
 
@@ -299,7 +301,7 @@ __global__ __launch_bounds__(256) void conv_gemm_v2_kernel(const ConvGemmArgs a,
   }
 }
 
-template <typename T, int BM, int BN, int GEOM, bool CAT> hipError_t launch_v2_t(const ConvGemmArgs &a, const V2Plan &pl, hipStream_t s) {
+template <typename T, int BM, int BN, int GEOM, bool CAT, int NSET> hipError_t launch_v2_n(const ConvGemmArgs &a, const V2Plan &pl, hipStream_t s) {
   constexpr int LD = BK + 16 / (int)sizeof(T);
   constexpr size_t stage_bytes = (size_t)2 * (BM + BN) * LD * sizeof(T);
   constexpr size_t red_bytes = (size_t)BM * (BN + 4) * sizeof(float) + 16;
@@ -313,7 +315,7 @@ template <typename T, int BM, int BN, int GEOM, bool CAT> hipError_t launch_v2_t
   else x.bytesA = (unsigned)((size_t)(a.M / (a.To * a.Ho * a.Wo)) * a.Ti * a.Hi * a.Wi * a.src_ld * es);
   x.bytesA2 = CAT ? (unsigned)((size_t)a.M * a.src2_ld * es) : 0u;
   x.bytesW = (unsigned)((size_t)a.N * a.K * es);
-  auto kern = conv_gemm_v2_kernel<T, BM, BN, GEOM, CAT>;
+  auto kern = conv_gemm_v2_kernel<T, BM, BN, GEOM, CAT, NSET>;
   static bool en = false;
   if (!en) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
@@ -322,6 +324,13 @@ template <typename T, int BM, int BN, int GEOM, bool CAT> hipError_t launch_v2_t
   }
   hipLaunchKernelGGL(kern, dim3(x.mtiles * x.ntiles), dim3(256), lds, s, a, x);
   return hipGetLastError();
+}
+
+// Two chunks in flight: four measured the same on every MFMA-bound shape (tools/gemm_big.py) -- these tiles are bound by
+// the L2 -> CU fill rate (~29 B/clk/CU), which a 128x128 tile needs at 64 B/clk and a 64x64 tile at 127 B/clk to keep the
+// matrix cores busy (utilisation ceilings 46 % and 23 %; measured 17-19 % and 18 %).
+template <typename T, int BM, int BN, int GEOM, bool CAT> hipError_t launch_v2_t(const ConvGemmArgs &a, const V2Plan &pl, hipStream_t s) {
+  return launch_v2_n<T, BM, BN, GEOM, CAT, 2>(a, pl, s);
 }
 
 template <typename T, int BM, int BN> hipError_t launch_v2_g(const ConvGemmArgs &a, const V2Plan &pl, hipStream_t s) {
