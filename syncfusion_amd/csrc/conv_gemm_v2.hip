@@ -237,6 +237,20 @@ __global__ __launch_bounds__(256) void conv_gemm_v2_kernel(const ConvGemmArgs a,
   };
 
   // ---- K loop: loads of chunk t+1 in flight under the MFMAs of chunk t; one barrier per chunk ---------------
+  if constexpr (NSET == 1) {
+    // one register set, one LDS buffer, two barriers per chunk: fewest registers / least LDS -> most workgroups per CU,
+    // which hide each other's load latency
+    prefetch(rs[0]);
+    stage(0, rs[0]);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+      if (kt + 1 < nkt) prefetch(rs[0]);
+      compute(0);
+      __syncthreads();
+      if (kt + 1 < nkt) stage(0, rs[0]);
+      __syncthreads();
+    }
+  } else {
 #pragma unroll
   for (int j = 0; j < NSET; ++j)
     if (j < nkt) prefetch(rs[j]);
@@ -253,6 +267,7 @@ __global__ __launch_bounds__(256) void conv_gemm_v2_kernel(const ConvGemmArgs a,
         __syncthreads();
       }
     }
+  }
   }
 
   // ---- accumulators -> LDS (fp32, row-major) --------------------------------------------------------------
@@ -303,7 +318,7 @@ __global__ __launch_bounds__(256) void conv_gemm_v2_kernel(const ConvGemmArgs a,
 
 template <typename T, int BM, int BN, int GEOM, bool CAT, int NSET> hipError_t launch_v2_n(const ConvGemmArgs &a, const V2Plan &pl, hipStream_t s) {
   constexpr int LD = BK + 16 / (int)sizeof(T);
-  constexpr size_t stage_bytes = (size_t)2 * (BM + BN) * LD * sizeof(T);
+  constexpr size_t stage_bytes = (size_t)(NSET == 1 ? 1 : 2) * (BM + BN) * LD * sizeof(T);
   constexpr size_t red_bytes = (size_t)BM * (BN + 4) * sizeof(float) + 16;
   const size_t lds = stage_bytes > red_bytes ? stage_bytes : red_bytes;
   V2Extra x;
@@ -326,11 +341,14 @@ template <typename T, int BM, int BN, int GEOM, bool CAT, int NSET> hipError_t l
   return hipGetLastError();
 }
 
-// Two chunks in flight: four measured the same on every MFMA-bound shape (tools/gemm_big.py) -- these tiles are bound by
-// the L2 -> CU fill rate (~29 B/clk/CU), which a 128x128 tile needs at 64 B/clk and a 64x64 tile at 127 B/clk to keep the
-// matrix cores busy (utilisation ceilings 46 % and 23 %; measured 17-19 % and 18 %).
+// bf16: ONE register set and ONE LDS buffer (two barriers per chunk).  These tiles are bound by the L2 -> CU fill rate
+// (~29 B/clk/CU; a 128x128 tile needs 64 B/clk and a 64x64 tile 127 B/clk to keep the matrix cores busy), so what counts is how
+// many workgroups a CU holds to overlap each other's loads: 54-92 registers instead of 88-192 give 7 / 4 / 3 workgroups per CU
+// for the 64x64 / 128x64 / 128x128 tiles and +15-45 % on every MFMA-bound shape (tools/gemm_big.py); two or four chunks in
+// flight per workgroup measured the same or slower.  fp32 (parity path) keeps the double-buffered form.
 template <typename T, int BM, int BN, int GEOM, bool CAT> hipError_t launch_v2_t(const ConvGemmArgs &a, const V2Plan &pl, hipStream_t s) {
-  return launch_v2_n<T, BM, BN, GEOM, CAT, 2>(a, pl, s);
+  if constexpr (sizeof(T) == 2) return launch_v2_n<T, BM, BN, GEOM, CAT, 1>(a, pl, s);
+  else return launch_v2_n<T, BM, BN, GEOM, CAT, 2>(a, pl, s);
 }
 
 template <typename T, int BM, int BN> hipError_t launch_v2_g(const ConvGemmArgs &a, const V2Plan &pl, hipStream_t s) {
@@ -352,7 +370,10 @@ bool conv_gemm_v2_plan(int dt, const ConvGemmArgs &a, V2Plan &pl) {
   auto tiles = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.n_store + bn - 1) / bn); };
   // Measured on MI355X (tools/gemm_sweep.py, bf16): 128x128 wins once it yields >= ~300 workgroups, 64x64 otherwise;
   // below ~500 64x64-tiles the wave-split-K kernel with 32x32 tiles is faster (see launch_conv_gemm).
-  pl.variant = (a.n_store >= 128 && tiles(128, 128) >= 300) ? 0 : 2;
+  // 64x64 wins almost everywhere once seven workgroups fit a CU; 128x64 where few row tiles meet wide outputs and a long K
+  // (deep U-Net levels at the guidance batch); fp32 keeps the old rule (two-buffer form, parity path only)
+  if (dt == F32) pl.variant = (a.n_store >= 128 && tiles(128, 128) >= 300) ? 0 : 2;
+  else pl.variant = (a.M <= 8192 && a.n_store >= 1024 && a.K >= 2048) ? 1 : 2;
   const ConvGemmForce &f = g_conv_gemm_force;
   if (f.path == 4 && f.tile >= 0 && f.tile <= 2) pl.variant = f.tile;
   return true;
