@@ -360,7 +360,7 @@ template <typename T, int BM, int BN> hipError_t launch_v2_g(const ConvGemmArgs 
 
 // eligibility + tile choice
 bool conv_gemm_v2_plan(int dt, const ConvGemmArgs &a, V2Plan &pl) {
-  if (a.pro != 0 || (a.cin % BK) || (a.cin2 % 32) || (a.K % 32) || a.N % 4) return false;
+  if (a.pro != 0 || (a.cin % BK) || (a.cin2 % 32) || (a.K % 32) || a.n_store % 4) return false;
   if (a.geom == 1 && a.cin2) return false;
   const size_t es = dsize(dt), lim = 0x7FFFFFF0ull;
   size_t bA;
