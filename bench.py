@@ -45,10 +45,13 @@ def build_model(dtype: str, device):
     from syncfusion_amd.reference_config import model_config
     import syncfusion_amd as sa
 
+    import contextlib
+
     torch.manual_seed(1234)
     cfg = model_config()
     cfg["model"]["net_t"]["dtype"] = dtype
-    model = sa.instantiate(cfg)
+    with contextlib.redirect_stdout(sys.stderr):   # the Model constructor prints like the reference's; stdout carries ONE JSON line
+        model = sa.instantiate(cfg)
     return model.to(device)
 
 
