@@ -114,6 +114,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
+    if not args.no_graph:
+        run(2)                                                 # setup, untimed: instantiates the step graphs (reused by every later call)
     if args.warmup > 0:
         run(args.warmup)
     fence()
