@@ -165,8 +165,10 @@ def main():
     total_ms = sum(a[0] for a in agg.values())
     dom = max(agg, key=lambda k: agg[k][0])
     d_ms, d_fl, d_by, d_n = agg[dom]
-    mfma_kernel = dom.startswith("conv_gemm")
     peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+    # the roofline that bounds the dominant kernel: whichever of its algorithmic FLOPs / MFMA peak and algorithmic bytes / HBM
+    # peak takes longer (the small-batch GEMMs sit BELOW the machine balance of ~310 FLOP/B: they are HBM-side kernels)
+    mfma_kernel = d_fl / (peak * 1e12) >= d_by / (PEAK_HBM_GBS * 1e9)
     if mfma_kernel:
         achieved = d_fl / (d_ms * 1e-3) / 1e12
         roof = dict(bound="mfma", achieved=round(achieved, 3), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 5))
