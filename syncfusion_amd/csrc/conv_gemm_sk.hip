@@ -379,8 +379,8 @@ bool conv_gemm_prefers_wp(const ConvGemmArgs &a) {
 hipError_t launch_conv_gemm_sk(int dt, const ConvGemmArgs &a, hipStream_t s) {
   if ((a.cin % 32) || (a.cin2 % 32) || (a.K % 32)) return hipErrorInvalidValue;
   const int v = conv_gemm_sk_variant(a);
-  // barrier-free wave-private pipelines: measured faster only on the shortest activations (M <= 512, long K);
-  // elsewhere the staged kernel wins because its loads are shared by more MFMA work per byte
+  // barrier-free wave-private pipelines where few tiles exist (conv_gemm_prefers_wp); with many tiles the staged kernel
+  // wins because its loads are shared by more MFMA work per byte
   const bool prefer_wp = g_conv_gemm_force.path == 5 || (g_conv_gemm_force.path == 0 && conv_gemm_prefers_wp(a));
   if (prefer_wp && conv_gemm_wp_ok(dt, a)) {
     hipError_t e = launch_conv_gemm_wp(dt, a, dt == F32 ? 2 : v, s);
