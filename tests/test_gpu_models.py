@@ -273,6 +273,24 @@ def test_onsetnet_train_mode_and_cpu_raise(cuda):
         net.eval()(torch.zeros(1, 4, 4, 32, 32, device=cuda))
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("B,mult", [(1, 1), (3, 1), (2, 3), (5, 7), (3, 33), (8, 100)])
+def test_unet_edge_shapes(cuda, dtype, B, mult):
+    """Clips shorter than a tile, a single position at the deepest level, ragged tiles, odd batch sizes, with and without
+    guidance (tools/edge_sweep.py runs the full 120-combination grid)."""
+    from oracle import unet_ref
+
+    net = small_unet_module(3, dtype).to(cuda)
+    P, cfg = oracle_params(net, "net."), dict(net.hparams)
+    L0 = 16 * mult
+    for scale in (1.0, 2.5):
+        x, sigma, emb, chans = synth_inputs(SMALL_UNET, B, L0, seed=B * 1000 + mult)
+        with torch.no_grad():
+            ref = unet_ref.unet_forward(P, cfg, x, sigma, embedding=emb, channels=chans, embedding_scale=scale)
+        out = net(x.to(cuda), sigma.to(cuda), embedding=emb.to(cuda), channels=[c.to(cuda) for c in chans], embedding_scale=scale)
+        assert rel_l2(out.cpu(), ref) < (FP32_TOL if dtype == "fp32" else 5e-2)
+
+
 # ----------------------------------------------------------------------------------------------------------
 # BASELINE-size checks (full 215 M-parameter U-Net, L0 = 45056): one evaluation against the oracle, then
 # size-independent properties of the sampler at batch 8.
