@@ -178,7 +178,8 @@ __global__ __launch_bounds__(1024) void conv_thin_kernel(const ConvThinArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   float *sc = reinterpret_cast<float *>(smem);
   float *sh = sc + CIN;
-  float *part = sh + CIN;   // [tile][G][2]
+  float *ep = sh + CIN;     // epilogue vectors: bias | per-clip scale | per-clip add, 64 floats each (fetched up front)
+  float *part = ep + 192;   // [tile][G][2]
   T *tile = reinterpret_cast<T *>(part + kThinMaxTiles * kThinMaxG * 2);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = blockDim.x >> 6;
@@ -242,7 +243,14 @@ __global__ __launch_bounds__(1024) void conv_thin_kernel(const ConvThinArgs a) {
                                         : K4<T>::zero();
   }
 
-  // ---- prologue parameters -> LDS ----------------------------------------------------------------------------
+  // ---- epilogue vectors and prologue parameters -> LDS (their loads ride in the same round trip as the rows above) ----
+  if (tid < 64) {
+    const int c = min(tid, NOUT - 1);
+    ep[tid] = a.bias ? a.bias[c] : 0.f;
+    ep[64 + tid] = a.bscale ? a.bscale[(size_t)b * a.bscale_ld + c] : 1.f;
+    ep[128 + tid] = a.badd ? a.badd[(size_t)b * a.badd_ld + c] : 0.f;
+  }
+  if constexpr (PRO == 0) __syncthreads();
   if constexpr (PRO == 1) {
     for (int g = tid >> 5; g < a.G; g += blockDim.x >> 5) {
       const float2 st = gn_merge_n(a.stats_in + ((size_t)b * a.nch_in * a.G + g) * 2, a.G, a.nch_in, a.chunk_in, a.L, cpg, a.eps, l32);
@@ -352,14 +360,9 @@ __global__ __launch_bounds__(1024) void conv_thin_kernel(const ConvThinArgs a) {
       if (!(NOUT >= 32 || 8 * v < NOUT)) continue;
       const int c0 = cb * 32 + half * 4 + 8 * v;
       float val[4];
-      const f32x4 bias = a.bias ? *reinterpret_cast<const f32x4 *>(a.bias + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 bias = *reinterpret_cast<const f32x4 *>(ep + c0), bs = *reinterpret_cast<const f32x4 *>(ep + 64 + c0);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) val[e] = acc[4 * v + e] + bias[e];
-      if (a.bscale) {
-        const f32x4 bs = *reinterpret_cast<const f32x4 *>(a.bscale + (size_t)b * a.bscale_ld + c0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) val[e] *= bs[e];
-      }
+      for (int e = 0; e < 4; ++e) val[e] = (acc[4 * v + e] + bias[e]) * bs[e];
       if (a.res_self) {   // residual = the staged (modulated) input itself (CIN == NOUT, no upsampling)
         const K4<T> rp = K4<T>::load(tile + (row_l + HALO) * SROW + c0);
 #pragma unroll
@@ -368,8 +371,8 @@ __global__ __launch_bounds__(1024) void conv_thin_kernel(const ConvThinArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) val[e] += resf[v].get(e);
       }
-      if (a.badd) {
-        const f32x4 ba = *reinterpret_cast<const f32x4 *>(a.badd + (size_t)b * a.badd_ld + c0);
+      {
+        const f32x4 ba = *reinterpret_cast<const f32x4 *>(ep + 128 + c0);
 #pragma unroll
         for (int e = 0; e < 4; ++e) val[e] += ba[e];
       }
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(1024) void conv_thin_kernel(const ConvThinArgs a) {
 template <typename T> size_t thin_lds_bytes(int cin, int taps, int rw, int up_shift) {
   const int halo = taps / 2;
   const size_t rows = (size_t)(rw >> up_shift) + 2 * halo + 2;   // source rows a workgroup stages (+ slack)
-  return (size_t)(2 * cin + kThinMaxTiles * kThinMaxG * 2) * sizeof(float) + rows * (cin + 8) * sizeof(T);
+  return (size_t)(2 * cin + 192 + kThinMaxTiles * kThinMaxG * 2) * sizeof(float) + rows * (cin + 8) * sizeof(T);
 }
 
 template <typename T, int CIN, int TAPS, int C2, int PRO, int NOUT> hipError_t thin_go(const ConvThinArgs &a, hipStream_t s) {
@@ -550,7 +553,8 @@ __global__ __launch_bounds__(1024) void thin_tail_kernel(const ThinTailArgs a) {
   float *sh = sc + C;
   float *lsc = sh + C;                                // 1 + modulation scale, modulation shift
   float *lsh = lsc + C;
-  float *part = lsh + C;                              // [tile][G][2]
+  float *ep = lsh + C;                                // bias2 | bias3 + per-clip add, 64 floats each
+  float *part = ep + 128;                             // [tile][G][2]
   T *w2s = reinterpret_cast<T *>(part + kThinMaxTiles * kThinMaxG * 2);
   T *w3s = w2s + C * P2;
   T *tile = w3s + C * P3;
@@ -597,6 +601,8 @@ __global__ __launch_bounds__(1024) void thin_tail_kernel(const ThinTailArgs a) {
   if (tid < C) {
     lsc[tid] = 1.0f + a.ss[(size_t)b * a.ss_ld + tid];
     lsh[tid] = a.ss[(size_t)b * a.ss_ld + C + tid];
+    ep[tid] = a.bias2[tid];
+    ep[64 + tid] = a.bias3[tid] + (a.badd ? a.badd[(size_t)b * a.badd_ld + tid] : 0.f);
   }
   __syncthreads();
 #pragma unroll
@@ -628,6 +634,14 @@ __global__ __launch_bounds__(1024) void thin_tail_kernel(const ThinTailArgs a) {
       const int q2 = 2 * i + half;
       cf[i] = (rvalid && q2 < SC) ? K8<T>::load(static_cast<const T *>(a.ctx) + grow * a.ctx_ld + q2 * E) : K8<T>::zero();
     }
+    K4<T> rxf[NCB][4];   // residual x of this tile, issued with the context fragments
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int c0 = cb * 32 + half * 4 + 8 * v;
+        rxf[cb][v] = (c0 < C && rvalid) ? K4<T>::load(static_cast<const T *>(a.x) + grow * C + c0) : K4<T>::zero();
+      }
     // ---- conv2 over the staged SiLU(GN2(h)) ----------------------------------------------------------------------
     f32x16 acc[NCB];
 #pragma unroll
@@ -658,8 +672,8 @@ __global__ __launch_bounds__(1024) void thin_tail_kernel(const ThinTailArgs a) {
       for (int v = 0; v < 4; ++v) {
         const int c0 = cb * 32 + half * 4 + 8 * v;
         if (c0 < C) {
-          const f32x4 bias = *reinterpret_cast<const f32x4 *>(a.bias2 + c0);
-          const K4<T> rx = rvalid ? K4<T>::load(static_cast<const T *>(a.x) + grow * C + c0) : K4<T>::zero();
+          const f32x4 bias = *reinterpret_cast<const f32x4 *>(ep + c0);
+          const K4<T> rx = rxf[cb][v];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float y = to_f(from_f<T>(acc[cb][4 * v + e] + bias[e] + rx.get(e)));   // as stored by the unfused path
@@ -744,15 +758,10 @@ __global__ __launch_bounds__(1024) void thin_tail_kernel(const ThinTailArgs a) {
       for (int v = 0; v < 4; ++v) {
         const int c0 = cb * 32 + half * 4 + 8 * v;
         if (c0 >= C) continue;
-        const f32x4 bias = *reinterpret_cast<const f32x4 *>(a.bias3 + c0);
+        const f32x4 bias = *reinterpret_cast<const f32x4 *>(ep + 64 + c0);   // bias3 + per-clip add
         float val[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) val[e] = zc[cb][4 * v + e] + bias[e] + acc[cb][4 * v + e];
-        if (a.badd) {
-          const f32x4 ba = *reinterpret_cast<const f32x4 *>(a.badd + (size_t)b * a.badd_ld + c0);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) val[e] += ba[e];
-        }
         T o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = from_f<T>(val[e]);
@@ -825,7 +834,7 @@ __global__ __launch_bounds__(1024) void thin_tail_kernel(const ThinTailArgs a) {
 }
 
 template <typename T> size_t tail_lds_bytes(int C, int C2, int rw) {
-  return (size_t)(4 * C + kThinMaxTiles * kThinMaxG * 2) * sizeof(float) +
+  return (size_t)(4 * C + 128 + kThinMaxTiles * kThinMaxG * 2) * sizeof(float) +
          ((size_t)C * (3 * C + 8) + (size_t)C * (C + C2 + 8) + (size_t)(rw + 4) * (C + 8)) * sizeof(T);
 }
 
