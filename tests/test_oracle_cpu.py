@@ -165,3 +165,30 @@ def test_resample_oracle_properties():
     hf = torch.sin(2 * math.pi * 15000.0 * t).float()[None]          # above the 11.025 kHz Nyquist of the output
     assert float(resample_ref.resample(hf, sr, new)[0, 200:-200].abs().max()) < 5e-3
     assert resample_ref.resample(tone, sr, sr) is tone
+
+
+def test_oracle_selfcheck_frozen_outputs():
+    """The parity-unpinned oracles against their own frozen outputs (oracle/gen_selfcheck_unet.py): guards the restatement
+    against accidental edits; it does NOT pin it to the reference."""
+    gold = np.load(os.path.join(GOLDEN, "oracle_selfcheck.npz"))
+    net = small_unet_module(1234)
+    P, cfg = oracle_params(net, "net."), dict(net.hparams)
+    B, L0 = 2, 16 * 9
+    x, sigma, emb, chans = synth_inputs(SMALL_UNET, B, L0, seed=31)
+    with torch.no_grad():
+        taps = {}
+        v1 = unet_ref.unet_forward(P, cfg, x, sigma, embedding=emb, channels=chans, embedding_scale=1.0, taps=taps)
+        assert np.abs(v1.numpy() - gold["unet_v_s1"]).max() < 1e-5
+        for k in ("d1.down", "d2.items_down.0", "d3.items_up.1", "d0.out"):
+            assert abs(float(taps[k].double().mean()) - float(gold["tap_" + k.replace(".", "_") + "_mean"])) < 1e-6
+            assert abs(float(taps[k].double().std()) - float(gold["tap_" + k.replace(".", "_") + "_std"])) < 1e-5
+        v25 = unet_ref.unet_forward(P, cfg, x, sigma, embedding=emb, channels=chans, embedding_scale=2.5)
+        assert np.abs(v25.numpy() - gold["unet_v_s25"]).max() < 1e-5
+        fn = lambda xx, ss: unet_ref.unet_forward(P, cfg, xx, ss, embedding=emb, channels=chans, embedding_scale=2.0)  # noqa: E731
+        assert np.abs(sampler_ref.vsample(fn, x, 6).numpy() - gold["sample_6"]).max() < 1e-5
+        enc = small_encoder_module(4321)
+        y = torch.zeros(2, 1, 16 * 10)
+        y[:, 0, ::37] = 1.0
+        z, info = encoder1d_ref.encoder1d_forward(oracle_params(enc), dict(enc.hparams), y)
+        assert np.abs(z.numpy() - gold["enc_z"]).max() < 1e-5
+        assert np.abs(np.array([float(t.double().mean()) for t in info["xs"]]) - gold["enc_xs_means"]).max() < 1e-6
