@@ -294,22 +294,22 @@ __global__ __launch_bounds__(512) void gn_silu_reg_kernel(const T *__restrict__ 
   const int nv = L * vr;
   const T *base = x + (size_t)b * L * ld + (size_t)g * cpg;
   T *obase = out + (size_t)b * L * out_ld + (size_t)g * cpg;
+  // the launcher guarantees 512 % vr == 0: every vector of a thread sits in the same channel octet (one gamma / beta fetch)
   Vec16<T> v[RV];
-  f32x4 ga[RV][V / 4], be[RV][V / 4];
-  int rr[RV], cc[RV];
+  const int cv = tid % vr;
+  f32x4 ga[V / 4], be[V / 4];
+#pragma unroll
+  for (int q = 0; q < V / 4; ++q) {
+    ga[q] = *reinterpret_cast<const f32x4 *>(gamma + g * cpg + cv * V + 4 * q);
+    be[q] = *reinterpret_cast<const f32x4 *>(beta + g * cpg + cv * V + 4 * q);
+  }
+  int rr[RV];
 #pragma unroll
   for (int i = 0; i < RV; ++i) {
     const int idx = tid + i * 512;
     const bool on = idx < nv;
-    const int r = on ? idx / vr : 0, cv = on ? idx - r * vr : 0;
-    rr[i] = r;
-    cc[i] = cv;
-    v[i] = on ? ld16<T>(base + (size_t)r * ld + cv * V) : zero16<T>();
-#pragma unroll
-    for (int q = 0; q < V / 4; ++q) {
-      ga[i][q] = *reinterpret_cast<const f32x4 *>(gamma + g * cpg + cv * V + 4 * q);
-      be[i][q] = *reinterpret_cast<const f32x4 *>(beta + g * cpg + cv * V + 4 * q);
-    }
+    rr[i] = on ? idx / vr : 0;
+    v[i] = on ? ld16<T>(base + (size_t)rr[i] * ld + cv * V) : zero16<T>();
   }
   const float n = (float)L * (float)cpg;
   float s = 0.f;
@@ -342,16 +342,19 @@ __global__ __launch_bounds__(512) void gn_silu_reg_kernel(const T *__restrict__ 
 #pragma unroll
   for (int w = 0; w < 8; ++w) tq += red[1][w];
   const float rstd = rsqrtf(tq / n + eps);
+  float sc[V], sh[V];   // y = x * sc + sh
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    sc[j] = rstd * ga[j >> 2][j & 3];
+    sh[j] = fmaf(-mean, sc[j], be[j >> 2][j & 3]);
+  }
 #pragma unroll
   for (int i = 0; i < RV; ++i) {
     if (tid + i * 512 < nv) {
       Vec16<T> o;
 #pragma unroll
-      for (int j = 0; j < V; ++j) {
-        const float sc = rstd * ga[i][j >> 2][j & 3];
-        o.set(j, silu_t<FAST>(fmaf(v[i].get(j) - mean, sc, be[i][j >> 2][j & 3])));
-      }
-      st16<T>(obase + (size_t)rr[i] * out_ld + cc[i] * V, o);
+      for (int j = 0; j < V; ++j) o.set(j, silu_t<FAST>(fmaf(v[i].get(j), sc[j], sh[j])));
+      st16<T>(obase + (size_t)rr[i] * out_ld + cv * V, o);
     }
   }
 }
@@ -367,7 +370,7 @@ hipError_t gn_silu_go(const void *x, int ld, int B, int L, int C, int G, const f
   dim3 grid(B * G);
 #define SF_GNS(VW) hipLaunchKernelGGL((gn_silu_kernel<T, VW>), grid, dim3(512), 0, s, xp, ld, L, C, G, gamma, beta, eps, op, out_ld)
   const bool al = (ld % V == 0) && (out_ld % V == 0);
-  if (al && cpg % V == 0 && (int64_t)L * (cpg / V) <= 4 * 512) {   // slab fits the registers of one workgroup
+  if (al && cpg % V == 0 && 512 % (cpg / V) == 0 && (int64_t)L * (cpg / V) <= 4 * 512) {   // slab fits the registers of one workgroup
     const int64_t nv = (int64_t)L * (cpg / V);
     if (nv <= 2 * 512) hipLaunchKernelGGL((gn_silu_reg_kernel<T, 2>), grid, dim3(512), 0, s, xp, ld, L, C, G, gamma, beta, eps, op, out_ld);
     else hipLaunchKernelGGL((gn_silu_reg_kernel<T, 4>), grid, dim3(512), 0, s, xp, ld, L, C, G, gamma, beta, eps, op, out_ld);
