@@ -130,3 +130,27 @@ def test_int16_round_trip_matches_reference_utils():
     q = float32_to_int16(x)
     assert q.dtype == torch.int16 and q.tolist() == [-32767, -32767, -16383, 0, 9830, 32767, 32767]
     assert torch.allclose(int16_to_float32(q), torch.tensor(q.tolist()) / 32767.0)
+
+
+def test_committed_bench_line_follows_the_contract():
+    """The newest profiles/*_bench.json (a bench.py output line committed with the rocprof summaries) carries every field the
+    driver's contract names, with the right types."""
+    import glob
+    import json
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    paths = sorted(p for p in glob.glob(os.path.join(root, "profiles", "r*_bench.json")) if "cfg3" not in p)
+    assert paths, "no committed bench line under profiles/"
+    line = json.loads(open(paths[-1]).read().strip().splitlines()[-1])
+    for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
+                     ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(line[key], typ), key
+    assert "vs_baseline" in line and line["scaling"] == "weak" and line["higher_is_better"] is True
+    assert "workload" in line["config"] and "model" not in line["config"]
+    roof = line["roofline"]
+    assert roof["bound"] in ("hbm", "mfma") and roof["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    assert roof["traffic"] is None or roof["traffic"] > 0
+    cpu = line["cpu_baseline"]
+    assert cpu["kind"] in ("port", "reference") and cpu["cores"] >= 1 and cpu["value"] > 0 and isinstance(cpu["sample"], str)
+    assert abs(line["value"] - line["n_gpus"] * line["steps"] / (line["ms_per_step"] * line["steps"] / 1e3)) / line["value"] < 1e-2
