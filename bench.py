@@ -12,23 +12,32 @@ batch: one U-Net evaluation + the sampler update, exactly what DiffusionModel.sa
 Timed region: `sample(num_steps=K)` -- inputs resident in HBM, barrier + synchronize on both sides, max over
 ranks.  value = N * K / t  (batch-steps per second summed over the N independent per-GPU batches; weak scaling).
 
+`--gpus N` without a torch.distributed environment (no WORLD_SIZE): this process starts N fresh ranks with
+`python -m torch.distributed.run` BEFORE touching the GPU and relays rank 0's JSON line.  Under the driver's own
+torchrun launch (WORLD_SIZE set) it is a rank; a WORLD_SIZE that disagrees with --gpus is an error.
+
 Extra objects on the JSON line:
-  roofline      the dominant kernel (largest share of a step's device time).  `achieved` = the ALGORITHMIC FLOPs
-                of its launches in one evaluation / their summed durations, measured with HIP events recorded
-                on the launch stream around every kernel of an instrumented evaluation in this process.
+  roofline      the dominant kernel (largest share of a step's device time).  `achieved` = the ALGORITHMIC bytes (or
+                FLOPs) of its launches in one evaluation / their summed durations, measured with HIP events recorded
+                on the launch stream around every kernel of an instrumented evaluation in this process.  The whole-step
+                figures (`step_*`) use the closed-form work of syncfusion_amd/workmodel.py (every weight
+                counted ONCE per step, independent of how the engine splits the batch).
   cpu_baseline  the CPU oracle (oracle/unet_ref.py, a port -- the reference's U-Net source is not in its tree)
                 timed on this box's host cores on a bounded sample of the same workload (rank 0, N = 1 only).
+  extra         secondary workloads measured in the same process (rank 0, N = 1 only): the fp32 parity path on
+                configs[1], BASELINE configs[2] (batch 32, guidance, real conditioning), the reference's own evaluation
+                shape (exp/evaluate_gh_gen.yaml:8,21-23), the onset net at N = 32, and the rel-L2 distance between the
+                bf16 and fp32 engines' final samples at the benched shape.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 from collections import defaultdict
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -36,16 +45,58 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 L0 = 45056
 BATCH = 8
-PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md chip table
+BASELINE_STEPS = 50         # BASELINE.json configs[1]: 50-step DDIM
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 / fp16 MFMA, MI355X_MICROARCH.md chip table
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
+ES = {"bf16": 2, "fp16": 2, "fp32": 4}
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=BASELINE_STEPS)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--scale", type=float, default=1.0, help="embedding_scale (!= 1 -> classifier-free guidance, 2 evals/step)")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads of the `extra` object")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--dump-launches", default=None, help="write the per-launch event timings of one evaluation to this file")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank: exercises the N > 1 code path on a 1-GPU box")
+    ap.add_argument("--master-port", type=int, default=29533)
+    return ap.parse_args(argv)
+
+
+def spawn_ranks(args) -> int:
+    """--gpus N from a plain shell: N fresh child ranks (one per GPU) under torchrun.  The parent never initialises HIP."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(args.master_port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        print(f"bench.py: the {args.gpus}-rank child run failed (rc {proc.returncode})", file=sys.stderr)
+        return proc.returncode or 1
+    print(line)
+    return 0
 
 
 def build_model(dtype: str, device):
-    from syncfusion_amd.reference_config import model_config
-    import syncfusion_amd as sa
-
     import contextlib
+
+    import torch
+
+    import syncfusion_amd as sa
+    from syncfusion_amd.reference_config import model_config
 
     torch.manual_seed(1234)
     cfg = model_config()
@@ -55,22 +106,145 @@ def build_model(dtype: str, device):
     return model.to(device)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=BATCH)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--scale", type=float, default=1.0, help="embedding_scale (!= 1 -> classifier-free guidance, 2 evals/step)")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--dump-launches", default=None, help="write the per-launch event timings of one evaluation to this file")
-    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank: exercises the N > 1 code path on a 1-GPU box")
-    args = ap.parse_args()
+def synthetic_conditioning(model, B, L, device, real: bool):
+    """(channels, embedding): dummy (one impulse at sample 0, zero embedding) or the SURVEY 8d seeded "real" conditioning."""
+    import torch
 
+    track = torch.zeros(B, 1, L, device=device)
+    if real:
+        g = torch.Generator().manual_seed(3000)
+        for b in range(B):
+            k = int(torch.randint(1, 9, (1,), generator=g))
+            track[b, 0, torch.randint(0, L, (k,), generator=g).to(device)] = 1.0
+        emb = torch.nn.functional.normalize(torch.randn(B, 1, 512, generator=torch.Generator().manual_seed(2000)), dim=-1).to(device)
+    else:
+        track[:, 0, 0] = 1.0
+        emb = torch.zeros(B, 1, 512, device=device)
+    _, info = model.onsets_encoder(track, with_info=True)
+    return info["xs"][2:-1], emb
+
+
+def timed_sample(model, device, noise, channels, emb, scale, steps, warm=2):
+    import torch
+
+    def run(n):
+        return model.model.sample(x_noisy=noise, num_steps=n, channels=channels, embedding=emb, embedding_scale=scale)
+
+    run(2)
+    if warm:
+        run(warm)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    out = run(steps)
+    torch.cuda.synchronize(device)
+    return steps / (time.perf_counter() - t0), out
+
+
+def extra_workloads(model, device, args, noise, channels, emb) -> dict:
+    """Secondary numbers (driver-visible, same process).  Each leg is independent: a failure is recorded, not raised."""
+    import torch
+
+    from syncfusion_amd import workmodel
+
+    net = model.model.net
+    hp = dict(net.hparams)
+    out: dict = {}
+
+    def leg(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as e:  # noqa: BLE001 -- the headline line must survive a failing secondary leg
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        torch.cuda.synchronize(device)
+
+    def roof_ms(clips, evals, L, dtype):
+        w = workmodel.unet_work(hp, L, clips, evals, ES[dtype])
+        peak = (PEAK_F32_TFLOPS if dtype == "fp32" else PEAK_BF16_TFLOPS) * 1e12
+        return workmodel.step_roofline_ms(w, peak, PEAK_HBM_GBS * 1e9)
+
+    def fp32_leg():
+        # the same torch module, engine repacked in fp32 (identical weights): the path gated at 1e-4 against the oracle
+        steps = 10
+        ref_steps = min(args.steps, 20)
+        lo = model.model.sample(x_noisy=noise, num_steps=ref_steps, channels=channels, embedding=emb, embedding_scale=args.scale)
+        prev = net.compute_dtype
+        net.compute_dtype = "fp32"
+        try:
+            rate, _ = timed_sample(model, device, noise, channels, emb, args.scale, steps, warm=2)
+            hi = model.model.sample(x_noisy=noise, num_steps=ref_steps, channels=channels, embedding=emb, embedding_scale=args.scale)
+        finally:
+            net.compute_dtype = prev
+            net.engine()
+        rel = float((lo.double() - hi.double()).norm() / hi.double().norm())
+        ms = 1e3 / rate
+        return dict(steps_per_s=round(rate, 2), ms_per_step=round(ms, 3), dtype="fp32", batch=noise.shape[0], timed_steps=steps,
+                    step_roofline_frac=round(roof_ms(noise.shape[0], 1 if args.scale == 1.0 else 2, L0, "fp32") / ms, 4),
+                    lowp_vs_fp32_final_sample_rel_l2=round(rel, 6), lowp_dtype=args.dtype, rel_l2_steps=ref_steps)
+
+    def config2_leg():
+        B, scale, steps = 32, 2.0, 10
+        nz = torch.randn(B, 1, L0, generator=torch.Generator().manual_seed(1000)).to(device)
+        ch, e = synthetic_conditioning(model, B, L0, device, real=True)
+        rate, o = timed_sample(model, device, nz, ch, e, scale, steps, warm=2)
+        assert torch.isfinite(o).all()
+        ms = 1e3 / rate
+        w = workmodel.unet_work(hp, L0, B, 2, ES[args.dtype])
+        return dict(workload="BASELINE configs[2]: batch=32, guidance scale 2.0 (64 evaluations/step), CLAP-shaped embedding + onset conditioning",
+                    steps_per_s=round(rate, 2), ms_per_step=round(ms, 3), dtype=args.dtype, timed_steps=steps,
+                    algorithmic_tflop_per_step=round(w["flops"] / 1e12, 3), tflops=round(w["flops"] / 1e12 / (ms * 1e-3), 1),
+                    step_roofline_frac=round(roof_ms(B, 2, L0, args.dtype) / ms, 4))
+
+    def reference_leg():
+        B, L, scale, steps = 10, 262144, 2.0, 4      # exp/evaluate_gh_gen.yaml:8 (length), :21 (batch_size), :23 (embedding_scale)
+        nz = torch.randn(B, 1, L, generator=torch.Generator().manual_seed(1000)).to(device)
+        ch, e = synthetic_conditioning(model, B, L, device, real=True)
+        rate, o = timed_sample(model, device, nz, ch, e, scale, steps, warm=0)
+        assert torch.isfinite(o).all()
+        ms = 1e3 / rate
+        w = workmodel.unet_work(hp, L, B, 2, ES[args.dtype])
+        return dict(workload="reference evaluation shape: batch=10, length=2**18, embedding_scale=2.0 (exp/evaluate_gh_gen.yaml:8,21-23)",
+                    steps_per_s=round(rate, 2), ms_per_step=round(ms, 3), dtype=args.dtype, timed_steps=steps,
+                    tflops=round(w["flops"] / 1e12 / (ms * 1e-3), 1), step_roofline_frac=round(roof_ms(B, 2, L, args.dtype) / ms, 4))
+
+    def onset_leg():
+        from syncfusion_amd.onset_net import VideoOnsetNet
+
+        N, iters = 32, 5
+        torch.manual_seed(7)
+        onset = VideoOnsetNet(False, dtype=args.dtype if args.dtype != "fp32" else "bf16").to(device).eval()
+        frames = torch.randn(N, 3, 30, 112, 112, generator=torch.Generator().manual_seed(4000)).to(device)
+        onset(frames)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            y = onset(frames)
+        torch.cuda.synchronize(device)
+        dt = (time.perf_counter() - t0) / iters
+        assert y.shape == (N, 30) and torch.isfinite(y).all()
+        tf = N * workmodel.ONSET_NET_GFLOP_PER_CLIP / 1e3 / dt
+        return dict(workload="VideoOnsetNet (R(2+1)D-18) forward, N=32 clips of (3,30,112,112)", clips_per_s=round(N / dt, 1),
+                    tflops=round(tf, 1), mfma_frac=round(tf / PEAK_BF16_TFLOPS, 4), dtype=onset.compute_dtype)
+
+    if args.dtype != "fp32":
+        leg("fp32_config1", fp32_leg)
+    leg("config2_b32_cfg", config2_leg)
+    leg("reference_eval_shape", reference_leg)
+    leg("onset_net_n32", onset_leg)
+    return out
+
+
+def main() -> int:
+    args = parse_args()
+    have_env = "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not have_env:
+        return spawn_ranks(args)            # before `import torch` touches the GPU: the parent stays a plain launcher
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if have_env and world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} disagrees with WORLD_SIZE={world}", file=sys.stderr)
+        return 2
+
+    import torch
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist_on = world > 1 or args.force_dist
@@ -78,16 +252,16 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("MASTER_PORT", str(args.master_port))
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
     from syncfusion_amd import dist as sfd
+    from syncfusion_amd import workmodel
 
     sfd.FORCE_COLLECTIVES = bool(args.force_dist)
-    import syncfusion_amd as sa
 
     B = args.batch
     model = build_model(args.dtype, device)
@@ -97,11 +271,7 @@ def main():
 
     # synthetic inputs, identical bits on every run: per-rank noise seed 1000 + rank
     noise = torch.randn(B, 1, L0, generator=torch.Generator().manual_seed(sfd.rank_seed(1000, rank))).to(device)
-    track = torch.zeros(B, 1, L0, device=device)
-    track[:, 0, 0] = 1.0                                       # "dummy cond": one impulse at sample 0
-    _, info = model.onsets_encoder(track, with_info=True)
-    channels = info["xs"][2:-1]
-    emb = torch.zeros(B, 1, 512, device=device)                # dummy CLAP embedding
+    channels, emb = synthetic_conditioning(model, B, L0, device, real=False)   # "dummy cond" of configs[1]
 
     def run(steps):
         return model.model.sample(x_noisy=noise, num_steps=steps, channels=channels, embedding=emb, embedding_scale=args.scale)
@@ -109,8 +279,6 @@ def main():
     def fence():
         torch.cuda.synchronize(device)
         if dist_on:
-            import torch.distributed as dist
-
             dist.barrier()
             torch.cuda.synchronize(device)
 
@@ -124,8 +292,6 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if dist_on:
-        import torch.distributed as dist
-
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
@@ -133,11 +299,9 @@ def main():
     gathered = sfd.gather_clips(out, B * world, dst=0)         # RCCL gather of the finished clips, once, after the loop
 
     if rank != 0:
-        if world > 1:
-            import torch.distributed as dist
-
+        if dist_on:
             dist.destroy_process_group()
-        return
+        return 0
 
     # ---------------- roofline: per-kernel HIP-event timing of one instrumented evaluation ----------------
     evals = 2 if args.scale != 1.0 else 1
@@ -151,7 +315,7 @@ def main():
     # HIP events bracket launch latency as well as execution: the engine times an empty kernel the same way
     # ("calib_empty"); its duration minus ~1.5 us of real execution is the fixed cost subtracted from every launch
     calib = sorted(ms for label, ms, _, _ in recs if label == "calib_empty")
-    # Calibrated against rocprofv3 --kernel-trace of the same command (profiles/r1_*_kernel_stats.csv): about half of the
+    # Calibrated against rocprofv3 --kernel-trace of the same command (profiles/*_kernel_stats.csv): about half of the
     # empty-kernel event time overlaps with a real kernel's own launch ramp, so half of it is subtracted.
     overhead_ms = 0.5 * max(0.0, (calib[len(calib) // 2] if calib else 0.0) - 1.5e-3)
     recs = [(label, max(ms - overhead_ms, 1e-4), fl, by) for label, ms, fl, by in recs if label != "calib_empty"]
@@ -165,7 +329,7 @@ def main():
     total_ms = sum(a[0] for a in agg.values())
     dom = max(agg, key=lambda k: agg[k][0])
     d_ms, d_fl, d_by, d_n = agg[dom]
-    peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+    peak = PEAK_F32_TFLOPS if args.dtype == "fp32" else PEAK_BF16_TFLOPS
     # the roofline that bounds the dominant kernel: whichever of its algorithmic FLOPs / MFMA peak and algorithmic bytes / HBM
     # peak takes longer (the small-batch GEMMs sit BELOW the machine balance of ~310 FLOP/B: they are HBM-side kernels)
     mfma_kernel = d_fl / (peak * 1e12) >= d_by / (PEAK_HBM_GBS * 1e9)
@@ -180,10 +344,10 @@ def main():
     # THIS command (tools/pmc_traffic.py; FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as is); null when the
     # summary has no entry for the kernel or the workload is not the profiled one.
     traffic, traffic_src = None, None
-    if args.batch == 8 and args.dtype == "bf16" and args.scale == 1.0:
+    if args.batch == BATCH and args.dtype == "bf16" and args.scale == 1.0:
         import glob
 
-        for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))[::-1]:
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[::-1]:
             try:
                 with open(path) as f:
                     kern = json.load(f).get("kernels", {})
@@ -191,7 +355,7 @@ def main():
                 continue
             ent = kern.get(dom.split("<")[0])
             if ent:
-                traffic, traffic_src = ent["traffic_bytes_per_launch"], os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))
+                traffic, traffic_src = ent["traffic_bytes_per_launch"], os.path.relpath(path, ROOT)
                 break
     roof.update(traffic=traffic, traffic_source=traffic_src, algorithmic_bytes_per_launch=round(d_by / d_n), kernel=dom, launches_per_eval=d_n, avg_launch_us=round(d_ms / d_n * 1e3, 3),
                 share_of_eval_time=round(d_ms / total_ms, 4),
@@ -199,11 +363,16 @@ def main():
                                     gbs=round(v[2] / max(v[0], 1e-9) / 1e6, 1)) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])},
                 eval_device_ms=round(total_ms, 4), launches_per_eval_total=len(recs),
                 event_overhead_us_subtracted=round(overhead_ms * 1e3, 3))
-    # whole-step roofline: t_roofline = max(alg FLOPs / MFMA peak, alg bytes / HBM peak) summed per launch
-    t_roof = sum(max(fl / (peak * 1e12), by / (PEAK_HBM_GBS * 1e9)) for _, _, fl, by in recs) * 1e3
+    # whole-step roofline, closed form: t_roofline = sum_depth max(F_d / P_mfma, Q_d / BW_hbm) with every weight
+    # counted once per step -- independent of the engine's clip-parallel branches and of its launch structure
+    work = workmodel.unet_work(dict(net.hparams), L0, B, evals, ES[args.dtype])
+    t_roof = workmodel.step_roofline_ms(work, peak * 1e12, PEAK_HBM_GBS * 1e9)
     ms_per_step = elapsed / args.steps * 1e3
+    roof["step_algorithmic_tflop"] = round(work["flops"] / 1e12, 4)
+    roof["step_algorithmic_gb"] = round(work["bytes"] / 1e9, 4)
     roof["step_roofline_ms"] = round(t_roof, 4)
-    roof["step_roofline_frac"] = round(t_roof / (ms_per_step / 1.0), 5)
+    roof["step_roofline_frac"] = round(t_roof / ms_per_step, 5)
+    roof["step_hbm_gbs_algorithmic"] = round(work["bytes"] / 1e9 / (ms_per_step * 1e-3), 1)
 
     # ---------------- cpu_baseline: the oracle on this box's host cores, bounded sample ----------------
     cpu = None
@@ -235,6 +404,10 @@ def main():
                    sample=f"{n} timed denoise steps (U-Net evaluation, batch {B}, L0 {L0}, fp32) after 1 warm-up; "
                           "the sampler's element-wise update is excluded (<0.01% of a step)")
 
+    extra = None
+    if not args.no_extra and world == 1 and not args.force_dist:
+        extra = extra_workloads(model, device, args, noise, channels, emb)
+
     line = {
         "metric": "U-Net denoise steps/sec (batch x 2 s@22.05 kHz)",
         "value": round(world * args.steps / elapsed, 3),
@@ -248,20 +421,23 @@ def main():
         "vs_baseline": None,
         "dtype": args.dtype,
         "data": "synthetic",
-        "config": {"workload": f"batch={B}/GPU, {args.steps}-step DDIM (v-sampler), L0={L0} (2 s @ 22.05 kHz padded to 44*1024), "
-                               f"{args.dtype}, embedding_scale={args.scale} ({evals} U-Net eval/step), dummy cond; BASELINE configs[1]",
+        "config": {"workload": f"BASELINE configs[1]: batch={B}/GPU, {BASELINE_STEPS}-step DDIM (v-sampler) denoising of 2 s @ 22.05 kHz clips "
+                               f"(L0={L0} = 44*1024, cropped to 44100), {args.dtype}, embedding_scale={args.scale} ({evals} U-Net eval/step), "
+                               f"dummy cond; this run timed {args.steps} consecutive sampler steps (the cost of a step does not depend on the "
+                               "schedule length)",
                    "batch_per_gpu": B, "L0": L0, "evals_per_step": evals, "clip_steps_per_s": round(world * B * args.steps / elapsed, 2),
                    "params_M": round(sum(p.numel() for p in net.parameters()) / 1e6, 2), "hip_graph": not args.no_graph,
                    "weights_broadcast_bytes": bcast_bytes, "gathered_clips": None if gathered is None else int(gathered.shape[0])},
         "roofline": roof,
         "cpu_baseline": cpu,
+        "extra": extra,
     }
     print(json.dumps(line))
+    sys.stdout.flush()
     if dist_on:
-        import torch.distributed as dist
-
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

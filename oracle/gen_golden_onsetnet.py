@@ -28,7 +28,11 @@ from syncfusion_amd.onset_net import VideoOnsetNet as OurNet  # noqa: E402
 CASES = {  # name: (seed, N, T, H, W)
     "small": (7, 2, 8, 32, 32),
     "rect": (11, 1, 5, 48, 40),
+    # the BASELINE shape (2 s x 15 fps at 112 x 112, main/onset_net.py:68): the 4.5 MB input is NOT stored -- the tests
+    # regenerate it from the seed and check it against the stored checksum before trusting the comparison
+    "full": (13, 1, 30, 112, 112),
 }
+STORE_INPUT_MAX = 1 << 18   # floats
 
 
 def main():
@@ -60,7 +64,10 @@ def main():
         err = float((y_or - y).abs().max())
         print(f"{name}: logits {tuple(y.shape)}  oracle-vs-reference max|diff| = {err:.3e}")
         assert err < 1e-5
-        out = dict(x=x.numpy(), y=y.numpy(), seed=np.int64(seed), keys_hash=np.int64(hash(tuple(ref_sd.keys())) & 0x7FFFFFFF))
+        out = dict(y=y.numpy(), seed=np.int64(seed), keys_hash=np.int64(hash(tuple(ref_sd.keys())) & 0x7FFFFFFF),
+                   x_shape=np.array(x.shape, dtype=np.int64), x_sum=np.float64(x.double().sum()), x_head=x.reshape(-1)[:16].numpy())
+        if x.numel() <= STORE_INPUT_MAX:
+            out["x"] = x.numpy()
         for nm, t in stages.items():
             out[f"{nm}_mean"] = np.float64(t.double().mean())
             out[f"{nm}_absmean"] = np.float64(t.double().abs().mean())
@@ -80,7 +87,14 @@ def main():
         yk = m(xk)
         yo = onsetnet_forward(m.state_dict(), xk)
     print("survey KAT y[0,:4] =", [round(float(v), 6) for v in yk[0, :4]], " oracle diff", float((yo - yk).abs().max()))
-    np.savez_compressed(os.path.join(GOLDEN, "onsetnet_kat_seed0.npz"), y=yk.numpy())
+    # survey KAT at the full shape: same seed protocol, x = randn(1,3,30,112,112) drawn after the init
+    torch.manual_seed(0)
+    m = RefNet(False).eval()
+    xf = torch.randn(1, 3, 30, 112, 112)
+    with torch.no_grad():
+        yf = m(xf)
+    print("survey KAT (full) y[0,:6] =", [round(float(v), 6) for v in yf[0, :6]], " sum", round(float(yf.sum()), 6))
+    np.savez_compressed(os.path.join(GOLDEN, "onsetnet_kat_seed0.npz"), y=yk.numpy(), y_full=yf.numpy())
 
 
 if __name__ == "__main__":

@@ -11,11 +11,11 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import GOLDEN, SMALL_ENCODER, SMALL_UNET, oracle_params, rel_l2, seeded_state, small_encoder_module, small_unet_module, synth_inputs
+from helpers import GOLDEN, SMALL_ENCODER, SMALL_UNET, golden_onsetnet_input, oracle_params, rel_l2, seeded_state, small_encoder_module, small_unet_module, synth_inputs
 from oracle import encoder1d_ref, onsetnet_ref, sampler_ref, unet_ref
 
 
-@pytest.mark.parametrize("case", ["small", "rect"])
+@pytest.mark.parametrize("case", ["small", "rect", "full"])
 def test_onsetnet_oracle_matches_reference_golden(case):
     from syncfusion_amd.onset_net import VideoOnsetNet
 
@@ -24,7 +24,7 @@ def test_onsetnet_oracle_matches_reference_golden(case):
     sd = {k: v.float() for k, v in seeded_state(net, int(gold["seed"])).items()}
     taps = {}
     with torch.no_grad():
-        y = onsetnet_ref.onsetnet_forward(sd, torch.from_numpy(gold["x"]), taps)
+        y = onsetnet_ref.onsetnet_forward(sd, golden_onsetnet_input(gold), taps)
     assert np.abs(y.numpy() - gold["y"]).max() < 1e-5
     for nm in ("stem", "layer1", "layer2", "layer3", "layer4"):
         assert tuple(taps[nm].shape) == tuple(int(v) for v in gold[f"{nm}_shape"])
@@ -38,11 +38,20 @@ def test_onsetnet_state_dict_is_the_references():
     from syncfusion_amd.onset_net import VideoOnsetNet
 
     sd = VideoOnsetNet(False).state_dict()
-    assert len([k for k in sd if "num_batches_tracked" not in k]) == 226 - 0 or len(sd) >= 226
+    assert len(sd) == 226      # the reference's count, num_batches_tracked buffers included
     assert "net.model.stem.0.weight" in sd and "fc.2.bias" in sd
     assert tuple(sd["net.model.layer2.0.conv1.0.3.weight"].shape) == (128, 230, 3, 1, 1)   # main/onset_net.py:19
     assert tuple(sd["net.model.layer4.0.conv2.0.0.weight"].shape) == (921, 512, 1, 3, 3)   # one midplanes per block
     assert sum(v.numel() for k, v in sd.items() if v.is_floating_point() and "running" not in k) == 31_365_918
+
+
+def test_onsetnet_survey_kat_fixture():
+    """SURVEY 8c known-answer values, produced by the reference under its own default init (manual_seed(0)) and stored by
+    oracle/gen_golden_onsetnet.py (which also checks the oracle against them, on the reference's own weights)."""
+    kat = np.load(os.path.join(GOLDEN, "onsetnet_kat_seed0.npz"))
+    assert np.allclose(kat["y"][0, :4], [0.080375, 0.079831, 0.081027, 0.087990], atol=2e-6)
+    assert np.allclose(kat["y_full"][0, :6], [0.095996, 0.098838, 0.104082, 0.108999, 0.110326, 0.111024], atol=2e-6)
+    assert abs(float(kat["y_full"].sum()) - 3.321533) < 2e-5
 
 
 def test_onsetnet_flops_match_survey():
