@@ -34,7 +34,7 @@ enum {
   SF_ERR_UNSUPPORTED = 6
 };
 
-enum { SF_F32 = 0, SF_BF16 = 1 }; /* arithmetic/storage type of the activations and packed weights */
+enum { SF_F32 = 0, SF_BF16 = 1, SF_F16 = 2 }; /* arithmetic/storage type of the activations and packed weights (accumulation, statistics, softmax and the sampler state are fp32 in every mode) */
 
 /* One named parameter of a torch state_dict: fp32, contiguous, PyTorch layout, device memory. */
 typedef struct {
@@ -69,7 +69,7 @@ typedef struct {
   int32_t embedding_max_length;
   int32_t modulation_features;
   int32_t resnet_groups;
-  int32_t dtype; /* SF_F32 (parity path) or SF_BF16 */
+  int32_t dtype; /* SF_F32 (parity path), SF_BF16 or SF_F16 */
 } sf_unet_config;
 
 typedef struct sf_unet sf_unet;

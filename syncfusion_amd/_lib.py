@@ -13,8 +13,8 @@ from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 import torch
 
 SF_MAX_DEPTH = 12
-SF_F32, SF_BF16 = 0, 1
-DTYPES = {"fp32": SF_F32, "float32": SF_F32, "f32": SF_F32, "bf16": SF_BF16, "bfloat16": SF_BF16}
+SF_F32, SF_BF16, SF_F16 = 0, 1, 2
+DTYPES = {"fp32": SF_F32, "float32": SF_F32, "f32": SF_F32, "bf16": SF_BF16, "bfloat16": SF_BF16, "fp16": SF_F16, "float16": SF_F16, "f16": SF_F16, "half": SF_F16}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libsyncfusion_amd.so")

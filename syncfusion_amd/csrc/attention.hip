@@ -152,15 +152,15 @@ hipError_t go(const void *q, int ldq, const void *kv, int ldkv, int B, int L, in
 
 }  // namespace
 
-hipError_t launch_attention_mfma(const void *q, int ldq, const void *kv, int ldkv, int B, int L, int H, int Dh, void *out, int ldo,
+hipError_t launch_attention_mfma(int dt, const void *q, int ldq, const void *kv, int ldkv, int B, int L, int H, int Dh, void *out, int ldo,
                                  hipStream_t s);
 
 hipError_t launch_attention(int dt, const void *q, int ldq, const void *kv, int ldkv, int B, int L, int H, int Dh, void *out,
                             int ldo, hipStream_t s) {
   if (Dh != D || L <= 0) return hipErrorInvalidValue;
-  if (dt == BF16 && (ldq % 8) == 0 && (ldkv % 8) == 0 && (ldo % 8) == 0)   // matrix-core path (attention_mfma.hip)
-    return launch_attention_mfma(q, ldq, kv, ldkv, B, L, H, Dh, out, ldo, s);
-  return dt == F32 ? go<float>(q, ldq, kv, ldkv, B, L, H, out, ldo, s) : go<bf16>(q, ldq, kv, ldkv, B, L, H, out, ldo, s);
+  if (dt != F32 && (ldq % 8) == 0 && (ldkv % 8) == 0 && (ldo % 8) == 0)   // matrix-core path (attention_mfma.hip)
+    return launch_attention_mfma(dt, q, ldq, kv, ldkv, B, L, H, Dh, out, ldo, s);
+  return SF_DISPATCH_T(dt, go<T>(q, ldq, kv, ldkv, B, L, H, out, ldo, s));
 }
 
 }  // namespace sf

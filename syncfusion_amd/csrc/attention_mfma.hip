@@ -22,11 +22,11 @@ constexpr int LDK = D + 8;                // bf16 elements per K-tile row   (144
 constexpr int LDV = TK + 8;               // bf16 elements per V^T-tile row
 constexpr int LDO = D + 8;
 
-__global__ __launch_bounds__(128) void attention_mfma_kernel(const bf16 *__restrict__ q, int ldq, const bf16 *__restrict__ kv, int ldkv,
-                                                             int L, int H, bf16 *__restrict__ out, int ldo, float scale) {
-  __shared__ __attribute__((aligned(16))) bf16 Ks[TK * LDK];
-  __shared__ __attribute__((aligned(16))) bf16 Vt[D * LDV];
-  __shared__ __attribute__((aligned(16))) bf16 Os[WAVES * QW * LDO];
+template <typename T> __global__ __launch_bounds__(128) void attention_mfma_kernel(const T *__restrict__ q, int ldq, const T *__restrict__ kv, int ldkv,
+                                                             int L, int H, T *__restrict__ out, int ldo, float scale) {
+  __shared__ __attribute__((aligned(16))) T Ks[TK * LDK];
+  __shared__ __attribute__((aligned(16))) T Vt[D * LDV];
+  __shared__ __attribute__((aligned(16))) T Os[WAVES * QW * LDO];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
@@ -37,14 +37,14 @@ __global__ __launch_bounds__(128) void attention_mfma_kernel(const bf16 *__restr
   const bool qvalid = qi < L;
 
   // Q^T as the B operand of S^T = K.Q^T: lane holds Q[q = fr][d = 16 s + 8 fh + j], pre-scaled by 1/sqrt(D)
-  bf16x8 qf[4];
+  typename Frag16<T>::type qf[4];
   {
-    const bf16 *qp = q + (rowbase + (qvalid ? qi : 0)) * ldq + h * D;
+    const T *qp = q + (rowbase + (qvalid ? qi : 0)) * ldq + h * D;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      Vec16<bf16> v = ld16<bf16>(qp + 16 * s + 8 * fh);
+      Vec16<T> v = ld16<T>(qp + 16 * s + 8 * fh);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) qf[s][j] = (bf16)((float)v.v[j] * scale);
+      for (int j = 0; j < 8; ++j) qf[s][j] = (T)((float)v.v[j] * scale);
     }
   }
 
@@ -58,18 +58,18 @@ __global__ __launch_bounds__(128) void attention_mfma_kernel(const bf16 *__restr
   const int koff = h * D, voff = H * D + h * D;
   // staging: 128 threads x 16 B = 16 rows of 64 bf16 per pass; 4 passes per tile for K and for V
   const int srow = tid >> 3, svec = tid & 7;
-  Vec16<bf16> rk[4], rv[4];
+  Vec16<T> rk[4], rv[4];
   auto prefetch = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int kj = k0 + i * 16 + srow;
       if (kj < L) {
-        const bf16 *kp = kv + (rowbase + kj) * ldkv;
-        rk[i] = ld16<bf16>(kp + koff + svec * 8);
-        rv[i] = ld16<bf16>(kp + voff + svec * 8);
+        const T *kp = kv + (rowbase + kj) * ldkv;
+        rk[i] = ld16<T>(kp + koff + svec * 8);
+        rv[i] = ld16<T>(kp + voff + svec * 8);
       } else {
-        rk[i] = zero16<bf16>();
-        rv[i] = zero16<bf16>();
+        rk[i] = zero16<T>();
+        rv[i] = zero16<T>();
       }
     }
   };
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(128) void attention_mfma_kernel(const bf16 *__restr
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int kr = i * 16 + srow;
-      st16<bf16>(Ks + kr * LDK + svec * 8, rk[i]);
+      st16<T>(Ks + kr * LDK + svec * 8, rk[i]);
 #pragma unroll
       for (int j = 0; j < 8; ++j) Vt[(svec * 8 + j) * LDV + kr] = rv[i].v[j];   // transposed image: Vt[d][key]
     }
@@ -98,8 +98,8 @@ __global__ __launch_bounds__(128) void attention_mfma_kernel(const bf16 *__restr
       for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        bf16x8 kf = *reinterpret_cast<const bf16x8 *>(Ks + (32 * t + fr) * LDK + 16 * s + 8 * fh);
-        st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[t], 0, 0, 0);
+        typename Frag16<T>::type kf = *reinterpret_cast<const typename Frag16<T>::type *>(Ks + (32 * t + fr) * LDK + 16 * s + 8 * fh);
+        st[t] = mfma32x16(kf, qf[s], st[t]);
       }
     }
     // ---- online softmax (fp32) ----
@@ -116,14 +116,14 @@ __global__ __launch_bounds__(128) void attention_mfma_kernel(const bf16 *__restr
     const float mnew = fmaxf(mrun, tmax);
     const float alpha = __expf(mrun - mnew);
     float psum = 0.f;
-    bf16x8 pf[4];   // P^T as B operand: k-step (t, s) takes accumulator registers 8 s .. 8 s + 7 of tile t
+    typename Frag16<T>::type pf[4];   // P^T as B operand: k-step (t, s) takes accumulator registers 8 s .. 8 s + 7 of tile t
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float pv = __expf(st[t][r] - mnew);
         psum += pv;
-        pf[2 * t + (r >> 3)][r & 7] = (bf16)pv;
+        pf[2 * t + (r >> 3)][r & 7] = (T)pv;
       }
     lrun = lrun * alpha + psum;
     mrun = mnew;
@@ -136,34 +136,34 @@ __global__ __launch_bounds__(128) void attention_mfma_kernel(const bf16 *__restr
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const bf16 *vp = Vt + (32 * i + fr) * LDV + 16 * ks + 4 * fh;
-        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-        bf16x4 lo = *reinterpret_cast<const bf16x4 *>(vp);
-        bf16x4 hi = *reinterpret_cast<const bf16x4 *>(vp + 8);
-        bf16x8 vf;
+        const T *vp = Vt + (32 * i + fr) * LDV + 16 * ks + 4 * fh;
+        typedef __attribute__((ext_vector_type(4))) T x4_t;
+        x4_t lo = *reinterpret_cast<const x4_t *>(vp);
+        x4_t hi = *reinterpret_cast<const x4_t *>(vp + 8);
+        typename Frag16<T>::type vf;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           vf[j] = lo[j];
           vf[4 + j] = hi[j];
         }
-        o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], o[i], 0, 0, 0);
+        o[i] = mfma32x16(vf, pf[ks], o[i]);
       }
   }
   lrun += __shfl_xor(lrun, 32, 64);
   const float inv = 1.0f / lrun;
   // ---- O^T (d on rows, q on lanes) -> LDS [q][d] -> 16-byte row stores ----
-  bf16 *os = Os + wave * QW * LDO;
+  T *os = Os + wave * QW * LDO;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) os[fr * LDO + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh] = (bf16)(o[i][r] * inv);
+    for (int r = 0; r < 16; ++r) os[fr * LDO + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh] = (T)(o[i][r] * inv);
   __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's LDS writes have landed before it reads them back
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int pass = 0; pass < 4; ++pass) {
     const int row = pass * 8 + (lane >> 3), c8 = lane & 7;
     const int qq = q0 + row;
-    if (qq < L) st16<bf16>(out + (rowbase + qq) * ldo + h * D + c8 * 8, ld16<bf16>(os + row * LDO + c8 * 8));
+    if (qq < L) st16<T>(out + (rowbase + qq) * ldo + h * D + c8 * 8, ld16<T>(os + row * LDO + c8 * 8));
   }
 }
 
@@ -178,8 +178,8 @@ constexpr int KS = 4, TK2 = 32;
 constexpr int LDK2 = D + 8, LDV2 = TK2 + 8;
 constexpr int WSTG = TK2 * LDK2 + D * LDV2;   // bf16 elements of one wave's staging area (K tile | V^T tile)
 
-__global__ __launch_bounds__(256) void attention_ksplit_kernel(const bf16 *__restrict__ q, int ldq, const bf16 *__restrict__ kv, int ldkv,
-                                                               int L, int H, bf16 *__restrict__ out, int ldo, float scale) {
+template <typename T> __global__ __launch_bounds__(256) void attention_ksplit_kernel(const T *__restrict__ q, int ldq, const T *__restrict__ kv, int ldkv,
+                                                               int L, int H, T *__restrict__ out, int ldo, float scale) {
   // staging: KS x WSTG bf16 (39 KB); merge (aliases it after a barrier): KS x 32 x (D + 1) floats + KS x 32 x 2
   __shared__ __attribute__((aligned(16))) unsigned char smem[KS * WSTG * 2 > KS * 32 * (D + 4) * 4 ? KS * WSTG * 2 : KS * 32 * (D + 4) * 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -189,17 +189,17 @@ __global__ __launch_bounds__(256) void attention_ksplit_kernel(const bf16 *__res
   const int q0 = blockIdx.x * 32;
   const int qi = q0 + fr;
   const bool qvalid = qi < L;
-  bf16 *Ks = reinterpret_cast<bf16 *>(smem) + (size_t)wave * WSTG;
-  bf16 *Vt = Ks + TK2 * LDK2;
+  T *Ks = reinterpret_cast<T *>(smem) + (size_t)wave * WSTG;
+  T *Vt = Ks + TK2 * LDK2;
 
-  bf16x8 qf[4];
+  typename Frag16<T>::type qf[4];
   {
-    const bf16 *qp = q + (rowbase + (qvalid ? qi : 0)) * ldq + h * D;
+    const T *qp = q + (rowbase + (qvalid ? qi : 0)) * ldq + h * D;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      Vec16<bf16> v = ld16<bf16>(qp + 16 * s + 8 * fh);
+      Vec16<T> v = ld16<T>(qp + 16 * s + 8 * fh);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) qf[s][j] = (bf16)((float)v.v[j] * scale);
+      for (int j = 0; j < 8; ++j) qf[s][j] = (T)((float)v.v[j] * scale);
     }
   }
   f32x16 o[2];
@@ -212,18 +212,18 @@ __global__ __launch_bounds__(256) void attention_ksplit_kernel(const bf16 *__res
   const int koff = h * D, voff = H * D + h * D;
   const int srow = lane >> 3, svec = lane & 7;   // one wave stages 8 rows x 64 d per pass, 4 passes per 32-key tile
   const int ntk = (L + TK2 - 1) / TK2;
-  Vec16<bf16> rk[4], rv[4];
+  Vec16<T> rk[4], rv[4];
   auto prefetch = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int kj = k0 + i * 8 + srow;
       if (kj < L) {
-        const bf16 *kp = kv + (rowbase + kj) * ldkv;
-        rk[i] = ld16<bf16>(kp + koff + svec * 8);
-        rv[i] = ld16<bf16>(kp + voff + svec * 8);
+        const T *kp = kv + (rowbase + kj) * ldkv;
+        rk[i] = ld16<T>(kp + koff + svec * 8);
+        rv[i] = ld16<T>(kp + voff + svec * 8);
       } else {
-        rk[i] = zero16<bf16>();
-        rv[i] = zero16<bf16>();
+        rk[i] = zero16<T>();
+        rv[i] = zero16<T>();
       }
     }
   };
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void attention_ksplit_kernel(const bf16 *__res
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int kr = i * 8 + srow;
-      st16<bf16>(Ks + kr * LDK2 + svec * 8, rk[i]);
+      st16<T>(Ks + kr * LDK2 + svec * 8, rk[i]);
 #pragma unroll
       for (int j = 0; j < 8; ++j) Vt[(svec * 8 + j) * LDV2 + kr] = rv[i].v[j];
     }
@@ -252,8 +252,8 @@ __global__ __launch_bounds__(256) void attention_ksplit_kernel(const bf16 *__res
     for (int r = 0; r < 16; ++r) st[r] = 0.f;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      bf16x8 kf = *reinterpret_cast<const bf16x8 *>(Ks + fr * LDK2 + 16 * s + 8 * fh);
-      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st, 0, 0, 0);
+      typename Frag16<T>::type kf = *reinterpret_cast<const typename Frag16<T>::type *>(Ks + fr * LDK2 + 16 * s + 8 * fh);
+      st = mfma32x16(kf, qf[s], st);
     }
     float tmax = -INFINITY;
 #pragma unroll
@@ -266,12 +266,12 @@ __global__ __launch_bounds__(256) void attention_ksplit_kernel(const bf16 *__res
     const float mnew = fmaxf(mrun, tmax);   // finite: a tile always holds at least one valid key
     const float alpha = __expf(mrun - mnew);
     float psum = 0.f;
-    bf16x8 pf[2];
+    typename Frag16<T>::type pf[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float pv = __expf(st[r] - mnew);
       psum += pv;
-      pf[r >> 3][r & 7] = (bf16)pv;
+      pf[r >> 3][r & 7] = (T)pv;
     }
     lrun = lrun * alpha + psum;
     mrun = mnew;
@@ -283,17 +283,17 @@ __global__ __launch_bounds__(256) void attention_ksplit_kernel(const bf16 *__res
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        const bf16 *vp = Vt + (32 * i + fr) * LDV2 + 16 * ks + 4 * fh;
-        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-        bf16x4 lo = *reinterpret_cast<const bf16x4 *>(vp);
-        bf16x4 hi = *reinterpret_cast<const bf16x4 *>(vp + 8);
-        bf16x8 vf;
+        const T *vp = Vt + (32 * i + fr) * LDV2 + 16 * ks + 4 * fh;
+        typedef __attribute__((ext_vector_type(4))) T x4_t;
+        x4_t lo = *reinterpret_cast<const x4_t *>(vp);
+        x4_t hi = *reinterpret_cast<const x4_t *>(vp + 8);
+        typename Frag16<T>::type vf;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           vf[j] = lo[j];
           vf[4 + j] = hi[j];
         }
-        o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], o[i], 0, 0, 0);
+        o[i] = mfma32x16(vf, pf[ks], o[i]);
       }
   }
   lrun += __shfl_xor(lrun, 32, 64);
@@ -336,31 +336,36 @@ __global__ __launch_bounds__(256) void attention_ksplit_kernel(const bf16 *__res
     }
     const float inv = 1.0f / lsum;
     if (q0 + qq < L) {
-      Vec16<bf16> ov;
+      Vec16<T> ov;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) ov.v[j] = (bf16)(acc[j] * inv);
-      st16<bf16>(out + (rowbase + q0 + qq) * ldo + h * D + c8 * 8, ov);
+      for (int j = 0; j < 8; ++j) ov.v[j] = (T)(acc[j] * inv);
+      st16<T>(out + (rowbase + q0 + qq) * ldo + h * D + c8 * 8, ov);
     }
   }
 }
 
 }  // namespace
 
-hipError_t launch_attention_mfma(const void *q, int ldq, const void *kv, int ldkv, int B, int L, int H, int Dh, void *out, int ldo,
-                                 hipStream_t s) {
-  if (Dh != D || L <= 0) return hipErrorInvalidValue;
+template <typename T>
+static hipError_t attention_mfma_go(const void *q, int ldq, const void *kv, int ldkv, int B, int L, int H, void *out, int ldo, hipStream_t s) {
   // short sequences: the 2-wave kernel would launch fewer waves than the chip has SIMDs -> split the keys across waves
   const long waves_plain = (long)((L + WAVES * QW - 1) / (WAVES * QW)) * H * B * WAVES;
   if (waves_plain < 2048 && L <= 4096) {
     dim3 g2((L + 31) / 32, H, B);
-    hipLaunchKernelGGL(attention_ksplit_kernel, g2, dim3(256), 0, s, static_cast<const bf16 *>(q), ldq, static_cast<const bf16 *>(kv), ldkv,
-                       L, H, static_cast<bf16 *>(out), ldo, 1.0f / sqrtf((float)D));
+    hipLaunchKernelGGL((attention_ksplit_kernel<T>), g2, dim3(256), 0, s, static_cast<const T *>(q), ldq, static_cast<const T *>(kv), ldkv,
+                       L, H, static_cast<T *>(out), ldo, 1.0f / sqrtf((float)D));
     return hipGetLastError();
   }
   dim3 grid((L + WAVES * QW - 1) / (WAVES * QW), H, B);
-  hipLaunchKernelGGL(attention_mfma_kernel, grid, dim3(128), 0, s, static_cast<const bf16 *>(q), ldq, static_cast<const bf16 *>(kv), ldkv,
-                     L, H, static_cast<bf16 *>(out), ldo, 1.0f / sqrtf((float)D));
+  hipLaunchKernelGGL((attention_mfma_kernel<T>), grid, dim3(128), 0, s, static_cast<const T *>(q), ldq, static_cast<const T *>(kv), ldkv,
+                     L, H, static_cast<T *>(out), ldo, 1.0f / sqrtf((float)D));
   return hipGetLastError();
+}
+
+hipError_t launch_attention_mfma(int dt, const void *q, int ldq, const void *kv, int ldkv, int B, int L, int H, int Dh, void *out, int ldo,
+                                 hipStream_t s) {
+  if (Dh != D || L <= 0 || dt == F32) return hipErrorInvalidValue;
+  return dt == F16 ? attention_mfma_go<f16>(q, ldq, kv, ldkv, B, L, H, out, ldo, s) : attention_mfma_go<bf16>(q, ldq, kv, ldkv, B, L, H, out, ldo, s);
 }
 
 }  // namespace sf

@@ -6,9 +6,11 @@
 namespace sf {
 
 typedef __bf16 bf16;
+typedef _Float16 f16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 constexpr int WAVE = 64;
@@ -27,6 +29,23 @@ template <> struct Vec16<bf16> {
   __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
   __device__ __forceinline__ void set(int i, float x) { v[i] = (bf16)x; }
 };
+
+template <> struct Vec16<f16> {
+  static constexpr int N = 8;
+  f16x8 v;
+  __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+  __device__ __forceinline__ void set(int i, float x) { v[i] = (f16)x; }
+};
+
+// 16-bit MFMA operand fragment of T (8 consecutive k of one row) and the 32x32x16 product on it
+template <typename T> struct Frag16 {
+  using type = bf16x8;
+};
+template <> struct Frag16<f16> {
+  using type = f16x8;
+};
+__device__ __forceinline__ f32x16 mfma32x16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mfma32x16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
 template <typename T> __device__ __forceinline__ Vec16<T> ld16(const T *p) {
   Vec16<T> r;

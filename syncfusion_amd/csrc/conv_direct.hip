@@ -175,7 +175,11 @@ hipError_t launch_conv_direct(int dt_in, int dt_out, const ConvGemmArgs &a, hipS
   if (dt_in == F32 && dt_out == F32) return go<float, float>(a, s);
   if (dt_in == F32 && dt_out == BF16) return go<float, bf16>(a, s);
   if (dt_in == BF16 && dt_out == BF16) return go<bf16, bf16>(a, s);
-  return go<bf16, float>(a, s);
+  if (dt_in == BF16 && dt_out == F32) return go<bf16, float>(a, s);
+  if (dt_in == F32 && dt_out == F16) return go<float, f16>(a, s);
+  if (dt_in == F16 && dt_out == F16) return go<f16, f16>(a, s);
+  if (dt_in == F16 && dt_out == F32) return go<f16, float>(a, s);
+  return hipErrorInvalidValue;
 }
 
 }  // namespace sf

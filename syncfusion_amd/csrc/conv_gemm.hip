@@ -12,6 +12,9 @@
 //
 //   fp32 path : v_mfma_f32_32x32x2_f32  (exact fp32 fma chain; K order permuted {s, 16+s})
 //   bf16 path : v_mfma_f32_32x32x16_bf16 (fp32 accumulate)
+#include <set>
+#include <string>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -251,18 +254,19 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        bf16x8 af[TM], bfr[TN];
+        using frag = typename Frag16<T>::type;
+        frag af[TM], bfr[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-          af[i] = *reinterpret_cast<const bf16x8 *>(As + (wr * WTM + i * 32 + fr) * LD + 16 * s + 8 * fh);
+          af[i] = *reinterpret_cast<const frag *>(As + (wr * WTM + i * 32 + fr) * LD + 16 * s + 8 * fh);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          bfr[j] = *reinterpret_cast<const bf16x8 *>(Bs + (wc * WTN + j * 32 + fr) * LD + 16 * s + 8 * fh);
+          bfr[j] = *reinterpret_cast<const frag *>(Bs + (wc * WTN + j * 32 + fr) * LD + 16 * s + 8 * fh);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = mfma32x16(af[i], bfr[j], acc[i][j]);
       }
     } else {
 #pragma unroll
@@ -411,7 +415,20 @@ static bool use_sk(const ConvGemmArgs &a) {
   return blocks < 256 && a.K >= 256;
 }
 
-const char *conv_gemm_variant_name(int dt, const ConvGemmArgs &a) {
+// profiling label of a 16-bit kernel in the f16 build: the bf16 label with the type renamed (interned: labels are kept by pointer)
+const char *label_for_dtype(int dt, const char *bf16_label) {
+  if (dt != F16) return bf16_label;
+  static std::set<std::string> pool;
+  std::string s(bf16_label);
+  const size_t at = s.find("bf16");
+  if (at != std::string::npos) s.replace(at, 4, "f16");
+  return pool.insert(s).first->c_str();
+}
+
+static const char *variant_name_bf16(int dt, const ConvGemmArgs &a);
+const char *conv_gemm_variant_name(int dt, const ConvGemmArgs &a) { return label_for_dtype(dt, variant_name_bf16(dt, a)); }
+
+static const char *variant_name_bf16(int dt, const ConvGemmArgs &a) {
   static const char *names[2][5] = {{"conv_gemm<f32,64x64,scalarA>", "conv_gemm<f32,128x32>", "conv_gemm<f32,128x64>", "conv_gemm<f32,64x64>", "conv_gemm<f32,128x128>"},
                                     {"conv_gemm<bf16,64x64,scalarA>", "conv_gemm<bf16,128x32>", "conv_gemm<bf16,128x64>", "conv_gemm<bf16,64x64>", "conv_gemm<bf16,128x128>"}};
   static const char *sk_names[2][3] = {{"conv_gemm_sk<f32,64x64>", "conv_gemm_sk<f32,64x32>", "conv_gemm_sk<f32,32x32>"},
@@ -458,7 +475,7 @@ hipError_t launch_conv_gemm(int dt, const ConvGemmArgs &a, hipStream_t s) {
     if (f.path == 4) return hipErrorInvalidValue;
   }
   if (f.path == 2 || f.path == 5 || (f.path == 0 && (short_act || use_sk(a)))) return launch_conv_gemm_sk(dt, a, s);
-  return dt == F32 ? dispatch<float>(a, s) : dispatch<bf16>(a, s);
+  return SF_DISPATCH_T(dt, dispatch<T>(a, s));
 }
 
 }  // namespace sf

@@ -193,15 +193,16 @@ __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(const ConvGemmArgs 
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
       for (int s = 0; s < KW / 16; ++s) {
-        bf16x8 af[TM], bfr[TN];
+        using frag = typename Frag16<T>::type;
+        frag af[TM], bfr[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8 *>(As + (i * 32 + fr) * LD + kw0 + 16 * s + 8 * fh);
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const frag *>(As + (i * 32 + fr) * LD + kw0 + 16 * s + 8 * fh);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8 *>(Bs + (j * 32 + fr) * LD + kw0 + 16 * s + 8 * fh);
+        for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const frag *>(Bs + (j * 32 + fr) * LD + kw0 + 16 * s + 8 * fh);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j) acc[i][j] = mfma32x16(af[i], bfr[j], acc[i][j]);
       }
     } else {
 #pragma unroll
@@ -456,8 +457,7 @@ bool conv_gemm_ln_ok(int dt, const ConvGemmArgs &a) {
 
 hipError_t launch_conv_gemm_ln(int dt, const ConvGemmArgs &a, hipStream_t s) {
   if (!conv_gemm_ln_ok(dt, a)) return hipErrorInvalidValue;
-  if (dt == F32) return a.cin2 ? launch_fast3<float, 32, 32, true, 32, 2, true>(a, s) : launch_fast3<float, 32, 32, false, 32, 2, true>(a, s);
-  return a.cin2 ? launch_fast3<bf16, 32, 32, true, 32, 2, true>(a, s) : launch_fast3<bf16, 32, 32, false, 32, 2, true>(a, s);
+  return SF_DISPATCH_T(dt, (a.cin2 ? launch_fast3<T, 32, 32, true, 32, 2, true>(a, s) : launch_fast3<T, 32, 32, false, 32, 2, true>(a, s)));
 }
 
 hipError_t launch_conv_gemm_fast(int dt, const ConvGemmArgs &a, int variant, hipStream_t s) {
@@ -471,6 +471,13 @@ hipError_t launch_conv_gemm_fast(int dt, const ConvGemmArgs &a, int variant, hip
       case 0: return SF_FAST(float, 64, 64);
       case 1: return SF_FAST(float, 64, 32);
       default: return SF_FAST(float, 32, 32);
+    }
+  }
+  if (dt == F16) {
+    switch (variant) {
+      case 0: return SF_FAST(f16, 64, 64);
+      case 1: return SF_FAST(f16, 64, 32);
+      default: return SF_FAST(f16, 32, 32);
     }
   }
   switch (variant) {

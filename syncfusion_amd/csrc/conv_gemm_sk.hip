@@ -214,15 +214,16 @@ __global__ __launch_bounds__(256) void conv_gemm_sk_kernel(const ConvGemmArgs a,
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        bf16x8 af[TM], bfr[TN];
+        using frag = typename Frag16<T>::type;
+        frag af[TM], bfr[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8 *>(As + (i * 32 + fr) * LD + kw0 + 16 * s + 8 * fh);
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const frag *>(As + (i * 32 + fr) * LD + kw0 + 16 * s + 8 * fh);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8 *>(Bs + (j * 32 + fr) * LD + kw0 + 16 * s + 8 * fh);
+        for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const frag *>(Bs + (j * 32 + fr) * LD + kw0 + 16 * s + 8 * fh);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j) acc[i][j] = mfma32x16(af[i], bfr[j], acc[i][j]);
       }
     } else {
 #pragma unroll
@@ -392,6 +393,13 @@ hipError_t launch_conv_gemm_sk(int dt, const ConvGemmArgs &a, hipStream_t s) {
       case 0: return launch_sk<float, 64, 64>(a, s);
       case 1: return launch_sk<float, 64, 32>(a, s);
       default: return launch_sk<float, 32, 32>(a, s);
+    }
+  }
+  if (dt == F16) {
+    switch (v) {
+      case 0: return launch_sk<f16, 64, 64>(a, s);
+      case 1: return launch_sk<f16, 64, 32>(a, s);
+      default: return launch_sk<f16, 32, 32>(a, s);
     }
   }
   switch (v) {

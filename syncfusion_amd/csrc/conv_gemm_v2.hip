@@ -207,15 +207,16 @@ __global__ __launch_bounds__(256) void conv_gemm_v2_kernel(const ConvGemmArgs a,
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
       for (int s = 0; s < BK / 16; ++s) {
-        bf16x8 af[TM], bfr[TN];
+        using frag = typename Frag16<T>::type;
+        frag af[TM], bfr[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8 *>(As + (i * 32 + fr) * LD + 16 * s + 8 * fh);
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const frag *>(As + (i * 32 + fr) * LD + 16 * s + 8 * fh);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8 *>(Bs + (j * 32 + fr) * LD + 16 * s + 8 * fh);
+        for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const frag *>(Bs + (j * 32 + fr) * LD + 16 * s + 8 * fh);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j) acc[i][j] = mfma32x16(af[i], bfr[j], acc[i][j]);
       }
     } else {
       // fp32: v_mfma_f32_32x32x2_f32; the two k of a step are {s, 32 + s} of the chunk (same permutation for A and W)
@@ -382,7 +383,7 @@ bool conv_gemm_v2_plan(int dt, const ConvGemmArgs &a, V2Plan &pl) {
 const char *conv_gemm_v2_name(int dt, const V2Plan &pl) {
   static const char *n[2][3] = {{"conv_gemm_v2<f32,128x128>", "conv_gemm_v2<f32,128x64>", "conv_gemm_v2<f32,64x64>"},
                                 {"conv_gemm_v2<bf16,128x128>", "conv_gemm_v2<bf16,128x64>", "conv_gemm_v2<bf16,64x64>"}};
-  return n[dt == F32 ? 0 : 1][pl.variant];
+  return label_for_dtype(dt, n[dt == F32 ? 0 : 1][pl.variant]);
 }
 
 hipError_t launch_conv_gemm_v2(int dt, const ConvGemmArgs &a, const V2Plan &pl, hipStream_t s) {
@@ -391,6 +392,13 @@ hipError_t launch_conv_gemm_v2(int dt, const ConvGemmArgs &a, const V2Plan &pl, 
       case 0: return launch_v2_g<float, 128, 128>(a, pl, s);
       case 1: return launch_v2_g<float, 128, 64>(a, pl, s);
       default: return launch_v2_g<float, 64, 64>(a, pl, s);
+    }
+  }
+  if (dt == F16) {
+    switch (pl.variant) {
+      case 0: return launch_v2_g<f16, 128, 128>(a, pl, s);
+      case 1: return launch_v2_g<f16, 128, 64>(a, pl, s);
+      default: return launch_v2_g<f16, 64, 64>(a, pl, s);
     }
   }
   switch (pl.variant) {

@@ -167,15 +167,16 @@ __global__ __launch_bounds__(256) void conv_gemm_wp_kernel(const ConvGemmArgs a,
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
       for (int s = 0; s < BK / 16; ++s) {
-        bf16x8 af[TM], bfr[TN];
+        using frag = typename Frag16<T>::type;
+        frag af[TM], bfr[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8 *>(As + (i * 32 + fr) * LD + 16 * s + 8 * fh);
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const frag *>(As + (i * 32 + fr) * LD + 16 * s + 8 * fh);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8 *>(Bs + (j * 32 + fr) * LD + 16 * s + 8 * fh);
+        for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const frag *>(Bs + (j * 32 + fr) * LD + 16 * s + 8 * fh);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j) acc[i][j] = mfma32x16(af[i], bfr[j], acc[i][j]);
       }
     } else {
 #pragma unroll
@@ -352,6 +353,13 @@ hipError_t launch_conv_gemm_wp(int dt, const ConvGemmArgs &a, int variant, hipSt
       case 0: return SF_WP(float, 64, 64);
       case 1: return SF_WP(float, 64, 32);
       default: return SF_WP(float, 32, 32);
+    }
+  }
+  if (dt == F16) {
+    switch (variant) {
+      case 0: return SF_WP(f16, 64, 64);
+      case 1: return SF_WP(f16, 64, 32);
+      default: return SF_WP(f16, 32, 32);
     }
   }
   switch (variant) {

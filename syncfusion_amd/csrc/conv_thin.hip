@@ -51,6 +51,23 @@ template <> struct K8<bf16> {
     return r;
   }
 };
+template <> struct K8<f16> {
+  f16x8 v;
+  __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+  __device__ __forceinline__ void set(int i, float x) { v[i] = (f16)x; }
+  __device__ __forceinline__ static K8 load(const f16 *p) {
+    K8 r;
+    r.v = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4 *>(p));
+    return r;
+  }
+  __device__ __forceinline__ void store(f16 *p) const { *reinterpret_cast<u32x4 *>(p) = __builtin_bit_cast(u32x4, v); }
+  __device__ __forceinline__ static K8 zero() {
+    K8 r;
+    u32x4 z = {0u, 0u, 0u, 0u};
+    r.v = __builtin_bit_cast(f16x8, z);
+    return r;
+  }
+};
 template <> struct K8<float> {
   f32x4 v[2];
   __device__ __forceinline__ float get(int i) const { return v[i >> 2][i & 3]; }
@@ -75,6 +92,9 @@ template <> struct K8<float> {
 
 __device__ __forceinline__ void mma_step(f32x16 &acc, const K8<bf16> &a, const K8<bf16> &b) {
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma_step(f32x16 &acc, const K8<f16> &a, const K8<f16> &b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.v, b.v, acc, 0, 0, 0);
 }
 __device__ __forceinline__ void mma_step(f32x16 &acc, const K8<float> &a, const K8<float> &b) {
 #pragma unroll
@@ -140,6 +160,21 @@ template <> struct K4<bf16> {
   __device__ __forceinline__ static K4 zero() {
     K4 r;
     r.raw = make_uint2(0u, 0u);
+    return r;
+  }
+};
+template <> struct K4<f16> {
+  typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+  f16x4 v;
+  __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+  __device__ __forceinline__ static K4 load(const f16 *p) {
+    K4 r;
+    r.v = *reinterpret_cast<const f16x4 *>(p);
+    return r;
+  }
+  __device__ __forceinline__ static K4 zero() {
+    K4 r;
+    r.v = f16x4{(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
     return r;
   }
 };
@@ -884,7 +919,7 @@ bool thin_tail_supported(int dt, const ThinTailArgs &a) {
 
 hipError_t launch_thin_tail(int dt, const ThinTailArgs &a, hipStream_t s) {
   if (!thin_tail_supported(dt, a)) return hipErrorInvalidValue;
-  return dt == F32 ? tail_dispatch<float>(a, s) : tail_dispatch<bf16>(a, s);
+  return SF_DISPATCH_T(dt, tail_dispatch<T>(a, s));
 }
 
 ThinPlan conv_thin_plan(int B, int L, int C) {
@@ -936,7 +971,7 @@ bool conv_thin_supported(int dt, const ConvThinArgs &a) {
 
 hipError_t launch_conv_thin(int dt, const ConvThinArgs &a, hipStream_t s) {
   if (!conv_thin_supported(dt, a)) return hipErrorInvalidValue;
-  return dt == F32 ? thin_dispatch<float>(a, s) : thin_dispatch<bf16>(a, s);
+  return SF_DISPATCH_T(dt, thin_dispatch<T>(a, s));
 }
 
 }  // namespace sf

@@ -7,8 +7,20 @@
 
 namespace sf {
 
-enum DType { F32 = 0, BF16 = 1 };
+enum DType { F32 = 0, BF16 = 1, F16 = 2 };
 inline size_t dsize(int dt) { return dt == F32 ? 4 : 2; }
+// three-way dispatch on the arithmetic type: SF_DISPATCH_T(dt, f<T>(args)) evaluates f with T = float / bf16 / f16;
+// SF_DISPATCH_STMT(dt, statement using T) is the statement form (kernel launches)
+#define SF_DISPATCH_T(dt, EXPR_T)             \
+  ((dt) == ::sf::F32    ? [&] { using T = float; return EXPR_T; }()   \
+   : (dt) == ::sf::BF16 ? [&] { using T = ::sf::bf16; return EXPR_T; }() \
+                        : [&] { using T = ::sf::f16; return EXPR_T; }())
+#define SF_DISPATCH_STMT(dt, STMT)                                   \
+  do {                                                               \
+    if ((dt) == ::sf::F32) { using T = float; STMT; }                \
+    else if ((dt) == ::sf::BF16) { using T = ::sf::bf16; STMT; }     \
+    else { using T = ::sf::f16; STMT; }                              \
+  } while (0)
 
 // ---------------------------------------------------------------------------------------
 // Implicit-GEMM convolution on the matrix cores:  out[m][n] = epi( sum_k A(m,k) * W[n][k] )
@@ -69,6 +81,8 @@ struct ConvGemmForce {
 extern ConvGemmForce g_conv_gemm_force;
 // name of the tile variant launch_conv_gemm picks for these arguments (profiling labels)
 const char *conv_gemm_variant_name(int dt, const ConvGemmArgs &a);
+// the label of the bf16 build with the type renamed when dt == F16 (interned string)
+const char *label_for_dtype(int dt, const char *bf16_label);
 // bytes of dynamic LDS the GN table needs is bounded; returns false when the shape is unsupported.
 bool conv_gemm_supported(int dt, const ConvGemmArgs &a);
 

@@ -170,38 +170,31 @@ __global__ void bn_fold_kernel(const float *g, const float *b, const float *m, c
 
 }  // namespace
 
-#define SF_DT(dt, CALL_F, CALL_B) \
-  if ((dt) == F32) { CALL_F; } else { CALL_B; }
 
 hipError_t launch_cf_to_cl(int dt, const float *x, int B, int C, int L, void *out, int ld, hipStream_t s) {
   dim3 g = grid_for((int64_t)B * L);
-  SF_DT(dt, hipLaunchKernelGGL(cf_to_cl_kernel<float>, g, dim3(TPB), 0, s, x, B, C, L, (float *)out, ld),
-        hipLaunchKernelGGL(cf_to_cl_kernel<bf16>, g, dim3(TPB), 0, s, x, B, C, L, (bf16 *)out, ld));
+  SF_DISPATCH_STMT(dt, hipLaunchKernelGGL((cf_to_cl_kernel<T>), g, dim3(TPB), 0, s, x, B, C, L, (T *)out, ld));
   return hipGetLastError();
 }
 hipError_t launch_cl_to_cf(int dt, const void *x, int ld, int B, int C, int L, float *out, hipStream_t s) {
   dim3 g = grid_for((int64_t)B * L);
-  SF_DT(dt, hipLaunchKernelGGL(cl_to_cf_kernel<float>, g, dim3(TPB), 0, s, (const float *)x, ld, B, C, L, out),
-        hipLaunchKernelGGL(cl_to_cf_kernel<bf16>, g, dim3(TPB), 0, s, (const bf16 *)x, ld, B, C, L, out));
+  SF_DISPATCH_STMT(dt, hipLaunchKernelGGL((cl_to_cf_kernel<T>), g, dim3(TPB), 0, s, (const T *)x, ld, B, C, L, out));
   return hipGetLastError();
 }
-hipError_t launch_video_to_cl(int dt, const float *x, int N, int C, int T, int H, int W, void *out, int ld, hipStream_t s) {
-  dim3 g = grid_for((int64_t)N * T * H * W);
-  SF_DT(dt, hipLaunchKernelGGL(video_to_cl_kernel<float>, g, dim3(TPB), 0, s, x, N, C, T, H, W, (float *)out, ld),
-        hipLaunchKernelGGL(video_to_cl_kernel<bf16>, g, dim3(TPB), 0, s, x, N, C, T, H, W, (bf16 *)out, ld));
+hipError_t launch_video_to_cl(int dt, const float *x, int N, int C, int Tf, int H, int W, void *out, int ld, hipStream_t s) {
+  dim3 g = grid_for((int64_t)N * Tf * H * W);
+  SF_DISPATCH_STMT(dt, hipLaunchKernelGGL((video_to_cl_kernel<T>), g, dim3(TPB), 0, s, x, N, C, Tf, H, W, (T *)out, ld));
   return hipGetLastError();
 }
 hipError_t launch_to_f32(int dt, const void *x, int ld, int64_t rows, int C, float *out, hipStream_t s) {
   dim3 g = grid_for(rows * C);
-  SF_DT(dt, hipLaunchKernelGGL(to_f32_kernel<float>, g, dim3(TPB), 0, s, (const float *)x, ld, rows, C, out),
-        hipLaunchKernelGGL(to_f32_kernel<bf16>, g, dim3(TPB), 0, s, (const bf16 *)x, ld, rows, C, out));
+  SF_DISPATCH_STMT(dt, hipLaunchKernelGGL((to_f32_kernel<T>), g, dim3(TPB), 0, s, (const T *)x, ld, rows, C, out));
   return hipGetLastError();
 }
 hipError_t launch_time_fourier(int dt, const float *sig, const int *sig_idx, const float *w, int B, int half, void *out, int ld,
                                hipStream_t s) {
   dim3 g = grid_for((int64_t)B * ld);
-  SF_DT(dt, hipLaunchKernelGGL(time_fourier_kernel<float>, g, dim3(TPB), 0, s, sig, sig_idx, w, B, half, (float *)out, ld),
-        hipLaunchKernelGGL(time_fourier_kernel<bf16>, g, dim3(TPB), 0, s, sig, sig_idx, w, B, half, (bf16 *)out, ld));
+  SF_DISPATCH_STMT(dt, hipLaunchKernelGGL((time_fourier_kernel<T>), g, dim3(TPB), 0, s, sig, sig_idx, w, B, half, (T *)out, ld));
   return hipGetLastError();
 }
 hipError_t launch_vsampler_update(float *x, const float *v, const float *v_uncond, float scale, const float *sched,
@@ -217,8 +210,7 @@ template <typename T> __global__ void row_sums_kernel(const T *__restrict__ w, i
   if (threadIdx.x == 0) out[blockIdx.x] = acc;
 }
 hipError_t launch_row_sums(int dt, const void *w, int N, int K, float *out, hipStream_t s) {
-  SF_DT(dt, hipLaunchKernelGGL(row_sums_kernel<float>, dim3(N), dim3(64), 0, s, (const float *)w, K, out),
-        hipLaunchKernelGGL(row_sums_kernel<bf16>, dim3(N), dim3(64), 0, s, (const bf16 *)w, K, out));
+  SF_DISPATCH_STMT(dt, hipLaunchKernelGGL((row_sums_kernel<T>), dim3(N), dim3(64), 0, s, (const T *)w, K, out));
   return hipGetLastError();
 }
 // first[b] = index of the first non-zero sample of y[b, 0, :] (L when there is none): strided scan, block-wide minimum
@@ -265,8 +257,7 @@ hipError_t launch_cfg_combine(const float *v_c, const float *v_u, float scale, f
   return hipGetLastError();
 }
 hipError_t launch_spatial_mean(int dt, const void *x, int ld, int NT, int HW, int C, float *out, hipStream_t s) {
-  SF_DT(dt, hipLaunchKernelGGL(spatial_mean_kernel<float>, dim3(NT), dim3(TPB), 0, s, (const float *)x, ld, HW, C, out),
-        hipLaunchKernelGGL(spatial_mean_kernel<bf16>, dim3(NT), dim3(TPB), 0, s, (const bf16 *)x, ld, HW, C, out));
+  SF_DISPATCH_STMT(dt, hipLaunchKernelGGL((spatial_mean_kernel<T>), dim3(NT), dim3(TPB), 0, s, (const T *)x, ld, HW, C, out));
   return hipGetLastError();
 }
 hipError_t launch_onsets_to_track(const float *logits, int N, int T, const int32_t *start_frame, float frame_rate,
@@ -280,15 +271,13 @@ hipError_t launch_onsets_to_track(const float *logits, int N, int T, const int32
 hipError_t launch_pack_conv(int dt, const float *w, int N, int Ctot, int c_off, int Cin, int taps, int cin_pad, const float *nscale,
                             void *out, int64_t out_row, int64_t col0, hipStream_t s) {
   dim3 g = grid_for((int64_t)N * taps * cin_pad);
-  SF_DT(dt, hipLaunchKernelGGL(pack_conv_kernel<float>, g, dim3(TPB), 0, s, w, N, Ctot, c_off, Cin, taps, cin_pad, nscale, (float *)out, out_row, col0),
-        hipLaunchKernelGGL(pack_conv_kernel<bf16>, g, dim3(TPB), 0, s, w, N, Ctot, c_off, Cin, taps, cin_pad, nscale, (bf16 *)out, out_row, col0));
+  SF_DISPATCH_STMT(dt, hipLaunchKernelGGL((pack_conv_kernel<T>), g, dim3(TPB), 0, s, w, N, Ctot, c_off, Cin, taps, cin_pad, nscale, (T *)out, out_row, col0));
   return hipGetLastError();
 }
 hipError_t launch_pack_rows(int dt, const float *in, int64_t rows, int cols, int64_t ldi, const float *cscale, void *out,
                             int64_t ldo, hipStream_t s) {
   dim3 g = grid_for(rows * cols);
-  SF_DT(dt, hipLaunchKernelGGL(pack_rows_kernel<float>, g, dim3(TPB), 0, s, in, rows, cols, ldi, cscale, (float *)out, ldo),
-        hipLaunchKernelGGL(pack_rows_kernel<bf16>, g, dim3(TPB), 0, s, in, rows, cols, ldi, cscale, (bf16 *)out, ldo));
+  SF_DISPATCH_STMT(dt, hipLaunchKernelGGL((pack_rows_kernel<T>), g, dim3(TPB), 0, s, in, rows, cols, ldi, cscale, (T *)out, ldo));
   return hipGetLastError();
 }
 hipError_t launch_fold_bias(const float *w, int N, int K, const float *v, const float *add, float *out, hipStream_t s) {

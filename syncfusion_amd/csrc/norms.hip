@@ -431,20 +431,17 @@ hipError_t gn_go(const void *x, int ld, int B, int L, int C, int G, int nch, int
 
 hipError_t launch_gn_stats(int dt, const void *x, int ld, int B, int L, int C, int G, int nch, int chunk_rows, float *slab,
                            hipStream_t s) {
-  return dt == F32 ? gn_go<float>(x, ld, B, L, C, G, nch, chunk_rows, slab, s)
-                   : gn_go<bf16>(x, ld, B, L, C, G, nch, chunk_rows, slab, s);
+  return SF_DISPATCH_T(dt, gn_go<T>(x, ld, B, L, C, G, nch, chunk_rows, slab, s));
 }
 
 hipError_t launch_gn_silu(int dt, const void *x, int ld, int B, int L, int C, int G, const float *gamma, const float *beta, float eps,
                           void *out, int out_ld, hipStream_t s) {
-  return dt == F32 ? gn_silu_go<float>(x, ld, B, L, C, G, gamma, beta, eps, out, out_ld, s)
-                   : gn_silu_go<bf16>(x, ld, B, L, C, G, gamma, beta, eps, out, out_ld, s);
+  return SF_DISPATCH_T(dt, gn_silu_go<T>(x, ld, B, L, C, G, gamma, beta, eps, out, out_ld, s));
 }
 
 hipError_t launch_ln_modulate(int dt, const void *x, int ld, const float *ss, int ss_ld, float eps, int B, int L, int C,
                               void *out, int out_ld, hipStream_t s) {
-  return dt == F32 ? ln_go<float>(x, ld, ss, ss_ld, eps, B, L, C, out, out_ld, s)
-                   : ln_go<bf16>(x, ld, ss, ss_ld, eps, B, L, C, out, out_ld, s);
+  return SF_DISPATCH_T(dt, ln_go<T>(x, ld, ss, ss_ld, eps, B, L, C, out, out_ld, s));
 }
 
 }  // namespace sf

@@ -165,7 +165,7 @@ int sf_onsetnet_create(const sf_tensor *weights, int n_weights, int dtype, void 
   SF_API_BEGIN
   if (!out || !weights) fail(SF_ERR_INVALID, "null argument");
   *out = nullptr;
-  if (dtype != SF_F32 && dtype != SF_BF16) fail(SF_ERR_INVALID, "bad dtype");
+  if (dtype != SF_F32 && dtype != SF_BF16 && dtype != SF_F16) fail(SF_ERR_INVALID, "bad dtype");
   std::unique_ptr<sf_onsetnet> o(new sf_onsetnet());
   o->dt = dtype;
   WeightMap wm(weights, n_weights);

@@ -323,7 +323,7 @@ void build(sf_unet &u, const WeightMap *wm, hipStream_t s) {
   if (c.attention_features != 64) fail(SF_ERR_UNSUPPORTED, "attention_features must be 64 (got %d)", c.attention_features);
   if (c.embedding_max_length != 1) fail(SF_ERR_UNSUPPORTED, "embedding_max_length must be 1 (CLAP embedding), got %d", c.embedding_max_length);
   if (c.modulation_features % 32 || c.embedding_features % 32) fail(SF_ERR_UNSUPPORTED, "modulation/embedding features must be multiples of 32");
-  if (c.dtype != SF_F32 && c.dtype != SF_BF16) fail(SF_ERR_INVALID, "bad dtype");
+  if (c.dtype != SF_F32 && c.dtype != SF_BF16 && c.dtype != SF_F16) fail(SF_ERR_INVALID, "bad dtype");
   u.dt = c.dtype;
   u.mf = c.modulation_features;
   u.hd = c.attention_heads * c.attention_features;
@@ -547,7 +547,7 @@ struct Exec {
     if (w.direct) timed("conv_direct", flops, bytes, [&] { SF_HIP(launch_conv_direct(dt_in, dt_out, a, s)); });
     else {
       if (dt_in != u.dt || (dt_out != u.dt && !a.out_f32)) fail(SF_ERR_INVALID, "internal: dtype mismatch on the MFMA path");
-      if (ln) timed(u.dt == F32 ? "conv_gemm_fast<f32,32x32>" : "conv_gemm_fast<bf16,32x32>", flops + 8.0 * a.M * a.cin, bytes,
+      if (ln) timed(u.dt == F32 ? "conv_gemm_fast<f32,32x32>" : label_for_dtype(u.dt, "conv_gemm_fast<bf16,32x32>"), flops + 8.0 * a.M * a.cin, bytes,
                     [&] { SF_HIP(launch_conv_gemm_ln(u.dt, a, s)); });
       else timed(conv_gemm_variant_name(u.dt, a), flops, bytes, [&] { SF_HIP(launch_conv_gemm(u.dt, a, s)); });
     }

@@ -180,14 +180,15 @@ def test_vdiffusion_loss_fp32(cuda):
     assert abs(float(got) - float(ref)) < 1e-4 * abs(float(ref))
 
 
-def test_unet_bf16_stated_tolerance(cuda):
-    net = small_unet_module(dtype="bf16").to(cuda)
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_unet_lowp_stated_tolerance(cuda, dtype):
+    net = small_unet_module(dtype=dtype).to(cuda)
     B, L0 = 2, 16 * 44
     x, sigma, emb, chans = synth_inputs(SMALL_UNET, B, L0, seed=3)
     ref = _oracle_unet(net, x, sigma, emb, chans, 2.0)
     out = net(x.to(cuda), sigma.to(cuda), embedding=emb.to(cuda), channels=[c.to(cuda) for c in chans], embedding_scale=2.0)
     err = rel_l2(out.cpu(), ref)
-    print(f"bf16 single-eval rel-L2 = {err:.3e}")
+    print(f"{dtype} single-eval rel-L2 = {err:.3e}")
     assert err < BF16_TOL
 
 
@@ -238,7 +239,7 @@ def test_encoder1d_parity(cuda, B, L0):
 # VideoOnsetNet: golden vectors produced by the reference itself (oracle/gen_golden_onsetnet.py)
 # ----------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("case", ["small", "rect", "full"])
-@pytest.mark.parametrize("dtype,tol", [("fp32", FP32_TOL), ("bf16", BF16_TOL)])
+@pytest.mark.parametrize("dtype,tol", [("fp32", FP32_TOL), ("bf16", BF16_TOL), ("fp16", BF16_TOL)])
 def test_onsetnet_golden(cuda, case, dtype, tol):
     from syncfusion_amd.onset_net import VideoOnsetNet
 
@@ -273,7 +274,7 @@ def test_onsetnet_train_mode_and_cpu_raise(cuda):
         net.eval()(torch.zeros(1, 4, 4, 32, 32, device=cuda))
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("B,mult", [(1, 1), (3, 1), (2, 3), (5, 7), (3, 33), (8, 100)])
 def test_unet_edge_shapes(cuda, dtype, B, mult):
     """Clips shorter than a tile, a single position at the deepest level, ragged tiles, odd batch sizes, with and without

@@ -1,7 +1,7 @@
 """Kernel-level parity (MI355X): each HIP kernel family, through the C ABI, against the same op in fp32 torch on the CPU.
 
 These localise a failure to one kernel; the model-level parity tests are in test_gpu_models.py.
-Tolerances: fp32 path 2e-5 rel-L2 (exact-fp32 MFMA, different summation order); bf16 path 2e-2.
+Tolerances: fp32 path 2e-5 rel-L2 (exact-fp32 MFMA, different summation order); bf16 path 2e-2; fp16 path 4e-3.
 """
 import ctypes as C
 
@@ -13,8 +13,8 @@ from helpers import rel_l2
 
 pytestmark = pytest.mark.gpu
 
-TOL = {"fp32": 2e-5, "bf16": 2e-2}
-TD = {"fp32": torch.float32, "bf16": torch.bfloat16}
+TOL = {"fp32": 2e-5, "bf16": 2e-2, "fp16": 4e-3}
+TD = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
 
 
 def _lib():
@@ -58,7 +58,7 @@ def _conv_case(cuda, dtype, B, L, C, N, taps, stride, pad, up, groups, residual,
     return rel_l2(got, ref)
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("shape", [
     # B, L, C, N, taps, stride, pad, up, groups, residual
     (2, 352, 64, 64, 3, 1, 1, 1, 8, True),      # ResnetItem conv, 64x64 tile
@@ -80,7 +80,7 @@ def test_conv_gemm(cuda, dtype, shape):
     assert _conv_case(cuda, dtype, *shape) < TOL[dtype]
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("shape", [
     (2, 2816, 8, 8, 3, 1, 1, 1, 8, True),       # U-Net depth 0 ResnetItem
     (2, 704, 1, 8, 1, 1, 0, 1, 0, False),       # 1 -> 8 entry conv
@@ -94,7 +94,7 @@ def test_conv_direct(cuda, dtype, shape):
     assert _conv_case(cuda, dtype, *shape) < TOL[dtype]
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("C", [8, 32, 64, 256, 1024])
 @pytest.mark.parametrize("mod", [True, False])
 def test_ln_modulate(cuda, dtype, C, mod):
@@ -116,7 +116,7 @@ def test_ln_modulate(cuda, dtype, C, mod):
     assert rel_l2(out.float().cpu(), ref) < (1e-5 if dtype == "fp32" else 8e-3)
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("L", [1, 44, 64, 100, 352])
 def test_attention(cuda, dtype, L):
     _l, lib = _lib()
