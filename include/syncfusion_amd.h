@@ -34,6 +34,7 @@ enum {
   SF_ERR_UNSUPPORTED = 6
 };
 
+enum { SF_UP_NEAREST_CONV3 = 0, SF_UP_TRANSPOSE = 1 };
 enum { SF_F32 = 0, SF_BF16 = 1, SF_F16 = 2 }; /* arithmetic/storage type of the activations and packed weights (accumulation, statistics, softmax and the sampler state are fp32 in every mode) */
 
 /* One named parameter of a torch state_dict: fp32, contiguous, PyTorch layout, device memory. */
@@ -70,6 +71,9 @@ typedef struct {
   int32_t modulation_features;
   int32_t resnet_groups;
   int32_t dtype; /* SF_F32 (parity path), SF_BF16 or SF_F16 */
+  /* Up path of a block (a-unet apex.py): SF_UP_NEAREST_CONV3 = nn.Upsample(nearest) + Conv1d(k=3) [UpsampleInterpolate];
+   * SF_UP_TRANSPOSE = ConvTranspose1d(kernel = stride = factor) [Upsample]; `blocks.{d}.up.weight` is (in, C, 3) resp. (C, in, factor). */
+  int32_t upsample_mode;
 } sf_unet_config;
 
 typedef struct sf_unet sf_unet;

@@ -132,8 +132,13 @@ def _block(P, cfg, d: int, x, f, emb, ctx, taps=None):
         h = _item_group(P, cfg, f"{pre}.items_up.{j}", d, h, f, emb, ctx)
         if taps is not None:
             taps[f"d{d}.items_up.{j}"] = h
-    h = F.interpolate(h, scale_factor=fac, mode="nearest")
-    h = F.conv1d(h, P[pre + ".up.weight"], P[pre + ".up.bias"], padding=1)
+    if cfg.get("upsample_mode", "nearest") == "transpose":
+        # a-unet `Upsample` (apex.py): ConvTranspose1d(C -> in, kernel_size=factor, stride=factor); weight (C, in, factor)
+        h = F.conv_transpose1d(h, P[pre + ".up.weight"], P[pre + ".up.bias"], stride=fac)
+    else:
+        # a-unet `UpsampleInterpolate`: nn.Upsample(scale_factor, mode="nearest") then Conv1d(C -> in, 3, padding=1)
+        h = F.interpolate(h, scale_factor=fac, mode="nearest")
+        h = F.conv1d(h, P[pre + ".up.weight"], P[pre + ".up.bias"], padding=1)
     # SkipModulate: skip + Linear(SiLU(f))[:, :, None] * h
     scale = _lin(P, pre + ".skip.to_scale", F.silu(f))
     out = skip + scale[:, :, None] * h
@@ -186,7 +191,7 @@ def unet_flops_per_eval(cfg, L0: int) -> float:
         total += g * (12.0 * L * C * C + 2.0 * L * (C + ctx[d]) * C + L * C)
         if att[d]:
             total += g * (2.0 * L * C * 3 * hd + 2.0 * L * hd * C + 4.0 * L * L * hd)
-        total += 6.0 * Lprev * cin * C                             # up conv (k=3) at the outer length
+        total += (2.0 if cfg.get("upsample_mode", "nearest") == "transpose" else 6.0) * Lprev * cin * C   # up conv at the outer length
         cin = C
         Lprev = L
     return total

@@ -60,6 +60,7 @@ class UNetEngine(_Base):
                       "modulation_features", "resnet_groups"):
             setattr(cfg, field, int(hp[field]))
         cfg.dtype = _lib.DTYPES[dtype]
+        cfg.upsample_mode = _lib.UPSAMPLE_MODES[hp.get("upsample_mode", "nearest")]
         self.cfg = cfg
         self.hp = dict(hp)
         self.dtype = dtype

@@ -14,6 +14,7 @@ import torch
 
 SF_MAX_DEPTH = 12
 SF_F32, SF_BF16, SF_F16 = 0, 1, 2
+UPSAMPLE_MODES = {"nearest": 0, "transpose": 1}
 DTYPES = {"fp32": SF_F32, "float32": SF_F32, "f32": SF_F32, "bf16": SF_BF16, "bfloat16": SF_BF16, "fp16": SF_F16, "float16": SF_F16, "f16": SF_F16, "half": SF_F16}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -33,6 +34,7 @@ class UnetConfig(C.Structure):
         ("attention_heads", C.c_int32), ("attention_features", C.c_int32),
         ("embedding_features", C.c_int32), ("embedding_max_length", C.c_int32),
         ("modulation_features", C.c_int32), ("resnet_groups", C.c_int32), ("dtype", C.c_int32),
+        ("upsample_mode", C.c_int32),
     ]
 
 

@@ -206,6 +206,8 @@ hipError_t launch_row_sums(int dt, const void *w, int N, int K, float *out, hipS
 // zero for ci in [Cin, cin_pad)  (+ optional per-N scale = folded BatchNorm)
 hipError_t launch_pack_conv(int dt, const float *w, int N, int Ctot, int c_off, int Cin, int taps, int cin_pad, const float *nscale,
                             void *out, int64_t out_row, int64_t col0, hipStream_t s);
+// ConvTranspose1d weight (Cin, Cout, f) fp32 (kernel = stride = f) -> [n = t*Cout + o][k = c] as DT, row length out_row >= Cin (zero padded)
+hipError_t launch_pack_convT(int dt, const float *w, int Cin, int Cout, int f, void *out, int64_t out_row, hipStream_t s);
 // generic strided copy/convert: out[r*ldo + c] = (DT) in[r*ldi + c] * (cscale ? cscale[c] : 1)
 hipError_t launch_pack_rows(int dt, const float *in, int64_t rows, int cols, int64_t ldi, const float *cscale, void *out,
                             int64_t ldo, hipStream_t s);

@@ -274,6 +274,21 @@ hipError_t launch_pack_conv(int dt, const float *w, int N, int Ctot, int c_off, 
   SF_DISPATCH_STMT(dt, hipLaunchKernelGGL((pack_conv_kernel<T>), g, dim3(TPB), 0, s, w, N, Ctot, c_off, Cin, taps, cin_pad, nscale, (T *)out, out_row, col0));
   return hipGetLastError();
 }
+// ConvTranspose1d weight (Cin, Cout, f) -> the GEMM matrix of its "un-patchify" form: out[(t * Cout + o) * out_row + c] = w[c][o][t]
+template <typename T> __global__ void pack_convT_kernel(const float *__restrict__ w, int Cin, int Cout, int f, T *__restrict__ out, int64_t out_row) {
+  const int64_t n = (int64_t)f * Cout * out_row;
+  SF_GRID_STRIDE(i, n) {
+    const int c = (int)(i % out_row);
+    const int64_t r = i / out_row;
+    const int o = (int)(r % Cout), t = (int)(r / Cout);
+    out[i] = from_f<T>(c < Cin ? w[((int64_t)c * Cout + o) * f + t] : 0.f);
+  }
+}
+hipError_t launch_pack_convT(int dt, const float *w, int Cin, int Cout, int f, void *out, int64_t out_row, hipStream_t s) {
+  dim3 g = grid_for((int64_t)f * Cout * out_row);
+  SF_DISPATCH_STMT(dt, hipLaunchKernelGGL((pack_convT_kernel<T>), g, dim3(TPB), 0, s, w, Cin, Cout, f, (T *)out, out_row));
+  return hipGetLastError();
+}
 hipError_t launch_pack_rows(int dt, const float *in, int64_t rows, int cols, int64_t ldi, const float *cscale, void *out,
                             int64_t ldo, hipStream_t s) {
   dim3 g = grid_for(rows * cols);

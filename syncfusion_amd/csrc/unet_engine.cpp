@@ -40,7 +40,8 @@ struct Group {
 struct Block {
   int C = 0, cin = 0, factor = 1, ctx = 0, ctx_ld = 0, up_shift = 0;
   ConvW down, up;
-  int skip_off = 0;
+  bool up_transposed = false;   // ConvTranspose1d(kernel = stride = factor): a plain GEMM onto the (rows, factor * cin) view of the output
+  int skip_off = 0, skip_cols = 0;   // SkipModulate scale inside mod_all (tiled `factor` times for the transposed up path)
   std::vector<Group> down_items, up_items;
 };
 
@@ -366,11 +367,35 @@ void build(sf_unet &u, const WeightMap *wm, hipStream_t s) {
     const bool down_direct = ((b.factor * cin) % 32) != 0;
     if (down_direct && b.C > 32) fail(SF_ERR_UNSUPPORTED, "down conv at depth %d: %d -> %d needs (factor*in) %% 32 == 0", d, cin, b.C);
     b.down = bd.conv(pre + ".down", b.C, cin, b.factor, 0, true, down_direct, cin, 0);
-    // Upsample: nearest x f then Conv1d(C, cin, 3, padding=1)
     if (thin && cin > 32) fail(SF_ERR_UNSUPPORTED, "up conv at depth %d unsupported (%d -> %d)", d, b.C, cin);
-    b.up = bd.conv(pre + ".up", cin, b.C, 3, 0, true, thin, b.C, 0);
+    b.up_transposed = c.upsample_mode == SF_UP_TRANSPOSE;
+    if (b.up_transposed) {
+      // Upsample (a-unet `Upsample`): ConvTranspose1d(C -> cin, kernel = stride = f), weight (C, cin, f).  out[b, o, l*f + t] =
+      // sum_c x[b, c, l] w[c][o][t] + bias[o]: the mirror image of the patchify down-conv, ONE GEMM with N = f * cin columns
+      // over the (rows, f * cin) view of the output; bias and SkipModulate scale are tiled f times.
+      const int N = b.factor * cin;
+      const float *w = bd.get(pre + ".up.weight", (int64_t)b.C * cin * b.factor);
+      const float *bi = bd.get(pre + ".up.bias", cin);
+      ConvW &u_ = b.up;
+      u_.N = N;
+      u_.taps = 1;
+      u_.direct = thin;
+      u_.cin = b.C;
+      u_.K = u_.kreal = b.C;
+      if (!u.listing) {
+        const int wdt = thin ? F32 : u.dt;
+        u_.w = u.arena.alloc((int64_t)N * u_.K * dsize(wdt));
+        SF_HIP(launch_pack_convT(wdt, w, b.C, cin, b.factor, u_.w, u_.K, s));
+        u_.bias = u.arena.alloc_n<float>(N);
+        for (int t = 0; t < b.factor; ++t) SF_HIP(hipMemcpyAsync(u_.bias + (int64_t)t * cin, bi, cin * sizeof(float), hipMemcpyDeviceToDevice, s));
+      }
+    } else {
+      // UpsampleInterpolate: nearest x f then Conv1d(C, cin, 3, padding=1)
+      b.up = bd.conv(pre + ".up", cin, b.C, 3, 0, true, thin, b.C, 0);
+    }
     b.skip_off = mod_cols;
-    mod_cols = pad_to(mod_cols + cin, 4);   // every entry of the shared modulation vector starts 16-byte aligned
+    b.skip_cols = b.up_transposed ? b.factor * cin : cin;
+    mod_cols = pad_to(mod_cols + b.skip_cols, 4);   // every entry of the shared modulation vector starts 16-byte aligned
     b.down_items.assign(c.items[d], Group());
     b.up_items.assign(c.items[d], Group());
     for (int j = 0; j < c.items[d]; ++j) build_group(bd, b.down_items[j], pre + ".items_down." + std::to_string(j), d, mod_cols, ca_cols, n_ca);
@@ -392,8 +417,10 @@ void build(sf_unet &u, const WeightMap *wm, hipStream_t s) {
       const float *w = bd.get(pre + ".skip.to_scale.weight", (int64_t)b.cin * u.mf);
       const float *bi = bd.get(pre + ".skip.to_scale.bias", b.cin);
       if (!u.listing) {
-        bd.linear_into(u.mod, b.skip_off, w, b.cin, u.mf, nullptr);
-        SF_HIP(hipMemcpyAsync(u.mod.bias + b.skip_off, bi, b.cin * sizeof(float), hipMemcpyDeviceToDevice, s));
+        for (int t = 0; t < b.skip_cols / b.cin; ++t) {
+          bd.linear_into(u.mod, b.skip_off + t * b.cin, w, b.cin, u.mf, nullptr);
+          SF_HIP(hipMemcpyAsync(u.mod.bias + b.skip_off + t * b.cin, bi, b.cin * sizeof(float), hipMemcpyDeviceToDevice, s));
+        }
       }
     }
     for (int pass = 0; pass < 2; ++pass) {
@@ -1010,7 +1037,23 @@ struct Exec {
     }
     for (size_t j = 0; j < b.up_items.size(); ++j) group(b.up_items[j], d, cur, tA, tB, pre + ".items_up." + std::to_string(j));
     bool up_stats = false, up_done = false;
-    if (!b.up.direct && xout_dt == u.dt && xin_dt == u.dt) {   // nearest-upsample + conv3 + SkipModulate as a thin-level kernel
+    if (b.up_transposed) {   // x_out = skip + scale * ConvTranspose(h): one GEMM onto the (rows, f * cin) view of the outer level
+      ConvGemmArgs a;
+      a.src = cur;
+      a.src_ld = l.C;
+      a.M = (int)l.rows;
+      a.Lout = a.Lsrc = l.L;
+      a.out = xout;
+      a.out_ld = b.factor * b.cin;
+      a.res = xin;
+      a.res_ld = b.factor * b.cin;
+      a.bscale = p.mod_all + b.skip_off;
+      a.bscale_ld = p.mod_stride;
+      if (xout_dt != u.dt && !b.up.direct) fail(SF_ERR_UNSUPPORTED, "depth 0 must be a thin level (channels[0] %% 32 != 0)");
+      conv(b.up, a, u.dt, xout_dt);
+      up_done = true;
+    }
+    if (!up_done && !b.up.direct && xout_dt == u.dt && xin_dt == u.dt) {   // nearest-upsample + conv3 + SkipModulate as a thin-level kernel
       const ThinPlan tp = conv_thin_plan(p.Bt, Lprev, b.cin);
       ConvThinArgs a;
       a.B = p.Bt;

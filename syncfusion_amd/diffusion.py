@@ -72,7 +72,7 @@ class UNetV0(nn.Module):
                  embedding_features: Optional[int] = None, resnet_groups: int = 8, use_modulation: bool = True,
                  modulation_features: int = 1024, embedding_max_length: Optional[int] = None,
                  use_time_conditioning: bool = True, use_embedding_cfg: bool = False, use_text_conditioning: bool = False,
-                 out_channels: Optional[int] = None, dtype: str = "fp32", seed: Optional[int] = None):
+                 out_channels: Optional[int] = None, upsample_mode: str = "nearest", dtype: str = "fp32", seed: Optional[int] = None):
         super().__init__()
         n = len(channels)
         assert dim == 1, "only the 1-D U-Net of the reference config is implemented"
@@ -82,6 +82,9 @@ class UNetV0(nn.Module):
         assert embedding_max_length is not None, "use_embedding_cfg requires embedding_max_length"
         assert not use_text_conditioning, "use_text_conditioning (T5) is not part of the reference config"
         assert out_channels in (None, in_channels)
+        # a-unet UpsampleItem: "nearest" = nn.Upsample + Conv1d(k=3) (its default, what exp/model/diffusion.yaml selects by not
+        # overriding it); "transpose" = ConvTranspose1d(kernel = stride = factor) (a-unet's `Upsample`)
+        assert upsample_mode in ("nearest", "transpose"), f"upsample_mode must be 'nearest' or 'transpose', got {upsample_mode!r}"
         attentions = list(attentions) if attentions is not None else [0] * n
         cross_attentions = list(cross_attentions) if cross_attentions is not None else [0] * n
         context_channels = list(context_channels) if context_channels is not None else [0] * n
@@ -94,7 +97,7 @@ class UNetV0(nn.Module):
                             attentions=attentions, cross_attentions=cross_attentions, context_channels=context_channels,
                             attention_heads=attention_heads or 0, attention_features=attention_features or 0,
                             embedding_features=embedding_features or 0, embedding_max_length=embedding_max_length,
-                            modulation_features=modulation_features, resnet_groups=resnet_groups)
+                            modulation_features=modulation_features, resnet_groups=resnet_groups, upsample_mode=upsample_mode)
         self.compute_dtype = dtype
         self._engine: Optional[UNetEngine] = None
         gen = torch.Generator().manual_seed(seed) if seed is not None else None
@@ -128,7 +131,12 @@ class UNetV0(nn.Module):
             pre = f"blocks.{d}"
             f = hp["factors"][d]
             self._add_conv(pre + ".down", (C, cin, f), gen)
-            self._add_conv(pre + ".up", (cin, C, 3), gen)
+            if hp["upsample_mode"] == "transpose":   # torch ConvTranspose1d layout: weight (in = C, out = cin, kernel = f)
+                bound = 1.0 / math.sqrt(cin * f)       # torch computes fan_in from weight.size(1) * kernel for transposed convs too
+                self._add(pre + ".up.weight", (torch.rand(C, cin, f, generator=gen) * 2 - 1) * bound)
+                self._add(pre + ".up.bias", (torch.rand(cin, generator=gen) * 2 - 1) * bound)
+            else:
+                self._add_conv(pre + ".up", (cin, C, 3), gen)
             self._add_conv(pre + ".skip.to_scale", (cin, mf), gen)
             for side in ("items_down", "items_up"):
                 for j in range(hp["items"][d]):

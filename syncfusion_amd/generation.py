@@ -67,9 +67,9 @@ def generate_dataset(experiment_path: Union[str, Path], model, dataset: Iterable
     """Same signature as main/generation.py:12-30.  ``dataset`` yields already-collated batches."""
     experiment_path = Path(experiment_path)
     experiment_path.mkdir(exist_ok=True, parents=True)
-    if model_path:
+    if model_path:                                                                  # :40-44
         checkpoint = torch.load(model_path, map_location=device)
-        model.load_state_dict(checkpoint["state_dict"])
+        model.load_state_dict(checkpoint["state_dict"])     # upstream or local key layout (syncfusion_amd/keymap.py)
     model.to(device)
     written: List[Path] = []
     chunk_id = 0
@@ -84,12 +84,21 @@ def generate_dataset(experiment_path: Union[str, Path], model, dataset: Iterable
         gen = generate_batch(model, y, z, text, num_steps=num_steps, length=length, embedding_scale=embedding_scale,
                              cut_prefix=cut_prefix, cond_text=cond_text, cut_length=cut_length)
         out_sr = sample_rate
+        cond = z.to(gen.device).to(torch.float32) if (save_cond and not cond_text) else None   # :93-96: the conditioning audio itself
         if downsample_rate:                                                       # :90-98, on the device instead of the CPU
             gen = resample(gen, orig_freq=sample_rate, new_freq=downsample_rate)
+            if cond is not None:
+                cond = resample(cond, orig_freq=sample_rate, new_freq=downsample_rate)
             out_sr = downsample_rate
         for i in range(B):
-            name = f"{chunk_id}.wav" if not one_chunk_per_track else f"{str(filenames[i]).split('/')[-1]}.wav"
+            stem = f"{chunk_id}" if not one_chunk_per_track else str(filenames[i]).split('/')[-1]
+            # file set of :104-122: `{stem}.wav`; with save_cond `{stem}_{text}.wav` (text conditioning, replaces the plain name)
+            # or `{stem}.wav` + `{stem}_cond.wav` (audio conditioning)
+            name = f"{stem}_{text[i]}.wav" if (save_cond and cond_text) else f"{stem}.wav"
             save_wav(experiment_path / name, gen[i], out_sr)
             written.append(experiment_path / name)
+            if cond is not None:
+                save_wav(experiment_path / f"{stem}_cond.wav", cond[i], out_sr)
+                written.append(experiment_path / f"{stem}_cond.wav")
             chunk_id += 1
     return written

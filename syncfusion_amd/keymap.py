@@ -1,0 +1,244 @@
+"""Checkpoint compatibility: upstream ``state_dict`` layout -> this build's parameter names.
+
+The reference loads ``checkpoint['state_dict']`` straight into ``main.module_diffusion.Model``
+(main/generation.py:40-44; checkpoint named at script/run_evaluate_gh_gen.sh:9), so a drop-in must accept the key layout
+of the THIRD-PARTY module trees the reference instantiates (exp/model/diffusion.yaml:11-43):
+
+* ``model.*``            audio_diffusion_pytorch.DiffusionModel   (requirements.txt:23, ==0.1.3; U-Net blocks from ``a-unet``)
+* ``onsets_encoder.*``   audio_encoders_pytorch.Encoder1d         (requirements.txt:24, ==0.0.22)
+* ``clap.*``             laion_clap.CLAP_Module                   (frozen embedder; out of scope, ignored here)
+
+None of those packages is in /root/reference or installable offline, so everything below about THEIR naming is
+**[RECALLED]** -- written from memory of the upstream sources, to be confirmed by ``tools/pin_upstream.py`` on a
+networked machine.  Because of that the translation does not trust names more than it has to:
+
+1. keys that already are this build's names pass through;
+2. the duplicates upstream registers are dropped: ``DiffusionModel`` holds the same ``net`` three times (``model.net``,
+   ``model.diffusion.net``, ``model.sampler.net`` -- [RECALLED]: ``VDiffusion`` / ``VSampler`` assign ``self.net = net``);
+3. ``onsets_encoder.*`` uses an explicit rename table ([RECALLED] audio_encoders_pytorch: ``Patcher.block``,
+   ``DownsampleBlock1d.downsample`` / ``.blocks``, ``ConvBlock1d.groupnorm`` / ``.project``, ``ResnetBlock1d.to_out``);
+4. the U-Net is matched by STRUCTURE, not by name: tensors are grouped by (shape, weight/bias kind) and paired in order.
+   a-unet builds its tree from anonymous ``Module([...])`` / ``nn.ModuleList`` nodes whose indices cannot be recalled
+   reliably, but the ORDER of registration follows the forward order of the network, which the oracle restates:
+   ``[time embedding] -> block_d( down, items_down..., block_{d+1}, items_up..., up ) -> skip scale``, and inside an item
+   ``resnet(gn1, conv1, gn2, conv2) -> modulation -> inject -> attention(norm, norm_context, to_q, to_kv, to_out) ->
+   cross-attention(same)``.  Two placements cannot be settled by shapes alone and are explicit hypotheses
+   (``OrderHypothesis``): whether the time-embedding parameters are registered before or after the U-Net, and whether a
+   block's SkipModulate ``Linear`` comes before or after the block's items.  ``tools/pin_upstream.py`` decides them
+   numerically (the wrong choice changes the network's output).
+
+Every translation is verified: each local parameter receives exactly one tensor of its own shape, nothing is left over
+except ignorable subtrees, otherwise ``KeyMapError`` names what did not fit.
+"""
+from __future__ import annotations
+
+import re
+from collections import OrderedDict, defaultdict
+from dataclasses import dataclass
+from typing import Dict, Iterable, List, Mapping, Optional, Tuple
+
+import torch
+
+Tensor = torch.Tensor
+
+
+class KeyMapError(RuntimeError):
+    pass
+
+
+@dataclass(frozen=True)
+class OrderHypothesis:
+    """The two registration-order facts about a-unet that shapes cannot settle ([RECALLED] defaults)."""
+    time_first: bool = False     # TimeConditioningPlugin builds `net` first, then its embedding MLP ([RECALLED])
+    skip_last: bool = True       # SkipModulate's Linear is registered after the wrapped items ([RECALLED])
+
+    @staticmethod
+    def all() -> List["OrderHypothesis"]:
+        return [OrderHypothesis(a, b) for a in (False, True) for b in (True, False)]
+
+
+IGNORED_PREFIXES = ("clap.", "embedder.")
+_DUP_NET = re.compile(r"^(model\.)(diffusion|sampler)\.net\.")
+
+# [RECALLED] audio_encoders_pytorch==0.0.22 -> this build (syncfusion_amd/encoder1d.py)
+ENCODER_RULES: List[Tuple[re.Pattern, str]] = [
+    (re.compile(r"^to_in\.block\.(block[12])\.groupnorm\.(weight|bias)$"), r"to_in.\1.gn.\2"),
+    (re.compile(r"^to_in\.block\.(block[12])\.project\.(weight|bias)$"), r"to_in.\1.conv.\2"),
+    (re.compile(r"^to_in\.block\.to_out\.(weight|bias)$"), r"to_in.to_out.\1"),
+    (re.compile(r"^downsamples\.(\d+)\.downsample\.(weight|bias)$"), r"downsamples.\1.down.\2"),
+    (re.compile(r"^downsamples\.(\d+)\.blocks\.(\d+)\.(block[12])\.groupnorm\.(weight|bias)$"), r"downsamples.\1.blocks.\2.\3.gn.\4"),
+    (re.compile(r"^downsamples\.(\d+)\.blocks\.(\d+)\.(block[12])\.project\.(weight|bias)$"), r"downsamples.\1.blocks.\2.\3.conv.\4"),
+    (re.compile(r"^downsamples\.(\d+)\.blocks\.(\d+)\.to_out\.(weight|bias)$"), r"downsamples.\1.blocks.\2.to_out.\3"),
+]
+
+
+def _kind(name: str) -> str:
+    tail = name.rsplit(".", 1)[-1]
+    return tail if tail in ("weight", "bias") else "other"
+
+
+def unet_forward_order(hp: Mapping, hyp: OrderHypothesis = OrderHypothesis()) -> List[str]:
+    """This build's U-Net parameter names (without the ``net.`` prefix) in upstream REGISTRATION order under ``hyp``."""
+    time = ["time.fourier_w", "time.lin0.weight", "time.lin0.bias"] + [f"time.mlp.{i}.{k}" for i in range(2) for k in ("weight", "bias")]
+    cfg = ["cfg.fixed_embedding.weight"]
+
+    def item(pre: str, d: int) -> List[str]:
+        out = []
+        for nm in ("gn1", "conv1", "gn2", "conv2"):
+            out += [f"{pre}.resnet.{nm}.weight", f"{pre}.resnet.{nm}.bias"]
+        out += [f"{pre}.mod.to_scale_shift.weight", f"{pre}.mod.to_scale_shift.bias"]
+        if hp["context_channels"][d] > 0:
+            out += [f"{pre}.inject.conv.weight", f"{pre}.inject.conv.bias"]
+        for kind, on in (("attn", hp["attentions"][d]), ("cross", hp["cross_attentions"][d])):
+            if on:
+                a = f"{pre}.{kind}"
+                out += [a + ".norm.weight", a + ".norm.bias", a + ".norm_context.weight", a + ".norm_context.bias",
+                        a + ".to_q.weight", a + ".to_kv.weight", a + ".to_out.weight"]
+        return out
+
+    def block(d: int) -> List[str]:
+        pre = f"blocks.{d}"
+        skip = [pre + ".skip.to_scale.weight", pre + ".skip.to_scale.bias"]
+        out = [] if hyp.skip_last else list(skip)
+        out += [pre + ".down.weight", pre + ".down.bias"]
+        for j in range(hp["items"][d]):
+            out += item(f"{pre}.items_down.{j}", d)
+        if d + 1 < len(hp["channels"]):
+            out += block(d + 1)
+        for j in range(hp["items"][d]):
+            out += item(f"{pre}.items_up.{j}", d)
+        out += [pre + ".up.weight", pre + ".up.bias"]
+        if hyp.skip_last:
+            out += skip
+        return out
+
+    # ClassifierFreeGuidancePlugin wraps the XUNet and owns the fixed embedding; TimeConditioningPlugin wraps both
+    inner = block(0) + cfg
+    return (time + inner) if hyp.time_first else (inner + time)
+
+
+def match_by_structure(src: "OrderedDict[str, Tensor]", dst_order: List[str], dst_shapes: Mapping[str, Tuple[int, ...]]) -> Dict[str, str]:
+    """Pair tensors of ``src`` (in its own order) with the names of ``dst_order``: the k-th source tensor of a
+    (shape, weight/bias) class goes to the k-th destination of that class.  Returns {dst_name: src_name}."""
+    pools: Dict[Tuple, List[str]] = defaultdict(list)
+    for k, v in src.items():
+        pools[(tuple(v.shape), _kind(k))].append(k)
+    want: Dict[Tuple, List[str]] = defaultdict(list)
+    for k in dst_order:
+        want[(tuple(dst_shapes[k]), _kind(k))].append(k)
+    problems = []
+    for cls in sorted(set(pools) | set(want), key=str):
+        if len(pools.get(cls, [])) != len(want.get(cls, [])):
+            problems.append(f"{cls[1]} tensors of shape {cls[0]}: checkpoint has {len(pools.get(cls, []))}, the model needs {len(want.get(cls, []))}")
+    if problems:
+        raise KeyMapError("U-Net checkpoint does not fit this configuration:\n  " + "\n  ".join(problems[:12]))
+    out: Dict[str, str] = {}
+    for cls, names in want.items():
+        for dst, s in zip(names, pools[cls]):
+            out[dst] = s
+    return out
+
+
+def _strip(sd: Mapping[str, Tensor], prefix: str) -> "OrderedDict[str, Tensor]":
+    return OrderedDict((k[len(prefix):], v) for k, v in sd.items() if k.startswith(prefix))
+
+
+def translate_state_dict(sd: Mapping[str, Tensor], model: torch.nn.Module, hypothesis: Optional[OrderHypothesis] = None) -> "OrderedDict[str, Tensor]":
+    """Checkpoint ``state_dict`` of the reference's ``Model`` (upstream layout, or already this build's) -> this build's keys.
+
+    ``model`` is a ``syncfusion_amd.Model`` (anything with ``.model.net`` and ``.onsets_encoder``)."""
+    hyp = hypothesis or OrderHypothesis()
+    own = model.state_dict()
+    own_keys = [k for k in own if not k.startswith(IGNORED_PREFIXES)]
+    sd = OrderedDict((k, v) for k, v in sd.items() if not k.startswith(IGNORED_PREFIXES) and not _DUP_NET.match(k))
+    if set(own_keys) <= set(sd):                                 # already this build's layout
+        return OrderedDict((k, sd[k]) for k in own_keys)
+    out: "OrderedDict[str, Tensor]" = OrderedDict()
+    # --- Encoder1d: explicit [RECALLED] rename table, local names pass through ---
+    enc_own = {k[len("onsets_encoder."):] for k in own_keys if k.startswith("onsets_encoder.")}
+    left = []
+    for k, v in _strip(sd, "onsets_encoder.").items():
+        if k in enc_own:
+            out["onsets_encoder." + k] = v
+            continue
+        for pat, rep in ENCODER_RULES:
+            if pat.match(k):
+                out["onsets_encoder." + pat.sub(rep, k)] = v
+                break
+        else:
+            left.append("onsets_encoder." + k)
+    # --- U-Net: structure ---
+    net = model.model.net
+    net_own = OrderedDict((k[len("model.net."):], tuple(v.shape)) for k, v in own.items() if k.startswith("model.net."))
+    src = _strip(sd, "model.net.")
+    if not src:
+        raise KeyMapError("checkpoint has no `model.net.*` tensors (neither upstream nor local layout)")
+    if set(net_own) <= set(src):
+        for k in net_own:
+            out["model.net." + k] = src[k]
+    else:
+        order = unet_forward_order(net.hparams, hyp)
+        assert set(order) == set(net_own), "internal: forward-order list out of sync with UNetV0._build"
+        pairing = match_by_structure(src, order, net_own)
+        for dst, s in pairing.items():
+            out["model.net." + dst] = src[s]
+    other = [k for k in sd if not k.startswith(("model.net.", "onsets_encoder."))]
+    missing = [k for k in own_keys if k not in out]
+    bad_shape = [k for k in out if tuple(out[k].shape) != tuple(own[k].shape)]
+    if missing or bad_shape or left or other:
+        raise KeyMapError("checkpoint does not map onto this model: "
+                          f"missing {missing[:6]}{'...' if len(missing) > 6 else ''}; wrong shape {bad_shape[:6]}; "
+                          f"unrecognised {(left + other)[:6]}{'...' if len(left + other) > 6 else ''}")
+    return OrderedDict((k, out[k]) for k in own_keys)
+
+
+def to_upstream_layout(model: torch.nn.Module, hypothesis: Optional[OrderHypothesis] = None, anonymous: bool = True) -> "OrderedDict[str, Tensor]":
+    """The inverse, for tests and for ``tools/pin_upstream.py``: this model's tensors laid out as an upstream checkpoint
+    would be under ``hypothesis`` -- U-Net tensors in upstream registration order under index-style names
+    (``model.net.p{i}.weight``: a-unet's real node names are not recallable and the translation never reads them),
+    registered three times like upstream, Encoder1d under its [RECALLED] upstream names, plus a ``clap.*`` tensor."""
+    hyp = hypothesis or OrderHypothesis()
+    own = model.state_dict()
+    out: "OrderedDict[str, Tensor]" = OrderedDict()
+    order = unet_forward_order(model.model.net.hparams, hyp)
+    for prefix in ("model.net.", "model.diffusion.net.", "model.sampler.net."):
+        for i, k in enumerate(order):
+            name = f"p{i:04d}.{_kind(k)}" if anonymous and _kind(k) != "other" else (f"p{i:04d}.{k.rsplit('.', 1)[-1]}" if anonymous else k)
+            out[prefix + name] = own["model.net." + k]
+    inv = [(re.compile(r"^to_in\.(block[12])\.gn\.(weight|bias)$"), r"to_in.block.\1.groupnorm.\2"),
+           (re.compile(r"^to_in\.(block[12])\.conv\.(weight|bias)$"), r"to_in.block.\1.project.\2"),
+           (re.compile(r"^to_in\.to_out\.(weight|bias)$"), r"to_in.block.to_out.\1"),
+           (re.compile(r"^downsamples\.(\d+)\.down\.(weight|bias)$"), r"downsamples.\1.downsample.\2"),
+           (re.compile(r"^(downsamples\.\d+\.blocks\.\d+\.block[12])\.gn\.(weight|bias)$"), r"\1.groupnorm.\2"),
+           (re.compile(r"^(downsamples\.\d+\.blocks\.\d+\.block[12])\.conv\.(weight|bias)$"), r"\1.project.\2")]
+    for k, v in own.items():
+        if not k.startswith("onsets_encoder."):
+            continue
+        kk = k[len("onsets_encoder."):]
+        for pat, rep in inv:
+            if pat.match(kk):
+                kk = pat.sub(rep, kk)
+                break
+        out["onsets_encoder." + kk] = v
+    out["clap.model.logit_scale_a"] = torch.zeros(())
+    return out
+
+
+def load_checkpoint(model: torch.nn.Module, path: str, device="cpu", hypothesis: Optional[OrderHypothesis] = None) -> None:
+    """``torch.load(path)['state_dict']`` into ``model`` the way main/generation.py:40-44 does, accepting either layout."""
+    checkpoint = torch.load(path, map_location=device)
+    sd = checkpoint["state_dict"] if isinstance(checkpoint, Mapping) and "state_dict" in checkpoint else checkpoint
+    model.load_state_dict(sd, hypothesis=hypothesis) if _accepts_hypothesis(model) else model.load_state_dict(translate_state_dict(sd, model, hypothesis))
+
+
+def _accepts_hypothesis(model) -> bool:
+    import inspect
+
+    try:
+        return "hypothesis" in inspect.signature(model.load_state_dict).parameters
+    except (TypeError, ValueError):
+        return False
+
+
+def iter_hypotheses() -> Iterable[OrderHypothesis]:
+    return OrderHypothesis.all()

@@ -94,6 +94,20 @@ class Model(_Base):
         for param in self.clap.parameters():
             param.requires_grad = False
 
+    def load_state_dict(self, state_dict, strict: bool = True, hypothesis=None, **kwargs):
+        """``model.load_state_dict(checkpoint['state_dict'])`` as main/generation.py:43 calls it.  Accepts this build's key
+        layout AND the upstream one (audio_diffusion_pytorch / a-unet / audio_encoders_pytorch module trees; see
+        syncfusion_amd/keymap.py for how, and for what is [RECALLED] about it).  The frozen embedder's ``clap.*`` tensors
+        are loaded only when this model's embedder actually has those keys (the offline stub does not)."""
+        from .keymap import IGNORED_PREFIXES, translate_state_dict
+
+        mapped = translate_state_dict(state_dict, self, hypothesis)
+        own = super().state_dict()
+        for k in own:
+            if k.startswith(IGNORED_PREFIXES):
+                mapped[k] = state_dict[k] if k in state_dict and tuple(state_dict[k].shape) == tuple(own[k].shape) else own[k]
+        return super().load_state_dict(mapped, strict=strict, **kwargs)
+
     def configure_optimizers(self):
         return torch.optim.AdamW(list(self.model.parameters()) + list(self.onsets_encoder.parameters()), lr=self.lr,
                                  betas=(self.lr_beta1, self.lr_beta2), eps=self.lr_eps, weight_decay=self.lr_weight_decay)

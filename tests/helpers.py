@@ -87,11 +87,11 @@ def reference_model_config() -> dict:
     return model_config()
 
 
-def small_unet_module(seed: int = 1234, dtype: str = "fp32"):
+def small_unet_module(seed: int = 1234, dtype: str = "fp32", upsample_mode: str = "nearest"):
     from syncfusion_amd.diffusion import UNetV0
 
     kw = {k: v for k, v in SMALL_UNET.items()}
-    net = UNetV0(dim=1, use_embedding_cfg=True, dtype=dtype, seed=seed, **kw)
+    net = UNetV0(dim=1, use_embedding_cfg=True, dtype=dtype, seed=seed, upsample_mode=upsample_mode, **kw)
     net.load_state_dict(seeded_state(net, seed))
     return net
 

@@ -60,6 +60,39 @@ def test_unet_forward_shapes_fp32(cuda, small_net, B, L0):
     assert rel_l2(out.cpu(), ref) < FP32_TOL
 
 
+@pytest.mark.parametrize("dtype,tol", [("fp32", FP32_TOL), ("bf16", BF16_TOL), ("fp16", BF16_TOL)])
+def test_unet_transposed_upsample_mode(cuda, dtype, tol):
+    """north_star's "transposed-conv blocks": upsample_mode="transpose" (ConvTranspose1d(kernel = stride = factor), a-unet's
+    `Upsample`) runs as an un-patchify GEMM with the SkipModulate epilogue; every block-level activation against the oracle,
+    with and without guidance, then a 6-step sample."""
+    net = small_unet_module(dtype=dtype, upsample_mode="transpose").to(cuda)
+    B, L0 = 3, 16 * 23
+    x, sigma, emb, chans = synth_inputs(SMALL_UNET, B, L0, seed=17)
+    taps_ref = {}
+    ref = _oracle_unet(net, x, sigma, emb, chans, 1.0, taps_ref)
+    out, taps = net.engine().forward_with_taps(x.to(cuda), sigma.to(cuda), [c.to(cuda) for c in chans], emb.to(cuda), 1.0)
+    for name, t in taps_ref.items():
+        got = taps[name].cpu().reshape(B, -1, t.shape[1]).transpose(1, 2)
+        assert rel_l2(got, t) < tol, f"tap {name}"
+    assert rel_l2(out.cpu(), ref) < tol
+    ref2 = _oracle_unet(net, x, sigma, emb, chans, 3.0)
+    out2 = net(x.to(cuda), sigma.to(cuda), embedding=emb.to(cuda), channels=[c.to(cuda) for c in chans], embedding_scale=3.0)
+    assert rel_l2(out2.cpu(), ref2) < 2 * tol
+    if dtype == "fp32":
+        import functools
+
+        from syncfusion_amd.diffusion import DiffusionModel, UNetV0, VDiffusion, VSampler
+
+        m = DiffusionModel(net_t=functools.partial(UNetV0, seed=1234, upsample_mode="transpose"), diffusion_t=VDiffusion, sampler_t=VSampler,
+                           use_embedding_cfg=True, **SMALL_UNET)
+        m.net.load_state_dict(seeded_state(m.net, 1234))
+        m = m.to(cuda)
+        noise = torch.randn(B, 1, L0, generator=torch.Generator().manual_seed(1000))
+        ref3 = _oracle_sample(m, noise, 6, emb, chans, 2.0)
+        out3 = m.sample(x_noisy=noise.to(cuda), num_steps=6, channels=[c.to(cuda) for c in chans], embedding=emb.to(cuda), embedding_scale=2.0)
+        assert rel_l2(out3.cpu(), ref3) < FP32_TOL
+
+
 def test_unet_cfg_batched_equals_two_passes(cuda, small_net):
     """embedding_scale != 1: the engine's single 2B batch == upstream's two sequential passes (oracle)."""
     B, L0 = 2, 16 * 20

@@ -26,13 +26,16 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert lib.sf_device_ok() in (0, 1)
 
 
-def test_param_enumeration_matches_module_state_dict():
-    """sf_unet_param_name (host-only call) lists exactly the UNetV0 state_dict with a `net.` prefix."""
+@pytest.mark.parametrize("upsample_mode", ["nearest", "transpose"])
+def test_param_enumeration_matches_module_state_dict(upsample_mode):
+    """sf_unet_param_name (host-only call) lists exactly the UNetV0 state_dict with a `net.` prefix, for both up-path forms
+    (nearest + Conv1d(k=3): `up.weight` (in, C, 3); ConvTranspose1d(kernel = stride = f): (C, in, f))."""
     from syncfusion_amd import _lib
 
     lib = _lib.load()
-    net = small_unet_module()
+    net = small_unet_module(upsample_mode=upsample_mode)
     cfg = _lib.UnetConfig()
+    cfg.upsample_mode = _lib.UPSAMPLE_MODES[upsample_mode]
     hp = net.hparams
     cfg.n_layers = len(hp["channels"])
     cfg.in_channels = hp["in_channels"]
@@ -41,6 +44,7 @@ def test_param_enumeration_matches_module_state_dict():
             getattr(cfg, f)[i] = v
     for f in ("attention_heads", "attention_features", "embedding_features", "embedding_max_length", "modulation_features", "resnet_groups"):
         setattr(cfg, f, hp[f])
+    assert tuple(net.state_dict()["blocks.1.up.weight"].shape) == ((8, 32, 3) if upsample_mode == "nearest" else (32, 8, 4))
     n = lib.sf_unet_param_count(C.byref(cfg))
     names = {}
     for i in range(n):

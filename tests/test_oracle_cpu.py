@@ -117,6 +117,32 @@ def test_cfg_scale_one_is_single_pass_and_batched_is_two_passes():
         assert rel_l2(both[2:] + (both[:2] - both[2:]) * 2.5, two) < 1e-5
 
 
+def test_unet_transposed_up_path_is_an_unpatchify_gemm():
+    """upsample_mode="transpose" (a-unet `Upsample`: ConvTranspose1d(kernel = stride = factor)): the oracle's conv_transpose1d
+    equals the (rows, factor * in) GEMM view the HIP engine runs, and the output keeps the U-Net's shape contract."""
+    net = small_unet_module(upsample_mode="transpose")
+    P, cfg = oracle_params(net, "net."), dict(net.hparams)
+    assert cfg["upsample_mode"] == "transpose"
+    x, sigma, emb, chans = synth_inputs(SMALL_UNET, 2, 16 * 6, seed=8)
+    with torch.no_grad():
+        v = unet_ref.unet_forward(P, cfg, x, sigma, embedding=emb, channels=chans)
+    assert v.shape == x.shape and torch.isfinite(v).all()
+    w, b = P["net.blocks.2.up.weight"], P["net.blocks.2.up.bias"]          # (C=64, in=32, f=2)
+    h = torch.randn(3, 64, 10, generator=torch.Generator().manual_seed(0))
+    ref = torch.nn.functional.conv_transpose1d(h, w, b, stride=2)           # (3, 32, 20)
+    mat = w.permute(2, 1, 0).reshape(2 * 32, 64)                             # [n = t*in + o][c]
+    got = (h.transpose(1, 2) @ mat.t() + b.repeat(2)).reshape(3, 10, 2, 32).reshape(3, 20, 32).transpose(1, 2)
+    assert rel_l2(got, ref) < 1e-6
+    # both modes have the same parameter count except the up kernels (3 taps vs f taps)
+    near = small_unet_module(upsample_mode="nearest")
+    d = sum(p.numel() for p in near.parameters()) - sum(p.numel() for p in net.parameters())
+    cin, want = SMALL_UNET["in_channels"], 0
+    for C, f in zip(SMALL_UNET["channels"], SMALL_UNET["factors"]):
+        want += cin * C * (3 - f)
+        cin = C
+    assert d == want
+
+
 def test_sampler_identities():
     x0 = torch.randn(3, 1, 50, generator=torch.Generator().manual_seed(1))
     for T in (1, 2, 7, 50):
