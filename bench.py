@@ -70,10 +70,10 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
-def spawn_ranks(args) -> int:
+def spawn_ranks(args, script: str = os.path.abspath(__file__), argv=None) -> int:
     """--gpus N from a plain shell: N fresh child ranks (one per GPU) under torchrun.  The parent never initialises HIP."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(args.master_port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-port", str(args.master_port), script] + list(sys.argv[1:] if argv is None else argv)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)

@@ -1368,8 +1368,37 @@ int sf_vsample(sf_unet *h, float *x, const float *const *ctx, const float *emb, 
   }
   Exec ex{*h, p, s};
   h->dbg.reset();
-  float *dbg_buf = h->dbg.buf;
-  h->dbg.buf = nullptr;  // taps are a forward()-only facility
+  // taps are a forward()-only facility: cleared for the call, restored on EVERY exit path
+  struct DbgGuard {
+    DebugTaps &d;
+    float *saved;
+    ~DbgGuard() { d.buf = saved; }
+  } dbg_guard{h->dbg, h->dbg.buf};
+  h->dbg.buf = nullptr;
+  // A failure below (EngineError, HIP error, failed capture) must not leave work queued on the engine's streams, nor a
+  // half-valid graph cache: drain the streams, drop the cached graphs, then report the error.
+  struct FailGuard {
+    sf_unet *h;
+    bool armed = true;
+    ~FailGuard() {
+      if (!armed) return;
+      if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
+      for (hipStream_t b : h->bstream)
+        if (b) (void)hipStreamSynchronize(b);
+      h->gkey.valid = false;
+      h->gexec_indep = false;
+      if (h->gexec) {
+        (void)hipGraphExecDestroy(h->gexec);
+        h->gexec = nullptr;
+      }
+      for (hipGraphExec_t &g : h->gexec_br)
+        if (g) {
+          (void)hipGraphExecDestroy(g);
+          g = nullptr;
+        }
+      (void)hipGetLastError();
+    }
+  } fail_guard{h};
   static const bool timing = getenv("SF_TIMING") != nullptr;   // debugging aid: host-side phase times on stderr
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto ms_since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(now() - t0).count(); };
@@ -1552,7 +1581,7 @@ int sf_vsample(sf_unet *h, float *x, const float *const *ctx, const float *emb, 
     SF_HIP(hipEventRecord(h->ev_out, s));
     SF_HIP(hipStreamWaitEvent(user, h->ev_out, 0));
   }
-  h->dbg.buf = dbg_buf;
+  fail_guard.armed = false;
   return SF_OK;
   SF_API_END
 }

@@ -44,7 +44,12 @@ def broadcast_module(module: torch.nn.Module, src: int = 0) -> int:
     if not tensors:
         return 0
     flat = torch.cat([t.detach().reshape(-1).to(torch.float32) for t in tensors])
-    dist.broadcast(flat, src=src)
+    if flat.is_cuda and dist.get_backend() != "nccl":      # gloo (CPU tests with device tensors): stage through the host
+        host = flat.cpu()
+        dist.broadcast(host, src=src)
+        flat = host.to(flat.device)
+    else:
+        dist.broadcast(flat, src=src)
     off = 0
     for t in tensors:
         n = t.numel()
@@ -59,6 +64,10 @@ def gather_clips(local: torch.Tensor, total: int, dst: int = 0) -> Optional[torc
     if _single():
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
+    dev = local.device
+    if local.is_cuda and dist.get_backend() != "nccl":     # gloo: gather on the host, return on the caller's device
+        out = gather_clips(local.cpu(), total, dst)
+        return None if out is None else out.to(dev)
     sizes = [shard_range(total, r, world) for r in range(world)]
     maxb = max(hi - lo for lo, hi in sizes)
     pad = torch.zeros((maxb,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)

@@ -52,3 +52,47 @@ def test_broadcast_and_gather_world2():
     assert moved0 == moved1 > 0
     assert out1 is None
     assert out0 == [0.0, 1.0, 2.0, 3.0, 4.0], "gathered clips are not the rank-order concatenation"
+
+
+_FAKE_RANK = r'''
+import json, os, sys
+import torch, torch.distributed as dist
+dist.init_process_group("gloo")
+t = torch.tensor([float(dist.get_rank() + 1)])
+dist.all_reduce(t)
+print("noise on stdout from rank", dist.get_rank())
+if dist.get_rank() == 0:
+    print(json.dumps({"metric": "fake", "n_gpus": dist.get_world_size(), "sum": float(t), "argv": sys.argv[1:]}))
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus_flag_spawns_fresh_ranks(tmp_path, capfd):
+    """`bench.py --gpus N` from a plain shell (no WORLD_SIZE) starts N ranks under torch.distributed.run and relays rank 0's
+    JSON line (the launcher itself, with a CPU stand-in for the rank body); a WORLD_SIZE that disagrees with --gpus is refused."""
+    import json
+    import subprocess
+
+    import bench
+
+    script = tmp_path / "fake_rank.py"
+    script.write_text(_FAKE_RANK)
+    args = bench.parse_args(["--gpus", "2", "--master-port", "29641"])
+    env_before = {k: os.environ.pop(k, None) for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    try:
+        rc = bench.spawn_ranks(args, script=str(script), argv=["--gpus", "2", "--steps", "3"])
+    finally:
+        for k, v in env_before.items():
+            if v is not None:
+                os.environ[k] = v
+    out, _ = capfd.readouterr()
+    assert rc == 0
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out                       # stdout carries exactly ONE JSON line; everything else went to stderr
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["sum"] == 3.0 and line["argv"] == ["--gpus", "2", "--steps", "3"]
+    # a rank environment that disagrees with --gpus is an error, not a silent single-GPU run
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=dict(os.environ, WORLD_SIZE="2", RANK="0"),
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode == 2 and "disagrees with WORLD_SIZE" in r.stderr

@@ -1,0 +1,97 @@
+"""Multi-GPU path on a 1-GPU box: the RCCL code path with one rank, and a 2-process run (gloo
+rendezvous, both ranks on cuda:0) that shards a real sampler call and gathers it.
+
+No data-path collective exists: clips are independent.  What is checked is the contract of 8e -- contiguous shards,
+per-rank noise seed 1000 + rank, weights broadcast once, outputs gathered once -- on actual model output:
+the gathered 2-rank result equals the concatenation of two single-process runs, bit for bit.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import ROOT, SMALL_ENCODER, SMALL_UNET, seeded_state
+
+pytestmark = pytest.mark.gpu
+
+B_TOTAL, L0, STEPS, SCALE = 4, 16 * 44, 4, 2.0
+
+
+def _build(seed_weights: int):
+    import functools
+
+    from syncfusion_amd import DiffusionModel, Encoder1d, Model, RandomEmbedder, UNetV0, VDiffusion, VSampler
+
+    dm = DiffusionModel(net_t=functools.partial(UNetV0, seed=seed_weights), diffusion_t=VDiffusion, sampler_t=VSampler, use_embedding_cfg=True, **SMALL_UNET)
+    enc = Encoder1d(seed=seed_weights, **SMALL_ENCODER)
+    m = Model(1e-4, 0.95, 0.999, 1e-6, 1e-3, dm, enc, RandomEmbedder(SMALL_UNET["embedding_features"]), None)
+    m.load_state_dict(seeded_state(m, seed_weights))
+    return m.to("cuda:0")
+
+
+def _shard_sample(model, rank: int, world: int):
+    """What a rank does: its contiguous clip slice, noise seed 1000 + rank, conditioning by GLOBAL clip index."""
+    from syncfusion_amd.dist import rank_seed, shard_range
+
+    lo, hi = shard_range(B_TOTAL, rank, world)
+    noise = torch.randn(hi - lo, 1, L0, generator=torch.Generator().manual_seed(rank_seed(1000, rank))).cuda()
+    y = torch.zeros(B_TOTAL, 1, L0)
+    for b in range(B_TOTAL):
+        y[b, 0, 17 + 29 * b] = 1.0
+    emb = torch.nn.functional.normalize(torch.randn(B_TOTAL, 1, SMALL_UNET["embedding_features"], generator=torch.Generator().manual_seed(2000)), dim=-1)
+    _, info = model.onsets_encoder(y[lo:hi].cuda(), with_info=True)
+    return model.model.sample(x_noisy=noise, num_steps=STEPS, channels=info["xs"][2:-1], embedding=emb[lo:hi].cuda(), embedding_scale=SCALE)
+
+
+def _worker(rank: int, world: int, port: int, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from syncfusion_amd.dist import broadcast_module, gather_clips
+
+        model = _build(seed_weights=100 + rank)            # ranks start with DIFFERENT weights: the broadcast must fix that
+        moved = broadcast_module(model, src=0)
+        out = _shard_sample(model, rank, world)
+        full = gather_clips(out, B_TOTAL, dst=0)
+        q.put((rank, moved, None if full is None else full.cpu()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_sharded_sample_equals_concatenated_single_runs(cuda):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, 29655, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=500) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, moved0, full0), (_, moved1, full1) = res
+    assert moved0 == moved1 > 0 and full1 is None and full0.shape == (B_TOTAL, 1, L0)
+    # the same two shards computed one after the other in THIS process with rank 0's weights
+    model = _build(seed_weights=100)
+    want = torch.cat([_shard_sample(model, r, 2).cpu() for r in range(2)])
+    assert torch.equal(full0, want), "2-rank gather differs from the concatenation of the single-rank runs"
+
+
+@pytest.mark.timeout(900)
+def test_bench_force_dist_runs_the_rccl_path_with_one_rank(cuda):
+    """bench.py --force-dist: init_process_group("nccl") = RCCL with world size 1, flat weight broadcast, all_gather of the clips."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--master-port", "29657"], capture_output=True, text=True, timeout=850,
+                       env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["gathered_clips"] == 8
+    assert line["config"]["weights_broadcast_bytes"] > 4 * 214e6      # every fp32 master of the 215 M-parameter U-Net + Encoder1d
+    assert line["value"] > 0 and line["extra"] is None
