@@ -225,11 +225,47 @@ def extra_workloads(model, device, args, noise, channels, emb) -> dict:
         return dict(workload="VideoOnsetNet (R(2+1)D-18) forward, N=32 clips of (3,30,112,112)", clips_per_s=round(N / dt, 1),
                     tflops=round(tf, 1), mfma_frac=round(tf / PEAK_BF16_TFLOPS, 4), dtype=onset.compute_dtype)
 
+    def e2e_leg():
+        # BASELINE configs[4] on one GPU's share (32 clips): 2 s x 15 fps RGB frames -> onset net -> logits-to-track glue ->
+        # Encoder1d -> 100-step guided diffusion -> cut_prefix / crop, everything in fp16, no host round trip in between
+        from syncfusion_amd.generation import generate_batch
+        from syncfusion_amd.onset_glue import onsets_to_track
+        from syncfusion_amd.onset_net import VideoOnsetNet
+
+        B, steps, scale = 32, 100, 2.0
+        torch.manual_seed(7)
+        onset = VideoOnsetNet(False, dtype="fp16").to(device).eval()
+        frames = torch.randn(B, 3, 30, 112, 112, generator=torch.Generator().manual_seed(4000)).to(device)
+        z = (torch.randn(B, 1, L0, generator=torch.Generator().manual_seed(1)) * 0.1).to(device)
+        prev = net.compute_dtype
+        net.compute_dtype = "fp16"
+        try:
+            def once(n_steps):
+                logits = onset(frames)
+                logits[:, 3] = 1.0   # random-init logits sit near 0.1 (no onsets): force one so cut_prefix has a first onset
+                track = onsets_to_track(logits, L0, frame_rate=15.0, sample_rate=22528.0)
+                return generate_batch(model, track, z, num_steps=n_steps, length=L0, embedding_scale=scale, cut_prefix=True, cut_length=44100)
+
+            once(2)
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            gen = once(steps)
+            torch.cuda.synchronize(device)
+            dt = time.perf_counter() - t0
+        finally:
+            net.compute_dtype = prev
+            net.engine()
+        assert gen.shape == (B, 1, 44100) and torch.isfinite(gen).all()
+        return dict(workload="BASELINE configs[4], one GPU's share: 32 clips of 30x112x112 RGB frames -> VideoOnsetNet -> onset track -> Encoder1d -> "
+                             "100-step diffusion (scale 2.0) -> cut/crop, fp16", clips_per_s=round(B / dt, 2), seconds_per_batch=round(dt, 3),
+                    denoise_steps_per_s=round(steps / dt, 2), dtype="fp16")
+
     if args.dtype != "fp32":
         leg("fp32_config1", fp32_leg)
     leg("config2_b32_cfg", config2_leg)
     leg("reference_eval_shape", reference_leg)
     leg("onset_net_n32", onset_leg)
+    leg("e2e_config4_fp16", e2e_leg)
     return out
 
 

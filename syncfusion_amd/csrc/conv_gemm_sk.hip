@@ -359,6 +359,14 @@ int conv_gemm_sk_variant(const ConvGemmArgs &a) {
   // measured (tools/gemm_sweep.py): on short activations the smallest tile wins at every U-Net shape -- more
   // workgroups in flight matter more than operand reuse
   auto blocks = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.n_store + bn - 1) / bn); };
+  static const int exp_rule = [] {   // tuning hook (tools/): alternative tile rules under the two-branch bench
+    const char *e = getenv("SF_SK_TILE_RULE");
+    return e ? atoi(e) : 0;
+  }();
+  if (exp_rule == 1 && blocks(32, 32) > 300 && a.K >= 512) return 1;
+  if (exp_rule == 2 && a.K >= 1024) return 1;
+  if (exp_rule == 3 && blocks(32, 32) > 300 && a.K >= 512) return 0;
+  if (exp_rule == 4 && a.K >= 1024) return 0;
   if (blocks(32, 32) <= 4096) return 2;
   if (blocks(64, 32) <= 4096) return 1;
   return 0;

@@ -931,7 +931,12 @@ ThinPlan conv_thin_plan(int B, int L, int C) {
   }();
   // a wave's fixed cost (weights, prologue table, epilogue bookkeeping) is amortised over 32 positions x C channels
   // per tile: the 8-channel level gives each wave several tiles
-  const int max_rows = C <= 8 ? rows8 : 512;
+  static const int rows_cap = [] {   // tuning hook: upper bound of positions per workgroup above 8 channels
+    const char *e = getenv("SF_THIN_MAXROWS");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 512;
+  }();
+  const int max_rows = C <= 8 ? rows8 : rows_cap;
   static const int wgs = [] {   // tuning hook: workgroups a launch aims for
     const char *e = getenv("SF_THIN_WGS");
     const int v = e ? atoi(e) : 0;

@@ -129,6 +129,65 @@ struct sf_unet {
       return valid && o.valid && B == o.B && L0 == o.L0 && T == o.T && nbr == o.nbr && two == o.two && scale == o.scale && ws == o.ws;
     }
   } gkey;
+  // Step graphs of OTHER recently used (shape, workspace, guidance) combinations: a server alternating between a few request
+  // shapes replays cached graphs instead of re-capturing and re-instantiating on every switch.
+  struct GraphEntry {
+    GraphKey key;
+    hipGraphExec_t g = nullptr, br[8] = {};
+    bool indep = false;
+    void destroy() {
+      if (g) (void)hipGraphExecDestroy(g);
+      for (hipGraphExec_t &b : br)
+        if (b) (void)hipGraphExecDestroy(b);
+      g = nullptr;
+      for (hipGraphExec_t &b : br) b = nullptr;
+    }
+  };
+  static constexpr size_t kGraphStash = 3;
+  std::vector<GraphEntry> gstash;   // most recently stashed last
+  // make `key` the active graph set: a stashed set is swapped in, the displaced active set is stashed (oldest evicted)
+  void activate_graphs(const GraphKey &key) {
+    if (gkey == key) return;
+    GraphEntry cur;
+    cur.key = gkey;
+    cur.g = gexec;
+    cur.indep = gexec_indep;
+    for (int i = 0; i < 8; ++i) cur.br[i] = gexec_br[i];
+    gexec = nullptr;
+    gexec_indep = false;
+    for (hipGraphExec_t &b : gexec_br) b = nullptr;
+    gkey.valid = false;
+    for (size_t i = 0; i < gstash.size(); ++i)
+      if (gstash[i].key == key) {
+        gkey = gstash[i].key;
+        gexec = gstash[i].g;
+        gexec_indep = gstash[i].indep;
+        for (int j = 0; j < 8; ++j) gexec_br[j] = gstash[i].br[j];
+        gstash.erase(gstash.begin() + i);
+        break;
+      }
+    if (cur.key.valid && (cur.g || cur.br[0])) {
+      if (gstash.size() >= kGraphStash) {
+        gstash.front().destroy();
+        gstash.erase(gstash.begin());
+      }
+      gstash.push_back(cur);
+    } else {
+      cur.destroy();
+    }
+  }
+  void drop_all_graphs() {
+    gkey.valid = false;
+    gexec_indep = false;
+    if (gexec) (void)hipGraphExecDestroy(gexec);
+    gexec = nullptr;
+    for (hipGraphExec_t &g : gexec_br) {
+      if (g) (void)hipGraphExecDestroy(g);
+      g = nullptr;
+    }
+    for (GraphEntry &e : gstash) e.destroy();
+    gstash.clear();
+  }
 
   // stream capture is illegal on the legacy null stream (torch's default): the sampling loop runs on an
   // engine-owned stream, fenced against the caller's stream with events on both sides
@@ -151,9 +210,7 @@ struct sf_unet {
   }
 
   ~sf_unet() {
-    if (gexec) (void)hipGraphExecDestroy(gexec);
-    for (hipGraphExec_t g : gexec_br)
-      if (g) (void)hipGraphExecDestroy(g);
+    drop_all_graphs();
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     for (int i = 0; i < kMaxBranches; ++i) {
       if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
@@ -1385,17 +1442,7 @@ int sf_vsample(sf_unet *h, float *x, const float *const *ctx, const float *emb, 
       if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
       for (hipStream_t b : h->bstream)
         if (b) (void)hipStreamSynchronize(b);
-      h->gkey.valid = false;
-      h->gexec_indep = false;
-      if (h->gexec) {
-        (void)hipGraphExecDestroy(h->gexec);
-        h->gexec = nullptr;
-      }
-      for (hipGraphExec_t &g : h->gexec_br)
-        if (g) {
-          (void)hipGraphExecDestroy(g);
-          g = nullptr;
-        }
+      h->drop_all_graphs();
       (void)hipGetLastError();
     }
   } fail_guard{h};
@@ -1466,6 +1513,7 @@ int sf_vsample(sf_unet *h, float *x, const float *const *ctx, const float *emb, 
   key.scale = embedding_scale;
   key.ws = ws;
   key.valid = true;
+  if (use_graph && T > 1 && !h->prof_on) h->activate_graphs(key);
   // One host synchronisation per call, placed HERE: the pageable H2D copies of the schedule above must have been staged
   // before `host` dies, and the step graphs are measurably faster when their streams are idle at the first launch
   // (449 vs 408 steps/s at 50 steps: launching onto busy streams leaves the two branch pipelines out of phase).
