@@ -428,7 +428,21 @@ const char *label_for_dtype(int dt, const char *bf16_label) {
 static const char *variant_name_bf16(int dt, const ConvGemmArgs &a);
 const char *conv_gemm_variant_name(int dt, const ConvGemmArgs &a) { return label_for_dtype(dt, variant_name_bf16(dt, a)); }
 
+// Macro tiles pay when they fill the chip: >= ~5/8 of the CUs get a 256x128 tile and the reduction is long enough for the
+// three-slot ring to reach steady state (measured against conv_gemm_v2: tools/gemm_big.py).
+bool conv_gemm_prefers_mt(const ConvGemmArgs &a) {
+  static const int mode = [] {   // SF_MT=0 disables the kernel, SF_MT=2 prefers it wherever it is eligible (tuning / tests)
+    const char *e = getenv("SF_MT");
+    return e ? atoi(e) : 1;
+  }();
+  if (mode == 0) return false;
+  if (mode == 2) return true;
+  const long tiles = (long)((a.M + 255) / 256) * ((a.n_store + 127) / 128);
+  return tiles >= 160 && a.K >= 256;
+}
+
 static const char *variant_name_bf16(int dt, const ConvGemmArgs &a) {
+  if (g_conv_gemm_force.path == 6 || (g_conv_gemm_force.path == 0 && conv_gemm_mt_ok(dt, a) && conv_gemm_prefers_mt(a))) return "conv_gemm_mt<bf16,256x128>";
   static const char *names[2][5] = {{"conv_gemm<f32,64x64,scalarA>", "conv_gemm<f32,128x32>", "conv_gemm<f32,128x64>", "conv_gemm<f32,64x64>", "conv_gemm<f32,128x128>"},
                                     {"conv_gemm<bf16,64x64,scalarA>", "conv_gemm<bf16,128x32>", "conv_gemm<bf16,128x64>", "conv_gemm<bf16,64x64>", "conv_gemm<bf16,128x128>"}};
   static const char *sk_names[2][3] = {{"conv_gemm_sk<f32,64x64>", "conv_gemm_sk<f32,64x32>", "conv_gemm_sk<f32,32x32>"},
@@ -467,6 +481,8 @@ bool conv_gemm_emits_rowpart(int dt, const ConvGemmArgs &a) {
 hipError_t launch_conv_gemm(int dt, const ConvGemmArgs &a, hipStream_t s) {
   if (!conv_gemm_supported(dt, a)) return hipErrorInvalidValue;
   const ConvGemmForce &f = g_conv_gemm_force;
+  if (f.path == 6) return launch_conv_gemm_mt(dt, a, s);
+  if (f.path == 0 && conv_gemm_mt_ok(dt, a) && conv_gemm_prefers_mt(a)) return launch_conv_gemm_mt(dt, a, s);
   const long t64 = (long)((a.M + 63) / 64) * ((a.n_store + 63) / 64);
   const bool short_act = t64 < 500 && a.K >= 256 && (a.K % 32) == 0 && (a.cin % 32) == 0 && (a.cin2 % 32) == 0;
   if (f.path == 4 || (f.path == 0 && !short_act)) {

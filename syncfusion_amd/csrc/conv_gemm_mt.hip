@@ -1,0 +1,288 @@
+// Macro-tile MFMA implicit GEMM ("mt") for LONG activations in the 16-bit types: the MFMA-bound regime of the path
+// (VideoOnsetNet at any batch, the U-Net's deep levels at the guidance batch of BASELINE configs[2]).
+//
+// Why another GEMM: a CU's L2 -> LDS fill rate (~29 B/clk, MI355X_MICROARCH.md) caps a bm x bn tile at
+// 4069 (bm + bn) / (bm bn) B/clk of operand traffic per unit of matrix-core time -- 127 B/clk for 64x64 (ceiling 23 % of
+// the dense bf16 peak), 64 B/clk for 128x128, 43 B/clk for 256x128.  conv_gemm_v2 (64x64 ... 128x128 tiles, register
+// staging, one LDS buffer) therefore stalls at 230-490 TFLOP/s.  This kernel follows the guide's deep-pipeline recipe
+// (cdna_hip_programming.md section 5, "Pipelining across barriers" / the 8-phase template's rules):
+//   * 256 x 128 block tile, 512 threads = 8 waves as 4 (rows) x 2 (columns), wave tile 64 x 64 = 2 x 2 MFMA 32x32x16 tiles;
+//   * operands go global -> LDS DIRECTLY (`buffer_load_dwordx4 ... lds`, 16 B per lane, out-of-range offsets return zero, so
+//     padding rows / taps outside the clip / M and N tails need no predication) into a 3-slot LDS ring of 64-deep K steps;
+//     the LDS image is lane-linear, so the bank-conflict swizzle sits on the SOURCE side (16-byte chunk c of row r is fetched
+//     from chunk c ^ (r & 7)) and on the fragment reads (rule 21 of the guide);
+//   * one raw s_barrier per K step and a COUNTED s_waitcnt vmcnt(N): the loads of step k+1 stay in flight across the barrier
+//     while step k is multiplied, those of step k+2 are issued right after the barrier (the slot they overwrite was read during
+//     step k-1, which every wave has finished when it passes the barrier);
+//   * no ordinary global load inside the K loop (hipcc would drain the DMA queue for it): epilogue operands are read after it;
+//   * epilogue through LDS: row-major 16-byte stores; bias / per-clip scale / residual / per-clip add / activation as in
+//     ConvGemmArgs.
+// Geometry: 1-D (taps, stride, nearest upsampling) and video (kt x kh x kw taps), channel counts that are multiples of 64,
+// no concatenated second source, no prologue.
+#include "common.h"
+#include "kernels.h"
+
+namespace sf {
+namespace {
+
+constexpr int BK = 64;                 // K step: 64 elements = 128 bytes = 8 sixteen-byte chunks per row
+constexpr int ROWB = BK * 2;           // bytes per staged row
+constexpr unsigned OOB = 0x80000000u;
+constexpr int NSTAGE = 3;
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <typename T, int BM, int BN, int GEOM>
+__global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a, const int mtiles, const int ntiles, const unsigned bytesA,
+                                                           const unsigned bytesW) {
+  static_assert(sizeof(T) == 2, "16-bit types only");
+  static_assert(BM == 256 && BN == 128, "wave layout below assumes 4 x 2 waves of 64 x 64");
+  constexpr int STAGE = (BM + BN) * ROWB;          // bytes per ring slot: A rows then W rows
+  constexpr int PA = BM / 64, PB = BN / 64;         // DMA instructions per thread and K step (8 rows per wave-instruction, 8 waves)
+  constexpr int NLD = PA + PB;
+  using frag = typename Frag16<T>::type;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 31, fh = lane >> 5;
+
+  // ---- block -> tile: each XCD gets a contiguous run of the m-major tile list (the column tiles of a row band share its A panel)
+  int wg;
+  {
+    const int nwg = mtiles * ntiles, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int mt = wg / ntiles, nt = wg - mt * ntiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.src), 0, bytesA, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.w), 0, bytesW, 0x00020000);
+
+  // ---- DMA lane geometry: a wave-instruction fills 8 rows x 128 B; lane -> (row lane>>3, LDS chunk lane&7), source chunk swizzled
+  const int lrow = lane >> 3;
+  const unsigned gchunk_b = (unsigned)(((lane & 7) ^ lrow) * 16);
+  int rbase[PA], rp0[PA], rh[PA], rw_[PA];
+  unsigned vmask[PA], woff[PB];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int m = m0 + (i * 8 + wave) * 8 + lrow;
+    const bool vm = m < a.M;
+    const int mm = vm ? m : 0;
+    vmask[i] = vm ? 0u : OOB;
+    if constexpr (GEOM == 0) {
+      const int b = mm / a.Lout, l = mm - b * a.Lout;
+      rbase[i] = b * a.Lsrc;
+      rp0[i] = l * a.stride - a.pad;
+      rh[i] = rw_[i] = 0;
+    } else {
+      const int w_ = mm % a.Wo;
+      int r = mm / a.Wo;
+      const int h_ = r % a.Ho;
+      r /= a.Ho;
+      const int t_ = r % a.To, n_ = r / a.To;
+      rbase[i] = n_ * a.Ti;
+      rp0[i] = t_ * a.st - a.pt;
+      rh[i] = h_ * a.sh - a.ph;
+      rw_[i] = w_ * a.sw - a.pw;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < PB; ++j) {
+    const int n = n0 + (j * 8 + wave) * 8 + lrow;
+    woff[j] = n < a.N ? ((unsigned)(n * a.K * 2) + gchunk_b) : OOB;
+  }
+  const int pmax = (a.Lsrc << a.up_shift) - 1;
+  unsigned cur[PA];
+  auto retap = [&](int t) {
+    if constexpr (GEOM == 0) {
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        const int p = rp0[i] + t;
+        const unsigned bad = ((unsigned)p > (unsigned)pmax) ? OOB : 0u;
+        cur[i] = ((unsigned)(((rbase[i] + (max(p, 0) >> a.up_shift)) * a.src_ld) * 2) + gchunk_b) | bad | vmask[i];
+      }
+    } else {
+      const int dw = t % a.kw;
+      const int r = t / a.kw;
+      const int dh = r % a.kh, dt = r / a.kh;
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        const int ti = rp0[i] + dt, hi = rh[i] + dh, wi = rw_[i] + dw;
+        const bool ok = (unsigned)ti < (unsigned)a.Ti && (unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi;
+        cur[i] = ((unsigned)(((((rbase[i] + max(ti, 0)) * a.Hi + max(hi, 0)) * a.Wi + max(wi, 0)) * a.src_ld) * 2) + gchunk_b) |
+                 (ok ? 0u : OOB) | vmask[i];
+      }
+    }
+  };
+
+  // ---- load stream state (runs two K steps ahead of the multiply) ------------------------------------------------
+  const int nk = a.K / BK;
+  const unsigned tap_bytes = (unsigned)(a.cin * 2);
+  unsigned cb = 0, kb = 0;   // byte offset inside the tap's channels / inside a W row
+  int tap = 0;
+  retap(0);
+  auto issue = [&](int slot) {
+    unsigned char *base = smem + slot * STAGE;
+#pragma unroll
+    for (int i = 0; i < PA; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void *)(base + (i * 8 + wave) * 1024), 16, (int)(cur[i] + cb), 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < PB; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_void *)(base + BM * ROWB + (j * 8 + wave) * 1024), 16, (int)(woff[j] + kb), 0, 0, 0);
+    kb += ROWB;
+    cb += ROWB;
+    if (cb >= tap_bytes) {   // wave-uniform
+      cb = 0;
+      ++tap;
+      if (tap < a.taps) retap(tap);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment read offsets inside a slot: row-dependent part once, the k sub-step enters through the XOR
+  unsigned offA[2], offB[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = wm * 64 + i * 32 + fr;
+    offA[i] = (unsigned)(row * ROWB);
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = wn * 64 + j * 32 + fr;
+    offB[j] = (unsigned)(BM * ROWB + row * ROWB);
+  }
+  const unsigned sw = (unsigned)(fr & 7);   // rows of a fragment: (row & 7) == (fr & 7) since every row base is a multiple of 8
+
+  // ---- prologue: two K steps in flight ---------------------------------------------------------------------------
+  issue(0);
+  if (nk > 1) issue(1);
+
+  for (int k = 0; k < nk; ++k) {
+    // own DMA of step k has landed when at most the NLD loads of step k+1 are still outstanding
+    if (k + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // every wave's step-k data is in LDS; every wave is done reading step k-1's slot
+    if (k + 2 < nk) issue((k + 2) % NSTAGE);
+    const unsigned char *slot = smem + (k % NSTAGE) * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const unsigned ch = (unsigned)(((2 * ks + fh) ^ sw) * 16);
+      frag af[2], bf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const frag *>(slot + offA[i] + ch);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const frag *>(slot + offB[j] + ch);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma32x16(af[i], bf[j], acc[i][j]);
+    }
+  }
+
+  // ---- epilogue through LDS: each wave parks its 64 x 64 fp32 tile, then streams it out row-major ----------------------
+  __builtin_amdgcn_s_barrier();   // all fragment reads of the last steps are done before the ring is reused
+  constexpr int LDR = 64 + 4;
+  float *red = reinterpret_cast<float *>(smem) + (size_t)wave * 64 * LDR;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LDR + j * 32 + fr] = acc[i][j][r];
+  __builtin_amdgcn_wave_barrier();   // same-wave LDS operations execute in order; this only pins the compiler
+  T *out = static_cast<T *>(a.out);
+  const T *res = static_cast<const T *>(a.res);
+  const bool has_bs = a.bscale != nullptr, has_ba = a.badd != nullptr;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int idx = it * 64 + lane;
+    const int rl = idx >> 3, oct = idx & 7;
+    const int m = m0 + wm * 64 + rl, n = n0 + wn * 64 + oct * 8;
+    const bool live = m < a.M && n < a.n_store;
+    const int mc = min(m, a.M - 1), nc = min(n, a.N - 8 >= 0 ? a.N - 8 : 0);
+    const int b = (has_bs || has_ba) ? mc / a.Lout : 0;
+    const f32x4 v0 = *reinterpret_cast<const f32x4 *>(red + rl * LDR + oct * 8);
+    const f32x4 v1 = *reinterpret_cast<const f32x4 *>(red + rl * LDR + oct * 8 + 4);
+    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    Vec16<T> rv = zero16<T>();
+    if (res && live) rv = ld16<T>(res + (size_t)mc * a.res_ld + nc);
+    float bi[8], sc[8], ad[8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {   // N % 8 == 0 and nc + 8 <= N: whole 16-byte vectors of the per-column operands
+      const f32x4 bv = a.bias ? *reinterpret_cast<const f32x4 *>(a.bias + nc + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 sv = has_bs ? *reinterpret_cast<const f32x4 *>(a.bscale + (size_t)b * a.bscale_ld + nc + 4 * h) : f32x4{1.f, 1.f, 1.f, 1.f};
+      const f32x4 av = has_ba ? *reinterpret_cast<const f32x4 *>(a.badd + (size_t)b * a.badd_ld + nc + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        bi[4 * h + e] = bv[e];
+        sc[4 * h + e] = sv[e];
+        ad[4 * h + e] = av[e];
+      }
+    }
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float x = (v[e] + bi[e]) * sc[e] + rv.get(e) + ad[e];
+      if (a.act == 1) x = fmaxf(x, 0.f);
+      o.set(e, x);
+    }
+    if (live) st16<T>(out + (size_t)m * a.out_ld + n, o);
+  }
+}
+
+template <typename T, int GEOM> hipError_t launch_mt(const ConvGemmArgs &a, hipStream_t s) {
+  constexpr int BM = 256, BN = 128;
+  constexpr size_t ring = (size_t)NSTAGE * (BM + BN) * ROWB;
+  constexpr size_t redb = (size_t)8 * 64 * 68 * sizeof(float);
+  constexpr size_t lds = ring > redb ? ring : redb;
+  const int mtiles = (a.M + BM - 1) / BM, ntiles = (a.n_store + BN - 1) / BN;
+  size_t bA;
+  if (GEOM == 0) bA = (size_t)(a.M / a.Lout + (a.M % a.Lout ? 1 : 0)) * a.Lsrc * a.src_ld * 2;
+  else bA = (size_t)((a.M + a.To * a.Ho * a.Wo - 1) / (a.To * a.Ho * a.Wo)) * a.Ti * a.Hi * a.Wi * a.src_ld * 2;
+  const size_t bW = (size_t)a.N * a.K * 2;
+  auto kern = conv_gemm_mt_kernel<T, BM, BN, GEOM>;
+  static bool en = false;
+  if (!en) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    en = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(mtiles * ntiles), dim3(512), lds, s, a, mtiles, ntiles, (unsigned)bA, (unsigned)bW);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+// eligibility (what the kernel implements) -- the CHOICE between this kernel and conv_gemm_v2 is conv_gemm_prefers_mt
+bool conv_gemm_mt_ok(int dt, const ConvGemmArgs &a) {
+  if (dt == F32) return false;
+  if (a.pro != 0 || a.cin2 != 0 || a.src2 || (a.cin % BK) || a.taps < 1 || a.K != a.taps * a.cin) return false;
+  if (a.ln_part || a.ln_colsum || a.rowpart_out || a.out_f32 || a.act > 1) return false;
+  if ((a.bscale && (a.bscale_ld % 4)) || (a.badd && (a.badd_ld % 4))) return false;
+  if ((a.n_store % 8) || a.n_store > a.N + 7 || (a.N % 8) || (a.out_ld % 8) || (a.res && (a.res_ld % 8)) || (a.src_ld % 8)) return false;
+  if (a.geom == 1 && (a.bscale || a.badd)) return false;
+  const size_t lim = 0x7FFFFFF0ull;
+  size_t bA;
+  if (a.geom == 0) bA = (size_t)(a.M / a.Lout + 1) * a.Lsrc * a.src_ld * 2;
+  else bA = (size_t)(a.M / (a.To * a.Ho * a.Wo) + 1) * a.Ti * a.Hi * a.Wi * a.src_ld * 2;
+  if (bA >= lim || (size_t)a.N * a.K * 2 >= lim) return false;
+  return true;
+}
+
+hipError_t launch_conv_gemm_mt(int dt, const ConvGemmArgs &a, hipStream_t s) {
+  if (!conv_gemm_mt_ok(dt, a)) return hipErrorInvalidValue;
+  if (dt == F16) return a.geom == 1 ? launch_mt<f16, 1>(a, s) : launch_mt<f16, 0>(a, s);
+  return a.geom == 1 ? launch_mt<bf16, 1>(a, s) : launch_mt<bf16, 0>(a, s);
+}
+
+}  // namespace sf

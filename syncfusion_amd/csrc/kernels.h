@@ -67,6 +67,10 @@ bool conv_gemm_v2_plan(int dt, const ConvGemmArgs &a, V2Plan &pl);
 const char *conv_gemm_v2_name(int dt, const V2Plan &pl);
 hipError_t launch_conv_gemm_v2(int dt, const ConvGemmArgs &a, const V2Plan &pl, hipStream_t s);
 hipError_t launch_conv_gemm(int dt, const ConvGemmArgs &a, hipStream_t s);
+// macro-tile kernel (conv_gemm_mt.hip): 256x128 tiles, LDS-DMA ring; 16-bit types, long activations
+bool conv_gemm_mt_ok(int dt, const ConvGemmArgs &a);
+bool conv_gemm_prefers_mt(const ConvGemmArgs &a);
+hipError_t launch_conv_gemm_mt(int dt, const ConvGemmArgs &a, hipStream_t s);
 // true when launch_conv_gemm would run `a` on a kernel that honours rowpart_out (fast / wp, 32x32 tiles)
 bool conv_gemm_emits_rowpart(int dt, const ConvGemmArgs &a);
 // GEMM whose first source is LayerNorm-modulated on the fly from producer-side row partials (see ConvGemmArgs)

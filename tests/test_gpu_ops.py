@@ -75,6 +75,9 @@ def _conv_case(cuda, dtype, B, L, C, N, taps, stride, pad, up, groups, residual,
     (8, 44, 512, 256, 3, 1, 1, 1, 0, True),     # wave-split-K with clips shorter than a tile
     (2, 100, 256, 320, 1, 1, 0, 1, 0, False),   # ragged M and N on the wave-split-K kernels
     (2, 352, 128, 128, 3, 1, 1, 2, 0, True),    # upsample x2 on the main (v2) path
+    (8, 5632, 64, 128, 3, 1, 1, 1, 0, True),    # long activation: macro-tile kernel (16-bit types), 176 tiles of 256x128, residual
+    (9, 5000, 128, 320, 1, 1, 0, 1, 0, False),  # macro tiles with ragged M (45000 rows) and a partial column tile (320 = 2.5 x 128)
+    (8, 2816, 64, 64, 3, 1, 1, 2, 0, True),     # macro tiles reading a nearest-upsampled source, half-empty column tile
 ])
 def test_conv_gemm(cuda, dtype, shape):
     assert _conv_case(cuda, dtype, *shape) < TOL[dtype]
