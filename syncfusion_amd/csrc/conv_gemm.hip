@@ -428,8 +428,10 @@ const char *label_for_dtype(int dt, const char *bf16_label) {
 static const char *variant_name_bf16(int dt, const ConvGemmArgs &a);
 const char *conv_gemm_variant_name(int dt, const ConvGemmArgs &a) { return label_for_dtype(dt, variant_name_bf16(dt, a)); }
 
-// Macro tiles pay when they fill the chip: >= ~5/8 of the CUs get a 256x128 tile and the reduction is long enough for the
-// three-slot ring to reach steady state (measured against conv_gemm_v2: tools/gemm_big.py).
+// Macro tiles pay from ~80 tiles of 256x128 per launch: a launch then occupies ~1/3 of the CUs at 4+ TFLOP/s each, and the
+// engine's second clip-parallel branch fills most of the rest (measured on BASELINE configs[2]: threshold 160 -> 138, 80 -> 145.5
+// steps/s; alone on the chip the 64x64 kernel still wins below ~160 tiles, tools/gemm_mt.py).  K >= 256: the three-slot ring
+// needs a few steps to reach steady state.
 bool conv_gemm_prefers_mt(const ConvGemmArgs &a) {
   static const int mode = [] {   // SF_MT=0 disables the kernel, SF_MT=2 prefers it wherever it is eligible (tuning / tests)
     const char *e = getenv("SF_MT");
@@ -437,8 +439,13 @@ bool conv_gemm_prefers_mt(const ConvGemmArgs &a) {
   }();
   if (mode == 0) return false;
   if (mode == 2) return true;
+  static const int min_tiles = [] {   // tuning hook
+    const char *e = getenv("SF_MT_TILES");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 80;
+  }();
   const long tiles = (long)((a.M + 255) / 256) * ((a.n_store + 127) / 128);
-  return tiles >= 160 && a.K >= 256;
+  return tiles >= min_tiles && a.K >= 256;
 }
 
 static const char *variant_name_bf16(int dt, const ConvGemmArgs &a) {
@@ -467,6 +474,11 @@ ConvGemmForce g_conv_gemm_force;
 
 bool conv_gemm_emits_rowpart(int dt, const ConvGemmArgs &a) {
   if (g_conv_gemm_force.path != 0 || !conv_gemm_supported(dt, a)) return false;
+  {   // long activations: the macro-tile kernel (no row-statistics epilogue) beats the 32x32 kernels that have one
+    ConvGemmArgs plain = a;
+    plain.rowpart_out = nullptr;
+    if (conv_gemm_mt_ok(dt, plain) && conv_gemm_prefers_mt(plain)) return false;
+  }
   if ((a.n_store % 32) || a.n_store != a.N) return false;
   const long t64 = (long)((a.M + 63) / 64) * ((a.n_store + 63) / 64);
   const bool short_act = t64 < 500 && a.K >= 256 && (a.K % 32) == 0 && (a.cin % 32) == 0 && (a.cin2 % 32) == 0;

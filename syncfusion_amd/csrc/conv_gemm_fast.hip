@@ -447,6 +447,15 @@ bool conv_gemm_fast_ok(int dt, const ConvGemmArgs &a) {
 
 bool conv_gemm_ln_ok(int dt, const ConvGemmArgs &a) {
   if (!conv_gemm_fast_ok(dt, a)) return false;
+  {   // long activations: a separate ln_modulate launch + the macro-tile GEMM beats the LayerNorm-fused 32x32 kernel
+    ConvGemmArgs plain = a;
+    plain.ln_part = nullptr;
+    plain.ln_colsum = nullptr;
+    plain.ln_ss = nullptr;
+    plain.rowpart_out = nullptr;
+    plain.res_ln = 0;
+    if (conv_gemm_mt_ok(dt, plain) && conv_gemm_prefers_mt(plain)) return false;
+  }
   if (a.taps != 1 || a.stride != 1 || a.up_shift != 0 || a.Lout != a.Lsrc || a.Lout < 32) return false;
   if (!a.ln_part || a.ln_nt * 32 != a.cin || a.ln_nt > 32) return false;
   if (a.res_ln && (a.N != a.cin || !a.res)) return false;

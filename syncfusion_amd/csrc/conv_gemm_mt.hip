@@ -32,9 +32,10 @@ constexpr int NSTAGE = 3;
 
 typedef __attribute__((address_space(3))) void lds_void;
 
-template <typename T, int BM, int BN, int GEOM>
+// CAT: K = taps * cin + cin2, the last cin2 columns read row m of a second source (InjectChannels: Conv1x1 over cat[x, ctx])
+template <typename T, int BM, int BN, int GEOM, bool CAT>
 __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a, const int mtiles, const int ntiles, const unsigned bytesA,
-                                                           const unsigned bytesW) {
+                                                           const unsigned bytesA2, const unsigned bytesW) {
   static_assert(sizeof(T) == 2, "16-bit types only");
   static_assert(BM == 256 && BN == 128, "wave layout below assumes 4 x 2 waves of 64 x 64");
   constexpr int STAGE = (BM + BN) * ROWB;          // bytes per ring slot: A rows then W rows
@@ -60,18 +61,20 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
 
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.src), 0, bytesA, 0x00020000);
   const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.w), 0, bytesW, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(CAT ? a.src2 : a.src), 0, CAT ? bytesA2 : 0, 0x00020000);
 
   // ---- DMA lane geometry: a wave-instruction fills 8 rows x 128 B; lane -> (row lane>>3, LDS chunk lane&7), source chunk swizzled
   const int lrow = lane >> 3;
   const unsigned gchunk_b = (unsigned)(((lane & 7) ^ lrow) * 16);
   int rbase[PA], rp0[PA], rh[PA], rw_[PA];
-  unsigned vmask[PA], woff[PB];
+  unsigned vmask[PA], woff[PB], roff2[PA];
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
     const int m = m0 + (i * 8 + wave) * 8 + lrow;
     const bool vm = m < a.M;
     const int mm = vm ? m : 0;
     vmask[i] = vm ? 0u : OOB;
+    roff2[i] = CAT ? (((unsigned)(mm * a.src2_ld * 2) + gchunk_b) | vmask[i]) : OOB;
     if constexpr (GEOM == 0) {
       const int b = mm / a.Lout, l = mm - b * a.Lout;
       rbase[i] = b * a.Lsrc;
@@ -123,21 +126,28 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
   const unsigned tap_bytes = (unsigned)(a.cin * 2);
   unsigned cb = 0, kb = 0;   // byte offset inside the tap's channels / inside a W row
   int tap = 0;
+  bool second = false;   // the stream has reached the concatenated source
   retap(0);
   auto issue = [&](int slot) {
     unsigned char *base = smem + slot * STAGE;
+    const __amdgpu_buffer_rsrc_t rs = (CAT && second) ? rA2 : rA;
 #pragma unroll
     for (int i = 0; i < PA; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void *)(base + (i * 8 + wave) * 1024), 16, (int)(cur[i] + cb), 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(base + (i * 8 + wave) * 1024), 16, (int)(cur[i] + cb), 0, 0, 0);
 #pragma unroll
     for (int j = 0; j < PB; ++j)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_void *)(base + BM * ROWB + (j * 8 + wave) * 1024), 16, (int)(woff[j] + kb), 0, 0, 0);
     kb += ROWB;
     cb += ROWB;
-    if (cb >= tap_bytes) {   // wave-uniform
+    if (!second && cb >= tap_bytes) {   // wave-uniform
       cb = 0;
       ++tap;
       if (tap < a.taps) retap(tap);
+      else if (CAT) {
+        second = true;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) cur[i] = roff2[i];
+      }
     }
   };
 
@@ -209,24 +219,36 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
     const int rl = idx >> 3, oct = idx & 7;
     const int m = m0 + wm * 64 + rl, n = n0 + wn * 64 + oct * 8;
     const bool live = m < a.M && n < a.n_store;
-    const int mc = min(m, a.M - 1), nc = min(n, a.N - 8 >= 0 ? a.N - 8 : 0);
+    const int mc = min(m, a.M - 1);
+    const bool full = n + 8 <= a.N;            // whole octet inside the real columns (pad columns [N, n_store) are stored as zeros)
+    const int nc = full ? n : 0;
     const int b = (has_bs || has_ba) ? mc / a.Lout : 0;
     const f32x4 v0 = *reinterpret_cast<const f32x4 *>(red + rl * LDR + oct * 8);
     const f32x4 v1 = *reinterpret_cast<const f32x4 *>(red + rl * LDR + oct * 8 + 4);
     float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
     Vec16<T> rv = zero16<T>();
-    if (res && live) rv = ld16<T>(res + (size_t)mc * a.res_ld + nc);
+    if (res && live) rv = ld16<T>(res + (size_t)mc * a.res_ld + n);   // residual rows are n_store wide (pad columns hold zeros)
     float bi[8], sc[8], ad[8];
+    if (full) {   // 16-byte vectors of the per-column operands (n is a multiple of 8)
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {   // N % 8 == 0 and nc + 8 <= N: whole 16-byte vectors of the per-column operands
-      const f32x4 bv = a.bias ? *reinterpret_cast<const f32x4 *>(a.bias + nc + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
-      const f32x4 sv = has_bs ? *reinterpret_cast<const f32x4 *>(a.bscale + (size_t)b * a.bscale_ld + nc + 4 * h) : f32x4{1.f, 1.f, 1.f, 1.f};
-      const f32x4 av = has_ba ? *reinterpret_cast<const f32x4 *>(a.badd + (size_t)b * a.badd_ld + nc + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int h = 0; h < 2; ++h) {
+        const f32x4 bv = a.bias ? *reinterpret_cast<const f32x4 *>(a.bias + nc + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 sv = has_bs ? *reinterpret_cast<const f32x4 *>(a.bscale + (size_t)b * a.bscale_ld + nc + 4 * h) : f32x4{1.f, 1.f, 1.f, 1.f};
+        const f32x4 av = has_ba ? *reinterpret_cast<const f32x4 *>(a.badd + (size_t)b * a.badd_ld + nc + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        bi[4 * h + e] = bv[e];
-        sc[4 * h + e] = sv[e];
-        ad[4 * h + e] = av[e];
+        for (int e = 0; e < 4; ++e) {
+          bi[4 * h + e] = bv[e];
+          sc[4 * h + e] = sv[e];
+          ad[4 * h + e] = av[e];
+        }
+      }
+    } else {      // the octet that straddles N (odd channel counts of the onset net): element-wise, clamped
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int ne = min(n + e, a.N - 1);
+        bi[e] = a.bias ? a.bias[ne] : 0.f;
+        sc[e] = has_bs ? a.bscale[(size_t)b * a.bscale_ld + ne] : 1.f;
+        ad[e] = has_ba ? a.badd[(size_t)b * a.badd_ld + ne] : 0.f;
       }
     }
     Vec16<T> o;
@@ -234,13 +256,13 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
     for (int e = 0; e < 8; ++e) {
       float x = (v[e] + bi[e]) * sc[e] + rv.get(e) + ad[e];
       if (a.act == 1) x = fmaxf(x, 0.f);
-      o.set(e, x);
+      o.set(e, (n + e < a.N) ? x : 0.f);
     }
     if (live) st16<T>(out + (size_t)m * a.out_ld + n, o);
   }
 }
 
-template <typename T, int GEOM> hipError_t launch_mt(const ConvGemmArgs &a, hipStream_t s) {
+template <typename T, int GEOM, bool CAT> hipError_t launch_mt(const ConvGemmArgs &a, hipStream_t s) {
   constexpr int BM = 256, BN = 128;
   constexpr size_t ring = (size_t)NSTAGE * (BM + BN) * ROWB;
   constexpr size_t redb = (size_t)8 * 64 * 68 * sizeof(float);
@@ -250,14 +272,15 @@ template <typename T, int GEOM> hipError_t launch_mt(const ConvGemmArgs &a, hipS
   if (GEOM == 0) bA = (size_t)(a.M / a.Lout + (a.M % a.Lout ? 1 : 0)) * a.Lsrc * a.src_ld * 2;
   else bA = (size_t)((a.M + a.To * a.Ho * a.Wo - 1) / (a.To * a.Ho * a.Wo)) * a.Ti * a.Hi * a.Wi * a.src_ld * 2;
   const size_t bW = (size_t)a.N * a.K * 2;
-  auto kern = conv_gemm_mt_kernel<T, BM, BN, GEOM>;
+  const size_t bA2 = CAT ? (size_t)a.M * a.src2_ld * 2 : 0;
+  auto kern = conv_gemm_mt_kernel<T, BM, BN, GEOM, CAT>;
   static bool en = false;
   if (!en) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     en = true;
   }
-  hipLaunchKernelGGL(kern, dim3(mtiles * ntiles), dim3(512), lds, s, a, mtiles, ntiles, (unsigned)bA, (unsigned)bW);
+  hipLaunchKernelGGL(kern, dim3(mtiles * ntiles), dim3(512), lds, s, a, mtiles, ntiles, (unsigned)bA, (unsigned)bA2, (unsigned)bW);
   return hipGetLastError();
 }
 
@@ -266,10 +289,12 @@ template <typename T, int GEOM> hipError_t launch_mt(const ConvGemmArgs &a, hipS
 // eligibility (what the kernel implements) -- the CHOICE between this kernel and conv_gemm_v2 is conv_gemm_prefers_mt
 bool conv_gemm_mt_ok(int dt, const ConvGemmArgs &a) {
   if (dt == F32) return false;
-  if (a.pro != 0 || a.cin2 != 0 || a.src2 || (a.cin % BK) || a.taps < 1 || a.K != a.taps * a.cin) return false;
+  if (a.pro != 0 || (a.cin % BK) || (a.cin2 % BK) || a.taps < 1 || a.K != a.taps * a.cin + a.cin2) return false;
+  if (a.cin2 && (a.geom != 0 || !a.src2 || (a.src2_ld % 8) || a.src2_ld < a.cin2 || (size_t)a.M * a.src2_ld * 2 >= 0x7FFFFFF0ull)) return false;
   if (a.ln_part || a.ln_colsum || a.rowpart_out || a.out_f32 || a.act > 1) return false;
   if ((a.bscale && (a.bscale_ld % 4)) || (a.badd && (a.badd_ld % 4))) return false;
-  if ((a.n_store % 8) || a.n_store > a.N + 7 || (a.N % 8) || (a.out_ld % 8) || (a.res && (a.res_ld % 8)) || (a.src_ld % 8)) return false;
+  if ((a.n_store % 8) || a.n_store < a.N || (a.out_ld % 8) || a.out_ld < a.n_store || (a.res && ((a.res_ld % 8) || a.res_ld < a.n_store)) || (a.src_ld % 8)) return false;
+  if (a.bias && (reinterpret_cast<uintptr_t>(a.bias) & 15)) return false;
   if (a.geom == 1 && (a.bscale || a.badd)) return false;
   const size_t lim = 0x7FFFFFF0ull;
   size_t bA;
@@ -281,8 +306,8 @@ bool conv_gemm_mt_ok(int dt, const ConvGemmArgs &a) {
 
 hipError_t launch_conv_gemm_mt(int dt, const ConvGemmArgs &a, hipStream_t s) {
   if (!conv_gemm_mt_ok(dt, a)) return hipErrorInvalidValue;
-  if (dt == F16) return a.geom == 1 ? launch_mt<f16, 1>(a, s) : launch_mt<f16, 0>(a, s);
-  return a.geom == 1 ? launch_mt<bf16, 1>(a, s) : launch_mt<bf16, 0>(a, s);
+  if (dt == F16) return a.geom == 1 ? launch_mt<f16, 1, false>(a, s) : (a.cin2 ? launch_mt<f16, 0, true>(a, s) : launch_mt<f16, 0, false>(a, s));
+  return a.geom == 1 ? launch_mt<bf16, 1, false>(a, s) : (a.cin2 ? launch_mt<bf16, 0, true>(a, s) : launch_mt<bf16, 0, false>(a, s));
 }
 
 }  // namespace sf
