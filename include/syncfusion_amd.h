@@ -209,6 +209,15 @@ int sf_resampler_forward(sf_resampler *h, const float *x, int R, int L, float *o
 int sf_op_conv1d_cl(int dtype, const void *x, const float *w, const float *bias, const float *gamma, const float *beta,
                     int groups, float eps, const void *residual, int B, int L, int C, int N, int taps, int stride,
                     int pad, int upsample, void *out, void *ws, int64_t ws_bytes, void *stream);
+/* Training backward, first slice (the reference's training step is main/module_diffusion.py:73-82 under
+ * exp/train_diffusion_gh.yaml:84-96, fp32): gradients of  y = conv1d(act(x)) + bias  with  act = silu(groupnorm(x)) when
+ * groups > 0 (a ResnetItem convolution) or the identity when groups == 0 (the 1x1 InjectChannels convolution), stride 1,
+ * 2 * pad == taps - 1, everything fp32 channels-last: x, dx:(B,L,C); dy:(B,L,N); w, dw:(N,C,taps) PyTorch layout; db:(N) or NULL;
+ * dgb:(2C) = [dgamma | dbeta] (groups > 0).  No atomics: results are bit-reproducible. */
+int64_t sf_op_conv1d_bwd_workspace_bytes(int B, int L, int C, int N, int taps, int groups);
+int sf_op_conv1d_bwd_cl(const float *x, const float *w, const float *gamma, const float *beta, int groups, float eps, const float *dy,
+                        int B, int L, int C, int N, int taps, int pad, float *dx, float *dw, float *db, float *dgb, void *ws,
+                        int64_t ws_bytes, void *stream);
 /* Kernel tuning aid: average milliseconds of `iters` back-to-back launches of one channels-last conv1d
  * (x:(B,L,C) -> (B,L*upsample,N), `taps` taps, bias + residual epilogue) with a forced kernel family
  * (path 0 auto, 1 classic, 2 wave-split-K, 4 v2), tile variant (-1 auto) and grid split-K factor (-1 auto). */

@@ -1,0 +1,104 @@
+// Training backward, first slice: the op-level C-ABI entry points behind
+// syncfusion_amd/autograd.py.  fp32 only -- the reference trains in fp32 (exp/train_diffusion_gh.yaml:87).
+#include <algorithm>
+#include <exception>
+
+#include "engine_common.h"
+
+using namespace sf;
+
+#define SF_API_BEGIN try {
+#define SF_API_END                  \
+  }                                 \
+  catch (const EngineError &e) {    \
+    return e.code;                  \
+  }                                 \
+  catch (const std::exception &e) { \
+    set_error("%s", e.what());      \
+    return SF_ERR_INVALID;          \
+  }
+
+namespace {
+
+struct BwdPlan {
+  float *act = nullptr, *da = nullptr, *wd = nullptr, *wpart = nullptr, *bpart = nullptr, *gpart = nullptr;
+  int S = 1, Sb = 1, ldn = 0;
+};
+
+BwdPlan plan(Workspace &ws, int B, int L, int C, int N, int taps, int groups) {
+  BwdPlan p;
+  const int64_t rows = (int64_t)B * L;
+  p.ldn = (N % 32 == 0) ? N : N;   // dgrad reads dy rows of N channels: the MFMA path needs N % 32 == 0, else the direct kernel
+  if (groups > 0) p.act = ws.alloc_n<float>(rows * C);
+  p.da = ws.alloc_n<float>(rows * C);
+  p.wd = ws.alloc_n<float>((int64_t)C * taps * p.ldn);
+  p.S = conv_wgrad_splits(rows, N, taps * C);
+  p.wpart = ws.alloc_n<float>((int64_t)p.S * N * taps * C);
+  p.Sb = (int)std::min<int64_t>(256, std::max<int64_t>(1, rows / 64));
+  p.bpart = ws.alloc_n<float>((int64_t)p.Sb * N);
+  if (groups > 0) p.gpart = ws.alloc_n<float>((int64_t)B * 2 * C);
+  return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t sf_op_conv1d_bwd_workspace_bytes(int B, int L, int C, int N, int taps, int groups) {
+  try {
+    if (B < 1 || L < 1 || C < 1 || N < 1 || taps < 1) fail(SF_ERR_INVALID, "bad shape");
+    Workspace dry(nullptr, 0);
+    plan(dry, B, L, C, N, taps, groups);
+    return dry.used();
+  } catch (const EngineError &) {
+    return -1;
+  }
+}
+
+int sf_op_conv1d_bwd_cl(const float *x, const float *w, const float *gamma, const float *beta, int groups, float eps, const float *dy, int B, int L,
+                        int C, int N, int taps, int pad, float *dx, float *dw, float *db, float *dgb, void *ws, int64_t ws_bytes, void *stream) {
+  SF_API_BEGIN
+  if (!x || !w || !dy || !dx || !dw || !ws) fail(SF_ERR_INVALID, "null argument");
+  if (groups > 0 && (!gamma || !beta || !dgb)) fail(SF_ERR_INVALID, "GroupNorm backward needs gamma, beta and dgb");
+  if (taps < 1 || pad < 0 || pad >= taps || 2 * pad != taps - 1) fail(SF_ERR_UNSUPPORTED, "stride-1 'same' convolutions only (2 * pad == taps - 1)");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  Workspace wk(ws, ws_bytes);
+  BwdPlan p = plan(wk, B, L, C, N, taps, groups);
+  const float *act = x;
+  if (groups > 0) {   // recompute a = SiLU(GroupNorm(x)) (cheaper than keeping it from the forward pass)
+    SF_HIP(launch_gn_silu(F32, x, C, B, L, C, groups, gamma, beta, eps, p.act, C, s));
+    act = p.act;
+  }
+  // ---- dgrad: da = conv(dy; W flipped and transposed), same padding -------------------------------------------
+  {
+    SF_HIP(launch_pack_dgrad(w, N, C, taps, p.ldn, p.wd, s));
+    ConvGemmArgs a;
+    a.src = dy;
+    a.src_ld = N;
+    a.w = p.wd;
+    a.N = C;
+    a.K = taps * p.ldn;
+    a.cin = p.ldn;
+    a.taps = taps;
+    a.stride = 1;
+    a.pad = taps - 1 - pad;
+    a.Lsrc = a.Lout = L;
+    a.M = B * L;
+    a.out = groups > 0 ? p.da : dx;
+    a.out_ld = C;
+    a.n_store = C;
+    const bool direct = (N % 32) != 0;
+    if (direct && C > 32) fail(SF_ERR_UNSUPPORTED, "dgrad of a thin convolution (N %% 32 != 0) needs C <= 32");
+    if (direct) SF_HIP(launch_conv_direct(F32, F32, a, s));
+    else SF_HIP(launch_conv_gemm(F32, a, s));
+  }
+  // ---- wgrad / bias grad ------------------------------------------------------------------------------------------
+  SF_HIP(launch_conv_wgrad(dy, act, B, L, C, N, taps, pad, p.wpart, p.S, dw, s));
+  if (db) SF_HIP(launch_col_sums(dy, (int64_t)B * L, N, p.bpart, p.Sb, db, s));
+  // ---- GroupNorm + SiLU ----------------------------------------------------------------------------------------------
+  if (groups > 0) SF_HIP(launch_gn_silu_bwd(x, p.da, gamma, beta, B, L, C, groups, eps, dx, p.gpart, dgb, s));
+  return SF_OK;
+  SF_API_END
+}
+
+}  // extern "C"

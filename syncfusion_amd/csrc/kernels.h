@@ -217,6 +217,21 @@ hipError_t launch_pack_rows(int dt, const float *in, int64_t rows, int cols, int
                             int64_t ldo, hipStream_t s);
 // out[n] = sum_k w[n][k] * v[k] (+ add[n])   fp32 gemv used for folding LayerNorm biases at pack time
 hipError_t launch_fold_bias(const float *w, int N, int K, const float *v, const float *add, float *out, hipStream_t s);
+// ---------------------------------------------------------------------------------------
+// Training backward, first slice (train.hip): fp32, channels-last
+// ---------------------------------------------------------------------------------------
+// Conv1d weight (N, C, taps) -> dgrad matrix [c][t' * ldn + n] = W[n][c][taps-1-t'] (the forward kernels then compute da from dy)
+hipError_t launch_pack_dgrad(const float *w, int N, int C, int taps, int ldn, float *out, hipStream_t s);
+// dw (N, C, taps) = sum_rows dy[row][n] * act[row + t - pad][c];  partial: [S][N][taps*C] scratch, S = conv_wgrad_splits(...)
+int conv_wgrad_splits(int64_t rows, int N, int Q);
+hipError_t launch_conv_wgrad(const float *dy, const float *act, int B, int L, int C, int N, int taps, int pad, float *partial, int S, float *dw,
+                             hipStream_t s);
+// out[col] = sum_rows x[row][col]   (part: [S][cols] scratch)
+hipError_t launch_col_sums(const float *x, int64_t rows, int cols, float *part, int S, float *out, hipStream_t s);
+// backward of a = SiLU(GroupNorm_G(x; gamma, beta, eps)): dx, and dgb = [dgamma | dbeta]  (dgb_part: [B][2][C] scratch)
+hipError_t launch_gn_silu_bwd(const float *x, const float *da, const float *gamma, const float *beta, int B, int L, int C, int G, float eps,
+                              float *dx, float *dgb_part, float *dgb, hipStream_t s);
+
 // BatchNorm (eval) -> per-channel scale / shift
 hipError_t launch_bn_fold(const float *gamma, const float *beta, const float *mean, const float *var, float eps, int C,
                           float *scale, float *shift, hipStream_t s);

@@ -128,7 +128,14 @@ class Model(_Base):
         return self.model(x, channels=y_latent["xs"][2:-1], embedding=z_latent)
 
     def training_step(self, batch, batch_idx):
+        """main/module_diffusion.py:79-82.  The U-Net engine is inference-only: ``step`` computes the loss VALUE (as
+        ``validation_step`` needs) but carries no autograd graph, so returning it to a trainer would fail inside
+        ``loss.backward()`` with an opaque message.  The backward kernels exist for the ResnetItem / InjectChannels
+        convolutions only so far (syncfusion_amd/autograd.py)."""
         loss = self.step(batch)
+        if not loss.requires_grad:
+            raise NotImplementedError("syncfusion_amd is an inference build: DiffusionModel.forward returns the v-objective loss without "
+                                      "an autograd graph (training backward: only syncfusion_amd.autograd.{gn_silu_conv1d, conv1d} so far)")
         self.log("train_loss", loss)
         return loss
 
