@@ -200,6 +200,18 @@ int sf_resampler_out_length(const sf_resampler *h, int L);
 int sf_resampler_forward(sf_resampler *h, const float *x, int R, int L, float *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Input side
+ *   sf_frames_preprocess replaces the per-frame transform of main/dataset_onset.py:47-50,152-165
+ *     (ToTensor -> Resize((112,112), antialias=True) -> Normalize(mean, std) -> (C,T,H,W)) for a batch of decoded frames:
+ *     frames:(N,T,H,W,3) uint8 device memory -> out:(N,3,T,out_h,out_w) fp32; mean3 / std3 are HOST arrays of 3 floats.
+ *   sf_times_to_track replaces the impulse-track construction of main/dataset_diffusion.py:58-72
+ *     (`onset[:, int(t * sr)] = 1.0`): times:(n_times) float64 seconds and clip_of:(n_times) clip indices, device memory.
+ * ---------------------------------------------------------------------------------------- */
+int sf_frames_preprocess(const uint8_t *frames, int N, int T, int H, int W, int out_h, int out_w, const float *mean3, const float *std3,
+                         float *out, void *stream);
+int sf_times_to_track(const double *times, const int32_t *clip_of, int n_times, double sample_rate, int B, int L, float *track, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Op-level entry points (channels-last, used by tests/ to localise kernel bugs).
  *   dtype selects the storage type of x / w / out (fp32 or bf16 bit patterns).
  * ---------------------------------------------------------------------------------------- */

@@ -80,6 +80,8 @@ SYMBOLS = {
     "sf_onsetnet_debug_count": (_I, [_P]),
     "sf_onsetnet_debug_info": (_I, [_P, _I, C.c_char_p, _I, C.POINTER(_L), C.POINTER(_L), C.POINTER(C.c_int32)]),
     "sf_onsets_to_track": (_I, [_P, _I, _I, _P, _F, _F, _F, _P, _I, _P]),
+    "sf_frames_preprocess": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "sf_times_to_track": (_I, [_P, _P, _I, C.c_double, _I, _I, _P, _P]),
     "sf_cut_prefix_crop": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "sf_resampler_create": (_I, [_I, _I, _I, _F, C.POINTER(_P)]),
     "sf_resampler_destroy": (None, [_P]),

@@ -44,6 +44,27 @@ int sf_onsets_to_track(const float *logits, int N, int T, const int32_t *start_f
   SF_API_END
 }
 
+int sf_frames_preprocess(const uint8_t *frames, int N, int T, int H, int W, int out_h, int out_w, const float *mean3, const float *std3, float *out,
+                         void *stream) {
+  SF_API_BEGIN
+  if (!frames || !out || !mean3 || !std3 || N < 1 || T < 1 || H < 1 || W < 1 || out_h < 1 || out_w < 1) fail(SF_ERR_INVALID, "bad argument");
+  for (int i = 0; i < 3; ++i)
+    if (!(std3[i] > 0.f)) fail(SF_ERR_INVALID, "std must be positive");
+  hipError_t e = launch_frames_preprocess(frames, N, T, H, W, out_h, out_w, mean3, std3, out, static_cast<hipStream_t>(stream));
+  if (e == hipErrorInvalidValue) fail(SF_ERR_UNSUPPORTED, "down-scaling factor above 7.5 is not supported");
+  SF_HIP(e);
+  return SF_OK;
+  SF_API_END
+}
+
+int sf_times_to_track(const double *times, const int32_t *clip_of, int n_times, double sample_rate, int B, int L, float *track, void *stream) {
+  SF_API_BEGIN
+  if (!track || B < 1 || L < 1 || n_times < 0 || (n_times > 0 && (!times || !clip_of)) || !(sample_rate > 0)) fail(SF_ERR_INVALID, "bad argument");
+  SF_HIP(launch_times_to_track(times, clip_of, n_times, sample_rate, B, L, track, static_cast<hipStream_t>(stream)));
+  return SF_OK;
+  SF_API_END
+}
+
 int sf_cut_prefix_crop(const float *gen, const float *y, int B, int C, int L, int cut_length, float *out, int32_t *first_onset, void *stream) {
   SF_API_BEGIN
   if (!gen || !y || !out || !first_onset || B < 1 || C < 1 || L < 1 || cut_length < 1 || cut_length > L) fail(SF_ERR_INVALID, "bad argument");

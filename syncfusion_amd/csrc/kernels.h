@@ -218,6 +218,15 @@ hipError_t launch_pack_rows(int dt, const float *in, int64_t rows, int cols, int
 // out[n] = sum_k w[n][k] * v[k] (+ add[n])   fp32 gemv used for folding LayerNorm biases at pack time
 hipError_t launch_fold_bias(const float *w, int N, int K, const float *v, const float *add, float *out, hipStream_t s);
 // ---------------------------------------------------------------------------------------
+// Input side (input.hip)
+// ---------------------------------------------------------------------------------------
+// uint8 RGB frames (N, T, H, W, 3) -> (N, 3, T, oh, ow) fp32: /255, antialiased bilinear resize (ATen semantics), (x - mean) / std
+hipError_t launch_frames_preprocess(const unsigned char *frames, int N, int T, int H, int W, int oh, int ow, const float *mean, const float *stdv,
+                                    float *out, hipStream_t s);
+// track (B, L) = 0 except track[clip_of[i]][int(times[i] * sample_rate)] = 1
+hipError_t launch_times_to_track(const double *times, const int *clip_of, int n_times, double sample_rate, int B, int L, float *track, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------
 // Training backward, first slice (train.hip): fp32, channels-last
 // ---------------------------------------------------------------------------------------
 // Conv1d weight (N, C, taps) -> dgrad matrix [c][t' * ldn + n] = W[n][c][taps-1-t'] (the forward kernels then compute da from dy)
