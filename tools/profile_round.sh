@@ -1,0 +1,21 @@
+#!/bin/bash
+# Run ON the GPU box (gpurun): rocprofv3 kernel stats + separate PMC passes of the bench command, summaries under gpurun_out/$1
+set -u
+TAG=${1:-prof}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra > $O/bench_under_profiler.json 2> $O/stats.log
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- python3 $R/bench.py --no-cpu-baseline --no-extra --steps 3 --warmup 1 --no-graph > /dev/null 2> $O/fetch.log
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- python3 $R/bench.py --no-cpu-baseline --no-extra --steps 3 --warmup 1 --no-graph > /dev/null 2> $O/write.log
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $O/mfma -- python3 $R/bench.py --no-cpu-baseline --no-extra --steps 3 --warmup 1 --no-graph > /dev/null 2> $O/mfma.log
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $O/mfma_onset -- python3 $R/tools/onset_one.py 32 bf16 3 > /dev/null 2> $O/mfma_onset.log
+cd $R
+cp $(ls $O/stats/*/*kernel_stats.csv | head -1) $O/kernel_stats.csv
+python3 tools/pmc_traffic.py $(ls $O/fetch/*/*counter_collection.csv | head -1) $(ls $O/write/*/*counter_collection.csv | head -1) $O/pmc_traffic.json > $O/pmc_traffic.txt
+python3 tools/mfma_busy.py $O/mfma $O/pmc_mfma_by_kernel.csv > /dev/null
+python3 tools/mfma_busy.py $O/mfma_onset $O/pmc_mfma_onset_by_kernel.csv > /dev/null
+python3 bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
+rm -rf $O/stats $O/fetch $O/write $O/mfma $O/mfma_onset
+ls -la $O
