@@ -156,6 +156,7 @@ __global__ __launch_bounds__(256) void conv_gemm_wp_kernel(const ConvGemmArgs a,
   };
   auto stage = [&](RegSet &R) {
     T *As = wlds, *Bs = As + BM * LD;
+
 #pragma unroll
     for (int i = 0; i < PB; ++i) st16<T>(Bs + (i * RPI + lrow) * LD + lvec * VEC, R.rb[i]);
 #pragma unroll

@@ -183,6 +183,8 @@ hipError_t launch_vsampler_update(float *x, const float *v, const float *v_uncon
                                   const int *step_idx, int64_t n, hipStream_t s);
 // cur[0..ld) = table[*step_idx][0..ld), then (*step_idx)++  (single workgroup; first kernel of a sampling step)
 hipError_t launch_step_select(const float *table, int ld, int *step_idx, float *cur, hipStream_t s);
+// one wave busy-waits for `microseconds` (tuning aid)
+hipError_t launch_spin(double microseconds, hipStream_t s);
 // (*step_idx)++ -- its own 1-thread launch so that no kernel of a step races with the increment
 hipError_t launch_step_advance(int *step_idx, hipStream_t s);
 // out = v_u + (v_c - v_u) * scale   (single forward with CFG)

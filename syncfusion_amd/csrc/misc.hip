@@ -96,6 +96,11 @@ __global__ void step_select_kernel(const float *__restrict__ table, int ld, int 
   float4 *dst = reinterpret_cast<float4 *>(cur);
   for (int i = threadIdx.x; i < ld / 4; i += blockDim.x) dst[i] = src[i];
 }
+// busy-wait `ticks` of the 100 MHz constant clock (tuning aid: staggers the clip-parallel branch pipelines)
+__global__ void spin_kernel(unsigned long long ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
 __global__ void step_advance_kernel(int *step_idx) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *step_idx = *step_idx + 1;
 }
@@ -246,6 +251,10 @@ hipError_t launch_cut_prefix_crop(const float *gen, const float *y, int B, int C
 }
 hipError_t launch_step_select(const float *table, int ld, int *step_idx, float *cur, hipStream_t s) {
   hipLaunchKernelGGL(step_select_kernel, dim3(1), dim3(1024), 0, s, table, ld, step_idx, cur);
+  return hipGetLastError();
+}
+hipError_t launch_spin(double microseconds, hipStream_t s) {
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s, (unsigned long long)(microseconds * 100.0));
   return hipGetLastError();
 }
 hipError_t launch_step_advance(int *step_idx, hipStream_t s) {

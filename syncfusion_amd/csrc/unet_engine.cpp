@@ -1570,6 +1570,14 @@ int sf_vsample(sf_unet *h, float *x, const float *const *ctx, const float *emb, 
       h->gexec_indep = true;
       h->gkey = key;
     }
+    {
+      static const double stagger_us = [] {   // tuning aid: start branch b  b * stagger microseconds late
+        const char *e = getenv("SF_BRANCH_STAGGER_US");
+        return e ? atof(e) : 0.0;
+      }();
+      if (stagger_us > 0.0)
+        for (int br = 1; br < p.nbr; ++br) SF_HIP(launch_spin(stagger_us * br, stream_of(br)));
+    }
     // (the capture above only records step 1; replay it for the remaining steps -- all of them when the graphs were cached)
     for (int i = cached ? 0 : 1; i < T; ++i)
       for (int br = 0; br < p.nbr; ++br) SF_HIP(hipGraphLaunch(h->gexec_br[br], stream_of(br)));
