@@ -444,12 +444,13 @@ bool conv_gemm_prefers_mt(const ConvGemmArgs &a) {
     const int v = e ? atoi(e) : 0;
     return v > 0 ? v : 80;
   }();
-  const long tiles = (long)((a.M + 255) / 256) * ((a.n_store + 127) / 128);
-  return tiles >= min_tiles && a.K >= 256;
+  if (a.n_store <= 64) return false;   // half-empty column tiles: the 64x64 kernel wins (346 vs 259 TFLOP/s on the onset net's 192 -> 64 temporal conv)
+  const long tiles = (long)((a.M + 127) / 128) * ((a.n_store + 127) / 128);   // the 128x128 variant takes over below 160 tiles of 256x128
+  return tiles >= 2 * min_tiles && a.K >= 256;
 }
 
 static const char *variant_name_bf16(int dt, const ConvGemmArgs &a) {
-  if (g_conv_gemm_force.path == 6 || (g_conv_gemm_force.path == 0 && conv_gemm_mt_ok(dt, a) && conv_gemm_prefers_mt(a))) return "conv_gemm_mt<bf16,256x128>";
+  if (g_conv_gemm_force.path == 6 || (g_conv_gemm_force.path == 0 && conv_gemm_mt_ok(dt, a) && conv_gemm_prefers_mt(a))) return conv_gemm_mt_name(a);
   static const char *names[2][5] = {{"conv_gemm<f32,64x64,scalarA>", "conv_gemm<f32,128x32>", "conv_gemm<f32,128x64>", "conv_gemm<f32,64x64>", "conv_gemm<f32,128x128>"},
                                     {"conv_gemm<bf16,64x64,scalarA>", "conv_gemm<bf16,128x32>", "conv_gemm<bf16,128x64>", "conv_gemm<bf16,64x64>", "conv_gemm<bf16,128x128>"}};
   static const char *sk_names[2][3] = {{"conv_gemm_sk<f32,64x64>", "conv_gemm_sk<f32,64x32>", "conv_gemm_sk<f32,32x32>"},

@@ -33,11 +33,14 @@ constexpr int NSTAGE = 3;
 typedef __attribute__((address_space(3))) void lds_void;
 
 // CAT: K = taps * cin + cin2, the last cin2 columns read row m of a second source (InjectChannels: Conv1x1 over cat[x, ctx])
-template <typename T, int BM, int BN, int GEOM, bool CAT>
+// WM x WN = 8 waves; a wave owns (BM / WM) x (BN / WN) = (32 TM) x (32 TN) of the block tile
+template <typename T, int BM, int BN, int WM, int WN, int GEOM, bool CAT>
 __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a, const int mtiles, const int ntiles, const unsigned bytesA,
                                                            const unsigned bytesA2, const unsigned bytesW) {
   static_assert(sizeof(T) == 2, "16-bit types only");
-  static_assert(BM == 256 && BN == 128, "wave layout below assumes 4 x 2 waves of 64 x 64");
+  static_assert(WM * WN == 8 && BM % (32 * WM) == 0 && BN % (32 * WN) == 0 && BM % 64 == 0 && BN % 64 == 0, "tile / wave grid mismatch");
+  constexpr int RM = BM / WM, RN = BN / WN;          // rows / columns of a wave's tile
+  constexpr int TM = RM / 32, TN = RN / 32;
   constexpr int STAGE = (BM + BN) * ROWB;          // bytes per ring slot: A rows then W rows
   constexpr int PA = BM / 64, PB = BN / 64;         // DMA instructions per thread and K step (8 rows per wave-instruction, 8 waves)
   constexpr int NLD = PA + PB;
@@ -46,7 +49,7 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave - wm * WN;
   const int fr = lane & 31, fh = lane >> 5;
 
   // ---- block -> tile: each XCD gets a contiguous run of the m-major tile list (the column tiles of a row band share its A panel)
@@ -151,24 +154,24 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // fragment read offsets inside a slot: row-dependent part once, the k sub-step enters through the XOR
-  unsigned offA[2], offB[2];
+  unsigned offA[TM], offB[TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = wm * 64 + i * 32 + fr;
+  for (int i = 0; i < TM; ++i) {
+    const int row = wm * RM + i * 32 + fr;
     offA[i] = (unsigned)(row * ROWB);
   }
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int row = wn * 64 + j * 32 + fr;
+  for (int j = 0; j < TN; ++j) {
+    const int row = wn * RN + j * 32 + fr;
     offB[j] = (unsigned)(BM * ROWB + row * ROWB);
   }
   const unsigned sw = (unsigned)(fr & 7);   // rows of a fragment: (row & 7) == (fr & 7) since every row base is a multiple of 8
@@ -187,37 +190,38 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const unsigned ch = (unsigned)(((2 * ks + fh) ^ sw) * 16);
-      frag af[2], bf[2];
+      frag af[TM], bf[TN];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const frag *>(slot + offA[i] + ch);
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const frag *>(slot + offA[i] + ch);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const frag *>(slot + offB[j] + ch);
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const frag *>(slot + offB[j] + ch);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = mfma32x16(af[i], bf[j], acc[i][j]);
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma32x16(af[i], bf[j], acc[i][j]);
     }
   }
 
-  // ---- epilogue through LDS: each wave parks its 64 x 64 fp32 tile, then streams it out row-major ----------------------
+  // ---- epilogue through LDS: each wave parks its RM x RN fp32 tile, then streams it out row-major ----------------------
   __builtin_amdgcn_s_barrier();   // all fragment reads of the last steps are done before the ring is reused
-  constexpr int LDR = 64 + 4;
-  float *red = reinterpret_cast<float *>(smem) + (size_t)wave * 64 * LDR;
+  constexpr int LDR = RN + 4;
+  float *red = reinterpret_cast<float *>(smem) + (size_t)wave * RM * LDR;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) red[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LDR + j * 32 + fr] = acc[i][j][r];
   __builtin_amdgcn_wave_barrier();   // same-wave LDS operations execute in order; this only pins the compiler
   T *out = static_cast<T *>(a.out);
   const T *res = static_cast<const T *>(a.res);
   const bool has_bs = a.bscale != nullptr, has_ba = a.badd != nullptr;
+  constexpr int OCT = RN / 8;                      // 8-column groups per tile row
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
+  for (int it = 0; it < RM * OCT / 64; ++it) {
     const int idx = it * 64 + lane;
-    const int rl = idx >> 3, oct = idx & 7;
-    const int m = m0 + wm * 64 + rl, n = n0 + wn * 64 + oct * 8;
+    const int rl = idx / OCT, oct = idx - rl * OCT;
+    const int m = m0 + wm * RM + rl, n = n0 + wn * RN + oct * 8;
     const bool live = m < a.M && n < a.n_store;
     const int mc = min(m, a.M - 1);
     const bool full = n + 8 <= a.N;            // whole octet inside the real columns (pad columns [N, n_store) are stored as zeros)
@@ -262,18 +266,18 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
   }
 }
 
-template <typename T, int GEOM, bool CAT> hipError_t launch_mt(const ConvGemmArgs &a, hipStream_t s) {
-  constexpr int BM = 256, BN = 128;
+template <typename T, int BM, int BN, int WM, int WN, int GEOM, bool CAT> hipError_t launch_mt(const ConvGemmArgs &a, hipStream_t s) {
   constexpr size_t ring = (size_t)NSTAGE * (BM + BN) * ROWB;
-  constexpr size_t redb = (size_t)8 * 64 * 68 * sizeof(float);
+  constexpr size_t redb = (size_t)8 * (BM / WM) * (BN / WN + 4) * sizeof(float);
   constexpr size_t lds = ring > redb ? ring : redb;
+  static_assert(lds <= 160 * 1024, "LDS budget");
   const int mtiles = (a.M + BM - 1) / BM, ntiles = (a.n_store + BN - 1) / BN;
   size_t bA;
   if (GEOM == 0) bA = (size_t)(a.M / a.Lout + (a.M % a.Lout ? 1 : 0)) * a.Lsrc * a.src_ld * 2;
   else bA = (size_t)((a.M + a.To * a.Ho * a.Wo - 1) / (a.To * a.Ho * a.Wo)) * a.Ti * a.Hi * a.Wi * a.src_ld * 2;
   const size_t bW = (size_t)a.N * a.K * 2;
   const size_t bA2 = CAT ? (size_t)a.M * a.src2_ld * 2 : 0;
-  auto kern = conv_gemm_mt_kernel<T, BM, BN, GEOM, CAT>;
+  auto kern = conv_gemm_mt_kernel<T, BM, BN, WM, WN, GEOM, CAT>;
   static bool en = false;
   if (!en) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -282,6 +286,14 @@ template <typename T, int GEOM, bool CAT> hipError_t launch_mt(const ConvGemmArg
   }
   hipLaunchKernelGGL(kern, dim3(mtiles * ntiles), dim3(512), lds, s, a, mtiles, ntiles, (unsigned)bA, (unsigned)bA2, (unsigned)bW);
   return hipGetLastError();
+}
+
+template <typename T, int GEOM, bool CAT> hipError_t launch_mt_v(const ConvGemmArgs &a, int variant, hipStream_t s) {
+  switch (variant) {
+    case 1: return launch_mt<T, 128, 128, 2, 4, GEOM, CAT>(a, s);   // short M: twice the tiles of 256x128
+    case 2: return launch_mt<T, 128, 192, 4, 2, GEOM, CAT>(a, s);   // column counts that are multiples of 192 but not of 128
+    default: return launch_mt<T, 256, 128, 4, 2, GEOM, CAT>(a, s);
+  }
 }
 
 }  // namespace
@@ -304,10 +316,31 @@ bool conv_gemm_mt_ok(int dt, const ConvGemmArgs &a) {
   return true;
 }
 
+// tile variant: 0 = 256x128, 1 = 128x128, 2 = 128x192
+int conv_gemm_mt_variant(const ConvGemmArgs &a) {
+  static const int forced = [] {   // tuning hook
+    const char *e = getenv("SF_MT_VARIANT");
+    return e ? atoi(e) : -1;
+  }();
+  if (forced >= 0 && forced <= 2) return forced;
+  auto cols = [&](int bn) { return (long)((a.n_store + bn - 1) / bn) * bn; };
+  // 192-wide tiles: column counts they cover without empty tiles (192, 576, 960), and short reductions on counts both tile
+  // exactly (the 1536-column qkv projections: 423-427 vs 311-366 TFLOP/s, tools/gemm_mt.py)
+  if (cols(192) < cols(128) || (a.n_store % 192 == 0 && a.K <= 1024)) return 2;
+  const long t256 = (long)((a.M + 255) / 256) * ((a.n_store + 127) / 128);
+  return t256 < 160 ? 1 : 0;                                   // few row bands: halve the tile so that more CUs get one
+}
+
+const char *conv_gemm_mt_name(const ConvGemmArgs &a) {
+  static const char *n[3] = {"conv_gemm_mt<bf16,256x128>", "conv_gemm_mt<bf16,128x128>", "conv_gemm_mt<bf16,128x192>"};
+  return n[conv_gemm_mt_variant(a)];
+}
+
 hipError_t launch_conv_gemm_mt(int dt, const ConvGemmArgs &a, hipStream_t s) {
   if (!conv_gemm_mt_ok(dt, a)) return hipErrorInvalidValue;
-  if (dt == F16) return a.geom == 1 ? launch_mt<f16, 1, false>(a, s) : (a.cin2 ? launch_mt<f16, 0, true>(a, s) : launch_mt<f16, 0, false>(a, s));
-  return a.geom == 1 ? launch_mt<bf16, 1, false>(a, s) : (a.cin2 ? launch_mt<bf16, 0, true>(a, s) : launch_mt<bf16, 0, false>(a, s));
+  const int v = conv_gemm_mt_variant(a);
+  if (dt == F16) return a.geom == 1 ? launch_mt_v<f16, 1, false>(a, v, s) : (a.cin2 ? launch_mt_v<f16, 0, true>(a, v, s) : launch_mt_v<f16, 0, false>(a, v, s));
+  return a.geom == 1 ? launch_mt_v<bf16, 1, false>(a, v, s) : (a.cin2 ? launch_mt_v<bf16, 0, true>(a, v, s) : launch_mt_v<bf16, 0, false>(a, v, s));
 }
 
 }  // namespace sf

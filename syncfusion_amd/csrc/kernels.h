@@ -71,6 +71,7 @@ hipError_t launch_conv_gemm(int dt, const ConvGemmArgs &a, hipStream_t s);
 bool conv_gemm_mt_ok(int dt, const ConvGemmArgs &a);
 bool conv_gemm_prefers_mt(const ConvGemmArgs &a);
 hipError_t launch_conv_gemm_mt(int dt, const ConvGemmArgs &a, hipStream_t s);
+const char *conv_gemm_mt_name(const ConvGemmArgs &a);   // label of the tile variant it picks (bf16 spelling)
 // true when launch_conv_gemm would run `a` on a kernel that honours rowpart_out (fast / wp, 32x32 tiles)
 bool conv_gemm_emits_rowpart(int dt, const ConvGemmArgs &a);
 // GEMM whose first source is LayerNorm-modulated on the fly from producer-side row partials (see ConvGemmArgs)

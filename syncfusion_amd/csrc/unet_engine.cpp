@@ -531,8 +531,11 @@ Plan make_plan(const sf_unet &u, Workspace &ws, int B, int L0, bool two, int num
   }
   // branches: independent slices of the (doubled) batch; each gets its own GroupNorm scratch
   {
-    // measured (B = 8, bf16, MI355X): 2 branches +15 %, 4 branches -17 % vs 1 (the per-kernel grids get too small)
-    int want = u.branches_override > 0 ? u.branches_override : (p.Bt >= 4 ? 2 : 1);
+    // measured (bf16, MI355X): 8 evaluations per step: 2 branches 455 vs 1 branch 372 steps/s (more branches do not help: the
+    // chain length, not the rows per launch, sets the time); 16: 320 vs 262; from 32 evaluations on the launches are long enough
+    // to fill the chip and ONE branch wins (32: 210 vs 203, 32 with guidance 211 vs 198, 64 with guidance 154 vs 151) -- it also
+    // spares the two-stream step graph that guidance needs
+    int want = u.branches_override > 0 ? u.branches_override : ((p.Bt >= 4 && p.Bt < 32) ? 2 : 1);
     if (want > sf_unet::kMaxBranches) want = sf_unet::kMaxBranches;
     while (want > 1 && p.Bt % want) --want;
     p.nbr = u.dbg.buf ? 1 : want;
