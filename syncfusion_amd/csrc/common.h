@@ -71,7 +71,13 @@ template <bool FAST> __device__ __forceinline__ float exp_t(float x) {
   if constexpr (FAST) return __expf(x);
   else return expf(x);
 }
-template <bool FAST> __device__ __forceinline__ float silu_t(float x) { return x / (1.0f + exp_t<FAST>(-x)); }
+// 16-bit paths: x * rcp(1 + exp(-x)) -- v_exp_f32 + v_rcp_f32 (1 ulp each, far inside a 16-bit result) instead of the IEEE
+// division sequence (v_div_scale / v_rcp / 4 v_fma / v_div_fmas / v_div_fixup: ~10 VALU instructions per element, which made the
+// GroupNorm+SiLU prologues of the thin-level kernels VALU-bound: SQ_ACTIVE_INST_VALU = 73 % of their issue cycles at batch 64)
+template <bool FAST> __device__ __forceinline__ float silu_t(float x) {
+  if constexpr (FAST) return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+  else return x / (1.0f + expf(-x));
+}
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 // epilogue activation codes shared by the conv kernels: 0 none, 1 relu, 2 gelu(erf), 3 silu(gelu(v))
