@@ -221,6 +221,15 @@ hipError_t launch_pack_rows(int dt, const float *in, int64_t rows, int cols, int
 // out[n] = sum_k w[n][k] * v[k] (+ add[n])   fp32 gemv used for folding LayerNorm biases at pack time
 hipError_t launch_fold_bias(const float *w, int N, int K, const float *v, const float *add, float *out, hipStream_t s);
 // ---------------------------------------------------------------------------------------
+// VideoOnsetNet stem (onset_stem.hip): Conv3d(3 -> <= 64, (1,7,7), stride (1,2,2), pad (0,3,3)) + shift + ReLU, 16-bit types
+// ---------------------------------------------------------------------------------------
+size_t onset_stem_weight_elems();
+// generic packed weights [n][49 taps][4] (row length k_in, compute type) -> the kernel's [64][7][8][4] image
+hipError_t launch_onset_stem_repack(int dt, const void *w_generic, int n_real, int k_in, void *out, hipStream_t s);
+hipError_t launch_onset_stem(int dt, const void *in, int NT, int H, int W, const void *wk, const float *shift, int n_real, void *out, int out_ld,
+                             hipStream_t s);
+
+// ---------------------------------------------------------------------------------------
 // Input side (input.hip)
 // ---------------------------------------------------------------------------------------
 // uint8 RGB frames (N, T, H, W, 3) -> (N, 3, T, oh, ow) fp32: /255, antialiased bilinear resize (ATen semantics), (x - mean) / std

@@ -33,6 +33,7 @@ struct sf_onsetnet {
   int dt = SF_F32;
   DeviceArena arena;
   Conv3 stem_s, stem_t;
+  void *stem_wk = nullptr;   // 16-bit types: the stem's weights in the layout of the dedicated kernel (onset_stem.hip)
   std::vector<ResBlk> blocks;  // 8 residual blocks
   ConvW fc0, fc2;
   DebugTaps dbg;
@@ -174,6 +175,10 @@ int sf_onsetnet_create(const sf_tensor *weights, int n_weights, int dtype, void 
   const std::string m = "net.model.";
   o->stem_s = make_conv(*o, pk, m + "stem.0", m + "stem.1", 3, 45, 1, 7, 7, 2, 0, 3);
   o->stem_t = make_conv(*o, pk, m + "stem.3", m + "stem.4", 45, 64, 3, 1, 1, 1, 1, 0);
+  if (dtype != SF_F32 && getenv("SF_NO_ONSET_STEM") == nullptr) {
+    o->stem_wk = o->arena.alloc((int64_t)onset_stem_weight_elems() * dsize(dtype));
+    SF_HIP(launch_onset_stem_repack(dtype, o->stem_s.w.w, o->stem_s.cout, o->stem_s.w.K, o->stem_wk, s));
+  }
   int cin = 64;
   for (int st = 0; st < 4; ++st) {
     const int planes = kStagePlanes[st];
@@ -227,7 +232,12 @@ int sf_onsetnet_forward(sf_onsetnet *h, const float *frames, int N, int T, int H
   SF_HIP(launch_video_to_cl(h->dt, frames, N, 3, T, H, W, p.in, h->stem_s.cin_ld, s));
   void *X = p.buf[0], *M = p.buf[1], *Y = p.buf[2], *R = p.buf[3];
   int hh, ww, h2, w2;
-  ex.conv(h->stem_s, p.in, H, W, M, hh, ww, nullptr, true);
+  if (h->stem_wk && h->stem_s.cin_ld == 4 && h->stem_s.cout_ld == 64 && (int64_t)N * T * H * W * 8 < 0x7FFFFFF0ll) {
+    out_hw(H, W, h->stem_s, hh, ww);
+    SF_HIP(launch_onset_stem(h->dt, p.in, N * T, H, W, h->stem_wk, h->stem_s.w.bias, h->stem_s.cout, M, h->stem_s.cout_ld, s));
+  } else {
+    ex.conv(h->stem_s, p.in, H, W, M, hh, ww, nullptr, true);
+  }
   ex.conv(h->stem_t, M, hh, ww, X, h2, w2, nullptr, true);
   h->dbg.tap("stem", h->dt, X, h->stem_t.cout_ld, (int64_t)N * T * hh * ww, h->stem_t.cout, s);
   int bi = 0;
