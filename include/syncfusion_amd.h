@@ -116,6 +116,9 @@ int sf_unet_debug_info(const sf_unet *h, int i, char *name_out, int name_cap, in
 /* Per-kernel launch accounting of the last forward (host side, for bench.py's roofline):
  * number of kernel launches in one evaluation. */
 int sf_unet_launch_count(const sf_unet *h);
+/* Step graphs captured and instantiated by sf_vsample so far.  Graphs are cached per (shape, workspace, guidance) -- the active set
+ * plus three stashed ones -- so a server alternating between a few request shapes stops adding to this after its first round. */
+int sf_unet_graph_captures(const sf_unet *h);
 /* Number of clip-parallel branches (independent slices of the batch run concurrently on separate HIP streams,
  * forked/joined with events): 0 = automatic (2 for >= 4 clips), 1 = off, up to 8. */
 int sf_unet_set_branches(sf_unet *h, int n);

@@ -150,6 +150,9 @@ class UNetEngine(_Base):
     def launch_count(self) -> int:
         return int(self.lib.sf_unet_launch_count(self.handle))
 
+    def graph_captures(self) -> int:
+        return int(self.lib.sf_unet_graph_captures(self.handle))
+
     def profile_forward(self, x, sigma, channels, embedding, embedding_scale=1.0):
         """One evaluation with HIP events around every launch -> [(label, ms, algorithmic flops, algorithmic bytes)]."""
         check(self.lib.sf_unet_profile_enable(self.handle, 1), "sf_unet_profile_enable")

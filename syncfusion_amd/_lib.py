@@ -64,6 +64,7 @@ SYMBOLS = {
     "sf_unet_debug_count": (_I, [_P]),
     "sf_unet_debug_info": (_I, [_P, _I, C.c_char_p, _I, C.POINTER(_L), C.POINTER(_L), C.POINTER(C.c_int32)]),
     "sf_unet_launch_count": (_I, [_P]),
+    "sf_unet_graph_captures": (_I, [_P]),
     "sf_unet_set_branches": (_I, [_P, _I]),
     "sf_unet_profile_enable": (_I, [_P, _I]),
     "sf_unet_profile_count": (_I, [_P]),

@@ -89,6 +89,7 @@ struct sf_unet {
   std::vector<Block> blocks;
   DebugTaps dbg;
   int launches = 0;
+  int graph_captures = 0;   // step graphs captured + instantiated so far (diagnostic: a cached shape must not add to it)
   bool listing = false;
   // per-launch HIP-event timing (bench.py's roofline leg): events are recorded on the launch stream
   struct ProfRec {
@@ -1566,6 +1567,7 @@ int sf_vsample(sf_unet *h, float *x, const float *const *ctx, const float *emb, 
           (void)hipGraphExecDestroy(h->gexec_br[br]);
           h->gexec_br[br] = nullptr;
         }
+        ++h->graph_captures;
         hipError_t e = hipGraphInstantiate(&h->gexec_br[br], graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
         if (e != hipSuccess) fail(SF_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
@@ -1625,6 +1627,7 @@ int sf_vsample(sf_unet *h, float *x, const float *const *ctx, const float *emb, 
         (void)hipGraphExecDestroy(h->gexec);
         h->gexec = nullptr;
       }
+      ++h->graph_captures;
       hipError_t e = hipGraphInstantiate(&h->gexec, graph, nullptr, nullptr, 0);
       (void)hipGraphDestroy(graph);
       if (e != hipSuccess) fail(SF_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
@@ -1663,6 +1666,7 @@ int sf_unet_debug_info(const sf_unet *h, int i, char *name_out, int name_cap, in
   return SF_OK;
 }
 int sf_unet_launch_count(const sf_unet *h) { return h ? h->launches : -1; }
+int sf_unet_graph_captures(const sf_unet *h) { return h ? h->graph_captures : -1; }
 
 int sf_unet_set_branches(sf_unet *h, int n) {
   if (!h || n < 0 || n > sf_unet::kMaxBranches) return SF_ERR_INVALID;

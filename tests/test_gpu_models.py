@@ -176,6 +176,28 @@ def test_sample_reuses_cached_step_graph(cuda):
         assert torch.equal(a, b)
 
 
+def test_graph_stash_serves_alternating_request_shapes(cuda):
+    """A long-lived engine alternating between a few request shapes (batch, length, guidance) keeps one set of step graphs per
+    shape (up to four): the second round replays cached graphs -- no eager step, no capture, so the engine's launch counter does
+    not move -- and every result equals the eager loop bit for bit."""
+    m = _small_diffusion(cuda)
+    eng = m.net.engine()
+    shapes = [(4, 16 * 44, 2.0), (3, 16 * 20, 1.0), (2, 16 * 44, 1.0), (1, 16 * 8, 2.0)]   # largest first: the workspace (part of the key) is sized once
+    def run(B, L0, scale, seed, graph):
+        m.sampler.use_graph = graph
+        _, _, emb, chans = synth_inputs(SMALL_UNET, B, L0, seed=seed)
+        noise = torch.randn(B, 1, L0, generator=torch.Generator().manual_seed(seed)).to(cuda)
+        return m.sample(x_noisy=noise, num_steps=5, channels=[c.to(cuda) for c in chans], embedding=emb.to(cuda), embedding_scale=scale).cpu()
+    first = [run(B, L0, sc, 10 + i, True) for i, (B, L0, sc) in enumerate(shapes)]        # captures four graph sets
+    captured = eng.graph_captures()
+    assert captured >= len(shapes)
+    second = [run(B, L0, sc, 10 + i, True) for i, (B, L0, sc) in enumerate(shapes)]
+    assert eng.graph_captures() == captured, "a cached shape re-captured its step graph"
+    eager = [run(B, L0, sc, 10 + i, False) for i, (B, L0, sc) in enumerate(shapes)]
+    for a, b, c in zip(first, second, eager):
+        assert torch.equal(a, b) and torch.equal(b, c)
+
+
 def test_sampler_zero_net_identity(cuda):
     """Analytic identity: with v == 0 every step multiplies x by cos(pi/2T) -> x_T = x_0 cos(pi/2T)^T.
     A net whose output convs are zero returns v == 0 exactly (skip + scale * 0 at depth 0 gives v = x; so instead
