@@ -31,17 +31,23 @@ def _cl(x: Tensor) -> Tensor:
 
 class _ConvBlockFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], gamma: Optional[Tensor], beta: Optional[Tensor], groups: int, eps: float):
+    def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], gamma: Optional[Tensor], beta: Optional[Tensor], groups: int, eps: float,
+                channels_last: bool = False):
         _lib.require_gpu_tensor(x, "syncfusion_amd.autograd")
         lib = _lib.load()
-        B, Cc, L = x.shape
+        if channels_last:
+            B, L, Cc = x.shape
+        else:
+            B, Cc, L = x.shape
         N, Cw, taps = weight.shape
         if Cw != Cc or taps % 2 != 1:
             raise ValueError(f"weight {tuple(weight.shape)} does not match input channels {Cc} (odd kernel sizes only)")
         pad = taps // 2
-        c_real = Cc
+        c_real, n_real = Cc, N
+        if groups > 0 and Cc % 32 != 0 and (Cc > 32 or N > 32):
+            raise ValueError(f"gn_silu_conv1d: {Cc} -> {N} channels: channel counts above 32 must be multiples of 32")
         with torch.cuda.device(x.device):
-            x_cl = _cl(_lib.f32c(x))
+            x_cl = _lib.f32c(x) if channels_last else _cl(_lib.f32c(x))
             w = _lib.f32c(weight)
             if groups == 0 and Cc % 32 != 0 and N > 32:
                 # plain convolutions over odd channel counts (cat[x, ctx]) run on the MFMA kernels with the channels zero-padded
@@ -50,6 +56,12 @@ class _ConvBlockFn(torch.autograd.Function):
                 x_cl = torch.nn.functional.pad(x_cl, (0, Cp - Cc))
                 w = torch.nn.functional.pad(w, (0, 0, 0, Cp - Cc)).contiguous()
                 Cc = Cp
+            if groups == 0 and N % 32 != 0 and Cc > 32:
+                # ... and thin outputs of wide inputs get zero output channels up to a multiple of 32 (their dgrad runs on MFMA)
+                Np = (N + 31) // 32 * 32
+                w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, Np - N)).contiguous()
+                bias = torch.nn.functional.pad(bias, (0, Np - N)) if bias is not None else None
+                N = Np
             b = _lib.f32c(bias) if bias is not None else None
             g = _lib.f32c(gamma) if groups > 0 else None
             be = _lib.f32c(beta) if groups > 0 else None
@@ -60,17 +72,21 @@ class _ConvBlockFn(torch.autograd.Function):
                                            None, B, L, Cc, N, taps, 1, pad, 1, out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr(x.device)),
                        "sf_op_conv1d_cl")
         ctx.save_for_backward(x_cl, w, g if g is not None else x_cl.new_empty(0), be if be is not None else x_cl.new_empty(0))
-        ctx.meta = (B, L, Cc, N, taps, pad, int(groups), float(eps), bias is not None, c_real)
-        return out.transpose(1, 2)
+        ctx.meta = (B, L, Cc, N, taps, pad, int(groups), float(eps), bias is not None, c_real, n_real, bool(channels_last))
+        if n_real != N:
+            out = out[:, :, :n_real]
+        return out if channels_last else out.transpose(1, 2)
 
     @staticmethod
     def backward(ctx, dy: Tensor):
         lib = _lib.load()
         x_cl, w, g, be = ctx.saved_tensors
-        B, L, Cc, N, taps, pad, groups, eps, has_bias, c_real = ctx.meta
+        B, L, Cc, N, taps, pad, groups, eps, has_bias, c_real, n_real, channels_last = ctx.meta
         dev = x_cl.device
         with torch.cuda.device(dev):
-            dy_cl = _cl(_lib.f32c(dy))
+            dy_cl = _lib.f32c(dy) if channels_last else _cl(_lib.f32c(dy))
+            if n_real != N:
+                dy_cl = torch.nn.functional.pad(dy_cl, (0, N - n_real))
             dx = torch.empty_like(x_cl)
             dw = torch.empty_like(w)
             db = torch.empty(N, dtype=torch.float32, device=dev) if has_bias else None
@@ -85,14 +101,97 @@ class _ConvBlockFn(torch.autograd.Function):
                                                ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)), "sf_op_conv1d_bwd_cl")
         if c_real != Cc:
             dx, dw = dx[:, :, :c_real], dw[:, :c_real]
-        return (dx.transpose(1, 2), dw, db, dgb[:Cc] if dgb is not None else None, dgb[Cc:] if dgb is not None else None, None, None)
+        if n_real != N:
+            dw, db = dw[:n_real], (db[:n_real] if db is not None else None)
+        return (dx if channels_last else dx.transpose(1, 2), dw, db, dgb[:Cc] if dgb is not None else None, dgb[Cc:] if dgb is not None else None,
+                None, None, None)
 
 
-def gn_silu_conv1d(x: Tensor, weight: Tensor, bias: Optional[Tensor], gamma: Tensor, beta: Tensor, groups: int, eps: float = 1e-5) -> Tensor:
-    """``F.conv1d(F.silu(F.group_norm(x, groups, gamma, beta, eps)), weight, bias, padding=k//2)`` with HIP forward and backward."""
-    return _ConvBlockFn.apply(x, weight, bias, gamma, beta, int(groups), float(eps))
+def gn_silu_conv1d(x: Tensor, weight: Tensor, bias: Optional[Tensor], gamma: Tensor, beta: Tensor, groups: int, eps: float = 1e-5,
+                   channels_last: bool = False) -> Tensor:
+    """``F.conv1d(F.silu(F.group_norm(x, groups, gamma, beta, eps)), weight, bias, padding=k//2)`` with HIP forward and backward.
+    ``channels_last``: x and the result are ``(B, L, C)`` instead of ``(B, C, L)`` (no transposes around the kernels)."""
+    return _ConvBlockFn.apply(x, weight, bias, gamma, beta, int(groups), float(eps), bool(channels_last))
 
 
-def conv1d(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None) -> Tensor:
+def conv1d(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, channels_last: bool = False) -> Tensor:
     """``F.conv1d(x, weight, bias, padding=k//2)`` (stride 1) with HIP forward and backward."""
-    return _ConvBlockFn.apply(x, weight, bias, None, None, 0, 0.0)
+    return _ConvBlockFn.apply(x, weight, bias, None, None, 0, 0.0, bool(channels_last))
+
+
+class _LnModulateFn(torch.autograd.Function):
+    """y = LayerNorm_C(x; eps, no affine) * (1 + ss[:, :C]) + ss[:, C:] on channels-last ``(B, L, C)`` rows (ss: ``(B, 2C)`` or None)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, ss: Optional[Tensor], eps: float):
+        _lib.require_gpu_tensor(x, "syncfusion_amd.autograd")
+        lib = _lib.load()
+        B, L, Cc = x.shape
+        with torch.cuda.device(x.device):
+            xc = _lib.f32c(x)
+            sc = _lib.f32c(ss) if ss is not None else None
+            out = torch.empty_like(xc)
+            _lib.check(lib.sf_op_ln_modulate(_lib.SF_F32, xc.data_ptr(), sc.data_ptr() if sc is not None else None, float(eps), B, L, Cc, out.data_ptr(),
+                                             _lib.stream_ptr(x.device)), "sf_op_ln_modulate")
+        ctx.save_for_backward(xc, sc if sc is not None else xc.new_empty(0))
+        ctx.meta = (B, L, Cc, float(eps), ss is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        lib = _lib.load()
+        xc, sc = ctx.saved_tensors
+        B, L, Cc, eps, has_ss = ctx.meta
+        dev = xc.device
+        with torch.cuda.device(dev):
+            dyc = _lib.f32c(dy)
+            dx = torch.empty_like(xc)
+            dss = torch.empty(B, 2 * Cc, dtype=torch.float32, device=dev) if has_ss else None
+            ws = torch.empty(B * 64 * 2 * Cc * 4 + 256, dtype=torch.uint8, device=dev)
+            _lib.check(lib.sf_op_ln_modulate_bwd(xc.data_ptr(), sc.data_ptr() if has_ss else None, dyc.data_ptr(), eps, B, L, Cc, dx.data_ptr(),
+                                                 dss.data_ptr() if dss is not None else None, ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)),
+                       "sf_op_ln_modulate_bwd")
+        return dx, dss, None
+
+
+def ln_modulate(x: Tensor, scale_shift: Optional[Tensor], eps: float) -> Tensor:
+    """Modulation / pre-norm LayerNorm on ``(B, L, C)`` rows with HIP forward and backward.  An affine LayerNorm ``LN(x) * g + b``
+    is ``ln_modulate(x, cat[g - 1, b] broadcast over the clips, eps)``."""
+    return _LnModulateFn.apply(x, scale_shift, float(eps))
+
+
+class _AttentionFn(torch.autograd.Function):
+    """Multi-head softmax attention (head dim 64) on packed projections: q ``(B, L, H*64)``, kv ``(B, L, 2*H*64)`` -> ``(B, L, H*64)``."""
+
+    @staticmethod
+    def forward(ctx, q: Tensor, kv: Tensor, heads: int):
+        _lib.require_gpu_tensor(q, "syncfusion_amd.autograd")
+        lib = _lib.load()
+        B, L, HD = q.shape
+        with torch.cuda.device(q.device):
+            qc, kc = _lib.f32c(q), _lib.f32c(kv)
+            out = torch.empty_like(qc)
+            _lib.check(lib.sf_op_attention(_lib.SF_F32, qc.data_ptr(), kc.data_ptr(), B, L, int(heads), HD // int(heads), out.data_ptr(),
+                                           _lib.stream_ptr(q.device)), "sf_op_attention")
+        ctx.save_for_backward(qc, kc)
+        ctx.meta = (B, L, int(heads), HD // int(heads))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout: Tensor):
+        lib = _lib.load()
+        qc, kc = ctx.saved_tensors
+        B, L, H, D = ctx.meta
+        dev = qc.device
+        with torch.cuda.device(dev):
+            doc = _lib.f32c(dout)
+            dq, dkv = torch.empty_like(qc), torch.empty_like(kc)
+            ws = torch.empty(2 * B * H * L * 4 + 256, dtype=torch.uint8, device=dev)
+            _lib.check(lib.sf_op_attention_bwd(qc.data_ptr(), kc.data_ptr(), doc.data_ptr(), B, L, H, D, dq.data_ptr(), dkv.data_ptr(), ws.data_ptr(),
+                                               ws.numel(), _lib.stream_ptr(dev)), "sf_op_attention_bwd")
+        return dq, dkv, None
+
+
+def attention(q: Tensor, kv: Tensor, heads: int) -> Tensor:
+    """softmax(q k^T / sqrt(64)) v per head, HIP forward and backward."""
+    return _AttentionFn.apply(q, kv, int(heads))

@@ -101,4 +101,31 @@ int sf_op_conv1d_bwd_cl(const float *x, const float *w, const float *gamma, cons
   SF_API_END
 }
 
+int sf_op_ln_modulate_bwd(const float *x, const float *scale_shift, const float *dy, float eps, int B, int L, int C, float *dx, float *dss, void *ws,
+                          int64_t ws_bytes, void *stream) {
+  SF_API_BEGIN
+  if (!x || !dy || !dx || !ws) fail(SF_ERR_INVALID, "null argument");
+  if (C > 1024) fail(SF_ERR_UNSUPPORTED, "C must be <= 1024");
+  const int64_t need = (int64_t)B * ln_mod_bwd_chunks(L) * 2 * C * (int64_t)sizeof(float);
+  if (ws_bytes < need) fail(SF_ERR_WORKSPACE, "workspace too small: need %lld bytes", (long long)need);
+  SF_HIP(launch_ln_modulate_bwd(x, scale_shift, dy, eps, B, L, C, dx, static_cast<float *>(ws), dss, static_cast<hipStream_t>(stream)));
+  return SF_OK;
+  SF_API_END
+}
+
+int sf_op_attention_bwd(const float *q, const float *kv, const float *dout, int B, int L, int heads, int head_dim, float *dq, float *dkv, void *ws,
+                        int64_t ws_bytes, void *stream) {
+  SF_API_BEGIN
+  if (!q || !kv || !dout || !dq || !dkv || !ws) fail(SF_ERR_INVALID, "null argument");
+  if (head_dim != 64) fail(SF_ERR_UNSUPPORTED, "head_dim must be 64");
+  const int64_t need = (int64_t)2 * B * heads * L * (int64_t)sizeof(float);
+  if (ws_bytes < need) fail(SF_ERR_WORKSPACE, "workspace too small: need %lld bytes", (long long)need);
+  float *lse = static_cast<float *>(ws), *dsum = lse + (int64_t)B * heads * L;
+  hipError_t e = launch_attention_bwd(q, kv, dout, B, L, heads, head_dim, dq, dkv, lse, dsum, static_cast<hipStream_t>(stream));
+  if (e == hipErrorInvalidValue) fail(SF_ERR_UNSUPPORTED, "attention backward supports sequences up to ~1100 positions (got %d)", L);
+  SF_HIP(e);
+  return SF_OK;
+  SF_API_END
+}
+
 }  // extern "C"

@@ -167,6 +167,216 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_kernel(const float *__restric
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// LayerNorm-modulate backward:  y = xhat (1 + s_b) + t_b,  xhat = LayerNorm_C(x; eps, no affine)
+//   dx = rstd (g - mean_c(g) - xhat mean_c(g xhat)),  g = dy (1 + s_b);   ds_b[c] = sum_l dy xhat,  dt_b[c] = sum_l dy
+// One workgroup per (clip, chunk of rows); a wave owns a row at a time, a lane the channels lane, lane + 64, ... (C <= 1024).
+// The per-clip sums are accumulated per lane over the wave's rows, reduced over the four waves through LDS and written per chunk;
+// slices_reduce_kernel adds the chunks (fixed order).
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int kLnMaxPer = 16;   // channels per lane: C <= 1024
+__global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const float *__restrict__ x, const float *__restrict__ ss, int ss_ld, const float *__restrict__ dy,
+                                                         int L, int C, float eps, int rows_per_chunk, float *__restrict__ dx,
+                                                         float *__restrict__ dss_part /* [B][nchunk][2C] */) {
+  __shared__ float red[4][2 * 1024];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x, chunk = blockIdx.y, nchunk = gridDim.y;
+  const int per = (C + 63) / 64;
+  float sc[kLnMaxPer], acs[kLnMaxPer], act[kLnMaxPer];
+#pragma unroll
+  for (int k = 0; k < kLnMaxPer; ++k) {
+    const int c = lane + 64 * k;
+    sc[k] = (k < per && c < C) ? 1.0f + (ss ? ss[(size_t)b * ss_ld + c] : 0.f) : 0.f;
+    acs[k] = act[k] = 0.f;
+  }
+  const int l0 = chunk * rows_per_chunk, l1 = min(L, l0 + rows_per_chunk);
+  const float inv_c = 1.0f / (float)C;
+  for (int l = l0 + wave; l < l1; l += 4) {
+    const size_t row = ((size_t)b * L + l) * C;
+    float xv[kLnMaxPer], gv[kLnMaxPer];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < kLnMaxPer; ++k) {
+      const int c = lane + 64 * k;
+      xv[k] = (k < per && c < C) ? x[row + c] : 0.f;
+      s += xv[k];
+    }
+    const float mean = wave_sum_dpp(s) * inv_c;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < kLnMaxPer; ++k) {
+      const int c = lane + 64 * k;
+      const float d = (k < per && c < C) ? xv[k] - mean : 0.f;
+      q = fmaf(d, d, q);
+    }
+    const float rstd = rsqrtf(wave_sum_dpp(q) * inv_c + eps);
+    float g1 = 0.f, g2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < kLnMaxPer; ++k) {
+      const int c = lane + 64 * k;
+      const bool ok = k < per && c < C;
+      const float xh = ok ? (xv[k] - mean) * rstd : 0.f;
+      const float d = ok ? dy[row + c] : 0.f;
+      xv[k] = xh;
+      gv[k] = d * sc[k];
+      g1 += gv[k];
+      g2 = fmaf(gv[k], xh, g2);
+      acs[k] = fmaf(d, xh, acs[k]);
+      act[k] += d;
+    }
+    const float m1 = wave_sum_dpp(g1) * inv_c, m2 = wave_sum_dpp(g2) * inv_c;
+#pragma unroll
+    for (int k = 0; k < kLnMaxPer; ++k) {
+      const int c = lane + 64 * k;
+      if (k < per && c < C) dx[row + c] = rstd * (gv[k] - m1 - xv[k] * m2);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kLnMaxPer; ++k) {
+    const int c = lane + 64 * k;
+    if (k < per && c < C) {
+      red[wave][c] = acs[k];
+      red[wave][1024 + c] = act[k];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float *o = dss_part + ((size_t)b * nchunk + chunk) * 2 * C;
+    o[c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    o[C + c] = (red[0][1024 + c] + red[1][1024 + c]) + (red[2][1024 + c] + red[3][1024 + c]);
+  }
+}
+// out[b][j] = sum over chunks of part[b][chunk][j]
+__global__ void chunks_reduce_kernel(const float *__restrict__ part, int nchunk, int cols, float *__restrict__ out) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (col >= cols) return;
+  float s = 0.f;
+  for (int k = 0; k < nchunk; ++k) s += part[((size_t)b * nchunk + k) * cols + col];
+  out[(size_t)b * cols + col] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Multi-head softmax attention backward (head dim 64, fp32), two passes, no atomics:
+//   pass Q (one workgroup per (clip, head, 16 queries)): S = q K^T scale, P = softmax(S), dP = dO V^T, D_i = sum_j P_ij dP_ij,
+//            dS = P (dP - D) scale, dQ = dS K;  leaves lse_i = log sum_j exp(S_ij) and D_i for the second pass
+//   pass K (one workgroup per (clip, head, 16 keys)): p_ij = exp(S_ij - lse_i); dV_j = sum_i p_ij dO_i; dK_j = sum_i p_ij (dP_ij - D_i) scale q_i
+// q, dq, dout: (B, L, H*64) rows;  kv, dkv: (B, L, 2*H*64) rows (k | v).
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int AD = 64, AQ = 16;
+__global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float *__restrict__ q, const float *__restrict__ kv, const float *__restrict__ dout, int L, int H,
+                                                         float scale, float *__restrict__ dq, float *__restrict__ lse, float *__restrict__ dsum) {
+  extern __shared__ float sm[];
+  float *qs = sm;                   // [AQ][AD]
+  float *dos = qs + AQ * AD;        // [AQ][AD]
+  float *P = dos + AQ * AD;         // [AQ][L]
+  float *dP = P + (size_t)AQ * L;   // [AQ][L]
+  const int tid = threadIdx.x;
+  const int q0 = blockIdx.x * AQ, h = blockIdx.y, b = blockIdx.z;
+  const int ldq = H * AD, ldkv = 2 * H * AD;
+  const size_t rb = (size_t)b * L;
+  for (int i = tid; i < AQ * AD; i += 256) {
+    const int r = i / AD, d = i - r * AD;
+    const bool ok = q0 + r < L;
+    qs[i] = ok ? q[(rb + q0 + r) * ldq + h * AD + d] : 0.f;
+    dos[i] = ok ? dout[(rb + q0 + r) * ldq + h * AD + d] : 0.f;
+  }
+  __syncthreads();
+  for (int e = tid; e < AQ * L; e += 256) {   // S and dP: thread -> (query r, key j)
+    const int r = e / L, j = e - r * L;
+    const float *kp = kv + (rb + j) * ldkv + h * AD, *vp = kp + H * AD;
+    float s = 0.f, dp = 0.f;
+#pragma unroll 8
+    for (int d = 0; d < AD; ++d) {
+      s = fmaf(qs[r * AD + d], kp[d], s);
+      dp = fmaf(dos[r * AD + d], vp[d], dp);
+    }
+    P[e] = s * scale;
+    dP[e] = dp;
+  }
+  __syncthreads();
+  {   // softmax statistics: 16 lanes per query row
+    const int r = tid >> 4, sub = tid & 15;
+    float mx = -INFINITY;
+    for (int j = sub; j < L; j += 16) mx = fmaxf(mx, P[r * L + j]);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
+    float sum = 0.f;
+    for (int j = sub; j < L; j += 16) sum += expf(P[r * L + j] - mx);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
+    const float l = mx + logf(sum);
+    float dd = 0.f;
+    for (int j = sub; j < L; j += 16) {
+      const float p = expf(P[r * L + j] - l);
+      P[r * L + j] = p;
+      dd = fmaf(p, dP[r * L + j], dd);
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) dd += __shfl_xor(dd, o, 16);
+    for (int j = sub; j < L; j += 16) dP[r * L + j] = P[r * L + j] * (dP[r * L + j] - dd) * scale;   // dS
+    if (sub == 0 && q0 + r < L) {
+      lse[((size_t)b * H + h) * L + q0 + r] = l;
+      dsum[((size_t)b * H + h) * L + q0 + r] = dd;
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < AQ * AD; e += 256) {   // dQ = dS K
+    const int r = e / AD, d = e - r * AD;
+    float acc = 0.f;
+    for (int j = 0; j < L; ++j) acc = fmaf(dP[r * L + j], kv[(rb + j) * ldkv + h * AD + d], acc);
+    if (q0 + r < L) dq[(rb + q0 + r) * ldq + h * AD + d] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_k_kernel(const float *__restrict__ q, const float *__restrict__ kv, const float *__restrict__ dout,
+                                                         const float *__restrict__ lse, const float *__restrict__ dsum, int L, int H, float scale,
+                                                         float *__restrict__ dkv) {
+  __shared__ float ks[AQ][AD + 1], vs[AQ][AD + 1];
+  const int tid = threadIdx.x;
+  const int k0 = blockIdx.x * AQ, h = blockIdx.y, b = blockIdx.z;
+  const int ldq = H * AD, ldkv = 2 * H * AD;
+  const size_t rb = (size_t)b * L;
+  for (int i = tid; i < AQ * AD; i += 256) {
+    const int r = i / AD, d = i - r * AD;
+    const bool ok = k0 + r < L;
+    ks[r][d] = ok ? kv[(rb + k0 + r) * ldkv + h * AD + d] : 0.f;
+    vs[r][d] = ok ? kv[(rb + k0 + r) * ldkv + (H + h) * AD + d] : 0.f;
+  }
+  __syncthreads();
+  // thread -> (key j = tid / 16, dims 4 * (tid % 16) .. + 3); the 16 lanes of a key share its dot products
+  const int j = tid >> 4, sub = tid & 15;
+  float dk[4] = {0.f, 0.f, 0.f, 0.f}, dv[4] = {0.f, 0.f, 0.f, 0.f};
+  const float *lp = lse + ((size_t)b * H + h) * L, *dp_ = dsum + ((size_t)b * H + h) * L;
+  for (int i = 0; i < L; ++i) {
+    const float *qp = q + (rb + i) * ldq + h * AD + 4 * sub, *op = dout + (rb + i) * ldq + h * AD + 4 * sub;
+    const f32x4 qv = *reinterpret_cast<const f32x4 *>(qp), ov = *reinterpret_cast<const f32x4 *>(op);
+    float s = 0.f, dpv = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      s = fmaf(qv[e], ks[j][4 * sub + e], s);
+      dpv = fmaf(ov[e], vs[j][4 * sub + e], dpv);
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      s += __shfl_xor(s, o, 16);
+      dpv += __shfl_xor(dpv, o, 16);
+    }
+    const float p = expf(s * scale - lp[i]);
+    const float ds = p * (dpv - dp_[i]) * scale;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      dv[e] = fmaf(p, ov[e], dv[e]);
+      dk[e] = fmaf(ds, qv[e], dk[e]);
+    }
+  }
+  if (k0 + j < L) {
+    float *o = dkv + (rb + k0 + j) * ldkv + h * AD + 4 * sub;
+    *reinterpret_cast<f32x4 *>(o) = f32x4{dk[0], dk[1], dk[2], dk[3]};
+    *reinterpret_cast<f32x4 *>(o + H * AD) = f32x4{dv[0], dv[1], dv[2], dv[3]};
+  }
+}
+
 }  // namespace
 
 hipError_t launch_pack_dgrad(const float *w, int N, int C, int taps, int ldn, float *out, hipStream_t s) {
@@ -208,6 +418,36 @@ hipError_t launch_gn_silu_bwd(const float *x, const float *da, const float *gamm
   hipLaunchKernelGGL(gn_silu_bwd_kernel, dim3(B * G), dim3(256), 0, s, x, da, gamma, beta, L, C, G, eps, dx, dgb_part);
   // dgb_part is [B][2][C]: rows b, columns (2C) -> column sums give [dgamma | dbeta]
   hipLaunchKernelGGL(slices_reduce_kernel, dim3((2 * C + 63) / 64), dim3(64), 0, s, dgb_part, B, 2 * C, dgb);
+  return hipGetLastError();
+}
+
+int ln_mod_bwd_chunks(int L) { return std::max(1, std::min(64, (L + 63) / 64)); }
+
+hipError_t launch_ln_modulate_bwd(const float *x, const float *ss, const float *dy, float eps, int B, int L, int C, float *dx, float *dss_part,
+                                  float *dss, hipStream_t s) {
+  if (C < 1 || C > 64 * kLnMaxPer) return hipErrorInvalidValue;
+  const int nchunk = ln_mod_bwd_chunks(L);
+  const int rpc = (L + nchunk - 1) / nchunk;
+  hipLaunchKernelGGL(ln_mod_bwd_kernel, dim3(B, nchunk), dim3(256), 0, s, x, ss, 2 * C, dy, L, C, eps, rpc, dx, dss_part);
+  if (dss) hipLaunchKernelGGL(chunks_reduce_kernel, dim3((2 * C + 63) / 64, B), dim3(64), 0, s, dss_part, nchunk, 2 * C, dss);
+  return hipGetLastError();
+}
+
+hipError_t launch_attention_bwd(const float *q, const float *kv, const float *dout, int B, int L, int H, int D, float *dq, float *dkv, float *lse,
+                                float *dsum, hipStream_t s) {
+  if (D != AD || L < 1) return hipErrorInvalidValue;
+  const size_t lds = ((size_t)2 * AQ * AD + (size_t)2 * AQ * L) * sizeof(float);
+  if (lds > 150 * 1024) return hipErrorInvalidValue;   // L <= ~1100: longer sequences need a tiled first pass
+  static bool en = false;
+  if (!en) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_q_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e != hipSuccess) return e;
+    en = true;
+  }
+  const float scale = 1.0f / sqrtf((float)AD);
+  dim3 grid((L + AQ - 1) / AQ, H, B);
+  hipLaunchKernelGGL(attn_bwd_q_kernel, grid, dim3(256), lds, s, q, kv, dout, L, H, scale, dq, lse, dsum);
+  hipLaunchKernelGGL(attn_bwd_k_kernel, grid, dim3(256), 0, s, q, kv, dout, lse, dsum, L, H, scale, dkv);
   return hipGetLastError();
 }
 

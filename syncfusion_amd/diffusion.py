@@ -8,8 +8,10 @@ it: ``model(x, channels=..., embedding=...)`` (main/module_diffusion.py:77) and
 keyword arguments and error behaviour; the arithmetic runs in the HIP engine behind the C ABI
 (``sf_unet_forward`` / ``sf_vsample``).  The ``torch.nn`` parameters here are the fp32 masters that
 ``state_dict()/load_state_dict()/parameters()`` expose; they are packed for the device once per
-weight version.  There is no CPU execution path and no autograd through the kernels (the training
-backward is out of scope).
+weight version.  There is no CPU execution path.  When autograd is recording (a training step: a parameter
+or an input requires a gradient and grad mode is on) ``UNetV0.forward`` runs the differentiable fp32
+composition of ``syncfusion_amd.training`` instead of the inference engine, so ``DiffusionModel.forward``
+returns a loss that ``loss.backward()`` can differentiate.
 """
 from __future__ import annotations
 
@@ -176,9 +178,14 @@ class UNetV0(nn.Module):
         assert time is not None, "TimeConditioningPlugin requires time in forward"
         assert embedding is not None, "ClassifierFreeGuidancePlugin requires embedding"
         assert features is None, "external modulation features are not supported"
+        from . import training
+
+        if training.wants_grad(self, x, embedding, *(channels or ())):
+            return training.unet_forward(self, x, time, embedding=embedding, channels=channels, embedding_scale=embedding_scale,
+                                         embedding_mask_proba=embedding_mask_proba)
         if embedding_mask_proba != 0.0:
-            raise NotImplementedError("embedding_mask_proba is a training-time option the reference never passes "
-                                      "(main/module_diffusion.py:77)")
+            raise NotImplementedError("embedding_mask_proba is a training-time option (it needs autograd to be recording); the "
+                                      "reference never passes it (main/module_diffusion.py:77)")
         with torch.no_grad():
             return self.engine().forward(x, time, channels, embedding, embedding_scale)
 

@@ -4,7 +4,9 @@
 factors=[1,4,4,4,2,2,2,2], num_blocks=[2]*8, resnet_groups=2, patch_size=1)``; the reference calls
 ``onsets_encoder(y, with_info=True)`` and slices ``info['xs'][2:-1]`` (main/generation.py:71,80,
 main/module_diffusion.py:76,196).  The forward runs in the HIP engine (``sf_encoder1d_forward``);
-the ``torch.nn`` parameters are the fp32 masters (SURVEY.md appendix A.4 for the structure).
+the ``torch.nn`` parameters are the fp32 masters (SURVEY.md appendix A.4 for the structure).  With autograd recording
+(the reference trains this encoder together with the U-Net, main/module_diffusion.py:53-61) the differentiable
+composition of ``syncfusion_amd.training`` runs instead.
 """
 from __future__ import annotations
 
@@ -64,9 +66,17 @@ class Encoder1d(nn.Module):
         self._engine = None
         return super()._apply(fn, *a, **k)
 
-    @torch.no_grad()
     def forward(self, x: Tensor, with_info: bool = False) -> Union[Tensor, Tuple[Tensor, Dict[str, List[Tensor]]]]:
         _lib.require_gpu_tensor(x, "Encoder1d.forward")
+        from . import training
+
+        if training.wants_grad(self, x):      # a training step: differentiable composition (syncfusion_amd/training.py)
+            z, info = training.encoder1d_forward(self, x)
+            return (z, info) if with_info else z
+        with torch.no_grad():
+            return self._forward_engine(x, with_info)
+
+    def _forward_engine(self, x: Tensor, with_info: bool):
         if self._engine is None or self._engine.stale(self):
             self._engine = EncoderEngine(self)
         outs = self._engine.forward(x)

@@ -128,14 +128,13 @@ class Model(_Base):
         return self.model(x, channels=y_latent["xs"][2:-1], embedding=z_latent)
 
     def training_step(self, batch, batch_idx):
-        """main/module_diffusion.py:79-82.  The U-Net engine is inference-only: ``step`` computes the loss VALUE (as
-        ``validation_step`` needs) but carries no autograd graph, so returning it to a trainer would fail inside
-        ``loss.backward()`` with an opaque message.  The backward kernels exist for the ResnetItem / InjectChannels
-        convolutions only so far (syncfusion_amd/autograd.py)."""
+        """main/module_diffusion.py:79-82.  With autograd recording, ``step`` runs the differentiable fp32 composition
+        (syncfusion_amd/training.py: HIP forward + backward kernels), so the returned loss carries a graph onto the U-Net's and
+        the onset encoder's parameters.  Called under ``torch.no_grad()`` or with every parameter frozen there is nothing to
+        train, and returning a graph-less loss to a trainer would fail inside ``loss.backward()`` with an opaque message."""
         loss = self.step(batch)
         if not loss.requires_grad:
-            raise NotImplementedError("syncfusion_amd is an inference build: DiffusionModel.forward returns the v-objective loss without "
-                                      "an autograd graph (training backward: only syncfusion_amd.autograd.{gn_silu_conv1d, conv1d} so far)")
+            raise RuntimeError("training_step: the loss carries no autograd graph (grad mode is off or every parameter is frozen)")
         self.log("train_loss", loss)
         return loss
 

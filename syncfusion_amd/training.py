@@ -1,0 +1,237 @@
+"""The training step of the reference: a differentiable fp32 forward of the U-Net and of the onset
+encoder whose heavy operations run -- forward AND backward -- in the HIP library.
+
+What the reference trains (main/module_diffusion.py:73-82, exp/train_diffusion_gh.yaml:87 ``precision: 32``):
+
+    _, info = onsets_encoder(y, with_info=True)                              # Encoder1d, TRAINED (configure_optimizers :53-61)
+    loss = DiffusionModel(x, channels=info["xs"][2:-1], embedding=clap(z))   # VDiffusion: mse(net(alpha x + beta eps, sigma), v)
+
+The inference engine behind ``UNetV0.forward`` / ``Encoder1d.forward`` is a fused, graph-replayed pipeline without an autograd
+graph.  Here the same networks are composed per operation from ``syncfusion_amd.autograd`` (convolutions incl. the fused
+GroupNorm + SiLU prologue, LayerNorm-modulate, multi-head attention: ``torch.autograd.Function``s over the C ABI, fp32, no
+atomics so gradients are reproducible bit for bit) on channels-last ``(B, L, C)`` activations.  torch itself is used for what
+the brief calls plumbing: the (B x features) conditioning Linears of the time MLP / modulation / skip scales (library GEMMs with
+M = batch), reshapes / gathers around the patchify, strided and up-sampling convolutions, and the residual / skip additions.
+
+The module's ``nn.Parameter`` masters are used directly, so ``loss.backward()`` fills ``.grad`` of exactly the tensors
+``Model.configure_optimizers`` hands to AdamW.  ``UNetV0.forward`` / ``Encoder1d.forward`` route here whenever autograd is
+recording and one of their parameters or inputs requires a gradient; otherwise the inference engine runs.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from . import autograd as sfa
+
+Tensor = torch.Tensor
+
+
+def wants_grad(module: torch.nn.Module, *tensors: Optional[Tensor]) -> bool:
+    """True when a forward call of ``module`` has to record an autograd graph."""
+    if not torch.is_grad_enabled():
+        return False
+    if any(t is not None and t.requires_grad for t in tensors):
+        return True
+    return any(p.requires_grad for p in module.parameters())
+
+
+def _params(module: torch.nn.Module) -> Dict[str, Tensor]:
+    return dict(module.named_parameters())
+
+
+def _lin(P, name: str, x: Tensor) -> Tensor:
+    return F.linear(x, P[name + ".weight"], P.get(name + ".bias"))
+
+
+def _pointwise(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
+    """Linear / 1x1 convolution over the channels of (B, L, C) rows: w is (N, C) or (N, C, 1)."""
+    return sfa.conv1d(x, w.reshape(w.shape[0], -1, 1), b, channels_last=True)
+
+
+def _affine_ln(x: Tensor, gamma: Tensor, beta: Tensor, eps: float) -> Tensor:
+    """LayerNorm_C with affine parameters, as LN-modulate with scale = gamma - 1, shift = beta for every clip."""
+    ss = torch.cat([gamma - 1.0, beta])[None, :].expand(x.shape[0], -1)
+    return sfa.ln_modulate(x, ss, eps)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# U-Net (a-unet XUNet behind TimeConditioningPlugin + ClassifierFreeGuidancePlugin)
+# ---------------------------------------------------------------------------------------------------------------------------
+def _time_features(P, sigma: Tensor) -> Tensor:
+    w = P["time.fourier_w"]
+    x = sigma.reshape(-1, 1).to(torch.float32)
+    freqs = x * w[None, :] * (2.0 * math.pi)
+    f = F.gelu(_lin(P, "time.lin0", torch.cat([x, freqs.sin(), freqs.cos()], dim=-1)))
+    for i in range(2):
+        f = F.gelu(_lin(P, f"time.mlp.{i}", f))
+    return f
+
+
+def _resnet(P, pre: str, x: Tensor, groups: int) -> Tensor:
+    h = sfa.gn_silu_conv1d(x, P[pre + ".conv1.weight"], P[pre + ".conv1.bias"], P[pre + ".gn1.weight"], P[pre + ".gn1.bias"], groups, 1e-5, True)
+    h = sfa.gn_silu_conv1d(h, P[pre + ".conv2.weight"], P[pre + ".conv2.bias"], P[pre + ".gn2.weight"], P[pre + ".gn2.bias"], groups, 1e-5, True)
+    return x + h
+
+
+def _self_attention(P, pre: str, x: Tensor, heads: int) -> Tensor:
+    q = _pointwise(_affine_ln(x, P[pre + ".norm.weight"], P[pre + ".norm.bias"], 1e-5), P[pre + ".to_q.weight"], None)
+    kv = _pointwise(_affine_ln(x, P[pre + ".norm_context.weight"], P[pre + ".norm_context.bias"], 1e-5), P[pre + ".to_kv.weight"], None)
+    return x + _pointwise(sfa.attention(q, kv, heads), P[pre + ".to_out.weight"], None)
+
+
+def _cross_attention(P, pre: str, x: Tensor, emb: Tensor, hd: int) -> Tensor:
+    """Cross-attention over ONE context token (embedding_max_length = 1, exp/model/diffusion.yaml:30): the softmax over a single
+    key is identically 1, so the block adds to_out(v(LN(emb))) to every position.  The query branch (norm, to_q) and the key
+    half of to_kv receive exactly-zero gradients upstream too; the zero-valued term below keeps them in the graph so the
+    optimizer sees zero gradients (and applies weight decay) rather than ``None``."""
+    if emb.shape[1] != 1:
+        raise NotImplementedError("training forward: cross-attention over more than one embedding token is not implemented")
+    c_in = F.layer_norm(emb, (emb.shape[-1],), P[pre + ".norm_context.weight"], P[pre + ".norm_context.bias"], eps=1e-5)
+    kv = F.linear(c_in, P[pre + ".to_kv.weight"])
+    o = F.linear(kv[..., hd:], P[pre + ".to_out.weight"])                        # (B, 1, C)
+    dead = P[pre + ".to_q.weight"].sum() + P[pre + ".norm.weight"].sum() + P[pre + ".norm.bias"].sum() + kv[..., :hd].sum()
+    return x + (o + 0.0 * dead)
+
+
+def _item_group(P, hp, pre: str, d: int, x: Tensor, f_act: Tensor, emb: Tensor, ctx: List[Tensor]) -> Tensor:
+    x = _resnet(P, pre + ".resnet", x, hp["resnet_groups"])
+    x = sfa.ln_modulate(x, _lin(P, pre + ".mod.to_scale_shift", f_act), 1e-6)
+    if hp["context_channels"][d] > 0:
+        x = _pointwise(torch.cat([x, ctx[d]], dim=-1), P[pre + ".inject.conv.weight"], P[pre + ".inject.conv.bias"]) + x
+    if hp["attentions"][d]:
+        x = _self_attention(P, pre + ".attn", x, hp["attention_heads"])
+    if hp["cross_attentions"][d]:
+        x = _cross_attention(P, pre + ".cross", x, emb, hp["attention_heads"] * hp["attention_features"])
+    return x
+
+
+def _block(P, hp, d: int, x: Tensor, f_act: Tensor, emb: Tensor, ctx: List[Tensor]) -> Tensor:
+    pre = f"blocks.{d}"
+    fac = hp["factors"][d]
+    B, L, cin = x.shape
+    if L % fac:
+        raise ValueError(f"length {L} at depth {d} is not divisible by the down-sampling factor {fac}")
+    wd = P[pre + ".down.weight"]                                               # (C, cin, fac): kernel = stride = fac, a patchify
+    C = wd.shape[0]
+    h = _pointwise(x.reshape(B, L // fac, fac * cin), wd.permute(0, 2, 1).reshape(C, fac * cin), P[pre + ".down.bias"])
+    for j in range(hp["items"][d]):
+        h = _item_group(P, hp, f"{pre}.items_down.{j}", d, h, f_act, emb, ctx)
+    if d + 1 < len(hp["channels"]):
+        h = _block(P, hp, d + 1, h, f_act, emb, ctx)
+    for j in range(hp["items"][d]):
+        h = _item_group(P, hp, f"{pre}.items_up.{j}", d, h, f_act, emb, ctx)
+    wu, bu = P[pre + ".up.weight"], P[pre + ".up.bias"]
+    if hp.get("upsample_mode", "nearest") == "transpose":
+        # ConvTranspose1d(kernel = stride = fac), weight (C, cin, fac): every position emits fac outputs -> a pointwise map to
+        # fac * cin features that is unfolded along the length
+        h = _pointwise(h, wu.permute(2, 1, 0).reshape(fac * cin, C), bu.repeat(fac)).reshape(B, L, cin)
+    else:
+        if fac > 1:
+            h = h.repeat_interleave(fac, dim=1)
+        h = sfa.conv1d(h, wu, bu, channels_last=True)
+    scale = _lin(P, pre + ".skip.to_scale", f_act)                              # SkipModulate
+    return x + scale[:, None, :] * h
+
+
+def unet_forward(net, x: Tensor, sigma: Tensor, *, embedding: Tensor, channels: Sequence[Tensor], embedding_scale: float = 1.0,
+                 embedding_mask_proba: float = 0.0) -> Tensor:
+    """Differentiable ``UNetV0.forward``: x (B, in_channels, L0), sigma (B,), embedding (B, 1, E), channels[d] (B, ctx_d, L_d)
+    -> v (B, in_channels, L0)."""
+    _lib.require_gpu_tensor(x, "syncfusion_amd.training.unet_forward")
+    hp = net.hparams
+    P = _params(net)
+    if len(channels) != len(hp["channels"]):
+        raise ValueError(f"channels: expected {len(hp['channels'])} context tensors, got {len(channels)}")
+    B = x.shape[0]
+    for d, c in enumerate(channels):
+        want = (B, hp["context_channels"][d])
+        assert tuple(c.shape[:2]) == want, f"context channels at depth {d}: {tuple(c.shape)} vs {want}"
+    ctx = [c.to(torch.float32).transpose(1, 2) for c in channels]
+    f_act = F.silu(_time_features(P, sigma))
+    emb = embedding.to(torch.float32)
+    fixed = P["cfg.fixed_embedding.weight"][: emb.shape[1]][None].expand(B, -1, -1)
+    if embedding_mask_proba > 0.0:   # ClassifierFreeGuidancePlugin: per-clip replacement by the learned fixed embedding
+        mask = torch.rand(B, 1, 1, device=x.device) < embedding_mask_proba
+        emb = torch.where(mask, fixed, emb)
+    x_cl = x.to(torch.float32).transpose(1, 2)
+    out = _block(P, hp, 0, x_cl, f_act, emb, ctx)
+    if embedding_scale != 1.0:
+        out_masked = _block(P, hp, 0, x_cl, f_act, fixed, ctx)
+        out = out_masked + (out - out_masked) * embedding_scale
+    return out.transpose(1, 2)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Encoder1d (audio_encoders_pytorch)
+# ---------------------------------------------------------------------------------------------------------------------------
+def _enc_resnet(P, pre: str, x: Tensor, groups: int) -> Tensor:
+    h = x
+    for blk in ("block1", "block2"):
+        h = sfa.gn_silu_conv1d(h, P[f"{pre}.{blk}.conv.weight"], P[f"{pre}.{blk}.conv.bias"], P[f"{pre}.{blk}.gn.weight"], P[f"{pre}.{blk}.gn.bias"],
+                               groups, 1e-5, True)
+    if (pre + ".to_out.weight") in P:
+        x = _pointwise(x, P[pre + ".to_out.weight"], P[pre + ".to_out.bias"])
+    return h + x
+
+
+def encoder1d_forward(enc, y: Tensor) -> Tuple[Tensor, Dict[str, List[Tensor]]]:
+    """Differentiable ``Encoder1d.forward(y, with_info=True)``: (z, {"xs": [y, to_in, ds_0 .. ds_{n-1}, to_out]}), channels-first
+    tensors exactly as the reference slices them (main/module_diffusion.py:76)."""
+    _lib.require_gpu_tensor(y, "syncfusion_amd.training.encoder1d_forward")
+    hp = enc.hparams
+    P = _params(enc)
+    x = y.to(torch.float32).transpose(1, 2)
+    xs = [y]
+    x = _enc_resnet(P, "to_in", x, 1)
+    xs.append(x.transpose(1, 2))
+    for i, f in enumerate(hp["factors"]):
+        pre = f"downsamples.{i}"
+        w = P[pre + ".down.weight"]                                            # (N, C, 2f + 1), stride f, padding f
+        N, Cc, k = w.shape
+        cols = F.pad(x, (0, 0, f, f)).unfold(1, k, f)                           # (B, Lout, C, k) windows
+        Bq, Lout = cols.shape[:2]
+        cols = cols.permute(0, 1, 3, 2).reshape(Bq, Lout, k * Cc)
+        x = _pointwise(cols, w.permute(0, 2, 1).reshape(N, k * Cc), P[pre + ".down.bias"])
+        for j in range(hp["num_blocks"][i]):
+            x = _enc_resnet(P, f"{pre}.blocks.{j}", x, hp["resnet_groups"])
+        xs.append(x.transpose(1, 2))
+    xs.append(xs[-1])
+    return xs[-1], dict(xs=xs)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# data-parallel gradient exchange
+# ---------------------------------------------------------------------------------------------------------------------------
+def allreduce_gradients(module: torch.nn.Module, bucket_bytes: int = 256 << 20) -> int:
+    """Average ``.grad`` over the ranks of the default process group in flat buckets (the reference trains with Lightning's
+    single-node DDP defaults, exp/train_diffusion_gh.yaml:82-90).  One bucket of 256 MB amortises the per-link ring latency of
+    xGMI; the whole model is 1.6 GB of fp32 gradients.  Returns the number of collectives issued (0 when not distributed)."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 0
+    world = dist.get_world_size()
+    grads = [p.grad for p in module.parameters() if p.requires_grad and p.grad is not None]
+    stage_host = dist.get_backend() == "gloo"
+    calls, i = 0, 0
+    while i < len(grads):
+        j, size = i, 0
+        while j < len(grads) and (j == i or size + grads[j].numel() * 4 <= bucket_bytes):
+            size += grads[j].numel() * 4
+            j += 1
+        flat = torch.cat([g.reshape(-1) for g in grads[i:j]])
+        buf = flat.cpu() if stage_host and flat.is_cuda else flat
+        dist.all_reduce(buf)
+        buf = buf.to(flat.device) / world
+        off = 0
+        for g in grads[i:j]:
+            g.copy_(buf[off: off + g.numel()].view_as(g))
+            off += g.numel()
+        calls += 1
+        i = j
+    return calls

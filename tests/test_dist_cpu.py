@@ -54,6 +54,53 @@ def test_broadcast_and_gather_world2():
     assert out0 == [0.0, 1.0, 2.0, 3.0, 4.0], "gathered clips are not the rank-order concatenation"
 
 
+def _grad_worker(rank: int, world: int, port: int, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from syncfusion_amd.training import allreduce_gradients
+
+        torch.manual_seed(7)                                # same weights everywhere, DIFFERENT data per rank
+        net = torch.nn.Sequential(torch.nn.Linear(6, 9), torch.nn.Tanh(), torch.nn.Linear(9, 3))
+        net[2].bias.requires_grad_(False)                   # frozen tensors are skipped
+        x = torch.randn(4, 6, generator=torch.Generator().manual_seed(50 + rank))
+        net(x).square().mean().backward()
+        calls = allreduce_gradients(net, bucket_bytes=200)  # tiny buckets: several collectives, one oversize tensor alone in its own
+        q.put((rank, calls, torch.cat([p.grad.reshape(-1) for p in net.parameters() if p.grad is not None]).tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.autograd
+@pytest.mark.timeout(300)
+def test_gradient_allreduce_world2_equals_the_full_batch_gradient():
+    """Data-parallel training exchange (syncfusion_amd/training.py): bucketed mean of .grad over 2 gloo ranks == the gradient of
+    the mean loss over both ranks' batches computed in one process."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world, port = 2, 29613
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, calls0, g0), (_, calls1, g1) = res
+    assert g0 == g1 and calls0 == calls1 >= 2
+    torch.manual_seed(7)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 9), torch.nn.Tanh(), torch.nn.Linear(9, 3))
+    net[2].bias.requires_grad_(False)
+    xs = [torch.randn(4, 6, generator=torch.Generator().manual_seed(50 + r)) for r in range(world)]
+    (sum(net(x).square().mean() for x in xs) / world).backward()
+    ref = torch.cat([p.grad.reshape(-1) for p in net.parameters() if p.grad is not None])
+    assert torch.allclose(torch.tensor(g0), ref, rtol=1e-5, atol=1e-7)
+    from syncfusion_amd.training import allreduce_gradients
+
+    assert allreduce_gradients(net) == 0                    # no process group: a no-op
+
+
 _FAKE_RANK = r'''
 import json, os, sys
 import torch, torch.distributed as dist

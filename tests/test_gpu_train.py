@@ -5,9 +5,9 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from helpers import SMALL_UNET, oracle_params, rel_l2, small_unet_module
+from helpers import SMALL_UNET, oracle_params, rel_l2, small_unet_module, synth_inputs
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.autograd]
 TOL = 2e-5
 
 
@@ -81,3 +81,190 @@ def test_resnet_item_and_inject_chain_against_oracle_autograd(cuda):
     assert rel_l2(xs.grad.cpu(), x.grad) < 5 * TOL
     for k in keys:
         assert rel_l2(Q[k].grad.cpu(), P[k].grad) < 5 * TOL, k
+
+
+@pytest.mark.parametrize("B,L,C,with_ss", [
+    (2, 352, 64, True),     # ModulationItem at a thin level
+    (3, 100, 256, True),    # ragged length
+    (2, 44, 1024, True),    # deepest level: 16 channels per lane
+    (2, 704, 32, False),    # pre-norm LayerNorm (no modulation), half-empty wave
+    (1, 1, 128, True),      # a single row
+    (2, 5000, 128, True),   # more rows than one chunk pass
+])
+def test_ln_modulate_gradients(cuda, B, L, C, with_ss):
+    from syncfusion_amd import autograd as sfa
+
+    g = torch.Generator().manual_seed(L + C)
+    x = (torch.randn(B, L, C, generator=g) * 1.7 + 0.3).requires_grad_()
+    ss = (0.3 * torch.randn(B, 2 * C, generator=g)).requires_grad_() if with_ss else None
+    dy = torch.randn(B, L, C, generator=g)
+    xh = F.layer_norm(x, (C,), eps=1e-5)
+    y_ref = xh * (1 + ss[:, None, :C]) + ss[:, None, C:] if with_ss else xh
+    y_ref.backward(dy)
+    xs = x.detach().clone().to(cuda).requires_grad_()
+    sss = ss.detach().clone().to(cuda).requires_grad_() if with_ss else None
+    y = sfa.ln_modulate(xs, sss, 1e-5)
+    assert rel_l2(y.detach().cpu(), y_ref.detach()) < TOL
+    y.backward(dy.to(cuda))
+    assert rel_l2(xs.grad.cpu(), x.grad) < TOL, f"dx {rel_l2(xs.grad.cpu(), x.grad):.3e}"
+    if with_ss:
+        assert rel_l2(sss.grad.cpu(), ss.grad) < TOL, f"dss {rel_l2(sss.grad.cpu(), ss.grad):.3e}"
+
+
+@pytest.mark.parametrize("B,L,H", [(2, 44, 8), (2, 100, 2), (1, 352, 8), (3, 1, 4), (1, 1000, 1), (2, 17, 3)])
+def test_attention_gradients(cuda, B, L, H):
+    from syncfusion_amd import autograd as sfa
+
+    D = 64
+    g = torch.Generator().manual_seed(L * 10 + H)
+    q = torch.randn(B, L, H * D, generator=g).requires_grad_()
+    kv = torch.randn(B, L, 2 * H * D, generator=g).requires_grad_()
+    do = torch.randn(B, L, H * D, generator=g)
+
+    def heads(t):
+        return t.reshape(B, L, H, D).transpose(1, 2)
+
+    k, v = kv[..., : H * D], kv[..., H * D:]
+    p = torch.softmax(heads(q) @ heads(k).transpose(-1, -2) * D ** -0.5, dim=-1)
+    o_ref = (p @ heads(v)).transpose(1, 2).reshape(B, L, H * D)
+    o_ref.backward(do)
+    qs, kvs = (t.detach().clone().to(cuda).requires_grad_() for t in (q, kv))
+    o = sfa.attention(qs, kvs, H)
+    assert rel_l2(o.detach().cpu(), o_ref.detach()) < TOL
+    o.backward(do.to(cuda))
+    assert rel_l2(qs.grad.cpu(), q.grad) < TOL, f"dq {rel_l2(qs.grad.cpu(), q.grad):.3e}"
+    assert rel_l2(kvs.grad.cpu(), kv.grad) < TOL, f"dkv {rel_l2(kvs.grad.cpu(), kv.grad):.3e}"
+
+
+def _grad_close(got: torch.Tensor, ref: torch.Tensor, tol: float, scale: float, zero_by_construction: bool = False) -> bool:
+    """rel-L2 against the reference gradient.  Gradients that are zero by construction hold rounding noise on both sides (or exact
+    zeros) and are only required to be negligible against the typical gradient size."""
+    if zero_by_construction:
+        return float(got.abs().max()) <= 1e-3 * scale and float(ref.abs().max()) <= 1e-3 * scale
+    return float((got - ref).norm()) <= tol * float(ref.norm()) + 1e-7 * scale * ref.numel() ** 0.5
+
+
+def _zero_by_construction(name: str, channels, groups: int) -> bool:
+    """* a convolution bias directly in front of a GroupNorm with ONE channel per group is normalised away;
+    * the query branch of a cross-attention over a single token (softmax over one key is constant)."""
+    parts = name.split(".")
+    if name.endswith(("conv1.bias", "block1.conv.bias")):
+        return channels(parts) == groups
+    return ".cross." in name and (".norm." in name or ".to_q." in name)
+
+
+@pytest.mark.parametrize("upsample_mode,scale,B,L0", [("nearest", 1.0, 2, 16 * 12), ("transpose", 1.0, 2, 16 * 5), ("nearest", 2.5, 3, 16 * 7)])
+def test_unet_training_forward_and_every_gradient_against_oracle_autograd(cuda, upsample_mode, scale, B, L0):
+    """The differentiable composition (syncfusion_amd/training.py) behind UNetV0.forward when autograd records: the output and
+    d(mse)/d(every parameter, x, every context channel) against autograd through the oracle (oracle/unet_ref.py)."""
+    from oracle import unet_ref
+
+    net = small_unet_module(upsample_mode=upsample_mode)
+    cfg = dict(net.hparams)
+    P = {k: v.clone().requires_grad_() for k, v in oracle_params(net, "net.").items()}
+    x, sigma, emb, chans = synth_inputs(SMALL_UNET, B, L0, seed=21)
+    target = torch.randn(B, 1, L0, generator=torch.Generator().manual_seed(22))
+    xr = x.clone().requires_grad_()
+    cr = [c.clone().requires_grad_() for c in chans]
+    v_ref = unet_ref.unet_forward(P, cfg, xr, sigma, embedding=emb, channels=cr, embedding_scale=scale)
+    F.mse_loss(v_ref, target).backward()
+
+    net = net.to(cuda)
+    xs = x.to(cuda).requires_grad_()
+    cs = [c.to(cuda).requires_grad_() for c in chans]
+    v = net(xs, sigma.to(cuda), embedding=emb.to(cuda), channels=cs, embedding_scale=scale)
+    assert v.requires_grad and v.shape == v_ref.shape
+    assert rel_l2(v.detach().cpu(), v_ref.detach()) < 1e-5
+    F.mse_loss(v, target.to(cuda)).backward()
+    typical = float(torch.cat([p.grad.reshape(-1) for p in P.values() if p.grad is not None]).abs().mean())
+    assert _grad_close(xs.grad.cpu(), xr.grad, 1e-4, typical), f"dx {rel_l2(xs.grad.cpu(), xr.grad):.3e}"
+    for d, (a, b) in enumerate(zip(cs, cr)):
+        assert _grad_close(a.grad.cpu(), b.grad, 1e-4, typical), f"dchannels[{d}] {rel_l2(a.grad.cpu(), b.grad):.3e}"
+    bad = []
+    for name, p in net.named_parameters():
+        ref = P["net." + name].grad
+        if ref is None:          # not on the path for this call (the fixed CFG embedding without guidance)
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        assert p.grad is not None, f"{name}: no gradient"
+        zero = _zero_by_construction(name, lambda parts: SMALL_UNET["channels"][int(parts[1])], SMALL_UNET["resnet_groups"])
+        if not _grad_close(p.grad.cpu(), ref, 1e-4, typical, zero):
+            bad.append((name, rel_l2(p.grad.cpu(), ref)))
+    assert not bad, bad[:8]
+    # inference engine and training composition are two implementations of one function
+    with torch.no_grad():
+        v_eng = net(xs.detach(), sigma.to(cuda), embedding=emb.to(cuda), channels=[c.detach() for c in cs], embedding_scale=scale)
+    assert not v_eng.requires_grad and rel_l2(v_eng.cpu(), v.detach().cpu()) < 1e-5
+
+
+def test_encoder1d_training_gradients_against_oracle_autograd(cuda):
+    from helpers import small_encoder_module
+    from oracle import encoder1d_ref
+
+    enc = small_encoder_module()
+    cfg = dict(enc.hparams)
+    P = {k: v.clone().requires_grad_() for k, v in oracle_params(enc).items()}
+    B, L0 = 2, 16 * 11
+    g = torch.Generator().manual_seed(31)
+    y = (torch.rand(B, 1, L0, generator=g) < 0.05).float()
+    _, info_ref = encoder1d_ref.encoder1d_forward(P, cfg, y)
+    weights = [torch.randn(t.shape, generator=g) for t in info_ref["xs"][2:-1]]
+    sum((t * w).sum() for t, w in zip(info_ref["xs"][2:-1], weights)).backward()
+    enc = enc.to(cuda)
+    z, info = enc(y.to(cuda), with_info=True)
+    assert z.requires_grad and len(info["xs"]) == len(info_ref["xs"])
+    for a, b in zip(info["xs"], info_ref["xs"]):
+        assert a.shape == b.shape and rel_l2(a.detach().cpu(), b.detach()) < 1e-5
+    sum((t * w.to(cuda)).sum() for t, w in zip(info["xs"][2:-1], weights)).backward()
+    typical = float(torch.cat([p.grad.reshape(-1) for p in P.values()]).abs().mean())
+    width = {n: p.shape[0] for n, p in enc.named_parameters()}
+    bad = [(n, rel_l2(p.grad.cpu(), P[n].grad)) for n, p in enc.named_parameters()
+           if not _grad_close(p.grad.cpu(), P[n].grad, 1e-4, typical, _zero_by_construction(n, lambda parts: width[n], 1 if n.startswith("to_in") else cfg["resnet_groups"]))]
+    assert not bad, bad
+
+
+def _small_training_model(cuda, seed=0):
+    import functools
+
+    import syncfusion_amd as sa
+    from helpers import SMALL_ENCODER
+
+    kw = dict(SMALL_UNET)
+    m = sa.Model(1e-3, 0.95, 0.999, 1e-6, 1e-3,
+                 sa.DiffusionModel(net_t=functools.partial(sa.UNetV0, seed=seed), diffusion_t=sa.VDiffusion, sampler_t=sa.VSampler,
+                                   use_embedding_cfg=True, **kw),
+                 sa.Encoder1d(seed=seed + 1, **SMALL_ENCODER), sa.RandomEmbedder(kw["embedding_features"]), None)
+    return m.to(cuda)
+
+
+def test_training_step_optimizer_loop_lowers_the_loss_and_the_engine_follows_the_weights(cuda):
+    """main/module_diffusion.py:53-61,73-82: AdamW over U-Net + onset encoder on `training_step`'s loss.  Same seeded noise
+    every step, so the loss must fall; after the updates the inference engine (validation_step, under no_grad) must see the
+    new weights and agree with the training composition's loss."""
+    m = _small_training_model(cuda)
+    opt = m.configure_optimizers()
+    B, L0 = 4, 16 * 16
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(B, 1, L0, generator=g).to(cuda)
+    y = (torch.rand(B, 1, L0, generator=g) < 0.03).float().to(cuda)
+    batch = (x, y, x, None, None)
+    losses = []
+    for it in range(12):
+        torch.manual_seed(1000)
+        loss = m.training_step(batch, it)
+        assert loss.requires_grad
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        missing = [n for n, p in m.named_parameters() if p.requires_grad and p.grad is None and "cfg.fixed_embedding" not in n]
+        assert not missing, missing
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < 0.85 * losses[0], losses
+    torch.manual_seed(1000)
+    with torch.no_grad():
+        val = float(m.validation_step(batch, 0))
+    torch.manual_seed(1000)
+    again = float(m.step(batch).detach())
+    assert abs(val - again) < 1e-4 * abs(again), (val, again)
+    with torch.no_grad(), pytest.raises(RuntimeError, match="no autograd graph"):
+        m.training_step(batch, 0)
