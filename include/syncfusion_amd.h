@@ -236,9 +236,10 @@ int sf_op_conv1d_bwd_cl(const float *x, const float *w, const float *gamma, cons
 /* backward of sf_op_ln_modulate (fp32): dx:(B,L,C); dss:(B,2C) = [dscale | dshift] or NULL; ws >= B * min(64, ceil(L/64)) * 2C floats */
 int sf_op_ln_modulate_bwd(const float *x, const float *scale_shift, const float *dy, float eps, int B, int L, int C, float *dx, float *dss,
                           void *ws, int64_t ws_bytes, void *stream);
-/* backward of sf_op_attention (fp32, head_dim 64, L <= ~1100): dq:(B,L,H*D), dkv:(B,L,2*H*D); ws >= 2 * B * H * L floats */
-int sf_op_attention_bwd(const float *q, const float *kv, const float *dout, int B, int L, int heads, int head_dim, float *dq, float *dkv,
-                        void *ws, int64_t ws_bytes, void *stream);
+/* backward of sf_op_attention (fp32 matrix cores, head_dim 64): out = the forward result; dq:(B,L,H*D), dkv:(B,L,2*H*D);
+ * ws >= 2 * B * H * L floats (log-sum-exp and dO.O per query) */
+int sf_op_attention_bwd(const float *q, const float *kv, const float *out, const float *dout, int B, int L, int heads, int head_dim, float *dq,
+                        float *dkv, void *ws, int64_t ws_bytes, void *stream);
 /* Kernel tuning aid: average milliseconds of `iters` back-to-back launches of one channels-last conv1d
  * (x:(B,L,C) -> (B,L*upsample,N), `taps` taps, bias + residual epilogue) with a forced kernel family
  * (path 0 auto, 1 classic, 2 wave-split-K, 4 v2), tile variant (-1 auto) and grid split-K factor (-1 auto). */

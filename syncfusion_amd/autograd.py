@@ -173,21 +173,21 @@ class _AttentionFn(torch.autograd.Function):
             out = torch.empty_like(qc)
             _lib.check(lib.sf_op_attention(_lib.SF_F32, qc.data_ptr(), kc.data_ptr(), B, L, int(heads), HD // int(heads), out.data_ptr(),
                                            _lib.stream_ptr(q.device)), "sf_op_attention")
-        ctx.save_for_backward(qc, kc)
+        ctx.save_for_backward(qc, kc, out)
         ctx.meta = (B, L, int(heads), HD // int(heads))
         return out
 
     @staticmethod
     def backward(ctx, dout: Tensor):
         lib = _lib.load()
-        qc, kc = ctx.saved_tensors
+        qc, kc, out = ctx.saved_tensors
         B, L, H, D = ctx.meta
         dev = qc.device
         with torch.cuda.device(dev):
             doc = _lib.f32c(dout)
             dq, dkv = torch.empty_like(qc), torch.empty_like(kc)
             ws = torch.empty(2 * B * H * L * 4 + 256, dtype=torch.uint8, device=dev)
-            _lib.check(lib.sf_op_attention_bwd(qc.data_ptr(), kc.data_ptr(), doc.data_ptr(), B, L, H, D, dq.data_ptr(), dkv.data_ptr(), ws.data_ptr(),
+            _lib.check(lib.sf_op_attention_bwd(qc.data_ptr(), kc.data_ptr(), out.data_ptr(), doc.data_ptr(), B, L, H, D, dq.data_ptr(), dkv.data_ptr(), ws.data_ptr(),
                                                ws.numel(), _lib.stream_ptr(dev)), "sf_op_attention_bwd")
         return dq, dkv, None
 

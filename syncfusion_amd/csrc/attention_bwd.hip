@@ -1,0 +1,273 @@
+// Multi-head softmax attention backward (head dim 64, fp32 as the reference trains: exp/train_diffusion_gh.yaml:87) on the fp32
+// matrix cores (v_mfma_f32_32x32x2_f32), two kernels, no atomics -> gradients are reproducible bit for bit.
+//
+//   S = q k^T / 8,  P = softmax_j(S),  O = P v            (forward, attention.hip)
+//   dP = dO v^T,  D_i = sum_j P_ij dP_ij = dO_i . O_i,  dS = P (dP - D) / 8
+//   dQ = dS k,   dK = dS^T q,   dV = P^T dO
+//
+// Both kernels exploit one property of the 32x32x2 MFMA: a lane's 16 accumulator values lie in ONE column (lane % 32) and in the
+// 16 rows r -> 8 (r / 4) + 4 (lane / 32) + r % 4.  A score tile computed with the reduction index of the NEXT product in its
+// rows can therefore be fed straight back as the A operand of that product (lane -> output row, k-step r -> the row the
+// accumulator register r belongs to); the B operand is read from LDS in the same row order.  No transposes through LDS, no
+// shuffles in the inner loops.
+//
+//   Q pass (a wave owns 32 queries; loops over 32-key tiles staged in LDS):
+//       S^T = K q^T  (lane -> query, registers -> keys)          pass 0: online log-sum-exp  -> lse_i
+//       pass 1: S^T, dP^T = V dO^T, dS^T = P^T (dP^T - D) / 8;   dQ += dS K  (A = dS^T registers, B = K tile rows)
+//   K pass (a wave owns 32 keys; loops over 32-query tiles staged in LDS):
+//       S = Q k^T (lane -> key, registers -> queries), dP = dO v^T, P = exp(S / 8 - lse), dS as above
+//       dV += P^T dO (A = P registers, B = dO tile rows),  dK += dS^T Q (A = dS registers, B = Q tile rows)
+// Per 32 x 32 tile and wave: 96 (Q pass; + 32 in pass 0) and 128 (K pass) MFMAs of 64 cycles; the LDS reads are a few % of that.
+#include "common.h"
+#include "kernels.h"
+
+namespace sf {
+namespace {
+
+constexpr int HD = 64, TILE = 32, PITCH = 66;   // row pitch 66 floats: the A-operand reads (32 rows, 2 adjacent columns) hit 64 distinct banks
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+__device__ __forceinline__ f32x16 mfma32x2(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+
+struct TileRegs {
+  f32x4 v[2];
+};
+
+// rows [row0, row0 + 32) x 64 columns starting at col0 of a row-major (.., ld) matrix -> two float4 per thread (zeros past row L)
+__device__ __forceinline__ void tile_fetch(TileRegs &t, const float *__restrict__ base, size_t rb, int row0, int L, int ld, int col0, int tid) {
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int idx = tid + 256 * e, r = idx >> 4, c4 = idx & 15;
+    const int row = row0 + r;
+    t.v[e] = row < L ? *reinterpret_cast<const f32x4 *>(base + (rb + row) * ld + col0 + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+__device__ __forceinline__ void tile_store(float *lds, const TileRegs &t, int tid) {
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int idx = tid + 256 * e, r = idx >> 4, c4 = idx & 15;
+    float *p = lds + r * PITCH + 4 * c4;
+    *reinterpret_cast<f32x2 *>(p) = f32x2{t.v[e][0], t.v[e][1]};
+    *reinterpret_cast<f32x2 *>(p + 2) = f32x2{t.v[e][2], t.v[e][3]};
+  }
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+
+__device__ __forceinline__ int acc_row(int r, int hf) { return 8 * (r >> 2) + 4 * hf + (r & 3); }
+
+__global__ __launch_bounds__(256) void attn_bwd_q_mfma_kernel(const float *__restrict__ q, const float *__restrict__ kv, const float *__restrict__ o,
+                                                              const float *__restrict__ dout, int L, int H, float scale, float *__restrict__ dq,
+                                                              float *__restrict__ lse_out, float *__restrict__ dsum_out) {
+  __shared__ __attribute__((aligned(16))) float Ks[TILE * PITCH];
+  __shared__ __attribute__((aligned(16))) float Vs[TILE * PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, hf = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int ldq = H * HD, ldkv = 2 * H * HD;
+  const size_t rb = (size_t)b * L;
+  const int qbase = blockIdx.x * 128 + wave * 32;
+  const int qi = qbase + li;
+  const bool qv = qi < L;
+  // this lane's query row as B operands: element d = 2 t + hf of q_i and dO_i;  D_i = dO_i . O_i
+  float qreg[32], doreg[32];
+  float dd = 0.f;
+  {
+    const size_t off = (rb + (qv ? qi : 0)) * ldq + h * HD + hf;
+#pragma unroll
+    for (int t = 0; t < 32; ++t) {
+      qreg[t] = qv ? q[off + 2 * t] : 0.f;
+      doreg[t] = qv ? dout[off + 2 * t] : 0.f;
+      dd = fmaf(doreg[t], qv ? o[off + 2 * t] : 0.f, dd);
+    }
+  }
+  dd += __shfl_xor(dd, 32);
+  const int nkt = (L + TILE - 1) / TILE;
+  TileRegs pk, pv;
+  // ---- pass 0: lse_i = log sum_j exp(S_ij) ---------------------------------------------------------------------------------
+  float m = -INFINITY, ssum = 0.f;
+  tile_fetch(pk, kv, rb, 0, L, ldkv, h * HD, tid);
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();
+    tile_store(Ks, pk, tid);
+    __syncthreads();
+    if (kt + 1 < nkt) tile_fetch(pk, kv, rb, (kt + 1) * TILE, L, ldkv, h * HD, tid);
+    f32x16 s = zero16();
+#pragma unroll
+    for (int t = 0; t < 32; ++t) s = mfma32x2(Ks[li * PITCH + 2 * t + hf], qreg[t], s);
+    float sv[16];
+    float tm = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      sv[r] = (kt * TILE + acc_row(r, hf) < L) ? s[r] * scale : -INFINITY;
+      tm = fmaxf(tm, sv[r]);
+    }
+    const float mn = fmaxf(m, tm);
+    if (mn > -INFINITY) {   // a half-wave can meet a tile without a valid key of its own (ragged last tile)
+      float add = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) add += expf(sv[r] - mn);
+      ssum = ssum * expf(m - mn) + add;
+      m = mn;
+    }
+  }
+  float lse;
+  {
+    const float m2 = __shfl_xor(m, 32), s2 = __shfl_xor(ssum, 32);
+    const float M = fmaxf(m, m2);
+    const float tot = (m > -INFINITY ? ssum * expf(m - M) : 0.f) + (m2 > -INFINITY ? s2 * expf(m2 - M) : 0.f);
+    lse = M + logf(tot);
+  }
+  if (hf == 0 && qv) {
+    lse_out[((size_t)b * H + h) * L + qi] = lse;
+    dsum_out[((size_t)b * H + h) * L + qi] = dd;
+  }
+  // ---- pass 1: dQ ------------------------------------------------------------------------------------------------------------
+  f32x16 acc0 = zero16(), acc1 = zero16();
+  tile_fetch(pk, kv, rb, 0, L, ldkv, h * HD, tid);
+  tile_fetch(pv, kv, rb, 0, L, ldkv, (H + h) * HD, tid);
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();
+    tile_store(Ks, pk, tid);
+    tile_store(Vs, pv, tid);
+    __syncthreads();
+    if (kt + 1 < nkt) {
+      tile_fetch(pk, kv, rb, (kt + 1) * TILE, L, ldkv, h * HD, tid);
+      tile_fetch(pv, kv, rb, (kt + 1) * TILE, L, ldkv, (H + h) * HD, tid);
+    }
+    f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+    for (int t = 0; t < 32; ++t) {
+      s = mfma32x2(Ks[li * PITCH + 2 * t + hf], qreg[t], s);
+      dp = mfma32x2(Vs[li * PITCH + 2 * t + hf], doreg[t], dp);
+    }
+    float ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = (kt * TILE + acc_row(r, hf) < L) ? expf(s[r] * scale - lse) : 0.f;
+      ds[r] = p * (dp[r] - dd) * scale;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float *krow = Ks + acc_row(r, hf) * PITCH + li;
+      acc0 = mfma32x2(ds[r], krow[0], acc0);
+      acc1 = mfma32x2(ds[r], krow[32], acc1);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = qbase + acc_row(r, hf);
+    if (row < L) {
+      float *p = dq + (rb + row) * ldq + h * HD + li;
+      p[0] = acc0[r];
+      p[32] = acc1[r];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_kv_mfma_kernel(const float *__restrict__ q, const float *__restrict__ kv, const float *__restrict__ dout,
+                                                               const float *__restrict__ lse, const float *__restrict__ dsum, int L, int H, float scale,
+                                                               float *__restrict__ dkv) {
+  __shared__ __attribute__((aligned(16))) float Qs[TILE * PITCH];
+  __shared__ __attribute__((aligned(16))) float Os[TILE * PITCH];
+  __shared__ float lse_s[TILE], dsum_s[TILE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, hf = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int ldq = H * HD, ldkv = 2 * H * HD;
+  const size_t rb = (size_t)b * L;
+  const int kbase = blockIdx.x * 128 + wave * 32;
+  const int kj = kbase + li;
+  const bool kvld = kj < L;
+  float kreg[32], vreg[32];
+  {
+    const size_t off = (rb + (kvld ? kj : 0)) * ldkv + h * HD + hf;
+#pragma unroll
+    for (int t = 0; t < 32; ++t) {
+      kreg[t] = kvld ? kv[off + 2 * t] : 0.f;
+      vreg[t] = kvld ? kv[off + H * HD + 2 * t] : 0.f;
+    }
+  }
+  const float *lp = lse + ((size_t)b * H + h) * L, *dp_ = dsum + ((size_t)b * H + h) * L;
+  f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
+  const int nqt = (L + TILE - 1) / TILE;
+  TileRegs pq, po;
+  float pl = 0.f, pd = 0.f;
+  tile_fetch(pq, q, rb, 0, L, ldq, h * HD, tid);
+  tile_fetch(po, dout, rb, 0, L, ldq, h * HD, tid);
+  if (tid < TILE) {
+    pl = tid < L ? lp[tid] : INFINITY;     // +inf -> P = exp(-inf) = 0 for the rows past the end
+    pd = tid < L ? dp_[tid] : 0.f;
+  }
+  for (int qt = 0; qt < nqt; ++qt) {
+    __syncthreads();
+    tile_store(Qs, pq, tid);
+    tile_store(Os, po, tid);
+    if (tid < TILE) {
+      lse_s[tid] = pl;
+      dsum_s[tid] = pd;
+    }
+    __syncthreads();
+    if (qt + 1 < nqt) {
+      tile_fetch(pq, q, rb, (qt + 1) * TILE, L, ldq, h * HD, tid);
+      tile_fetch(po, dout, rb, (qt + 1) * TILE, L, ldq, h * HD, tid);
+      if (tid < TILE) {
+        const int i = (qt + 1) * TILE + tid;
+        pl = i < L ? lp[i] : INFINITY;
+        pd = i < L ? dp_[i] : 0.f;
+      }
+    }
+    f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+    for (int t = 0; t < 32; ++t) {
+      s = mfma32x2(Qs[li * PITCH + 2 * t + hf], kreg[t], s);
+      dp = mfma32x2(Os[li * PITCH + 2 * t + hf], vreg[t], dp);
+    }
+    float p[16], ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = acc_row(r, hf);
+      p[r] = expf(s[r] * scale - lse_s[i]);
+      ds[r] = p[r] * (dp[r] - dsum_s[i]) * scale;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = acc_row(r, hf);
+      const float *orow = Os + i * PITCH + li, *qrow = Qs + i * PITCH + li;
+      dv0 = mfma32x2(p[r], orow[0], dv0);
+      dv1 = mfma32x2(p[r], orow[32], dv1);
+      dk0 = mfma32x2(ds[r], qrow[0], dk0);
+      dk1 = mfma32x2(ds[r], qrow[32], dk1);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = kbase + acc_row(r, hf);
+    if (row < L) {
+      float *pk_ = dkv + (rb + row) * ldkv + h * HD + li;
+      pk_[0] = dk0[r];
+      pk_[32] = dk1[r];
+      pk_[H * HD] = dv0[r];
+      pk_[H * HD + 32] = dv1[r];
+    }
+  }
+}
+
+}  // namespace
+
+// q, o, dout, dq: (B, L, H*64);  kv, dkv: (B, L, 2*H*64);  lse, dsum: (B, H, L) scratch
+hipError_t launch_attention_bwd(const float *q, const float *kv, const float *o, const float *dout, int B, int L, int H, int D, float *dq, float *dkv,
+                                float *lse, float *dsum, hipStream_t s) {
+  if (D != HD || L < 1 || B < 1 || H < 1 || H > 65535 || B > 65535) return hipErrorInvalidValue;
+  const float scale = 1.0f / sqrtf((float)HD);
+  const dim3 grid((L + 127) / 128, H, B);
+  hipLaunchKernelGGL(attn_bwd_q_mfma_kernel, grid, dim3(256), 0, s, q, kv, o, dout, L, H, scale, dq, lse, dsum);
+  hipLaunchKernelGGL(attn_bwd_kv_mfma_kernel, grid, dim3(256), 0, s, q, kv, dout, lse, dsum, L, H, scale, dkv);
+  return hipGetLastError();
+}
+
+}  // namespace sf

@@ -34,9 +34,9 @@ BwdPlan plan(Workspace &ws, int B, int L, int C, int N, int taps, int groups) {
   p.wd = ws.alloc_n<float>((int64_t)C * taps * p.ldn);
   p.S = conv_wgrad_splits(rows, N, taps * C);
   p.wpart = ws.alloc_n<float>((int64_t)p.S * N * taps * C);
-  p.Sb = (int)std::min<int64_t>(256, std::max<int64_t>(1, rows / 64));
+  p.Sb = (int)std::min<int64_t>(256, std::max<int64_t>(1, rows * N / 16384));   // >= 16 K elements per slice
   p.bpart = ws.alloc_n<float>((int64_t)p.Sb * N);
-  if (groups > 0) p.gpart = ws.alloc_n<float>((int64_t)B * 2 * C);
+  if (groups > 0) p.gpart = ws.alloc_n<float>(gn_silu_bwd_ws_floats(B, L, C, groups));
   return p;
 }
 
@@ -113,17 +113,16 @@ int sf_op_ln_modulate_bwd(const float *x, const float *scale_shift, const float 
   SF_API_END
 }
 
-int sf_op_attention_bwd(const float *q, const float *kv, const float *dout, int B, int L, int heads, int head_dim, float *dq, float *dkv, void *ws,
-                        int64_t ws_bytes, void *stream) {
+int sf_op_attention_bwd(const float *q, const float *kv, const float *out, const float *dout, int B, int L, int heads, int head_dim, float *dq,
+                        float *dkv, void *ws, int64_t ws_bytes, void *stream) {
   SF_API_BEGIN
-  if (!q || !kv || !dout || !dq || !dkv || !ws) fail(SF_ERR_INVALID, "null argument");
+  if (!q || !kv || !out || !dout || !dq || !dkv || !ws) fail(SF_ERR_INVALID, "null argument");
   if (head_dim != 64) fail(SF_ERR_UNSUPPORTED, "head_dim must be 64");
+  if (B < 1 || L < 1 || heads < 1) fail(SF_ERR_INVALID, "B, L and heads must be positive");
   const int64_t need = (int64_t)2 * B * heads * L * (int64_t)sizeof(float);
   if (ws_bytes < need) fail(SF_ERR_WORKSPACE, "workspace too small: need %lld bytes", (long long)need);
   float *lse = static_cast<float *>(ws), *dsum = lse + (int64_t)B * heads * L;
-  hipError_t e = launch_attention_bwd(q, kv, dout, B, L, heads, head_dim, dq, dkv, lse, dsum, static_cast<hipStream_t>(stream));
-  if (e == hipErrorInvalidValue) fail(SF_ERR_UNSUPPORTED, "attention backward supports sequences up to ~1100 positions (got %d)", L);
-  SF_HIP(e);
+  SF_HIP(launch_attention_bwd(q, kv, out, dout, B, L, heads, head_dim, dq, dkv, lse, dsum, static_cast<hipStream_t>(stream)));
   return SF_OK;
   SF_API_END
 }

@@ -252,6 +252,7 @@ hipError_t launch_col_sums(const float *x, int64_t rows, int cols, float *part, 
 // backward of a = SiLU(GroupNorm_G(x; gamma, beta, eps)): dx, and dgb = [dgamma | dbeta]  (dgb_part: [B][2][C] scratch)
 hipError_t launch_gn_silu_bwd(const float *x, const float *da, const float *gamma, const float *beta, int B, int L, int C, int G, float eps,
                               float *dx, float *dgb_part, float *dgb, hipStream_t s);
+int64_t gn_silu_bwd_ws_floats(int B, int L, int C, int G);
 
 // backward of y = LayerNorm_C(x; eps) * (1 + ss[b][c]) + ss[b][C + c] (ss == nullptr: plain normalisation): dx and, when dss != nullptr,
 // dss (B, 2C) = [dscale | dshift];  dss_part: [B][ln_mod_bwd_chunks(L)][2C] scratch
@@ -259,8 +260,8 @@ int ln_mod_bwd_chunks(int L);
 hipError_t launch_ln_modulate_bwd(const float *x, const float *ss, const float *dy, float eps, int B, int L, int C, float *dx, float *dss_part,
                                   float *dss, hipStream_t s);
 // backward of softmax attention on packed projections (head dim 64): dq (B,L,H*64), dkv (B,L,2*H*64); lse, dsum: (B,H,L) scratch
-hipError_t launch_attention_bwd(const float *q, const float *kv, const float *dout, int B, int L, int H, int D, float *dq, float *dkv, float *lse,
-                                float *dsum, hipStream_t s);
+hipError_t launch_attention_bwd(const float *q, const float *kv, const float *o, const float *dout, int B, int L, int H, int D, float *dq, float *dkv,
+                                float *lse, float *dsum, hipStream_t s);
 
 // BatchNorm (eval) -> per-channel scale / shift
 hipError_t launch_bn_fold(const float *gamma, const float *beta, const float *mean, const float *var, float eps, int C,

@@ -30,54 +30,100 @@ __global__ void pack_dgrad_kernel(const float *__restrict__ w, int N, int C, int
 }
 
 // partial[s][n][q],  q = t * C + c:  sum over the rows of split s of dy[row][n] * a[row + t - pad][c]
+// A wave holds TN x TQ accumulator tiles of 32 x 32 (2 x 2 for the wide layers: one A and one B value per tile row / column feed
+// TN * TQ MFMAs, which halves the L2 traffic per flop); the 4 waves take interleaved row pairs and are summed through LDS.
+template <int TN, int TQ>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict__ dy, const float *__restrict__ act, int rows, int L, int C, int N,
                                                          int taps, int pad, int rows_per_split, float *__restrict__ partial) {
   __shared__ float red[4][32][33];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 31, fh = lane >> 5;
   const int Q = taps * C;
-  const int n = blockIdx.x * 32 + fr;          // A operand: lane -> output channel
-  const int q = blockIdx.y * 32 + fr;          // B operand: lane -> (tap, input channel)
-  const int t = q < Q ? q / C : 0, c = q < Q ? q - t * C : 0;
-  const int shift = t - pad;
-  const int r_begin = blockIdx.z * rows_per_split, r_end = min(rows, r_begin + rows_per_split);
-  f32x16 acc;
+  int n[TN], c[TQ], shift[TQ];
+  bool qok[TQ];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int i = 0; i < TN; ++i) n[i] = (blockIdx.x * TN + i) * 32 + fr;   // A operand: lane -> output channel
+#pragma unroll
+  for (int j = 0; j < TQ; ++j) {                                         // B operand: lane -> (tap, input channel)
+    const int q = (blockIdx.y * TQ + j) * 32 + fr;
+    qok[j] = q < Q;
+    const int t = qok[j] ? q / C : 0;
+    c[j] = qok[j] ? q - t * C : 0;
+    shift[j] = t - pad;
+  }
+  const int r_begin = blockIdx.z * rows_per_split, r_end = min(rows, r_begin + rows_per_split);
+  f32x16 acc[TN][TQ];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TQ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   // wave w takes the row pairs w, w + 4, ...; inside a pair the half-wave picks the row (k index of the 32x32x2 MFMA)
   for (int r0 = r_begin + 2 * wave; r0 < r_end; r0 += 8) {
     const int r = r0 + fh;
     const bool rv = r < r_end;
-    const float av = (rv && n < N) ? dy[(size_t)r * N + n] : 0.f;
     const int l = r % L;
-    const int ls = l + shift;
-    const bool bv = rv && q < Q && ls >= 0 && ls < L;
-    const float bvv = bv ? act[(size_t)(r + shift) * C + c] : 0.f;
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bvv, acc, 0, 0, 0);
+    float av[TN], bv[TQ];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) av[i] = (rv && n[i] < N) ? dy[(size_t)r * N + n[i]] : 0.f;
+#pragma unroll
+    for (int j = 0; j < TQ; ++j) {
+      const int ls = l + shift[j];
+      bv[j] = (rv && qok[j] && ls >= 0 && ls < L) ? act[(size_t)(r + shift[j]) * C + c[j]] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TQ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
   }
 #pragma unroll
-  for (int i = 0; i < 16; ++i) red[wave][(i & 3) + 8 * (i >> 2) + 4 * fh][fr] = acc[i];
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TQ; ++j) {
+      if (i + j) __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 16; ++e) red[wave][(e & 3) + 8 * (e >> 2) + 4 * fh][fr] = acc[i][j][e];
+      __syncthreads();
+      for (int idx = threadIdx.x; idx < 32 * 32; idx += 256) {
+        const int a = idx >> 5, b = idx & 31;
+        const float v = (red[0][a][b] + red[1][a][b]) + (red[2][a][b] + red[3][a][b]);
+        const int nn = (blockIdx.x * TN + i) * 32 + a, qq = (blockIdx.y * TQ + j) * 32 + b;
+        if (nn < N && qq < Q) partial[((size_t)blockIdx.z * N + nn) * Q + qq] = v;
+      }
+    }
+}
+
+// Sum over the leading (slice) dimension: 32 outputs per workgroup, 8 threads per output take the slices k = kq, kq + 8, ... and
+// are combined through LDS in a fixed order (deterministic; the loads of a 32-lane group are 128 contiguous bytes).
+__device__ __forceinline__ float slice_sum_8(const float *__restrict__ part, int S, size_t stride, size_t col, bool valid, float *sh /* [256] */) {
+  const int kq = threadIdx.x >> 5;
+  float s = 0.f;
+  if (valid)
+    for (int k = kq; k < S; k += 8) s += part[(size_t)k * stride + col];
+  sh[threadIdx.x] = s;
   __syncthreads();
-  for (int idx = threadIdx.x; idx < 32 * 32; idx += 256) {
-    const int i = idx >> 5, j = idx & 31;
-    const float v = (red[0][i][j] + red[1][i][j]) + (red[2][i][j] + red[3][i][j]);
-    const int nn = blockIdx.x * 32 + i, qq = blockIdx.y * 32 + j;
-    if (nn < N && qq < Q) partial[((size_t)blockIdx.z * N + nn) * Q + qq] = v;
+  float t = 0.f;
+  if (kq == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t += sh[j * 32 + threadIdx.x];
   }
+  return t;
 }
 
 // dw[n][c][t] (PyTorch layout) = sum_s partial[s][n][t * C + c]
-__global__ void wgrad_reduce_kernel(const float *__restrict__ partial, int S, int N, int C, int taps, float *__restrict__ dw) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ partial, int S, int N, int C, int taps, float *__restrict__ dw) {
+  __shared__ float sh[256];
   const int64_t total = (int64_t)N * C * taps;
   const int Q = taps * C;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int t = (int)(i % taps);
-    const int64_t r = i / taps;
-    const int c = (int)(r % C), n = (int)(r / C);
-    float s = 0.f;
-    for (int k = 0; k < S; ++k) s += partial[((size_t)k * N + n) * Q + (size_t)t * C + c];
-    dw[i] = s;
-  }
+  const int64_t i = (int64_t)blockIdx.x * 32 + (threadIdx.x & 31);
+  const bool valid = i < total;
+  const int64_t ii = valid ? i : 0;
+  const int t = (int)(ii % taps);
+  const int64_t r = ii / taps;
+  const int c = (int)(r % C), n = (int)(r / C);
+  const float v = slice_sum_8(partial, S, (size_t)N * Q, (size_t)n * Q + (size_t)t * C + c, valid, sh);
+  if (threadIdx.x < 32 && valid) dw[i] = v;
 }
 
 // part[blockIdx.y][col] = sum of x[row][col] over the rows of the slice (one thread per column, rows strided by gridDim.y)
@@ -89,13 +135,43 @@ __global__ void col_sums_kernel(const float *__restrict__ x, int64_t rows, int c
   for (int64_t r = r0; r < r1; ++r) s += x[r * cols + col];
   part[(size_t)blockIdx.y * cols + col] = s;
 }
-// out[j] = sum_k part[k][j]   (optionally two interleaved quantities: out2[j] from part2)
-__global__ void slices_reduce_kernel(const float *__restrict__ part, int S, int cols, float *__restrict__ out) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= cols) return;
-  float s = 0.f;
-  for (int k = 0; k < S; ++k) s += part[(size_t)k * cols + col];
-  out[col] = s;
+// the same with V (4 or 1) columns per access, (cols / V) dividing 256: a thread always meets the same V columns; the
+// 256 / (cols / V) threads that share a column set are summed in thread order through LDS
+template <int V>
+__global__ __launch_bounds__(256) void col_sums_vec_kernel(const float *__restrict__ x, int64_t rows, int cols, int64_t rows_per_slice,
+                                                           float *__restrict__ part) {
+  __shared__ float red[V * 256];
+  const int tid = threadIdx.x, vpr = cols / V, cv = tid % vpr, rstep = 256 / vpr;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_slice, r1 = min(rows, r0 + rows_per_slice);
+  float acc[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) acc[j] = 0.f;
+  for (int64_t r = r0 + tid / vpr; r < r1; r += rstep) {
+    if constexpr (V == 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(x + r * cols + 4 * cv);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] += v[j];
+    } else {
+      acc[0] += x[r * cols + cv];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < V; ++j) red[j * 256 + tid] = acc[j];
+  __syncthreads();
+  for (int c = tid; c < cols; c += 256) {
+    const float *rp = red + (c % V) * 256 + (c / V);
+    float t = 0.f;
+    for (int sl = 0; sl < rstep; ++sl) t += rp[sl * vpr];
+    part[(size_t)blockIdx.x * cols + c] = t;
+  }
+}
+// out[j] = sum_k part[k][j]
+__global__ __launch_bounds__(256) void slices_reduce_kernel(const float *__restrict__ part, int S, int cols, float *__restrict__ out) {
+  __shared__ float sh[256];
+  const int col = blockIdx.x * 32 + (threadIdx.x & 31);
+  const bool valid = col < cols;
+  const float v = slice_sum_8(part, S, (size_t)cols, (size_t)(valid ? col : 0), valid, sh);
+  if (threadIdx.x < 32 && valid) out[col] = v;
 }
 
 __device__ __forceinline__ float block_sum_256(float v, float *sh) {   // every thread gets the total; fixed order
@@ -257,123 +333,168 @@ __global__ void chunks_reduce_kernel(const float *__restrict__ part, int nchunk,
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// Multi-head softmax attention backward (head dim 64, fp32), two passes, no atomics:
-//   pass Q (one workgroup per (clip, head, 16 queries)): S = q K^T scale, P = softmax(S), dP = dO V^T, D_i = sum_j P_ij dP_ij,
-//            dS = P (dP - D) scale, dQ = dS K;  leaves lse_i = log sum_j exp(S_ij) and D_i for the second pass
-//   pass K (one workgroup per (clip, head, 16 keys)): p_ij = exp(S_ij - lse_i); dV_j = sum_i p_ij dO_i; dK_j = sum_i p_ij (dP_ij - D_i) scale q_i
-// q, dq, dout: (B, L, H*64) rows;  kv, dkv: (B, L, 2*H*64) rows (k | v).
+// GroupNorm + SiLU backward, chunked (the per-(clip, group) kernel above has B * G workgroups: 32 at the training batch).  A
+// workgroup owns a chunk of rows of one clip over ALL channels (contiguous 16-byte accesses; a thread always meets the same 4
+// channels because C / 4 divides 256):
+//   gn_stats (norms.hip)   per-chunk (mean, M2) per group
+//   gn_bwd_part_kernel     per-chunk sums: dgamma, dbeta per channel; s1 = sum g, s2 = sum g xhat per group   (g = du * gamma)
+//   gn_bwd_dx_kernel       dx = rstd (g - mean(g) - xhat mean(g xhat))
+// Chunk partials are merged in chunk order by every consumer (Chan for the statistics): no atomics.
 // ---------------------------------------------------------------------------------------------------------------------------
-constexpr int AD = 64, AQ = 16;
-__global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float *__restrict__ q, const float *__restrict__ kv, const float *__restrict__ dout, int L, int H,
-                                                         float scale, float *__restrict__ dq, float *__restrict__ lse, float *__restrict__ dsum) {
-  extern __shared__ float sm[];
-  float *qs = sm;                   // [AQ][AD]
-  float *dos = qs + AQ * AD;        // [AQ][AD]
-  float *P = dos + AQ * AD;         // [AQ][L]
-  float *dP = P + (size_t)AQ * L;   // [AQ][L]
-  const int tid = threadIdx.x;
-  const int q0 = blockIdx.x * AQ, h = blockIdx.y, b = blockIdx.z;
-  const int ldq = H * AD, ldkv = 2 * H * AD;
-  const size_t rb = (size_t)b * L;
-  for (int i = tid; i < AQ * AD; i += 256) {
-    const int r = i / AD, d = i - r * AD;
-    const bool ok = q0 + r < L;
-    qs[i] = ok ? q[(rb + q0 + r) * ldq + h * AD + d] : 0.f;
-    dos[i] = ok ? dout[(rb + q0 + r) * ldq + h * AD + d] : 0.f;
-  }
-  __syncthreads();
-  for (int e = tid; e < AQ * L; e += 256) {   // S and dP: thread -> (query r, key j)
-    const int r = e / L, j = e - r * L;
-    const float *kp = kv + (rb + j) * ldkv + h * AD, *vp = kp + H * AD;
-    float s = 0.f, dp = 0.f;
-#pragma unroll 8
-    for (int d = 0; d < AD; ++d) {
-      s = fmaf(qs[r * AD + d], kp[d], s);
-      dp = fmaf(dos[r * AD + d], vp[d], dp);
+__device__ __forceinline__ void gn_group_stats(const float *__restrict__ slab_b, int nch, int G, int chunk_rows, int L, int cpg, float eps,
+                                               float *mean_s, float *rstd_s) {
+  for (int g = threadIdx.x; g < G; g += 256) {
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int ch = 0; ch < nch; ++ch) {
+      const float nb = (float)min(chunk_rows, L - ch * chunk_rows) * (float)cpg;
+      const float mb = slab_b[((size_t)ch * G + g) * 2], qb = slab_b[((size_t)ch * G + g) * 2 + 1];
+      const float delta = mb - mean, tot = n + nb;
+      mean += delta * (nb / tot);
+      m2 += qb + delta * delta * (n * nb / tot);
+      n = tot;
     }
-    P[e] = s * scale;
-    dP[e] = dp;
-  }
-  __syncthreads();
-  {   // softmax statistics: 16 lanes per query row
-    const int r = tid >> 4, sub = tid & 15;
-    float mx = -INFINITY;
-    for (int j = sub; j < L; j += 16) mx = fmaxf(mx, P[r * L + j]);
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
-    float sum = 0.f;
-    for (int j = sub; j < L; j += 16) sum += expf(P[r * L + j] - mx);
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
-    const float l = mx + logf(sum);
-    float dd = 0.f;
-    for (int j = sub; j < L; j += 16) {
-      const float p = expf(P[r * L + j] - l);
-      P[r * L + j] = p;
-      dd = fmaf(p, dP[r * L + j], dd);
-    }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) dd += __shfl_xor(dd, o, 16);
-    for (int j = sub; j < L; j += 16) dP[r * L + j] = P[r * L + j] * (dP[r * L + j] - dd) * scale;   // dS
-    if (sub == 0 && q0 + r < L) {
-      lse[((size_t)b * H + h) * L + q0 + r] = l;
-      dsum[((size_t)b * H + h) * L + q0 + r] = dd;
-    }
-  }
-  __syncthreads();
-  for (int e = tid; e < AQ * AD; e += 256) {   // dQ = dS K
-    const int r = e / AD, d = e - r * AD;
-    float acc = 0.f;
-    for (int j = 0; j < L; ++j) acc = fmaf(dP[r * L + j], kv[(rb + j) * ldkv + h * AD + d], acc);
-    if (q0 + r < L) dq[(rb + q0 + r) * ldq + h * AD + d] = acc;
+    mean_s[g] = mean;
+    rstd_s[g] = rsqrtf(m2 / n + eps);
   }
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_k_kernel(const float *__restrict__ q, const float *__restrict__ kv, const float *__restrict__ dout,
-                                                         const float *__restrict__ lse, const float *__restrict__ dsum, int L, int H, float scale,
-                                                         float *__restrict__ dkv) {
-  __shared__ float ks[AQ][AD + 1], vs[AQ][AD + 1];
-  const int tid = threadIdx.x;
-  const int k0 = blockIdx.x * AQ, h = blockIdx.y, b = blockIdx.z;
-  const int ldq = H * AD, ldkv = 2 * H * AD;
-  const size_t rb = (size_t)b * L;
-  for (int i = tid; i < AQ * AD; i += 256) {
-    const int r = i / AD, d = i - r * AD;
-    const bool ok = k0 + r < L;
-    ks[r][d] = ok ? kv[(rb + k0 + r) * ldkv + h * AD + d] : 0.f;
-    vs[r][d] = ok ? kv[(rb + k0 + r) * ldkv + (H + h) * AD + d] : 0.f;
+template <int V>
+__global__ __launch_bounds__(256) void gn_bwd_part_kernel(const float *__restrict__ x, const float *__restrict__ da, const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta, const float *__restrict__ slab, int L, int C, int G, int nch,
+                                                          int chunk_rows, float eps, float *__restrict__ dgb_part /* [B][nch][2][C] */,
+                                                          float *__restrict__ s12_part /* [B][nch][G][2] */) {
+  __shared__ float mean_s[256], rstd_s[256];
+  __shared__ float red[4 * V * 256];   // [quantity * V + j][thread]
+  __shared__ float chan[4 * 1024];   // [quantity][channel]: dgamma, dbeta, s1, s2 of this chunk
+  const int ch = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int cpg = C / G, vpr = C / V, cv = tid % vpr, rstep = 256 / vpr;
+  gn_group_stats(slab + (size_t)b * nch * G * 2, nch, G, chunk_rows, L, cpg, eps, mean_s, rstd_s);
+  __syncthreads();
+  const int c0 = cv * V;
+  float gam[V], bet[V], mu[V], rs[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    const int g = (c0 + j) / cpg;
+    gam[j] = gamma[c0 + j];
+    bet[j] = beta[c0 + j];
+    mu[j] = mean_s[g];
+    rs[j] = rstd_s[g];
+  }
+  const int r0 = ch * chunk_rows, rows = min(chunk_rows, L - r0);
+  const float *xb = x + ((size_t)b * L + r0) * C + c0, *db = da + ((size_t)b * L + r0) * C + c0;
+  float a[4][V];
+#pragma unroll
+  for (int qn = 0; qn < 4; ++qn)
+#pragma unroll
+    for (int j = 0; j < V; ++j) a[qn][j] = 0.f;
+  for (int r = tid / vpr; r < rows; r += rstep) {
+    float xv[V], dv[V];
+    if constexpr (V == 4) {
+      const f32x4 x4 = *reinterpret_cast<const f32x4 *>(xb + (size_t)r * C), d4 = *reinterpret_cast<const f32x4 *>(db + (size_t)r * C);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        xv[j] = x4[j];
+        dv[j] = d4[j];
+      }
+    } else {
+      xv[0] = xb[(size_t)r * C];
+      dv[0] = db[(size_t)r * C];
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float xh = (xv[j] - mu[j]) * rs[j];
+      const float u = fmaf(xh, gam[j], bet[j]);
+      const float sg = 1.0f / (1.0f + expf(-u));
+      const float du = dv[j] * sg * (1.0f + u * (1.0f - sg));
+      const float g1 = du * gam[j];
+      a[0][j] = fmaf(du, xh, a[0][j]);
+      a[1][j] += du;
+      a[2][j] += g1;
+      a[3][j] = fmaf(g1, xh, a[3][j]);
+    }
+  }
+#pragma unroll
+  for (int qn = 0; qn < 4; ++qn)
+#pragma unroll
+    for (int j = 0; j < V; ++j) red[(qn * V + j) * 256 + tid] = a[qn][j];
+  __syncthreads();
+  for (int o = tid; o < 4 * C; o += 256) {   // per-channel totals: the rstep threads that share a column set, in thread order
+    const int qn = o / C, c = o - qn * C;
+    const float *rp = red + (qn * V + (c % V)) * 256 + (c / V);
+    float t = 0.f;
+    for (int sl = 0; sl < rstep; ++sl) t += rp[sl * vpr];
+    chan[o] = t;
+    if (qn < 2) dgb_part[(((size_t)b * nch + ch) * 2 + qn) * C + c] = t;
   }
   __syncthreads();
-  // thread -> (key j = tid / 16, dims 4 * (tid % 16) .. + 3); the 16 lanes of a key share its dot products
-  const int j = tid >> 4, sub = tid & 15;
-  float dk[4] = {0.f, 0.f, 0.f, 0.f}, dv[4] = {0.f, 0.f, 0.f, 0.f};
-  const float *lp = lse + ((size_t)b * H + h) * L, *dp_ = dsum + ((size_t)b * H + h) * L;
-  for (int i = 0; i < L; ++i) {
-    const float *qp = q + (rb + i) * ldq + h * AD + 4 * sub, *op = dout + (rb + i) * ldq + h * AD + 4 * sub;
-    const f32x4 qv = *reinterpret_cast<const f32x4 *>(qp), ov = *reinterpret_cast<const f32x4 *>(op);
-    float s = 0.f, dpv = 0.f;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      s = fmaf(qv[e], ks[j][4 * sub + e], s);
-      dpv = fmaf(ov[e], vs[j][4 * sub + e], dpv);
+  for (int g = tid; g < G; g += 256) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+      s1 += chan[2 * C + c];
+      s2 += chan[3 * C + c];
     }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
-      s += __shfl_xor(s, o, 16);
-      dpv += __shfl_xor(dpv, o, 16);
-    }
-    const float p = expf(s * scale - lp[i]);
-    const float ds = p * (dpv - dp_[i]) * scale;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      dv[e] = fmaf(p, ov[e], dv[e]);
-      dk[e] = fmaf(ds, qv[e], dk[e]);
-    }
+    s12_part[(((size_t)b * nch + ch) * G + g) * 2] = s1;
+    s12_part[(((size_t)b * nch + ch) * G + g) * 2 + 1] = s2;
   }
-  if (k0 + j < L) {
-    float *o = dkv + (rb + k0 + j) * ldkv + h * AD + 4 * sub;
-    *reinterpret_cast<f32x4 *>(o) = f32x4{dk[0], dk[1], dk[2], dk[3]};
-    *reinterpret_cast<f32x4 *>(o + H * AD) = f32x4{dv[0], dv[1], dv[2], dv[3]};
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const float *__restrict__ x, const float *__restrict__ da, const float *__restrict__ gamma,
+                                                        const float *__restrict__ beta, const float *__restrict__ slab,
+                                                        const float *__restrict__ s12_part, int L, int C, int G, int nch, int chunk_rows, float eps,
+                                                        float *__restrict__ dx) {
+  __shared__ float mean_s[256], rstd_s[256], m1_s[256], m2_s[256];
+  const int ch = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int cpg = C / G, vpr = C / V, cv = tid % vpr, rstep = 256 / vpr;
+  gn_group_stats(slab + (size_t)b * nch * G * 2, nch, G, chunk_rows, L, cpg, eps, mean_s, rstd_s);
+  for (int g = tid; g < G; g += 256) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < nch; ++k) {
+      s1 += s12_part[(((size_t)b * nch + k) * G + g) * 2];
+      s2 += s12_part[(((size_t)b * nch + k) * G + g) * 2 + 1];
+    }
+    const float inv_n = 1.0f / ((float)L * (float)cpg);
+    m1_s[g] = s1 * inv_n;
+    m2_s[g] = s2 * inv_n;
+  }
+  __syncthreads();
+  const int c0 = cv * V;
+  float gam[V], bet[V], mu[V], rs[V], m1[V], m2[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    const int g = (c0 + j) / cpg;
+    gam[j] = gamma[c0 + j];
+    bet[j] = beta[c0 + j];
+    mu[j] = mean_s[g];
+    rs[j] = rstd_s[g];
+    m1[j] = m1_s[g];
+    m2[j] = m2_s[g];
+  }
+  const int r0 = ch * chunk_rows, rows = min(chunk_rows, L - r0);
+  const size_t base = ((size_t)b * L + r0) * C + c0;
+  for (int r = tid / vpr; r < rows; r += rstep) {
+    float xv[V], dv[V], o[V];
+    if constexpr (V == 4) {
+      const f32x4 x4 = *reinterpret_cast<const f32x4 *>(x + base + (size_t)r * C), d4 = *reinterpret_cast<const f32x4 *>(da + base + (size_t)r * C);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        xv[j] = x4[j];
+        dv[j] = d4[j];
+      }
+    } else {
+      xv[0] = x[base + (size_t)r * C];
+      dv[0] = da[base + (size_t)r * C];
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float xh = (xv[j] - mu[j]) * rs[j];
+      const float u = fmaf(xh, gam[j], bet[j]);
+      const float sg = 1.0f / (1.0f + expf(-u));
+      const float g1 = dv[j] * sg * (1.0f + u * (1.0f - sg)) * gam[j];
+      o[j] = rs[j] * (g1 - m1[j] - xh * m2[j]);
+    }
+    if constexpr (V == 4) *reinterpret_cast<f32x4 *>(dx + base + (size_t)r * C) = f32x4{o[0], o[1], o[2], o[3]};
+    else dx[base + (size_t)r * C] = o[0];
   }
 }
 
@@ -386,8 +507,11 @@ hipError_t launch_pack_dgrad(const float *w, int N, int C, int taps, int ldn, fl
   return hipGetLastError();
 }
 
+static int wgrad_tile(int N, int Q) { return (N >= 64 && Q >= 64) ? 2 : 1; }   // accumulator tiles per wave and dimension
+
 int conv_wgrad_splits(int64_t rows, int N, int Q) {
-  const int64_t tiles = (int64_t)((N + 31) / 32) * ((Q + 31) / 32);
+  const int T = 32 * wgrad_tile(N, Q);
+  const int64_t tiles = (int64_t)((N + T - 1) / T) * ((Q + T - 1) / T);
   int64_t S = std::max<int64_t>(1, 2048 / std::max<int64_t>(tiles, 1));
   S = std::min<int64_t>(S, std::max<int64_t>(1, rows / 256));
   return (int)std::min<int64_t>(S, 1024);
@@ -398,26 +522,70 @@ hipError_t launch_conv_wgrad(const float *dy, const float *act, int B, int L, in
   const int rows = B * L, Q = taps * C;
   int rps = (rows + S - 1) / S;
   rps = (rps + 7) / 8 * 8;
-  hipLaunchKernelGGL(conv_wgrad_kernel, dim3((N + 31) / 32, (Q + 31) / 32, S), dim3(256), 0, s, dy, act, rows, L, C, N, taps, pad, rps, partial);
+  if (wgrad_tile(N, Q) == 2)
+    hipLaunchKernelGGL((conv_wgrad_kernel<2, 2>), dim3((N + 63) / 64, (Q + 63) / 64, S), dim3(256), 0, s, dy, act, rows, L, C, N, taps, pad, rps, partial);
+  else
+    hipLaunchKernelGGL((conv_wgrad_kernel<1, 1>), dim3((N + 31) / 32, (Q + 31) / 32, S), dim3(256), 0, s, dy, act, rows, L, C, N, taps, pad, rps, partial);
   const int64_t total = (int64_t)N * Q;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)std::min<int64_t>((total + 255) / 256, 2048)), dim3(256), 0, s, partial, S, N, C, taps, dw);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, s, partial, S, N, C, taps, dw);
   return hipGetLastError();
 }
 
 hipError_t launch_col_sums(const float *x, int64_t rows, int cols, float *part, int S, float *out, hipStream_t s) {
   const int64_t rps = (rows + S - 1) / S;
-  hipLaunchKernelGGL(col_sums_kernel, dim3((cols + 63) / 64, S), dim3(64), 0, s, x, rows, cols, rps, part);
-  hipLaunchKernelGGL(slices_reduce_kernel, dim3((cols + 63) / 64), dim3(64), 0, s, part, S, cols, out);
+  if (cols % 4 == 0 && cols <= 1024 && (256 % (cols / 4)) == 0) hipLaunchKernelGGL(col_sums_vec_kernel<4>, dim3(S), dim3(256), 0, s, x, rows, cols, rps, part);
+  else if (cols <= 256 && (256 % cols) == 0) hipLaunchKernelGGL(col_sums_vec_kernel<1>, dim3(S), dim3(256), 0, s, x, rows, cols, rps, part);
+  else hipLaunchKernelGGL(col_sums_kernel, dim3((cols + 63) / 64, S), dim3(64), 0, s, x, rows, cols, rps, part);
+  hipLaunchKernelGGL(slices_reduce_kernel, dim3((cols + 31) / 32), dim3(256), 0, s, part, S, cols, out);
   return hipGetLastError();
 }
 
+static int gn_bwd_vec(int C, int G) {   // columns per access of the chunked kernels; 0 = unsupported shape
+  if (G < 1 || G > 256 || C % G) return 0;
+  if (C % 4 == 0 && C <= 1024 && (256 % (C / 4)) == 0) return 4;
+  if (C <= 256 && (256 % C) == 0) return 1;
+  return 0;
+}
+static bool gn_bwd_chunked_ok(int C, int G) { return gn_bwd_vec(C, G) != 0; }
+
+static void gn_bwd_plan(int L, int C, int &nch, int &chunk_rows) {
+  int64_t n = ((int64_t)L * C + 16383) / 16384;
+  n = std::max<int64_t>(1, std::min<int64_t>(n, 64));
+  chunk_rows = (int)((L + n - 1) / n);
+  nch = (L + chunk_rows - 1) / chunk_rows;
+}
+
+int64_t gn_silu_bwd_ws_floats(int B, int L, int C, int G) {
+  if (!gn_bwd_chunked_ok(C, G)) return (int64_t)B * 2 * C;
+  int nch, rows;
+  gn_bwd_plan(L, C, nch, rows);
+  return (int64_t)B * nch * (2 * C + 4 * G);
+}
+
 hipError_t launch_gn_silu_bwd(const float *x, const float *da, const float *gamma, const float *beta, int B, int L, int C, int G, float eps,
-                              float *dx, float *dgb_part, float *dgb /* [2C] = dgamma | dbeta */, hipStream_t s) {
+                              float *dx, float *ws /* gn_silu_bwd_ws_floats() */, float *dgb /* [2C] = dgamma | dbeta */, hipStream_t s) {
+  if (G < 1 || C % G) return hipErrorInvalidValue;
+  if (gn_bwd_chunked_ok(C, G)) {
+    int nch, chunk_rows;
+    gn_bwd_plan(L, C, nch, chunk_rows);
+    float *slab = ws, *dgb_part = slab + (size_t)B * nch * G * 2, *s12 = dgb_part + (size_t)B * nch * 2 * C;
+    hipError_t e = launch_gn_stats(F32, x, C, B, L, C, G, nch, chunk_rows, slab, s);
+    if (e != hipSuccess) return e;
+    if (gn_bwd_vec(C, G) == 4) {
+      hipLaunchKernelGGL(gn_bwd_part_kernel<4>, dim3(nch, B), dim3(256), 0, s, x, da, gamma, beta, slab, L, C, G, nch, chunk_rows, eps, dgb_part, s12);
+      hipLaunchKernelGGL(gn_bwd_dx_kernel<4>, dim3(nch, B), dim3(256), 0, s, x, da, gamma, beta, slab, s12, L, C, G, nch, chunk_rows, eps, dx);
+    } else {
+      hipLaunchKernelGGL(gn_bwd_part_kernel<1>, dim3(nch, B), dim3(256), 0, s, x, da, gamma, beta, slab, L, C, G, nch, chunk_rows, eps, dgb_part, s12);
+      hipLaunchKernelGGL(gn_bwd_dx_kernel<1>, dim3(nch, B), dim3(256), 0, s, x, da, gamma, beta, slab, s12, L, C, G, nch, chunk_rows, eps, dx);
+    }
+    hipLaunchKernelGGL(slices_reduce_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, s, dgb_part, B * nch, 2 * C, dgb);
+    return hipGetLastError();
+  }
   const int cpg = C / G;
-  if (G < 1 || C % G || cpg > 256 || (256 % cpg)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(gn_silu_bwd_kernel, dim3(B * G), dim3(256), 0, s, x, da, gamma, beta, L, C, G, eps, dx, dgb_part);
-  // dgb_part is [B][2][C]: rows b, columns (2C) -> column sums give [dgamma | dbeta]
-  hipLaunchKernelGGL(slices_reduce_kernel, dim3((2 * C + 63) / 64), dim3(64), 0, s, dgb_part, B, 2 * C, dgb);
+  if (cpg > 256 || (256 % cpg)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(gn_silu_bwd_kernel, dim3(B * G), dim3(256), 0, s, x, da, gamma, beta, L, C, G, eps, dx, ws);
+  // ws is [B][2][C]: rows b, columns (2C) -> column sums give [dgamma | dbeta]
+  hipLaunchKernelGGL(slices_reduce_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, s, ws, B, 2 * C, dgb);
   return hipGetLastError();
 }
 
@@ -430,24 +598,6 @@ hipError_t launch_ln_modulate_bwd(const float *x, const float *ss, const float *
   const int rpc = (L + nchunk - 1) / nchunk;
   hipLaunchKernelGGL(ln_mod_bwd_kernel, dim3(B, nchunk), dim3(256), 0, s, x, ss, 2 * C, dy, L, C, eps, rpc, dx, dss_part);
   if (dss) hipLaunchKernelGGL(chunks_reduce_kernel, dim3((2 * C + 63) / 64, B), dim3(64), 0, s, dss_part, nchunk, 2 * C, dss);
-  return hipGetLastError();
-}
-
-hipError_t launch_attention_bwd(const float *q, const float *kv, const float *dout, int B, int L, int H, int D, float *dq, float *dkv, float *lse,
-                                float *dsum, hipStream_t s) {
-  if (D != AD || L < 1) return hipErrorInvalidValue;
-  const size_t lds = ((size_t)2 * AQ * AD + (size_t)2 * AQ * L) * sizeof(float);
-  if (lds > 150 * 1024) return hipErrorInvalidValue;   // L <= ~1100: longer sequences need a tiled first pass
-  static bool en = false;
-  if (!en) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_q_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    if (e != hipSuccess) return e;
-    en = true;
-  }
-  const float scale = 1.0f / sqrtf((float)AD);
-  dim3 grid((L + AQ - 1) / AQ, H, B);
-  hipLaunchKernelGGL(attn_bwd_q_kernel, grid, dim3(256), lds, s, q, kv, dout, L, H, scale, dq, lse, dsum);
-  hipLaunchKernelGGL(attn_bwd_k_kernel, grid, dim3(256), 0, s, q, kv, dout, lse, dsum, L, H, scale, dkv);
   return hipGetLastError();
 }
 

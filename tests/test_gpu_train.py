@@ -111,7 +111,7 @@ def test_ln_modulate_gradients(cuda, B, L, C, with_ss):
         assert rel_l2(sss.grad.cpu(), ss.grad) < TOL, f"dss {rel_l2(sss.grad.cpu(), ss.grad):.3e}"
 
 
-@pytest.mark.parametrize("B,L,H", [(2, 44, 8), (2, 100, 2), (1, 352, 8), (3, 1, 4), (1, 1000, 1), (2, 17, 3)])
+@pytest.mark.parametrize("B,L,H", [(2, 44, 8), (2, 100, 2), (1, 352, 8), (3, 1, 4), (1, 1000, 1), (2, 17, 3), (1, 2048, 2), (1, 2500, 1)])
 def test_attention_gradients(cuda, B, L, H):
     from syncfusion_amd import autograd as sfa
 
@@ -132,8 +132,13 @@ def test_attention_gradients(cuda, B, L, H):
     o = sfa.attention(qs, kvs, H)
     assert rel_l2(o.detach().cpu(), o_ref.detach()) < TOL
     o.backward(do.to(cuda))
-    assert rel_l2(qs.grad.cpu(), q.grad) < TOL, f"dq {rel_l2(qs.grad.cpu(), q.grad):.3e}"
-    assert rel_l2(kvs.grad.cpu(), kv.grad) < TOL, f"dkv {rel_l2(kvs.grad.cpu(), kv.grad):.3e}"
+    if L == 1:   # softmax over a single key is constant: dq = dk = 0 (rounding noise of dP - D on the device), dv = dO
+        assert float(q.grad.abs().max()) == 0.0 and float(qs.grad.abs().max()) < 1e-5
+        assert float(kvs.grad[..., : H * D].abs().max()) < 1e-5
+        assert rel_l2(kvs.grad[..., H * D:].cpu(), kv.grad[..., H * D:]) < TOL
+    else:
+        assert rel_l2(qs.grad.cpu(), q.grad) < TOL, f"dq {rel_l2(qs.grad.cpu(), q.grad):.3e}"
+        assert rel_l2(kvs.grad.cpu(), kv.grad) < TOL, f"dkv {rel_l2(kvs.grad.cpu(), kv.grad):.3e}"
 
 
 def _grad_close(got: torch.Tensor, ref: torch.Tensor, tol: float, scale: float, zero_by_construction: bool = False) -> bool:
@@ -198,28 +203,46 @@ def test_unet_training_forward_and_every_gradient_against_oracle_autograd(cuda, 
 
 
 def test_encoder1d_training_gradients_against_oracle_autograd(cuda):
+    """Every Encoder1d parameter gradient against autograd through the oracle.  The onset track is sparse and binary, which makes
+    a few sums ill-conditioned in fp32 (to_in's GroupNorm weight: dgamma = -0.1 out of terms that add up to dbeta = 32), so the
+    yardstick is the oracle in float64 and the bar of 1e-4 widens by the amplification the float32 oracle itself shows."""
     from helpers import small_encoder_module
     from oracle import encoder1d_ref
 
     enc = small_encoder_module()
     cfg = dict(enc.hparams)
-    P = {k: v.clone().requires_grad_() for k, v in oracle_params(enc).items()}
     B, L0 = 2, 16 * 11
     g = torch.Generator().manual_seed(31)
     y = (torch.rand(B, 1, L0, generator=g) < 0.05).float()
-    _, info_ref = encoder1d_ref.encoder1d_forward(P, cfg, y)
-    weights = [torch.randn(t.shape, generator=g) for t in info_ref["xs"][2:-1]]
-    sum((t * w).sum() for t, w in zip(info_ref["xs"][2:-1], weights)).backward()
+    weights, grads, infos = None, {}, {}
+    for dt in (torch.float64, torch.float32):
+        P = {k: v.clone().to(dt).requires_grad_() for k, v in oracle_params(enc).items()}
+        _, info_ref = encoder1d_ref.encoder1d_forward(P, cfg, y.to(dt))
+        if weights is None:
+            weights = [torch.randn(t.shape, generator=g) for t in info_ref["xs"][2:-1]]
+        sum((t * w.to(dt)).sum() for t, w in zip(info_ref["xs"][2:-1], weights)).backward()
+        grads[dt] = {k: p.grad.double() for k, p in P.items()}
+        infos[dt] = info_ref
     enc = enc.to(cuda)
     z, info = enc(y.to(cuda), with_info=True)
-    assert z.requires_grad and len(info["xs"]) == len(info_ref["xs"])
-    for a, b in zip(info["xs"], info_ref["xs"]):
+    assert z.requires_grad and len(info["xs"]) == len(infos[torch.float64]["xs"])
+    for a, b in zip(info["xs"], infos[torch.float64]["xs"]):
         assert a.shape == b.shape and rel_l2(a.detach().cpu(), b.detach()) < 1e-5
     sum((t * w.to(cuda)).sum() for t, w in zip(info["xs"][2:-1], weights)).backward()
-    typical = float(torch.cat([p.grad.reshape(-1) for p in P.values()]).abs().mean())
-    width = {n: p.shape[0] for n, p in enc.named_parameters()}
-    bad = [(n, rel_l2(p.grad.cpu(), P[n].grad)) for n, p in enc.named_parameters()
-           if not _grad_close(p.grad.cpu(), P[n].grad, 1e-4, typical, _zero_by_construction(n, lambda parts: width[n], 1 if n.startswith("to_in") else cfg["resnet_groups"]))]
+    ref64, ref32 = grads[torch.float64], grads[torch.float32]
+    typical = float(torch.cat([v.reshape(-1) for v in ref64.values()]).abs().mean())
+    bad = []
+    for n, p in enc.named_parameters():
+        got = p.grad.double().cpu()
+        if _zero_by_construction(n, lambda parts: p.shape[0], 1 if n.startswith("to_in") else cfg["resnet_groups"]):
+            assert float(got.abs().max()) <= 1e-3 * typical, n
+            continue
+        nrm = float(ref64[n].norm())
+        err, err32 = float((got - ref64[n]).norm()) / nrm, float((ref32[n] - ref64[n]).norm()) / nrm
+        # torch's CPU kernels accumulate in double, so a float32 oracle that is off by more than ~1e-6 marks an ill-conditioned
+        # gradient; the bar scales with that measured amplification
+        if err > 1e-4 * max(1.0, err32 / 1e-6):
+            bad.append((n, err, err32))
     assert not bad, bad
 
 
