@@ -1,17 +1,21 @@
-"""Differentiable building blocks on the HIP kernels -- the first slice of the training step.
+"""Differentiable building blocks on the HIP kernels -- the operations of the training step.
 
 The reference trains ``DiffusionModel.forward`` (v-objective MSE, main/module_diffusion.py:73-82) in fp32
 (exp/train_diffusion_gh.yaml:87).  The inference engine behind ``UNetV0.forward`` keeps no autograd graph; this module
-provides, as ``torch.autograd.Function``s whose forward AND backward run in the HIP library (``sf_op_conv1d_cl`` /
-``sf_op_conv1d_bwd_cl``), the two operations that carry ~90 % of the U-Net's parameters and FLOPs:
+provides ``torch.autograd.Function``s whose forward AND backward run in the HIP library:
 
 * ``gn_silu_conv1d(x, weight, bias, gamma, beta, groups, eps)``  --  ``Conv1d(SiLU(GroupNorm(x)))`` with stride 1 and
-  "same" padding, the ResnetItem convolution (a-unet ResnetBlock);
-* ``conv1d(x, weight, bias)``  --  plain stride-1 "same" Conv1d, e.g. the 1x1 InjectChannels convolution over ``cat[x, ctx]``.
+  "same" padding, the ResnetItem convolution (a-unet ResnetBlock)
+  (``sf_op_conv1d_cl`` / ``sf_op_conv1d_bwd_cl``);
+* ``conv1d(x, weight, bias)``  --  plain stride-1 "same" Conv1d: the 1x1 InjectChannels convolution over ``cat[x, ctx]``, the
+  attention projections, and (after a reshape / gather) the patchify, strided and up-sampling convolutions;
+* ``ln_modulate(x, scale_shift, eps)``  --  LayerNorm over the channels fused with the a-unet Modulation, also the affine
+  pre-norm of the attention blocks (``sf_op_ln_modulate`` / ``sf_op_ln_modulate_bwd``);
+* ``attention(q, kv, heads)``  --  multi-head softmax attention, head dim 64 (``sf_op_attention`` / ``sf_op_attention_bwd``).
 
-Tensors are ``(B, C, L)`` fp32 CUDA tensors exactly as the reference's modules see them; the channels-last transposes around
-the kernels are plumbing.  Everything else of a full training step (LayerNorm-modulate, attention, the modulation Linears,
-the patchify / up convolutions) is not implemented yet: ``VDiffusion.forward`` still returns a loss without a graph.
+fp32 CUDA tensors; the convolutions take ``(B, C, L)`` as the reference's modules see them or, with ``channels_last=True``,
+the kernels' own ``(B, L, C)`` rows.  ``syncfusion_amd/training.py`` composes the U-Net and the onset encoder from these.
+No atomics anywhere: a second backward gives the same bits.
 """
 from __future__ import annotations
 

@@ -105,7 +105,7 @@ int sf_op_ln_modulate_bwd(const float *x, const float *scale_shift, const float 
                           int64_t ws_bytes, void *stream) {
   SF_API_BEGIN
   if (!x || !dy || !dx || !ws) fail(SF_ERR_INVALID, "null argument");
-  if (C > 1024) fail(SF_ERR_UNSUPPORTED, "C must be <= 1024");
+  if (C < 4 || C > 1024 || (C & (C - 1))) fail(SF_ERR_UNSUPPORTED, "C must be a power of two in [4, 1024] (got %d)", C);
   const int64_t need = (int64_t)B * ln_mod_bwd_chunks(L) * 2 * C * (int64_t)sizeof(float);
   if (ws_bytes < need) fail(SF_ERR_WORKSPACE, "workspace too small: need %lld bytes", (long long)need);
   SF_HIP(launch_ln_modulate_bwd(x, scale_shift, dy, eps, B, L, C, dx, static_cast<float *>(ws), dss, static_cast<hipStream_t>(stream)));

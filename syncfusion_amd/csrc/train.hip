@@ -247,82 +247,96 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_kernel(const float *__restric
 // ---------------------------------------------------------------------------------------------------------------------------
 // LayerNorm-modulate backward:  y = xhat (1 + s_b) + t_b,  xhat = LayerNorm_C(x; eps, no affine)
 //   dx = rstd (g - mean_c(g) - xhat mean_c(g xhat)),  g = dy (1 + s_b);   ds_b[c] = sum_l dy xhat,  dt_b[c] = sum_l dy
-// One workgroup per (clip, chunk of rows); a wave owns a row at a time, a lane the channels lane, lane + 64, ... (C <= 1024).
-// The per-clip sums are accumulated per lane over the wave's rows, reduced over the four waves through LDS and written per chunk;
-// slices_reduce_kernel adds the chunks (fixed order).
+// One workgroup per (clip, chunk of rows).  The per-clip sums are accumulated per lane over its rows, reduced over the row groups
+// through LDS and written per chunk; chunks_reduce_kernel adds the chunks (fixed order).
 // ---------------------------------------------------------------------------------------------------------------------------
-constexpr int kLnMaxPer = 16;   // channels per lane: C <= 1024
-__global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const float *__restrict__ x, const float *__restrict__ ss, int ss_ld, const float *__restrict__ dy,
-                                                         int L, int C, float eps, int rows_per_chunk, float *__restrict__ dx,
-                                                         float *__restrict__ dss_part /* [B][nchunk][2C] */) {
-  __shared__ float red[4][2 * 1024];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// C = 4 * TPR * PER (the powers of two from 4 to 1024 -- what the forward kernel accepts): TPR lanes share a row (16-byte accesses,
+// PER of them per lane), so a wave covers 64 / TPR rows at once and narrow levels keep every lane busy; the row sums are shuffles
+// inside the TPR-lane group.
+template <int TPR, int PER>
+__global__ __launch_bounds__(256) void ln_mod_bwd_vec_kernel(const float *__restrict__ x, const float *__restrict__ ss, int ss_ld,
+                                                             const float *__restrict__ dy, int L, float eps, int rows_per_chunk, float *__restrict__ dx,
+                                                             float *__restrict__ dss_part /* [B][nchunk][2C] */) {
+  constexpr int C = 4 * TPR * PER, NG = 256 / TPR;
+  __shared__ float red[2 * NG * C];
+  const int tid = threadIdx.x, sub = tid % TPR, grp = tid / TPR;
   const int b = blockIdx.x, chunk = blockIdx.y, nchunk = gridDim.y;
-  const int per = (C + 63) / 64;
-  float sc[kLnMaxPer], acs[kLnMaxPer], act[kLnMaxPer];
+  float sc[PER][4], acs[PER][4], act[PER][4];
 #pragma unroll
-  for (int k = 0; k < kLnMaxPer; ++k) {
-    const int c = lane + 64 * k;
-    sc[k] = (k < per && c < C) ? 1.0f + (ss ? ss[(size_t)b * ss_ld + c] : 0.f) : 0.f;
-    acs[k] = act[k] = 0.f;
-  }
+  for (int k = 0; k < PER; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      sc[k][j] = 1.0f + (ss ? ss[(size_t)b * ss_ld + 4 * (sub + TPR * k) + j] : 0.f);
+      acs[k][j] = act[k][j] = 0.f;
+    }
   const int l0 = chunk * rows_per_chunk, l1 = min(L, l0 + rows_per_chunk);
-  const float inv_c = 1.0f / (float)C;
-  for (int l = l0 + wave; l < l1; l += 4) {
+  constexpr float inv_c = 1.0f / (float)C;
+  auto group_sum = [](float v) {
+#pragma unroll
+    for (int o = TPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, TPR);
+    return v;
+  };
+  for (int l = l0 + grp; l < l1; l += NG) {
     const size_t row = ((size_t)b * L + l) * C;
-    float xv[kLnMaxPer], gv[kLnMaxPer];
+    f32x4 xv[PER], dv[PER];
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < kLnMaxPer; ++k) {
-      const int c = lane + 64 * k;
-      xv[k] = (k < per && c < C) ? x[row + c] : 0.f;
-      s += xv[k];
+    for (int k = 0; k < PER; ++k) {
+      xv[k] = *reinterpret_cast<const f32x4 *>(x + row + 4 * (sub + TPR * k));
+      dv[k] = *reinterpret_cast<const f32x4 *>(dy + row + 4 * (sub + TPR * k));
+      s += (xv[k][0] + xv[k][1]) + (xv[k][2] + xv[k][3]);
     }
-    const float mean = wave_sum_dpp(s) * inv_c;
+    const float mean = group_sum(s) * inv_c;
     float q = 0.f;
 #pragma unroll
-    for (int k = 0; k < kLnMaxPer; ++k) {
-      const int c = lane + 64 * k;
-      const float d = (k < per && c < C) ? xv[k] - mean : 0.f;
-      q = fmaf(d, d, q);
-    }
-    const float rstd = rsqrtf(wave_sum_dpp(q) * inv_c + eps);
+    for (int k = 0; k < PER; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        xv[k][j] -= mean;
+        q = fmaf(xv[k][j], xv[k][j], q);
+      }
+    const float rstd = rsqrtf(group_sum(q) * inv_c + eps);
     float g1 = 0.f, g2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < kLnMaxPer; ++k) {
-      const int c = lane + 64 * k;
-      const bool ok = k < per && c < C;
-      const float xh = ok ? (xv[k] - mean) * rstd : 0.f;
-      const float d = ok ? dy[row + c] : 0.f;
-      xv[k] = xh;
-      gv[k] = d * sc[k];
-      g1 += gv[k];
-      g2 = fmaf(gv[k], xh, g2);
-      acs[k] = fmaf(d, xh, acs[k]);
-      act[k] += d;
-    }
-    const float m1 = wave_sum_dpp(g1) * inv_c, m2 = wave_sum_dpp(g2) * inv_c;
+    for (int k = 0; k < PER; ++k)
 #pragma unroll
-    for (int k = 0; k < kLnMaxPer; ++k) {
-      const int c = lane + 64 * k;
-      if (k < per && c < C) dx[row + c] = rstd * (gv[k] - m1 - xv[k] * m2);
+      for (int j = 0; j < 4; ++j) {
+        const float xh = xv[k][j] * rstd, d = dv[k][j];
+        xv[k][j] = xh;
+        dv[k][j] = d * sc[k][j];
+        g1 += dv[k][j];
+        g2 = fmaf(dv[k][j], xh, g2);
+        acs[k][j] = fmaf(d, xh, acs[k][j]);
+        act[k][j] += d;
+      }
+    const float m1 = group_sum(g1) * inv_c, m2 = group_sum(g2) * inv_c;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = rstd * (dv[k][j] - m1 - xv[k][j] * m2);
+      *reinterpret_cast<f32x4 *>(dx + row + 4 * (sub + TPR * k)) = o;
     }
   }
 #pragma unroll
-  for (int k = 0; k < kLnMaxPer; ++k) {
-    const int c = lane + 64 * k;
-    if (k < per && c < C) {
-      red[wave][c] = acs[k];
-      red[wave][1024 + c] = act[k];
+  for (int k = 0; k < PER; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = 4 * (sub + TPR * k) + j;
+      red[grp * C + c] = acs[k][j];
+      red[(NG + grp) * C + c] = act[k][j];
     }
-  }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float *o = dss_part + ((size_t)b * nchunk + chunk) * 2 * C;
-    o[c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
-    o[C + c] = (red[0][1024 + c] + red[1][1024 + c]) + (red[2][1024 + c] + red[3][1024 + c]);
+  float *o = dss_part + ((size_t)b * nchunk + chunk) * 2 * C;
+  for (int c = tid; c < 2 * C; c += 256) {   // row groups in a fixed order
+    const float *rp = red + (c < C ? c : NG * C + (c - C));
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) t += rp[g * C];
+    o[c] = t;
   }
 }
+
 // out[b][j] = sum over chunks of part[b][chunk][j]
 __global__ void chunks_reduce_kernel(const float *__restrict__ part, int nchunk, int cols, float *__restrict__ out) {
   const int col = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
@@ -593,10 +607,22 @@ int ln_mod_bwd_chunks(int L) { return std::max(1, std::min(64, (L + 63) / 64)); 
 
 hipError_t launch_ln_modulate_bwd(const float *x, const float *ss, const float *dy, float eps, int B, int L, int C, float *dx, float *dss_part,
                                   float *dss, hipStream_t s) {
-  if (C < 1 || C > 64 * kLnMaxPer) return hipErrorInvalidValue;
   const int nchunk = ln_mod_bwd_chunks(L);
   const int rpc = (L + nchunk - 1) / nchunk;
-  hipLaunchKernelGGL(ln_mod_bwd_kernel, dim3(B, nchunk), dim3(256), 0, s, x, ss, 2 * C, dy, L, C, eps, rpc, dx, dss_part);
+#define SF_LNB(TPR, PER) hipLaunchKernelGGL((ln_mod_bwd_vec_kernel<TPR, PER>), dim3(B, nchunk), dim3(256), 0, s, x, ss, 2 * C, dy, L, eps, rpc, dx, dss_part)
+  switch (C) {
+    case 4: SF_LNB(1, 1); break;
+    case 8: SF_LNB(2, 1); break;
+    case 16: SF_LNB(4, 1); break;
+    case 32: SF_LNB(8, 1); break;
+    case 64: SF_LNB(16, 1); break;
+    case 128: SF_LNB(32, 1); break;
+    case 256: SF_LNB(64, 1); break;
+    case 512: SF_LNB(64, 2); break;
+    case 1024: SF_LNB(64, 4); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef SF_LNB
   if (dss) hipLaunchKernelGGL(chunks_reduce_kernel, dim3((2 * C + 63) / 64, B), dim3(64), 0, s, dss_part, nchunk, 2 * C, dss);
   return hipGetLastError();
 }

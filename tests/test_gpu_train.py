@@ -90,6 +90,8 @@ def test_resnet_item_and_inject_chain_against_oracle_autograd(cuda):
     (2, 704, 32, False),    # pre-norm LayerNorm (no modulation), half-empty wave
     (1, 1, 128, True),      # a single row
     (2, 5000, 128, True),   # more rows than one chunk pass
+    (2, 300, 8, True),      # depth 0: two lanes per row
+    (1, 130, 512, False),   # two 16-byte accesses per lane
 ])
 def test_ln_modulate_gradients(cuda, B, L, C, with_ss):
     from syncfusion_amd import autograd as sfa
