@@ -95,3 +95,68 @@ def test_bench_force_dist_runs_the_rccl_path_with_one_rank(cuda):
     assert line["n_gpus"] == 1 and line["config"]["gathered_clips"] == 8
     assert line["config"]["weights_broadcast_bytes"] > 4 * 214e6      # every fp32 master of the 215 M-parameter U-Net + Encoder1d
     assert line["value"] > 0 and line["extra"] is None
+
+
+def _train_batch(lo: int, hi: int):
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(B_TOTAL, 1, L0, generator=g)
+    y = (torch.rand(B_TOTAL, 1, L0, generator=g) < 0.03).float()
+    sig = torch.rand(B_TOTAL, generator=g)
+    eps = torch.randn(B_TOTAL, 1, L0, generator=g)
+    return tuple(t[lo:hi].cuda() for t in (x, y, sig, eps))
+
+
+def _loss_and_grads(model, lo: int, hi: int):
+    x, y, sig, eps = _train_batch(lo, hi)
+    z = model.clap_encode_audio(x)
+    _, info = model.onsets_encoder(y, with_info=True)
+    loss = model.model(x, channels=info["xs"][2:-1], embedding=z, sigmas=sig, noise=eps)
+    model.zero_grad(set_to_none=True)
+    loss.backward()
+    return loss.detach()
+
+
+def _train_worker(rank: int, world: int, port: int, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from syncfusion_amd.dist import broadcast_module, shard_range
+        from syncfusion_amd.training import allreduce_gradients
+
+        model = _build(seed_weights=200 + rank)
+        broadcast_module(model, src=0)
+        lo, hi = shard_range(B_TOTAL, rank, world)
+        _loss_and_grads(model, lo, hi)
+        calls = allreduce_gradients(model, bucket_bytes=1 << 20)
+        flat = torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.requires_grad and p.grad is not None]).cpu()
+        q.put((rank, calls, flat.numpy()))     # by value: the process exits right after
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.autograd
+@pytest.mark.timeout(600)
+def test_two_rank_data_parallel_gradients_equal_the_full_batch_gradient(cuda):
+    """main/module_diffusion.py:79-82 under DDP (exp/train_diffusion_gh.yaml:84-90): each rank runs `training_step`'s loss and
+    the HIP backward on its half of the batch, the bucketed all-reduce averages .grad; both ranks must end with the gradient
+    of the full-batch loss computed in one process."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, 29659, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=500) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, calls0, g0), (_, calls1, g1) = res
+    g0, g1 = torch.from_numpy(g0), torch.from_numpy(g1)
+    assert calls0 == calls1 >= 2 and torch.equal(g0, g1)
+    model = _build(seed_weights=200)
+    _loss_and_grads(model, 0, B_TOTAL)
+    want = torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.requires_grad and p.grad is not None]).cpu()
+    assert g0.shape == want.shape
+    err = float((g0 - want).norm() / want.norm())
+    assert err < 1e-5, err
