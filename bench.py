@@ -33,6 +33,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import subprocess
 import sys
@@ -260,12 +261,45 @@ def extra_workloads(model, device, args, noise, channels, emb) -> dict:
                              "100-step diffusion (scale 2.0) -> cut/crop, fp16", clips_per_s=round(B / dt, 2), seconds_per_batch=round(dt, 3),
                     denoise_steps_per_s=round(steps / dt, 2), dtype="fp16")
 
+    def train_leg():
+        # the reference's training configuration (exp/train_diffusion_gh.yaml:8,38,87): fp32, batch 4 per device, clips of 2^18
+        # samples; Model.training_step -> loss.backward() (HIP forward + backward kernels) -> AdamW over U-Net + onset encoder
+        B, L, iters = 4, 262144, 3
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(B, 1, L, generator=g).to(device)
+        y = (torch.rand(B, 1, L, generator=g) < 0.0005).float().to(device)
+        saved = {k: v.detach().clone() for k, v in model.state_dict().items() if not k.startswith("clap.")}   # the step moves the weights
+        opt = model.configure_optimizers()
+        losses = []
+        try:
+            with torch.enable_grad():
+                for it in range(iters + 1):
+                    if it == 1:
+                        torch.cuda.synchronize(device)
+                        t0 = time.perf_counter()
+                    loss = model.training_step((x, y, x, None, None), it)
+                    opt.zero_grad(set_to_none=True)
+                    loss.backward()
+                    opt.step()
+                    losses.append(round(float(loss.detach()), 5))
+                torch.cuda.synchronize(device)
+                dt = (time.perf_counter() - t0) / iters
+        finally:
+            del opt
+            model.zero_grad(set_to_none=True)
+            model.load_state_dict(saved, strict=False)
+            torch.cuda.empty_cache()
+        assert all(math.isfinite(v) for v in losses) and losses[-1] < losses[0], losses
+        return dict(workload="training step (exp/train_diffusion_gh.yaml): fp32, batch 4 x 2**18 samples, v-objective loss -> backward -> AdamW",
+                    ms_per_step=round(1e3 * dt, 2), clips_per_s=round(B / dt, 2), dtype="fp32", timed_steps=iters, losses=losses)
+
     if args.dtype != "fp32":
         leg("fp32_config1", fp32_leg)
     leg("config2_b32_cfg", config2_leg)
     leg("reference_eval_shape", reference_leg)
     leg("onset_net_n32", onset_leg)
     leg("e2e_config4_fp16", e2e_leg)
+    leg("train_step_fp32", train_leg)      # last: it updates (and then restores) the weights
     return out
 
 
