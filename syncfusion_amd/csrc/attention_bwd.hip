@@ -1,5 +1,6 @@
-// Multi-head softmax attention backward (head dim 64, fp32 as the reference trains: exp/train_diffusion_gh.yaml:87) on the fp32
-// matrix cores (v_mfma_f32_32x32x2_f32), two kernels, no atomics -> gradients are reproducible bit for bit.
+// Multi-head softmax attention in fp32 (head dim 64) on the fp32 matrix cores (v_mfma_f32_32x32x2_f32): the forward of the fp32
+// parity engine / training forward and the backward (the reference trains in fp32: exp/train_diffusion_gh.yaml:87), two backward
+// kernels, no atomics -> gradients are reproducible bit for bit.
 //
 //   S = q k^T / 8,  P = softmax_j(S),  O = P v            (forward, attention.hip)
 //   dP = dO v^T,  D_i = sum_j P_ij dP_ij = dO_i . O_i,  dS = P (dP - D) / 8
@@ -43,11 +44,11 @@ __device__ __forceinline__ void tile_fetch(TileRegs &t, const float *__restrict_
   }
 }
 
-__device__ __forceinline__ void tile_store(float *lds, const TileRegs &t, int tid) {
+__device__ __forceinline__ void tile_store(float *lds, const TileRegs &t, int tid, int pitch = PITCH) {
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     const int idx = tid + 256 * e, r = idx >> 4, c4 = idx & 15;
-    float *p = lds + r * PITCH + 4 * c4;
+    float *p = lds + r * pitch + 4 * c4;
     *reinterpret_cast<f32x2 *>(p) = f32x2{t.v[e][0], t.v[e][1]};
     *reinterpret_cast<f32x2 *>(p + 2) = f32x2{t.v[e][2], t.v[e][3]};
   }
@@ -61,6 +62,84 @@ __device__ __forceinline__ f32x16 zero16() {
 }
 
 __device__ __forceinline__ int acc_row(int r, int hf) { return 8 * (r >> 2) + 4 * hf + (r & 3); }
+
+// Forward, same machinery (the fp32 parity engine and the training forward): S^T = K q^T puts a query in every lane, so the online
+// softmax state (running max, running sum) is per lane and the output is accumulated TRANSPOSED, O^T = V^T P^T (A = V tile read
+// column-wise from LDS, B = the probabilities in the registers): rescaling by exp(m_old - m_new) is a per-lane scalar.  The two
+// half-waves of a query hold different keys; they agree on the tile maximum with one shuffle per tile.  64 MFMAs per 32 x 32 tile.
+constexpr int VPITCH = 72;   // V tile rows are read 4 apart by the two half-waves: 4 * 72 = 32 (mod 64) banks apart
+__global__ __launch_bounds__(256) void attn_fwd_f32_mfma_kernel(const float *__restrict__ q, int ldq, const float *__restrict__ kv, int ldkv, int L, int H,
+                                                                float scale_log2e, float *__restrict__ out, int ldo) {
+  __shared__ __attribute__((aligned(16))) float Ks[TILE * PITCH];
+  __shared__ __attribute__((aligned(16))) float Vs[TILE * VPITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, hf = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const size_t rb = (size_t)b * L;
+  const int qi = blockIdx.x * 128 + wave * 32 + li;
+  const bool qv = qi < L;
+  float qreg[32];
+  {
+    const size_t off = (rb + (qv ? qi : 0)) * ldq + h * HD + hf;
+#pragma unroll
+    for (int t = 0; t < 32; ++t) qreg[t] = qv ? q[off + 2 * t] * scale_log2e : 0.f;   // scores in log2 units: exp2f below
+  }
+  const int nkt = (L + TILE - 1) / TILE;
+  float m = -INFINITY, lsum = 0.f;
+  f32x16 o0 = zero16(), o1 = zero16();
+  TileRegs pk, pv;
+  tile_fetch(pk, kv, rb, 0, L, ldkv, h * HD, tid);
+  tile_fetch(pv, kv, rb, 0, L, ldkv, (H + h) * HD, tid);
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();
+    tile_store(Ks, pk, tid);
+    tile_store(Vs, pv, tid, VPITCH);
+    __syncthreads();
+    if (kt + 1 < nkt) {
+      tile_fetch(pk, kv, rb, (kt + 1) * TILE, L, ldkv, h * HD, tid);
+      tile_fetch(pv, kv, rb, (kt + 1) * TILE, L, ldkv, (H + h) * HD, tid);
+    }
+    f32x16 s = zero16();
+#pragma unroll
+    for (int t = 0; t < 32; ++t) s = mfma32x2(Ks[li * PITCH + 2 * t + hf], qreg[t], s);
+    float tm = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s[r] = (kt * TILE + acc_row(r, hf) < L) ? s[r] : -INFINITY;
+      tm = fmaxf(tm, s[r]);
+    }
+    tm = fmaxf(tm, __shfl_xor(tm, 32));          // key kt * 32 is valid, so the combined maximum is finite
+    const float mn = fmaxf(m, tm), alpha = exp2f(m - mn);
+    float add = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s[r] = exp2f(s[r] - mn);
+      add += s[r];
+    }
+    lsum = lsum * alpha + add;
+    m = mn;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      o0[r] *= alpha;
+      o1[r] *= alpha;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float *vrow = Vs + acc_row(r, hf) * VPITCH + li;
+      o0 = mfma32x2(vrow[0], s[r], o0);
+      o1 = mfma32x2(vrow[32], s[r], o1);
+    }
+  }
+  lsum += __shfl_xor(lsum, 32);
+  if (qv) {
+    const float inv = 1.0f / lsum;
+    float *op = out + (rb + qi) * ldo + h * HD + 4 * hf;   // O^T: registers 4 g .. 4 g + 3 = head dims 8 g + 4 hf .. + 3 of this lane's query
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      *reinterpret_cast<f32x4 *>(op + 8 * g) = f32x4{o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv};
+      *reinterpret_cast<f32x4 *>(op + 32 + 8 * g) = f32x4{o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv};
+    }
+  }
+}
 
 __global__ __launch_bounds__(256) void attn_bwd_q_mfma_kernel(const float *__restrict__ q, const float *__restrict__ kv, const float *__restrict__ o,
                                                               const float *__restrict__ dout, int L, int H, float scale, float *__restrict__ dq,
@@ -258,6 +337,15 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_mfma_kernel(const float *__re
 }
 
 }  // namespace
+
+bool attention_f32_mfma_ok(int ldq, int ldkv, int ldo, int B, int H) { return (ldkv % 4) == 0 && (ldo % 4) == 0 && ldq > 0 && B <= 65535 && H <= 65535; }
+
+hipError_t launch_attention_f32_mfma(const float *q, int ldq, const float *kv, int ldkv, int B, int L, int H, float *out, int ldo, hipStream_t s) {
+  if (L < 1 || B < 1 || H < 1) return hipErrorInvalidValue;
+  const float scale_log2e = 1.4426950408889634f / sqrtf((float)HD);
+  hipLaunchKernelGGL(attn_fwd_f32_mfma_kernel, dim3((L + 127) / 128, H, B), dim3(256), 0, s, q, ldq, kv, ldkv, L, H, scale_log2e, out, ldo);
+  return hipGetLastError();
+}
 
 // q, o, dout, dq: (B, L, H*64);  kv, dkv: (B, L, 2*H*64);  lse, dsum: (B, H, L) scratch
 hipError_t launch_attention_bwd(const float *q, const float *kv, const float *o, const float *dout, int B, int L, int H, int D, float *dq, float *dkv,
