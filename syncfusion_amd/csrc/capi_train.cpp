@@ -66,7 +66,7 @@ int sf_op_conv1d_bwd_cl(const float *x, const float *w, const float *gamma, cons
   BwdPlan p = plan(wk, B, L, C, N, taps, groups);
   const float *act = x;
   if (groups > 0) {   // recompute a = SiLU(GroupNorm(x)) (cheaper than keeping it from the forward pass)
-    SF_HIP(launch_gn_silu(F32, x, C, B, L, C, groups, gamma, beta, eps, p.act, C, s));
+    SF_HIP(launch_gn_silu_recompute(x, gamma, beta, B, L, C, groups, eps, p.act, p.gpart, s));
     act = p.act;
   }
   // ---- dgrad: da = conv(dy; W flipped and transposed), same padding -------------------------------------------

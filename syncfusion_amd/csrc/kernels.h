@@ -253,6 +253,8 @@ hipError_t launch_col_sums(const float *x, int64_t rows, int cols, float *part, 
 hipError_t launch_gn_silu_bwd(const float *x, const float *da, const float *gamma, const float *beta, int B, int L, int C, int G, float eps,
                               float *dx, float *dgb_part, float *dgb, hipStream_t s);
 int64_t gn_silu_bwd_ws_floats(int B, int L, int C, int G);
+hipError_t launch_gn_silu_recompute(const float *x, const float *gamma, const float *beta, int B, int L, int C, int G, float eps, float *act,
+                                    float *ws, hipStream_t s);
 
 // backward of y = LayerNorm_C(x; eps) * (1 + ss[b][c]) + ss[b][C + c] (ss == nullptr: plain normalisation): dx and, when dss != nullptr,
 // dss (B, 2C) = [dscale | dshift];  dss_part: [B][ln_mod_bwd_chunks(L)][2C] scratch

@@ -34,7 +34,8 @@ __global__ void pack_dgrad_kernel(const float *__restrict__ w, int N, int C, int
 // TN * TQ MFMAs, which halves the L2 traffic per flop); the 4 waves take interleaved row pairs and are summed through LDS.
 template <int TN, int TQ>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict__ dy, const float *__restrict__ act, int rows, int L, int C, int N,
-                                                         int taps, int pad, int rows_per_split, float *__restrict__ partial) {
+                                                         int taps, int pad, int rows_per_split, float *__restrict__ partial,
+                                                         float *__restrict__ dw_direct /* with ONE split: PyTorch layout, no reduce pass */) {
   __shared__ float red[4][32][33];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 31, fh = lane >> 5;
@@ -59,12 +60,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
     for (int j = 0; j < TQ; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  // wave w takes the row pairs w, w + 4, ...; inside a pair the half-wave picks the row (k index of the 32x32x2 MFMA)
-  for (int r0 = r_begin + 2 * wave; r0 < r_end; r0 += 8) {
+  // wave w takes the row pairs w, w + 4, ...; inside a pair the half-wave picks the row (k index of the 32x32x2 MFMA).  The
+  // operands of UNR row pairs are fetched before the first MFMA of the group, so UNR * (TN + TQ) loads are in flight per wave.
+  constexpr int UNR = 4;
+  auto fetch = [&](int r0, float (&av)[TN], float (&bv)[TQ]) {
     const int r = r0 + fh;
     const bool rv = r < r_end;
     const int l = r % L;
-    float av[TN], bv[TQ];
 #pragma unroll
     for (int i = 0; i < TN; ++i) av[i] = (rv && n[i] < N) ? dy[(size_t)r * N + n[i]] : 0.f;
 #pragma unroll
@@ -72,10 +74,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
       const int ls = l + shift[j];
       bv[j] = (rv && qok[j] && ls >= 0 && ls < L) ? act[(size_t)(r + shift[j]) * C + c[j]] : 0.f;
     }
+  };
+  for (int r0 = r_begin + 2 * wave; r0 < r_end; r0 += 8 * UNR) {
+    float av[UNR][TN], bv[UNR][TQ];
 #pragma unroll
-    for (int i = 0; i < TN; ++i)
+    for (int u = 0; u < UNR; ++u) fetch(r0 + 8 * u, av[u], bv[u]);   // rows past r_end load zeros
 #pragma unroll
-      for (int j = 0; j < TQ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    for (int u = 0; u < UNR; ++u)
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][i], bv[u][j], acc[i][j], 0, 0, 0);
   }
 #pragma unroll
   for (int i = 0; i < TN; ++i)
@@ -89,7 +98,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
         const int a = idx >> 5, b = idx & 31;
         const float v = (red[0][a][b] + red[1][a][b]) + (red[2][a][b] + red[3][a][b]);
         const int nn = (blockIdx.x * TN + i) * 32 + a, qq = (blockIdx.y * TQ + j) * 32 + b;
-        if (nn < N && qq < Q) partial[((size_t)blockIdx.z * N + nn) * Q + qq] = v;
+        if (nn < N && qq < Q) {
+          if (dw_direct) {
+            const int t = qq / C, cc = qq - t * C;
+            dw_direct[((size_t)nn * C + cc) * taps + t] = v;
+          } else {
+            partial[((size_t)blockIdx.z * N + nn) * Q + qq] = v;
+          }
+        }
       }
     }
 }
@@ -512,6 +528,43 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const float *__restrict_
   }
 }
 
+// a = SiLU(GroupNorm(x)) from the chunk statistics (the activation the weight gradient multiplies), same mapping as above
+template <int V>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                       const float *__restrict__ slab, int L, int C, int G, int nch, int chunk_rows, float eps,
+                                                       float *__restrict__ out) {
+  __shared__ float mean_s[256], rstd_s[256];
+  const int ch = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int cpg = C / G, vpr = C / V, cv = tid % vpr, rstep = 256 / vpr;
+  gn_group_stats(slab + (size_t)b * nch * G * 2, nch, G, chunk_rows, L, cpg, eps, mean_s, rstd_s);
+  __syncthreads();
+  const int c0 = cv * V;
+  float sc[V], sh[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    const int g = (c0 + j) / cpg;
+    sc[j] = rstd_s[g] * gamma[c0 + j];
+    sh[j] = fmaf(-mean_s[g], sc[j], beta[c0 + j]);
+  }
+  const int r0 = ch * chunk_rows, rows = min(chunk_rows, L - r0);
+  const size_t base = ((size_t)b * L + r0) * C + c0;
+  for (int r = tid / vpr; r < rows; r += rstep) {
+    if constexpr (V == 4) {
+      const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + base + (size_t)r * C);
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float u = fmaf(xv[j], sc[j], sh[j]);
+        o[j] = u / (1.0f + expf(-u));
+      }
+      *reinterpret_cast<f32x4 *>(out + base + (size_t)r * C) = o;
+    } else {
+      const float u = fmaf(x[base + (size_t)r * C], sc[0], sh[0]);
+      out[base + (size_t)r * C] = u / (1.0f + expf(-u));
+    }
+  }
+}
+
 }  // namespace
 
 hipError_t launch_pack_dgrad(const float *w, int N, int C, int taps, int ldn, float *out, hipStream_t s) {
@@ -536,12 +589,15 @@ hipError_t launch_conv_wgrad(const float *dy, const float *act, int B, int L, in
   const int rows = B * L, Q = taps * C;
   int rps = (rows + S - 1) / S;
   rps = (rps + 7) / 8 * 8;
+  float *direct = S == 1 ? dw : nullptr;
   if (wgrad_tile(N, Q) == 2)
-    hipLaunchKernelGGL((conv_wgrad_kernel<2, 2>), dim3((N + 63) / 64, (Q + 63) / 64, S), dim3(256), 0, s, dy, act, rows, L, C, N, taps, pad, rps, partial);
+    hipLaunchKernelGGL((conv_wgrad_kernel<2, 2>), dim3((N + 63) / 64, (Q + 63) / 64, S), dim3(256), 0, s, dy, act, rows, L, C, N, taps, pad, rps, partial, direct);
   else
-    hipLaunchKernelGGL((conv_wgrad_kernel<1, 1>), dim3((N + 31) / 32, (Q + 31) / 32, S), dim3(256), 0, s, dy, act, rows, L, C, N, taps, pad, rps, partial);
-  const int64_t total = (int64_t)N * Q;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, s, partial, S, N, C, taps, dw);
+    hipLaunchKernelGGL((conv_wgrad_kernel<1, 1>), dim3((N + 31) / 32, (Q + 31) / 32, S), dim3(256), 0, s, dy, act, rows, L, C, N, taps, pad, rps, partial, direct);
+  if (!direct) {
+    const int64_t total = (int64_t)N * Q;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, s, partial, S, N, C, taps, dw);
+  }
   return hipGetLastError();
 }
 
@@ -576,15 +632,29 @@ int64_t gn_silu_bwd_ws_floats(int B, int L, int C, int G) {
   return (int64_t)B * nch * (2 * C + 4 * G);
 }
 
+// Backward of a = SiLU(GroupNorm(x)) in three steps that share the chunk statistics (ws = gn_silu_bwd_ws_floats() floats):
+//   launch_gn_silu_recompute: statistics + the activation a (for the weight gradient);  launch_gn_silu_bwd: dx, dgamma, dbeta from da.
+hipError_t launch_gn_silu_recompute(const float *x, const float *gamma, const float *beta, int B, int L, int C, int G, float eps, float *act,
+                                    float *ws, hipStream_t s) {
+  if (G < 1 || C % G) return hipErrorInvalidValue;
+  if (!gn_bwd_chunked_ok(C, G)) return launch_gn_silu(F32, x, C, B, L, C, G, gamma, beta, eps, act, C, s);
+  int nch, chunk_rows;
+  gn_bwd_plan(L, C, nch, chunk_rows);
+  hipError_t e = launch_gn_stats(F32, x, C, B, L, C, G, nch, chunk_rows, ws, s);
+  if (e != hipSuccess) return e;
+  if (gn_bwd_vec(C, G) == 4) hipLaunchKernelGGL(gn_apply_kernel<4>, dim3(nch, B), dim3(256), 0, s, x, gamma, beta, ws, L, C, G, nch, chunk_rows, eps, act);
+  else hipLaunchKernelGGL(gn_apply_kernel<1>, dim3(nch, B), dim3(256), 0, s, x, gamma, beta, ws, L, C, G, nch, chunk_rows, eps, act);
+  return hipGetLastError();
+}
+
 hipError_t launch_gn_silu_bwd(const float *x, const float *da, const float *gamma, const float *beta, int B, int L, int C, int G, float eps,
-                              float *dx, float *ws /* gn_silu_bwd_ws_floats() */, float *dgb /* [2C] = dgamma | dbeta */, hipStream_t s) {
+                              float *dx, float *ws /* statistics already there (launch_gn_silu_recompute) */, float *dgb /* [2C] = dgamma | dbeta */,
+                              hipStream_t s) {
   if (G < 1 || C % G) return hipErrorInvalidValue;
   if (gn_bwd_chunked_ok(C, G)) {
     int nch, chunk_rows;
     gn_bwd_plan(L, C, nch, chunk_rows);
     float *slab = ws, *dgb_part = slab + (size_t)B * nch * G * 2, *s12 = dgb_part + (size_t)B * nch * 2 * C;
-    hipError_t e = launch_gn_stats(F32, x, C, B, L, C, G, nch, chunk_rows, slab, s);
-    if (e != hipSuccess) return e;
     if (gn_bwd_vec(C, G) == 4) {
       hipLaunchKernelGGL(gn_bwd_part_kernel<4>, dim3(nch, B), dim3(256), 0, s, x, da, gamma, beta, slab, L, C, G, nch, chunk_rows, eps, dgb_part, s12);
       hipLaunchKernelGGL(gn_bwd_dx_kernel<4>, dim3(nch, B), dim3(256), 0, s, x, da, gamma, beta, slab, s12, L, C, G, nch, chunk_rows, eps, dx);
