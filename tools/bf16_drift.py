@@ -4,6 +4,7 @@ import contextlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
+torch.set_grad_enabled(False)   # inference tools: with autograd recording the modules switch to the training composition
 import bench
 
 dev = torch.device("cuda", 0)

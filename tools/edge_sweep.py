@@ -4,6 +4,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
+torch.set_grad_enabled(False)   # inference tools: with autograd recording the modules switch to the training composition
 from helpers import SMALL_UNET, oracle_params, rel_l2, small_unet_module, synth_inputs
 from oracle import unet_ref
 

@@ -2,6 +2,7 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+torch.set_grad_enabled(False)   # inference tools: with autograd recording the modules switch to the training composition
 import bench
 
 dev = torch.device("cuda", 0)

@@ -3,6 +3,7 @@ configuration must reproduce its first result bit for bit.  python tools/stabili
 import contextlib, os, sys, time
 sys.path.insert(0, os.getcwd())
 import torch, bench
+torch.set_grad_enabled(False)   # inference tools: with autograd recording the modules switch to the training composition
 dev = torch.device("cuda", 0)
 with contextlib.redirect_stdout(sys.stderr):
     model = bench.build_model("bf16", dev)
