@@ -32,7 +32,7 @@ BwdPlan plan(Workspace &ws, int B, int L, int C, int N, int taps, int groups) {
   if (groups > 0) p.act = ws.alloc_n<float>(rows * C);
   p.da = ws.alloc_n<float>(rows * C);
   p.wd = ws.alloc_n<float>((int64_t)C * taps * p.ldn);
-  p.S = conv_wgrad_splits(rows, N, taps * C);
+  p.S = conv_wgrad_splits(rows, C, N, taps);
   p.wpart = ws.alloc_n<float>((int64_t)p.S * N * taps * C);
   p.Sb = (int)std::min<int64_t>(256, std::max<int64_t>(1, rows * N / 16384));   // >= 16 K elements per slice
   p.bpart = ws.alloc_n<float>((int64_t)p.Sb * N);

@@ -244,7 +244,7 @@ hipError_t launch_times_to_track(const double *times, const int *clip_of, int n_
 // Conv1d weight (N, C, taps) -> dgrad matrix [c][t' * ldn + n] = W[n][c][taps-1-t'] (the forward kernels then compute da from dy)
 hipError_t launch_pack_dgrad(const float *w, int N, int C, int taps, int ldn, float *out, hipStream_t s);
 // dw (N, C, taps) = sum_rows dy[row][n] * act[row + t - pad][c];  partial: [S][N][taps*C] scratch, S = conv_wgrad_splits(...)
-int conv_wgrad_splits(int64_t rows, int N, int Q);
+int conv_wgrad_splits(int64_t rows, int C, int N, int taps);
 hipError_t launch_conv_wgrad(const float *dy, const float *act, int B, int L, int C, int N, int taps, int pad, float *partial, int S, float *dw,
                              hipStream_t s);
 // out[col] = sum_rows x[row][col]   (part: [S][cols] scratch)

@@ -110,6 +110,125 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
     }
 }
 
+// The same product for the wide layers (N >= 64, Q >= 64, C % 32 == 0) with the operands staged in LDS: a workgroup owns a
+// (64 TW) x (64 TW) tile of dw (4 waves as 2 x 2, TW x TW accumulator tiles each) and walks its row range in chunks of 32 rows;
+// dy rows and the activation rows the chunk's taps touch are fetched once per workgroup with 16-byte loads (the next chunk's
+// loads are in flight while this one is multiplied) -- 32 (TW = 2) flops per byte of L2 traffic instead of 16, and no LDS
+// reduction at the end (every wave owns its outputs).  Two staging modes:
+//   single tap (taps == 1, or C a multiple of the tile width): the tile's columns are one tap's channels [cw0, cw0 + 64 TW);
+//   whole rows (C <= 64 TW): all C channels of the chunk's rows plus the halo rows of the other taps.
+// Rows whose shifted position leaves the clip are masked when the B operand is read (lrow[] = position inside the clip).
+template <int TW>
+__global__ __launch_bounds__(256) void conv_wgrad_lds_kernel(const float *__restrict__ dy, const float *__restrict__ act, int rows, int L, int C, int N,
+                                                             int taps, int pad, int rows_per_split, float *__restrict__ partial,
+                                                             float *__restrict__ dw_direct) {
+  constexpr int KR = 32, TILE = 64 * TW, PITCH = TILE + 32, NRMAX = KR + 8;
+  __shared__ __attribute__((aligned(16))) float dyS[KR * PITCH];
+  __shared__ __attribute__((aligned(16))) float actS[NRMAX * PITCH];
+  __shared__ int lrow[KR];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 31, fh = lane >> 5;
+  const int wn = wave >> 1, wq = wave & 1;
+  const int Q = taps * C;
+  const int n0 = blockIdx.x * TILE, q0 = blockIdx.y * TILE;
+  const bool single = taps == 1 || (C % TILE) == 0;
+  const int t0 = single ? q0 / C : 0;
+  const int cw0 = single ? q0 - t0 * C : 0;                 // first staged channel
+  const int cwid = single ? min(TILE, C - cw0) : C;          // staged channels per row
+  const int nr = single ? KR : KR + taps - 1;                // staged rows per chunk
+  const int rshift = single ? t0 - pad : -pad;               // staged row k' is global row r0 + k' + rshift
+  // this wave's column sub-tiles: tap (for the clip mask), row offset and channel offset inside the staged window
+  int tj[TW], koff[TW], coff[TW];
+  bool qok[TW];
+#pragma unroll
+  for (int j = 0; j < TW; ++j) {
+    const int qs = q0 + (wq * TW + j) * 32;
+    qok[j] = qs < Q;
+    const int t = qok[j] ? qs / C : 0;
+    tj[j] = t;
+    koff[j] = single ? 0 : t;
+    coff[j] = single ? (wq * TW + j) * 32 : (qok[j] ? qs - t * C : 0);
+  }
+  const int r_begin = blockIdx.z * rows_per_split, r_end = min(rows, r_begin + rows_per_split);
+  f32x16 acc[TW][TW];
+#pragma unroll
+  for (int i = 0; i < TW; ++i)
+#pragma unroll
+    for (int j = 0; j < TW; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  constexpr int DYV = KR * TILE / 4 / 256;                   // 16-byte loads of dy per thread and chunk
+  constexpr int ACV = (NRMAX * TILE / 4 + 255) / 256;        // upper bound for the activation window
+  f32x4 pdy[DYV], pac[ACV];
+  const int vpr = cwid / 4;                                  // 16-byte vectors per staged activation row (C % 32 == 0)
+  auto fetch = [&](int r0) {
+#pragma unroll
+    for (int u = 0; u < DYV; ++u) {
+      const int idx = tid + 256 * u, k = idx / (TILE / 4), c4 = idx - k * (TILE / 4);
+      const int r = r0 + k, n = n0 + 4 * c4;
+      pdy[u] = (r < r_end && n < N) ? *reinterpret_cast<const f32x4 *>(dy + (size_t)r * N + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < ACV; ++u) {
+      const int idx = tid + 256 * u, k = idx / vpr, c4 = idx - k * vpr;
+      const int g = r0 + k + rshift;
+      pac[u] = (k < nr && g >= 0 && g < rows) ? *reinterpret_cast<const f32x4 *>(act + (size_t)g * C + cw0 + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto stash = [&](int r0) {
+#pragma unroll
+    for (int u = 0; u < DYV; ++u) {
+      const int idx = tid + 256 * u, k = idx / (TILE / 4), c4 = idx - k * (TILE / 4);
+      *reinterpret_cast<f32x4 *>(dyS + k * PITCH + 4 * c4) = pdy[u];
+    }
+#pragma unroll
+    for (int u = 0; u < ACV; ++u) {
+      const int idx = tid + 256 * u, k = idx / vpr, c4 = idx - k * vpr;
+      if (k < nr) *reinterpret_cast<f32x4 *>(actS + k * PITCH + 4 * c4) = pac[u];
+    }
+    if (tid < KR) lrow[tid] = (r0 + tid) % L;
+  };
+  if (r_begin < r_end) fetch(r_begin);
+  for (int r0 = r_begin; r0 < r_end; r0 += KR) {
+    __syncthreads();
+    stash(r0);
+    __syncthreads();
+    if (r0 + KR < r_end) fetch(r0 + KR);
+#pragma unroll 4
+    for (int st = 0; st < KR / 2; ++st) {
+      const int k = 2 * st + fh;
+      const int l = lrow[k];
+      float av[TW], bv[TW];
+#pragma unroll
+      for (int i = 0; i < TW; ++i) av[i] = dyS[k * PITCH + (wn * TW + i) * 32 + fr];
+#pragma unroll
+      for (int j = 0; j < TW; ++j) {
+        const float v = actS[(k + koff[j]) * PITCH + coff[j] + fr];
+        bv[j] = (qok[j] && (unsigned)(l + tj[j] - pad) < (unsigned)L) ? v : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < TW; ++i)
+#pragma unroll
+        for (int j = 0; j < TW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TW; ++i)
+#pragma unroll
+    for (int j = 0; j < TW; ++j) {
+      const int qq = q0 + (wq * TW + j) * 32 + fr;
+      if (qq >= Q) continue;
+      const int t = qq / C, cc = qq - t * C;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int nn = n0 + (wn * TW + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        if (nn < N) {
+          if (dw_direct) dw_direct[((size_t)nn * C + cc) * taps + t] = acc[i][j][e];
+          else partial[((size_t)blockIdx.z * N + nn) * Q + qq] = acc[i][j][e];
+        }
+      }
+    }
+}
+
 // Sum over the leading (slice) dimension: 32 outputs per workgroup, 8 threads per output take the slices k = kq, kq + 8, ... and
 // are combined through LDS in a fixed order (deterministic; the loads of a 32-lane group are 128 contiguous bytes).
 __device__ __forceinline__ float slice_sum_8(const float *__restrict__ part, int S, size_t stride, size_t col, bool valid, float *sh /* [256] */) {
@@ -574,12 +693,21 @@ hipError_t launch_pack_dgrad(const float *w, int N, int C, int taps, int ldn, fl
   return hipGetLastError();
 }
 
-static int wgrad_tile(int N, int Q) { return (N >= 64 && Q >= 64) ? 2 : 1; }   // accumulator tiles per wave and dimension
+// kernel family: 0 = one 32 x 32 tile per workgroup (thin layers), 1 / 2 = LDS-staged 64 x 64 / 128 x 128 tiles
+static int wgrad_family(int C, int N, int taps) {
+  const int Q = taps * C;
+  if (N < 64 || Q < 64 || (C % 32) || (N % 4) || taps > 9) return 0;
+  const int TW = (N >= 128 && Q >= 128) ? 2 : 1;
+  const int T = 64 * TW;
+  if (!(taps == 1 || (C % T) == 0 || C <= T)) return TW == 2 && (C % 64 == 0 || C <= 64) ? 1 : 0;
+  return TW;
+}
 
-int conv_wgrad_splits(int64_t rows, int N, int Q) {
-  const int T = 32 * wgrad_tile(N, Q);
+int conv_wgrad_splits(int64_t rows, int C, int N, int taps) {
+  const int fam = wgrad_family(C, N, taps), Q = taps * C;
+  const int T = fam ? 64 * fam : 32;
   const int64_t tiles = (int64_t)((N + T - 1) / T) * ((Q + T - 1) / T);
-  int64_t S = std::max<int64_t>(1, 2048 / std::max<int64_t>(tiles, 1));
+  int64_t S = std::max<int64_t>(1, (fam ? 512 : 2048) / std::max<int64_t>(tiles, 1));
   S = std::min<int64_t>(S, std::max<int64_t>(1, rows / 256));
   return (int)std::min<int64_t>(S, 1024);
 }
@@ -588,10 +716,13 @@ hipError_t launch_conv_wgrad(const float *dy, const float *act, int B, int L, in
                              hipStream_t s) {
   const int rows = B * L, Q = taps * C;
   int rps = (rows + S - 1) / S;
-  rps = (rps + 7) / 8 * 8;
+  rps = (rps + 31) / 32 * 32;
   float *direct = S == 1 ? dw : nullptr;
-  if (wgrad_tile(N, Q) == 2)
-    hipLaunchKernelGGL((conv_wgrad_kernel<2, 2>), dim3((N + 63) / 64, (Q + 63) / 64, S), dim3(256), 0, s, dy, act, rows, L, C, N, taps, pad, rps, partial, direct);
+  const int fam = wgrad_family(C, N, taps);
+  if (fam == 2)
+    hipLaunchKernelGGL(conv_wgrad_lds_kernel<2>, dim3((N + 127) / 128, (Q + 127) / 128, S), dim3(256), 0, s, dy, act, rows, L, C, N, taps, pad, rps, partial, direct);
+  else if (fam == 1)
+    hipLaunchKernelGGL(conv_wgrad_lds_kernel<1>, dim3((N + 63) / 64, (Q + 63) / 64, S), dim3(256), 0, s, dy, act, rows, L, C, N, taps, pad, rps, partial, direct);
   else
     hipLaunchKernelGGL((conv_wgrad_kernel<1, 1>), dim3((N + 31) / 32, (Q + 31) / 32, S), dim3(256), 0, s, dy, act, rows, L, C, N, taps, pad, rps, partial, direct);
   if (!direct) {
