@@ -10,6 +10,8 @@
 //           fragment is read with the same permutation);
 //   O^T has the query on the lane too, so the online-softmax rescale is a per-lane scalar multiply.
 // K/V tiles are prefetched into registers while the previous tile is being multiplied (issue-early/write-late).
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -158,6 +160,160 @@ template <typename T> __global__ __launch_bounds__(128) void attention_mfma_kern
 #pragma unroll
     for (int r = 0; r < 16; ++r) os[fr * LDO + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh] = (T)(o[i][r] * inv);
   __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's LDS writes have landed before it reads them back
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int row = pass * 8 + (lane >> 3), c8 = lane & 7;
+    const int qq = q0 + row;
+    if (qq < L) st16<T>(out + (rowbase + qq) * ldo + h * D + c8 * 8, ld16<T>(os + row * LDO + c8 * 8));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Long sequences (the reference's 2^18-sample clips: L = 2048 / 1024 at depths 4 / 5): same products, but
+//   * 4 waves = 128 queries share every K / V tile (half the L2 -> LDS traffic per query of the 2-wave kernel);
+//   * V is staged ROW-major with 16-byte stores and its transposed fragments are gathered by the hardware
+//     (`ds_read_b64_tr_b16`, gfx950: a 16-lane group reads 4 keys x 16 head dims and every lane receives one head dim of the
+//     4 keys) -- the 2-wave kernel writes the transposed image with 32 two-byte stores per thread and tile.  The accumulator-
+//     as-operand k order (element j of half h = key 16 s + 8 (j >> 2) + 4 h + (j & 3)) is two blocks of 4 consecutive keys:
+//     exactly two transposed reads per fragment.  Row pitch 192 B: the 4 rows of a block fall in 4 disjoint 16-bank ranges;
+//   * scores are kept in log2 units (q pre-scaled by log2(e) / 8): the exponential is one v_exp_f32.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int W4 = 4;
+constexpr int LDV4 = 96;   // bf16 elements per row of the row-major V tile (192 B)
+typedef short v4i16 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4i16 lds_v4i16;
+
+template <typename T> __global__ __launch_bounds__(256) void attention_mfma4_kernel(const T *__restrict__ q, int ldq, const T *__restrict__ kv, int ldkv,
+                                                              int L, int H, T *__restrict__ out, int ldo, float scale_log2e) {
+  __shared__ __attribute__((aligned(16))) T Ks[TK * LDK];
+  __shared__ __attribute__((aligned(16))) T Vs[TK * LDV4];
+  __shared__ __attribute__((aligned(16))) T Os[W4 * QW * LDO];
+  using frag = typename Frag16<T>::type;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const size_t rowbase = (size_t)b * L;
+  const int q0 = blockIdx.x * (W4 * QW) + wave * QW;
+  const int qi = q0 + fr;
+  const bool qvalid = qi < L;
+
+  frag qf[4];
+  {
+    const T *qp = q + (rowbase + (qvalid ? qi : 0)) * ldq + h * D;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      Vec16<T> v = ld16<T>(qp + 16 * s + 8 * fh);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[s][j] = (T)((float)v.v[j] * scale_log2e);
+    }
+  }
+  f32x16 o[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  float mrun = -INFINITY, lrun = 0.f;
+
+  const int koff = h * D, voff = H * D + h * D;
+  const int srow = tid >> 3, svec = tid & 7;   // 256 threads x 16 B = 32 rows of 64 elements per pass
+  Vec16<T> rk[2], rv[2];
+  auto prefetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int kj = k0 + i * 32 + srow;
+      if (kj < L) {
+        const T *kp = kv + (rowbase + kj) * ldkv;
+        rk[i] = ld16<T>(kp + koff + svec * 8);
+        rv[i] = ld16<T>(kp + voff + svec * 8);
+      } else {
+        rk[i] = zero16<T>();
+        rv[i] = zero16<T>();
+      }
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int kr = i * 32 + srow;
+      st16<T>(Ks + kr * LDK + svec * 8, rk[i]);
+      st16<T>(Vs + kr * LDV4 + svec * 8, rv[i]);
+    }
+  };
+  // transposed-read lane geometry: group of 16 lanes -> (head-dim block 16 * ((lane >> 4) & 1), keys +4 for the upper half-wave);
+  // lane 4 q + p of the group addresses key row q, head dims 4 p .. 4 p + 3 of the block
+  const int tr_off = (4 * fh + ((lane & 15) >> 2)) * LDV4 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+
+  prefetch(0);
+  for (int k0 = 0; k0 < L; k0 += TK) {
+    __syncthreads();
+    stage();
+    __syncthreads();
+    if (k0 + TK < L) prefetch(k0 + TK);
+
+    f32x16 st[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const frag kf = *reinterpret_cast<const frag *>(Ks + (32 * t + fr) * LDK + 16 * s + 8 * fh);
+        st[t] = mfma32x16(kf, qf[s], st[t]);
+      }
+    }
+    float tmax = -INFINITY;
+    if (k0 + TK > L) {   // ragged last tile only
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (k0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * fh >= L) st[t][r] = -INFINITY;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, st[t][r]);
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float mnew = fmaxf(mrun, tmax);
+    const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+    float psum = 0.f;
+    frag pf[4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(st[t][r] - mnew);
+        psum += pv;
+        pf[2 * t + (r >> 3)][r & 7] = (T)pv;
+      }
+    lrun = lrun * alpha + psum;
+    mrun = mnew;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const T *vp = Vs + tr_off + (16 * ks) * LDV4 + 32 * i;
+        const v4i16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16 *)(vp));
+        const v4i16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16 *)(vp + 8 * LDV4));
+        typedef short v8i16 __attribute__((ext_vector_type(8)));
+        const v8i16 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        o[i] = mfma32x16(__builtin_bit_cast(frag, both), pf[ks], o[i]);
+      }
+  }
+  lrun += __shfl_xor(lrun, 32, 64);
+  const float inv = 1.0f / lrun;
+  T *os = Os + wave * QW * LDO;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) os[fr * LDO + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh] = (T)(o[i][r] * inv);
+  __builtin_amdgcn_s_waitcnt(0xC07F);
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int pass = 0; pass < 4; ++pass) {
@@ -350,10 +506,24 @@ template <typename T>
 static hipError_t attention_mfma_go(const void *q, int ldq, const void *kv, int ldkv, int B, int L, int H, void *out, int ldo, hipStream_t s) {
   // short sequences: the 2-wave kernel would launch fewer waves than the chip has SIMDs -> split the keys across waves
   const long waves_plain = (long)((L + WAVES * QW - 1) / (WAVES * QW)) * H * B * WAVES;
-  if (waves_plain < 2048 && L <= 4096) {
+  const long wgs4 = (long)((L + W4 * QW - 1) / (W4 * QW)) * H * B;   // workgroups of the 4-wave kernel
+  static const long wgs4_min = [] {   // tuning hook: from this many 4-wave workgroups on the long-sequence kernel runs instead of the key split
+    const char *e = getenv("SF_ATTN_WGS4_MIN");
+    const long v = e ? atol(e) : 0;
+    return v > 0 ? v : 128L;
+  }();
+  const bool long_kernel = L >= 256 && wgs4 >= wgs4_min;
+  if (!long_kernel && waves_plain < 2048 && L <= 4096) {
     dim3 g2((L + 31) / 32, H, B);
     hipLaunchKernelGGL((attention_ksplit_kernel<T>), g2, dim3(256), 0, s, static_cast<const T *>(q), ldq, static_cast<const T *>(kv), ldkv,
                        L, H, static_cast<T *>(out), ldo, 1.0f / sqrtf((float)D));
+    return hipGetLastError();
+  }
+  static const bool two_wave = getenv("SF_ATTN_2WAVE") != nullptr;   // tuning hook: the 2-wave kernel for every length
+  if (!two_wave && L >= 256) {
+    dim3 g4((L + W4 * QW - 1) / (W4 * QW), H, B);
+    hipLaunchKernelGGL((attention_mfma4_kernel<T>), g4, dim3(256), 0, s, static_cast<const T *>(q), ldq, static_cast<const T *>(kv), ldkv, L, H,
+                       static_cast<T *>(out), ldo, 1.4426950408889634f / sqrtf((float)D));
     return hipGetLastError();
   }
   dim3 grid((L + WAVES * QW - 1) / (WAVES * QW), H, B);

@@ -142,6 +142,31 @@ def test_attention(cuda, dtype, L):
     assert rel_l2(out.float().cpu(), ref) < (1e-5 if dtype == "fp32" else 8e-3)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16", "fp32"])
+@pytest.mark.parametrize("B,H,L", [(4, 8, 2048), (9, 8, 1100), (40, 8, 300)])
+def test_attention_long_sequences(cuda, dtype, B, H, L):
+    """Enough (clip, head, query-tile) work that the 16-bit types take the 4-wave kernel with hardware-transposed V reads
+    (the reference's 2^18-sample clips: L = 2048 at depth 4); ragged last tiles included."""
+    _l, lib = _lib()
+    D = 64
+    g = torch.Generator().manual_seed(L + B)
+    td = TD[dtype]
+    q = torch.randn(B, L, H * D, generator=g).to(td)
+    kv = torch.randn(B, L, 2 * H * D, generator=g).to(td)
+    qd, kvd = q.to(cuda), kv.to(cuda)
+    out = torch.empty_like(qd)
+    _l.check(lib.sf_op_attention(_l.DTYPES[dtype], qd.data_ptr(), kvd.data_ptr(), B, L, H, D, out.data_ptr(), _l.stream_ptr(cuda)),
+             "sf_op_attention")
+    torch.cuda.synchronize()
+    for b in (0, B - 1):      # two clips against an fp32 reference computed on the device
+        qf = qd[b].float().reshape(L, H, D).transpose(0, 1)
+        k, v = kvd[b].float().chunk(2, dim=-1)
+        kf, vf = k.reshape(L, H, D).transpose(0, 1), v.reshape(L, H, D).transpose(0, 1)
+        ref = ((qf @ kf.transpose(-1, -2)) * D ** -0.5).softmax(-1) @ vf
+        ref = ref.transpose(0, 1).reshape(L, H * D)
+        assert rel_l2(out[b].float().cpu(), ref.cpu()) < (1e-5 if dtype == "fp32" else 8e-3)
+
+
 def test_onsets_to_track_matches_reference_formatting(cuda):
     """sf_onsets_to_track vs the reference chain restated with real "%.4f" formatting
     (main/module_onset.py:160-183 + main/dataset_diffusion.py:69-72)."""
