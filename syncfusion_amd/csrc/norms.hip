@@ -233,6 +233,7 @@ __global__ __launch_bounds__(512) void gn_silu_kernel(const T *__restrict__ x, i
   T *obase = out + (size_t)b * L * out_ld + (size_t)g * cpg;
   const float pivot = to_f(base[0]);
   float s = 0.f, q = 0.f;
+#pragma unroll 4
   for (int i = tid; i < nv; i += 512) {
     const int r = i / vr, cv = i - r * vr;
     T v[VW];
@@ -263,6 +264,7 @@ __global__ __launch_bounds__(512) void gn_silu_kernel(const T *__restrict__ x, i
   }
   __syncthreads();
   const float mean = stat[0], rstd = stat[1];
+#pragma unroll 4
   for (int i = tid; i < nv; i += 512) {
     const int r = i / vr, cv = i - r * vr;
     T v[VW], o[VW];
