@@ -12,6 +12,8 @@ L0 = int(sys.argv[5]) if len(sys.argv) > 5 else bench.L0
 dev = torch.device("cuda", 0)
 with torch.no_grad():
     model = bench.build_model(dtype, dev)
+    if os.environ.get("SF_NO_GRAPH"):
+        model.model.sampler.use_graph = False      # per-kernel counters (rocprofv3 --pmc) need eager launches
     noise = torch.randn(B, 1, L0, device=dev)
     y = torch.zeros(B, 1, L0, device=dev); y[:, 0, ::2205] = 1.0
     _, info = model.onsets_encoder(y, with_info=True)
