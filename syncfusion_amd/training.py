@@ -235,3 +235,46 @@ def allreduce_gradients(module: torch.nn.Module, bucket_bytes: int = 256 << 20) 
         calls += 1
         i = j
     return calls
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# the optimisation step as exp/train_diffusion_gh.yaml configures Lightning's Trainer for it
+# ---------------------------------------------------------------------------------------------------------------------------
+def fit_batches(model, optimizer, batches, *, accumulate_grad_batches: int = 2, gradient_clip_val: Optional[float] = 0.5,
+                on_step=None) -> List[float]:
+    """Run ``Model.training_step`` over ``batches`` the way the reference's trainer section does
+    (exp/train_diffusion_gh.yaml:84-96: ``accumulate_grad_batches: 2``, ``gradient_clip_val: 0.5`` with Lightning's default
+    clip-by-global-norm, fp32): the loss of every micro-batch is divided by the accumulation count, gradients are summed over
+    ``accumulate_grad_batches`` micro-batches, averaged over the data-parallel ranks (``allreduce_gradients``), clipped to the
+    global L2 norm and applied.  A trailing incomplete accumulation window is applied as Lightning does at the end of an epoch.
+    Returns the micro-batch losses.  ``on_step(step_index, mean_loss)`` is called after every optimizer step."""
+    if accumulate_grad_batches < 1:
+        raise ValueError("accumulate_grad_batches must be >= 1")
+    params = [p for group in optimizer.param_groups for p in group["params"]]
+    losses: List[float] = []
+    window: List[float] = []
+    steps = 0
+
+    def apply():
+        nonlocal steps
+        allreduce_gradients(model)
+        if gradient_clip_val is not None and gradient_clip_val > 0:
+            torch.nn.utils.clip_grad_norm_(params, gradient_clip_val)
+        optimizer.step()
+        optimizer.zero_grad(set_to_none=True)
+        steps += 1
+        if on_step is not None:
+            on_step(steps, sum(window) / len(window))
+        window.clear()
+
+    optimizer.zero_grad(set_to_none=True)
+    for i, batch in enumerate(batches):
+        loss = model.training_step(batch, i)
+        (loss / accumulate_grad_batches).backward()
+        window.append(float(loss.detach()))
+        losses.append(window[-1])
+        if len(window) == accumulate_grad_batches:
+            apply()
+    if window:
+        apply()
+    return losses

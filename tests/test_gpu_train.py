@@ -335,3 +335,36 @@ def test_full_size_every_gradient_against_oracle_autograd(cuda):
         if not _grad_close(p.grad.cpu(), ref, 2e-4, typical):
             bad.append((name, rel_l2(p.grad.cpu(), ref)))
     assert n > 400 and not bad, (n, bad[:8])
+
+
+def test_fit_batches_accumulates_clips_and_steps_like_the_reference_trainer(cuda):
+    """exp/train_diffusion_gh.yaml:91-92: accumulate_grad_batches 2, gradient_clip_val 0.5 (global-norm clipping).  Two
+    micro-batches through `fit_batches` == one hand-written step: sum of the halved losses' gradients, clip, AdamW (clip value lowered to 0.1 so that
+    it is active on this small model)."""
+    from syncfusion_amd.training import fit_batches
+
+    def batches():
+        g = torch.Generator().manual_seed(61)
+        out = []
+        for _ in range(2):
+            x = torch.randn(2, 1, 16 * 12, generator=g).to(cuda)
+            y = (torch.rand(2, 1, 16 * 12, generator=g) < 0.05).float().to(cuda)
+            out.append((x, y, x, None, None))
+        return out
+
+    a, b = _small_training_model(cuda, seed=3), _small_training_model(cuda, seed=3)
+    oa, ob = a.configure_optimizers(), b.configure_optimizers()
+    torch.manual_seed(500)
+    seen = []
+    losses = fit_batches(a, oa, batches(), accumulate_grad_batches=2, gradient_clip_val=0.1, on_step=lambda i, m: seen.append((i, m)))
+    assert len(losses) == 2 and len(seen) == 1 and seen[0][0] == 1 and abs(seen[0][1] - sum(losses) / 2) < 1e-6
+    torch.manual_seed(500)
+    ob.zero_grad(set_to_none=True)
+    for i, bt in enumerate(batches()):
+        (b.training_step(bt, i) / 2).backward()
+    params = [p for p in b.parameters() if p.requires_grad]
+    norm = torch.nn.utils.clip_grad_norm_(params, 0.1)
+    assert float(norm) > 0.1, "the clip must be active for this check to mean something"
+    ob.step()
+    for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.equal(p, q), n
