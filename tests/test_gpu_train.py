@@ -368,3 +368,26 @@ def test_fit_batches_accumulates_clips_and_steps_like_the_reference_trainer(cuda
     ob.step()
     for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
         assert torch.equal(p, q), n
+
+
+def test_training_forward_mask_proba_and_errors(cuda):
+    """ClassifierFreeGuidancePlugin's training-time masking: with embedding_mask_proba = 1 every clip sees the learned fixed
+    embedding (which then receives a gradient) and the result equals a call with that embedding passed explicitly; lengths that
+    the down-sampling factors do not divide and multi-token embeddings raise."""
+    net = small_unet_module().to(cuda)
+    B, L0 = 2, 16 * 6
+    x, sigma, emb, chans = synth_inputs(SMALL_UNET, B, L0, seed=71)
+    g = lambda t: t.to(cuda)   # noqa: E731
+    v_mask = net(g(x), g(sigma), embedding=g(emb), channels=[g(c) for c in chans], embedding_mask_proba=1.0)
+    fixed = net.cfg.fixed_embedding.weight.detach()[None, :1].expand(B, -1, -1)
+    v_fixed = net(g(x), g(sigma), embedding=fixed, channels=[g(c) for c in chans])
+    assert torch.equal(v_mask, v_fixed)
+    v_mask.square().mean().backward()
+    assert net.cfg.fixed_embedding.weight.grad is not None and float(net.cfg.fixed_embedding.weight.grad.abs().max()) > 0
+    with pytest.raises(ValueError, match="not divisible"):
+        xs, ss, es, cs = synth_inputs(SMALL_UNET, B, L0 + 8, seed=72)
+        net(g(xs), g(ss), embedding=g(es), channels=[g(c) for c in cs])
+    with pytest.raises(NotImplementedError, match="more than one embedding token"):
+        net(g(x), g(sigma), embedding=g(emb).repeat(1, 2, 1), channels=[g(c) for c in chans])
+    with torch.no_grad(), pytest.raises(NotImplementedError, match="embedding_mask_proba"):
+        net(g(x), g(sigma), embedding=g(emb), channels=[g(c) for c in chans], embedding_mask_proba=0.5)
