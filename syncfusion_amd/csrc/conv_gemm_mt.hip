@@ -292,6 +292,7 @@ template <typename T, int GEOM, bool CAT> hipError_t launch_mt_v(const ConvGemmA
   switch (variant) {
     case 1: return launch_mt<T, 128, 128, 2, 4, GEOM, CAT>(a, s);   // short M: twice the tiles of 256x128
     case 2: return launch_mt<T, 128, 192, 4, 2, GEOM, CAT>(a, s);   // column counts that are multiples of 192 but not of 128
+    case 3: return launch_mt<T, 192, 128, 2, 4, GEOM, CAT>(a, s);   // 4/3 of the tiles of 256x128 at 5/6 of its fill per tile
     default: return launch_mt<T, 256, 128, 4, 2, GEOM, CAT>(a, s);
   }
 }
@@ -316,23 +317,32 @@ bool conv_gemm_mt_ok(int dt, const ConvGemmArgs &a) {
   return true;
 }
 
-// tile variant: 0 = 256x128, 1 = 128x128, 2 = 128x192
+// tile variant: 0 = 256x128, 1 = 128x128, 2 = 128x192, 3 = 192x128
 int conv_gemm_mt_variant(const ConvGemmArgs &a) {
   static const int forced = [] {   // tuning hook
     const char *e = getenv("SF_MT_VARIANT");
     return e ? atoi(e) : -1;
   }();
-  if (forced >= 0 && forced <= 2) return forced;
+  if (forced >= 0 && forced <= 3) return forced;
   auto cols = [&](int bn) { return (long)((a.n_store + bn - 1) / bn) * bn; };
   // 192-wide tiles: column counts they cover without empty tiles (192, 576, 960), and short reductions on counts both tile
   // exactly (the 1536-column qkv projections: 423-427 vs 311-366 TFLOP/s, tools/gemm_mt.py)
   if (cols(192) < cols(128) || (a.n_store % 192 == 0 && a.K <= 1024)) return 2;
+  if (a.geom == 0) {
+    // one workgroup per CU (the LDS ring fills it), each bound by its L2 -> LDS fill ~ (BM + BN) per K step: a launch costs
+    // rounds x (BM + BN).  192-row tiles turn the 176-tile launches of the guidance batch (69 % of the CUs) into 235-240.
+    const long nt = (a.n_store + 127) / 128;
+    auto cost = [&](int bm) { return (((long)((a.M + bm - 1) / bm) * nt + 255) / 256) * (bm + 128); };
+    const long c256 = cost(256), c192 = cost(192), c128 = cost(128);
+    if (c192 < c256 && c192 <= c128) return 3;
+    return c128 < c256 ? 1 : 0;
+  }
   const long t256 = (long)((a.M + 255) / 256) * ((a.n_store + 127) / 128);
   return t256 < 160 ? 1 : 0;                                   // few row bands: halve the tile so that more CUs get one
 }
 
 const char *conv_gemm_mt_name(const ConvGemmArgs &a) {
-  static const char *n[3] = {"conv_gemm_mt<bf16,256x128>", "conv_gemm_mt<bf16,128x128>", "conv_gemm_mt<bf16,128x192>"};
+  static const char *n[4] = {"conv_gemm_mt<bf16,256x128>", "conv_gemm_mt<bf16,128x128>", "conv_gemm_mt<bf16,128x192>", "conv_gemm_mt<bf16,192x128>"};
   return n[conv_gemm_mt_variant(a)];
 }
 
