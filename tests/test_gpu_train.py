@@ -391,3 +391,46 @@ def test_training_forward_mask_proba_and_errors(cuda):
         net(g(x), g(sigma), embedding=g(emb).repeat(1, 2, 1), channels=[g(c) for c in chans])
     with torch.no_grad(), pytest.raises(NotImplementedError, match="embedding_mask_proba"):
         net(g(x), g(sigma), embedding=g(emb), channels=[g(c) for c in chans], embedding_mask_proba=0.5)
+
+
+def test_train_checkpoint_generate_round_trip(cuda, tmp_path):
+    """The reference's life cycle on the small model: a few optimizer steps (fit_batches), a Lightning-style checkpoint
+    ({'state_dict': ...}), then main/generation.py's `generate_dataset(model_path=...)` with a FRESH model: the wavs it writes
+    equal what the trained instance generates -- the trained fp32 masters reach the inference engine through the checkpoint."""
+    import wave
+
+    import numpy as np
+
+    from syncfusion_amd.generation import generate_batch, generate_dataset
+    from syncfusion_amd.training import fit_batches
+
+    L0 = 16 * 16
+    g = torch.Generator().manual_seed(81)
+    mk = lambda: (torch.randn(2, 1, L0, generator=g).to(cuda), (torch.rand(2, 1, L0, generator=g) < 0.05).float().to(cuda))   # noqa: E731
+    trained = _small_training_model(cuda, seed=5)
+    before = {k: v.detach().clone() for k, v in trained.state_dict().items()}
+    batches = []
+    for _ in range(4):
+        x, y = mk()
+        batches.append((x, y, x, None, None))
+    torch.manual_seed(9)
+    losses = fit_batches(trained, trained.configure_optimizers(), batches)
+    assert len(losses) == 4 and any(not torch.equal(before[k], v) for k, v in trained.state_dict().items() if k.startswith("model.net."))
+    ckpt = tmp_path / "last.ckpt"
+    torch.save({"state_dict": trained.state_dict()}, ckpt)
+
+    x, y = mk()
+    batch = (x, y, x, ["a", "b"], ["f0", "f1"])
+    with torch.no_grad():
+        torch.manual_seed(123)
+        want = generate_batch(trained, y, x, None, num_steps=4, length=L0, embedding_scale=2.0)
+        fresh = _small_training_model(cuda, seed=99)          # different weights until the checkpoint is loaded
+        torch.manual_seed(123)
+        files = generate_dataset(tmp_path / "out", fresh, [batch], device="cuda", model_path=str(ckpt), sample_rate=22050, num_steps=4, length=L0,
+                                 embedding_scale=2.0)
+    assert [f.name for f in files] == ["0.wav", "1.wav"]
+    for i, f in enumerate(files):
+        with wave.open(str(f), "rb") as w:
+            pcm = np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16)
+        ref = (want[i, 0].clamp(-1, 1) * 32767.0).to(torch.int16).cpu().numpy()
+        assert pcm.shape == ref.shape and np.abs(pcm.astype(np.int32) - ref.astype(np.int32)).max() <= 1
