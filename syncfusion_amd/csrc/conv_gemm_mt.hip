@@ -293,6 +293,7 @@ template <typename T, int GEOM, bool CAT> hipError_t launch_mt_v(const ConvGemmA
     case 1: return launch_mt<T, 128, 128, 2, 4, GEOM, CAT>(a, s);   // short M: twice the tiles of 256x128
     case 2: return launch_mt<T, 128, 192, 4, 2, GEOM, CAT>(a, s);   // column counts that are multiples of 192 but not of 128
     case 3: return launch_mt<T, 192, 128, 2, 4, GEOM, CAT>(a, s);   // 4/3 of the tiles of 256x128 at 5/6 of its fill per tile
+    case 4: return launch_mt<T, 256, 64, 8, 1, GEOM, CAT>(a, s);    // outputs of <= 64 columns
     default: return launch_mt<T, 256, 128, 4, 2, GEOM, CAT>(a, s);
   }
 }
@@ -317,13 +318,13 @@ bool conv_gemm_mt_ok(int dt, const ConvGemmArgs &a) {
   return true;
 }
 
-// tile variant: 0 = 256x128, 1 = 128x128, 2 = 128x192, 3 = 192x128
+// tile variant: 0 = 256x128, 1 = 128x128, 2 = 128x192, 3 = 192x128, 4 = 256x64
 int conv_gemm_mt_variant(const ConvGemmArgs &a) {
   static const int forced = [] {   // tuning hook
     const char *e = getenv("SF_MT_VARIANT");
     return e ? atoi(e) : -1;
   }();
-  if (forced >= 0 && forced <= 3) return forced;
+  if (forced >= 0 && forced <= 4) return forced;
   auto cols = [&](int bn) { return (long)((a.n_store + bn - 1) / bn) * bn; };
   // 192-wide tiles: column counts they cover without empty tiles (192, 576, 960), and short reductions on counts both tile
   // exactly (the 1536-column qkv projections: 423-427 vs 311-366 TFLOP/s, tools/gemm_mt.py)
@@ -342,7 +343,8 @@ int conv_gemm_mt_variant(const ConvGemmArgs &a) {
 }
 
 const char *conv_gemm_mt_name(const ConvGemmArgs &a) {
-  static const char *n[4] = {"conv_gemm_mt<bf16,256x128>", "conv_gemm_mt<bf16,128x128>", "conv_gemm_mt<bf16,128x192>", "conv_gemm_mt<bf16,192x128>"};
+  static const char *n[5] = {"conv_gemm_mt<bf16,256x128>", "conv_gemm_mt<bf16,128x128>", "conv_gemm_mt<bf16,128x192>", "conv_gemm_mt<bf16,192x128>",
+                             "conv_gemm_mt<bf16,256x64>"};
   return n[conv_gemm_mt_variant(a)];
 }
 
