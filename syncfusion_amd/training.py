@@ -31,13 +31,22 @@ from . import autograd as sfa
 Tensor = torch.Tensor
 
 
+_warned_eval = False
+
+
 def wants_grad(module: torch.nn.Module, *tensors: Optional[Tensor]) -> bool:
     """True when a forward call of ``module`` has to record an autograd graph."""
+    global _warned_eval
     if not torch.is_grad_enabled():
         return False
-    if any(t is not None and t.requires_grad for t in tensors):
-        return True
-    return any(p.requires_grad for p in module.parameters())
+    want = any(t is not None and t.requires_grad for t in tensors) or any(p.requires_grad for p in module.parameters())
+    if want and not module.training and not _warned_eval:
+        _warned_eval = True
+        import warnings
+
+        warnings.warn(f"{type(module).__name__} is in eval() mode but autograd is recording: running the differentiable fp32 composition "
+                      "(syncfusion_amd.training), not the inference engine.  Wrap inference calls in torch.no_grad().", stacklevel=3)
+    return want
 
 
 def _params(module: torch.nn.Module) -> Dict[str, Tensor]:
