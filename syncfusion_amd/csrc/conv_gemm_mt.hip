@@ -34,7 +34,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 
 // CAT: K = taps * cin + cin2, the last cin2 columns read row m of a second source (InjectChannels: Conv1x1 over cat[x, ctx])
 // WM x WN = 8 waves; a wave owns (BM / WM) x (BN / WN) = (32 TM) x (32 TN) of the block tile
-template <typename T, int BM, int BN, int WM, int WN, int GEOM, bool CAT>
+template <typename T, int BM, int BN, int WM, int WN, int GEOM, bool CAT, int NST = NSTAGE, int EP = 1>
 __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a, const int mtiles, const int ntiles, const unsigned bytesA,
                                                            const unsigned bytesA2, const unsigned bytesW) {
   static_assert(sizeof(T) == 2, "16-bit types only");
@@ -178,15 +178,22 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
 
   // ---- prologue: two K steps in flight ---------------------------------------------------------------------------
   issue(0);
-  if (nk > 1) issue(1);
+  if (NST == 3 && nk > 1) issue(1);
 
   for (int k = 0; k < nk; ++k) {
-    // own DMA of step k has landed when at most the NLD loads of step k+1 are still outstanding
-    if (k + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // every wave's step-k data is in LDS; every wave is done reading step k-1's slot
-    if (k + 2 < nk) issue((k + 2) % NSTAGE);
-    const unsigned char *slot = smem + (k % NSTAGE) * STAGE;
+    if constexpr (NST == 3) {
+      // own DMA of step k has landed when at most the NLD loads of step k+1 are still outstanding
+      if (k + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // every wave's step-k data is in LDS; every wave is done reading step k-1's slot
+      if (k + 2 < nk) issue((k + 2) % 3);
+    } else {
+      // two slots (half the LDS: two workgroups share a CU and cover each other's prologue / epilogue): one step ahead only
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (k + 1 < nk) issue((k + 1) % 2);
+    }
+    const unsigned char *slot = smem + (k % NST) * STAGE;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const unsigned ch = (unsigned)(((2 * ks + fh) ^ sw) * 16);
@@ -202,26 +209,36 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
     }
   }
 
-  // ---- epilogue through LDS: each wave parks its RM x RN fp32 tile, then streams it out row-major ----------------------
+  // ---- epilogue through LDS: each wave parks its RM x RN fp32 tile (EP = 2: half of the rows of every 32-row MFMA tile at a time, so
+  // that the parking area fits inside a two-slot ring), then streams it out row-major ----------------------------------------------
   __builtin_amdgcn_s_barrier();   // all fragment reads of the last steps are done before the ring is reused
   constexpr int LDR = RN + 4;
-  float *red = reinterpret_cast<float *>(smem) + (size_t)wave * RM * LDR;
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) red[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LDR + j * 32 + fr] = acc[i][j][r];
-  __builtin_amdgcn_wave_barrier();   // same-wave LDS operations execute in order; this only pins the compiler
+  constexpr int RPT = 32 / EP;     // rows of a 32-row MFMA tile handled per pass
+  constexpr int RMP = RM / EP;     // rows a wave parks per pass
+  float *red = reinterpret_cast<float *>(smem) + (size_t)wave * RMP * LDR;
   T *out = static_cast<T *>(a.out);
   const T *res = static_cast<const T *>(a.res);
   const bool has_bs = a.bscale != nullptr, has_ba = a.badd != nullptr;
   constexpr int OCT = RN / 8;                      // 8-column groups per tile row
 #pragma unroll
-  for (int it = 0; it < RM * OCT / 64; ++it) {
+  for (int pass = 0; pass < EP; ++pass) {
+  if (pass) __builtin_amdgcn_wave_barrier();       // the previous pass's reads precede these writes (same-wave LDS order)
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (EP == 2 && (r >> 3) != pass) continue;   // registers 0-7 = rows 0-15 of the tile, 8-15 = rows 16-31
+        const int lr = EP == 1 ? (r & 3) + 8 * (r >> 2) + 4 * fh : (r & 3) + 8 * ((r >> 2) & 1) + 4 * fh;
+        red[(i * RPT + lr) * LDR + j * 32 + fr] = acc[i][j][r];
+      }
+  __builtin_amdgcn_wave_barrier();   // same-wave LDS operations execute in order; this only pins the compiler
+#pragma unroll
+  for (int it = 0; it < RMP * OCT / 64; ++it) {
     const int idx = it * 64 + lane;
     const int rl = idx / OCT, oct = idx - rl * OCT;
-    const int m = m0 + wm * RM + rl, n = n0 + wn * RN + oct * 8;
+    const int m = m0 + wm * RM + (rl / RPT) * 32 + pass * RPT + (rl % RPT), n = n0 + wn * RN + oct * 8;
     const bool live = m < a.M && n < a.n_store;
     const int mc = min(m, a.M - 1);
     const bool full = n + 8 <= a.N;            // whole octet inside the real columns (pad columns [N, n_store) are stored as zeros)
@@ -264,11 +281,12 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
     }
     if (live) st16<T>(out + (size_t)m * a.out_ld + n, o);
   }
+  }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int GEOM, bool CAT> hipError_t launch_mt(const ConvGemmArgs &a, hipStream_t s) {
-  constexpr size_t ring = (size_t)NSTAGE * (BM + BN) * ROWB;
-  constexpr size_t redb = (size_t)8 * (BM / WM) * (BN / WN + 4) * sizeof(float);
+template <typename T, int BM, int BN, int WM, int WN, int GEOM, bool CAT, int NST = NSTAGE, int EP = 1> hipError_t launch_mt(const ConvGemmArgs &a, hipStream_t s) {
+  constexpr size_t ring = (size_t)NST * (BM + BN) * ROWB;
+  constexpr size_t redb = (size_t)8 * (BM / WM / EP) * (BN / WN + 4) * sizeof(float);
   constexpr size_t lds = ring > redb ? ring : redb;
   static_assert(lds <= 160 * 1024, "LDS budget");
   const int mtiles = (a.M + BM - 1) / BM, ntiles = (a.n_store + BN - 1) / BN;
@@ -277,7 +295,7 @@ template <typename T, int BM, int BN, int WM, int WN, int GEOM, bool CAT> hipErr
   else bA = (size_t)((a.M + a.To * a.Ho * a.Wo - 1) / (a.To * a.Ho * a.Wo)) * a.Ti * a.Hi * a.Wi * a.src_ld * 2;
   const size_t bW = (size_t)a.N * a.K * 2;
   const size_t bA2 = CAT ? (size_t)a.M * a.src2_ld * 2 : 0;
-  auto kern = conv_gemm_mt_kernel<T, BM, BN, WM, WN, GEOM, CAT>;
+  auto kern = conv_gemm_mt_kernel<T, BM, BN, WM, WN, GEOM, CAT, NST, EP>;
   static bool en = false;
   if (!en) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -294,6 +312,8 @@ template <typename T, int GEOM, bool CAT> hipError_t launch_mt_v(const ConvGemmA
     case 2: return launch_mt<T, 128, 192, 4, 2, GEOM, CAT>(a, s);   // column counts that are multiples of 192 but not of 128
     case 3: return launch_mt<T, 192, 128, 2, 4, GEOM, CAT>(a, s);   // 4/3 of the tiles of 256x128 at 5/6 of its fill per tile
     case 4: return launch_mt<T, 256, 64, 8, 1, GEOM, CAT>(a, s);    // outputs of <= 64 columns
+    case 5: return launch_mt<T, 128, 128, 2, 4, GEOM, CAT, 2, 2>(a, s);   // two-slot ring, 64 KB of LDS: two workgroups per CU
+    case 6: return launch_mt<T, 128, 192, 4, 2, GEOM, CAT, 2, 2>(a, s);   // the same for 192-wide column tiles (80 KB)
     default: return launch_mt<T, 256, 128, 4, 2, GEOM, CAT>(a, s);
   }
 }
@@ -318,17 +338,33 @@ bool conv_gemm_mt_ok(int dt, const ConvGemmArgs &a) {
   return true;
 }
 
-// tile variant: 0 = 256x128, 1 = 128x128, 2 = 128x192, 3 = 192x128, 4 = 256x64
+// tile variant: 0 = 256x128, 1 = 128x128, 2 = 128x192, 3 = 192x128, 4 = 256x64 (three-slot ring, one workgroup per CU);
+//               5 = 128x128, 6 = 128x192 with a two-slot ring and a two-pass epilogue (two workgroups per CU)
 int conv_gemm_mt_variant(const ConvGemmArgs &a) {
   static const int forced = [] {   // tuning hook
     const char *e = getenv("SF_MT_VARIANT");
     return e ? atoi(e) : -1;
   }();
-  if (forced >= 0 && forced <= 4) return forced;
+  if (forced >= 0 && forced <= 6) return forced;
   auto cols = [&](int bn) { return (long)((a.n_store + bn - 1) / bn) * bn; };
+  static const int rule = [] {   // tuning hook: 0 = three-slot rings only, 1 = two-slot rings for every geometry, default: video geometry only
+    const char *e = getenv("SF_MT_RULE");
+    return e ? atoi(e) : -1;
+  }();
   // 192-wide tiles: column counts they cover without empty tiles (192, 576, 960), and short reductions on counts both tile
-  // exactly (the 1536-column qkv projections: 423-427 vs 311-366 TFLOP/s, tools/gemm_mt.py)
-  if (cols(192) < cols(128) || (a.n_store % 192 == 0 && a.K <= 1024)) return 2;
+  // exactly (the 1536-column qkv projections)
+  const bool wide = cols(192) < cols(128) || (a.n_store % 192 == 0 && a.K <= 1024);
+  const long t256 = (long)((a.M + 255) / 256) * ((a.n_store + 127) / 128);
+  if (rule == 1 || (rule < 0 && a.geom == 1)) {
+    // Two-slot rings (64 / 80 KB of LDS) put TWO workgroups on a CU: one's prologue and epilogue hide under the other's K loop.
+    // The onset net's convolutions stream activations that no cache holds (3 M rows at N = 32) through short reductions
+    // (K = 432 ... 2304 for most of its FLOPs): 477 -> 570 TFLOP/s.  Alone on the chip the two-slot 128x128 tile also wins 11 of
+    // 12 U-Net guidance-batch shapes (tools/mt_variants.py, up to 30 % on the K = 256-512 projections), but inside the U-Net
+    // step, where every GEMM starts on cold operands, the deeper three-slot ring holds its own (154 vs 162 steps/s at batch 32
+    // with guidance), so the 1-D geometry keeps the rule below.
+    return wide ? 6 : 5;
+  }
+  if (wide) return 2;
   if (a.geom == 0) {
     // one workgroup per CU (the LDS ring fills it), each bound by its L2 -> LDS fill ~ (BM + BN) per K step: a launch costs
     // rounds x (BM + BN).  192-row tiles turn the 176-tile launches of the guidance batch (69 % of the CUs) into 235-240.
@@ -338,13 +374,12 @@ int conv_gemm_mt_variant(const ConvGemmArgs &a) {
     if (c192 < c256 && c192 <= c128) return 3;
     return c128 < c256 ? 1 : 0;
   }
-  const long t256 = (long)((a.M + 255) / 256) * ((a.n_store + 127) / 128);
   return t256 < 160 ? 1 : 0;                                   // few row bands: halve the tile so that more CUs get one
 }
 
 const char *conv_gemm_mt_name(const ConvGemmArgs &a) {
-  static const char *n[5] = {"conv_gemm_mt<bf16,256x128>", "conv_gemm_mt<bf16,128x128>", "conv_gemm_mt<bf16,128x192>", "conv_gemm_mt<bf16,192x128>",
-                             "conv_gemm_mt<bf16,256x64>"};
+  static const char *n[7] = {"conv_gemm_mt<bf16,256x128>", "conv_gemm_mt<bf16,128x128>", "conv_gemm_mt<bf16,128x192>", "conv_gemm_mt<bf16,192x128>",
+                             "conv_gemm_mt<bf16,256x64>", "conv_gemm_mt<bf16,128x128,2wg>", "conv_gemm_mt<bf16,128x192,2wg>"};
   return n[conv_gemm_mt_variant(a)];
 }
 
