@@ -314,6 +314,7 @@ template <typename T, int GEOM, bool CAT> hipError_t launch_mt_v(const ConvGemmA
     case 4: return launch_mt<T, 256, 64, 8, 1, GEOM, CAT>(a, s);    // outputs of <= 64 columns
     case 5: return launch_mt<T, 128, 128, 2, 4, GEOM, CAT, 2, 2>(a, s);   // two-slot ring, 64 KB of LDS: two workgroups per CU
     case 6: return launch_mt<T, 128, 192, 4, 2, GEOM, CAT, 2, 2>(a, s);   // the same for 192-wide column tiles (80 KB)
+    case 7: return launch_mt<T, 128, 64, 4, 2, GEOM, CAT, 3, 1>(a, s);    // three-slot ring of a 128x64 tile (72 KB): two workgroups per CU
     default: return launch_mt<T, 256, 128, 4, 2, GEOM, CAT>(a, s);
   }
 }
@@ -345,7 +346,7 @@ int conv_gemm_mt_variant(const ConvGemmArgs &a) {
     const char *e = getenv("SF_MT_VARIANT");
     return e ? atoi(e) : -1;
   }();
-  if (forced >= 0 && forced <= 6) return forced;
+  if (forced >= 0 && forced <= 7) return forced;
   auto cols = [&](int bn) { return (long)((a.n_store + bn - 1) / bn) * bn; };
   static const int rule = [] {   // tuning hook: 0 = three-slot rings only, 1 = two-slot rings for every geometry, default: video geometry only
     const char *e = getenv("SF_MT_RULE");
@@ -378,8 +379,8 @@ int conv_gemm_mt_variant(const ConvGemmArgs &a) {
 }
 
 const char *conv_gemm_mt_name(const ConvGemmArgs &a) {
-  static const char *n[7] = {"conv_gemm_mt<bf16,256x128>", "conv_gemm_mt<bf16,128x128>", "conv_gemm_mt<bf16,128x192>", "conv_gemm_mt<bf16,192x128>",
-                             "conv_gemm_mt<bf16,256x64>", "conv_gemm_mt<bf16,128x128,2wg>", "conv_gemm_mt<bf16,128x192,2wg>"};
+  static const char *n[8] = {"conv_gemm_mt<bf16,256x128>", "conv_gemm_mt<bf16,128x128>", "conv_gemm_mt<bf16,128x192>", "conv_gemm_mt<bf16,192x128>",
+                             "conv_gemm_mt<bf16,256x64>", "conv_gemm_mt<bf16,128x128,2wg>", "conv_gemm_mt<bf16,128x192,2wg>", "conv_gemm_mt<bf16,128x64,2wg>"};
   return n[conv_gemm_mt_variant(a)];
 }
 
