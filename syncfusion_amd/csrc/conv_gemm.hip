@@ -444,7 +444,9 @@ bool conv_gemm_prefers_mt(const ConvGemmArgs &a) {
     const int v = e ? atoi(e) : 0;
     return v > 0 ? v : 80;
   }();
-  if (a.n_store <= 64) return false;   // half-empty column tiles: the 64x64 kernel wins (346 vs 259 TFLOP/s on the onset net's 192 -> 64 temporal conv)
+  // outputs of <= 64 columns: half-empty 128-wide tiles lose to the 64x64 kernel (346 vs 259 TFLOP/s on the onset net's 192 -> 64
+  // temporal convolution); the 128x64 tile with two workgroups per CU (video geometry) wins (542 vs 770 us on that shape)
+  if (a.n_store <= 64 && a.geom != 1) return false;
   const long tiles = (long)((a.M + 127) / 128) * ((a.n_store + 127) / 128);   // the 128x128 variant takes over below 160 tiles of 256x128
   return tiles >= 2 * min_tiles && a.K >= 256;
 }

@@ -363,6 +363,7 @@ int conv_gemm_mt_variant(const ConvGemmArgs &a) {
     // 12 U-Net guidance-batch shapes (tools/mt_variants.py, up to 30 % on the K = 256-512 projections), but inside the U-Net
     // step, where every GEMM starts on cold operands, the deeper three-slot ring holds its own (154 vs 162 steps/s at batch 32
     // with guidance), so the 1-D geometry keeps the rule below.
+    if (a.n_store <= 64) return 7;   // 128x64 tiles (three slots still fit twice)
     return wide ? 6 : 5;
   }
   if (wide) return 2;
