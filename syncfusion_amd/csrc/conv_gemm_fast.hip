@@ -8,6 +8,8 @@
 //     beyond M / N and K tails get an out-of-range offset and the hardware returns zeros -- no predication,
 //     no zero-fill pass, no 64-bit address arithmetic in the loop.
 // The K loop is then: 2 scalar ops + (1 select + 1 add + 1 load) per staged vector, LDS write, barrier, MFMAs.
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -464,8 +466,24 @@ bool conv_gemm_ln_ok(int dt, const ConvGemmArgs &a) {
   return true;
 }
 
+bool conv_gemm_wp_ok(int dt, const ConvGemmArgs &a);                                           // conv_gemm_wp.hip
+hipError_t launch_conv_gemm_wp(int dt, const ConvGemmArgs &a, int variant, hipStream_t s);
+
+static bool ln_goes_wp(int dt, const ConvGemmArgs &a) {
+  // tuning hook: the wave-private kernel also carries the epilogue fold, but on the qkv projections of this model (288 tiles,
+  // K = 1024) the staged kernel measured 1.2 % faster over a whole step (460 vs 455 steps/s), so it stays opt-in
+  static const bool use_wp = getenv("SF_LN_WP") != nullptr;
+  return use_wp && a.ln_colsum && !a.ln_ss && !a.res_ln && !a.rowpart_out && conv_gemm_wp_ok(dt, a);
+}
+
+const char *conv_gemm_ln_variant_name(int dt, const ConvGemmArgs &a) {
+  if (dt == F32) return ln_goes_wp(dt, a) ? "conv_gemm_wp<f32,32x32>" : "conv_gemm_fast<f32,32x32>";
+  return label_for_dtype(dt, ln_goes_wp(dt, a) ? "conv_gemm_wp<bf16,32x32>" : "conv_gemm_fast<bf16,32x32>");
+}
+
 hipError_t launch_conv_gemm_ln(int dt, const ConvGemmArgs &a, hipStream_t s) {
   if (!conv_gemm_ln_ok(dt, a)) return hipErrorInvalidValue;
+  if (ln_goes_wp(dt, a)) return launch_conv_gemm_wp(dt, a, 2, s);
   return SF_DISPATCH_T(dt, (a.cin2 ? launch_fast3<T, 32, 32, true, 32, 2, true>(a, s) : launch_fast3<T, 32, 32, false, 32, 2, true>(a, s)));
 }
 

@@ -203,8 +203,12 @@ __global__ __launch_bounds__(256) void conv_gemm_wp_kernel(const ConvGemmArgs a,
   constexpr int QN = BN / 4;
   constexpr int EIT = (BM * QN + 255) / 256;
   constexpr bool HOIST = EIT == 1;
+  // LayerNorm of the raw source folded into the accumulator (the qkv projection behind the attention pre-norm, see
+  // conv_gemm_fast.hip): out = rstd_m * (acc - mean_m * colsum(W)_n); the row statistics are pooled from the producer's per-tile
+  // partials, whose loads ride with the epilogue operands in front of the K loop (32-row tiles only)
+  const bool ln_epi = BM == 32 && a.ln_colsum != nullptr;
   struct EpiOps {
-    float bi[4], rv[4], sv[4], av[4];
+    float bi[4], rv[4], sv[4], av[4], cu[4];
   };
   auto epi_load = [&](int it) {
     EpiOps o;
@@ -220,11 +224,25 @@ __global__ __launch_bounds__(256) void conv_gemm_wp_kernel(const ConvGemmArgs a,
       o.rv[e] = has_res ? to_f(res[(size_t)mc * a.res_ld + nc]) : 0.f;
       o.sv[e] = has_bs ? a.bscale[(size_t)b * a.bscale_ld + nc] : 1.f;
       o.av[e] = has_ba ? a.badd[(size_t)b * a.badd_ld + nc] : 0.f;
+      o.cu[e] = ln_epi ? a.ln_colsum[nc] : 0.f;
     }
     return o;
   };
   EpiOps eo0;
   if constexpr (HOIST) eo0 = epi_load(0);
+  float ln_mp[4] = {0.f, 0.f, 0.f, 0.f}, ln_qp[4] = {0.f, 0.f, 0.f, 0.f};
+  if (ln_epi) {   // 8 threads per row: partial t8 + 8 j of row tid >> 3
+    const int m = min(m0 + (tid >> 3), a.M - 1), t8 = tid & 7;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int pidx = t8 + 8 * j;
+      if (pidx < a.ln_nt) {
+        const float2 pv = *reinterpret_cast<const float2 *>(a.ln_part + ((size_t)m * a.ln_nt + pidx) * 2);
+        ln_mp[j] = pv.x;
+        ln_qp[j] = pv.y;
+      }
+    }
+  }
 
   // ---- the wave's own pipeline: no workgroup barrier --------------------------------------------------------
 #pragma unroll
@@ -248,6 +266,23 @@ __global__ __launch_bounds__(256) void conv_gemm_wp_kernel(const ConvGemmArgs a,
 
   // ---- the four partial tiles meet here --------------------------------------------------------------------
   __syncthreads();   // every wave is done with its staging buffers (red aliases them)
+  float *rowstat = red + (size_t)4 * BM * LDR;   // (mean, rstd) per row, behind the four partial tiles
+  if (ln_epi) {
+    const int t8 = tid & 7;
+    const float mean = sum8_dpp((ln_mp[0] + ln_mp[1]) + (ln_mp[2] + ln_mp[3])) / (float)a.ln_nt;   // every partial covers 32 channels
+    float dq = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (t8 + 8 * j < a.ln_nt) {
+        const float d = ln_mp[j] - mean;
+        dq += fmaf(32.f * d, d, ln_qp[j]);
+      }
+    const float m2 = sum8_dpp(dq);
+    if (t8 == 0) {
+      rowstat[2 * (tid >> 3)] = mean;
+      rowstat[2 * (tid >> 3) + 1] = rsqrtf(m2 / (float)a.cin + a.ln_eps);
+    }
+  }
   float *myred = red + (size_t)wave * BM * LDR;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -277,6 +312,11 @@ __global__ __launch_bounds__(256) void conv_gemm_wp_kernel(const ConvGemmArgs a,
       v[1] += t[1];
       v[2] += t[2];
       v[3] += t[3];
+    }
+    if (ln_epi) {
+      const float mu = rowstat[2 * mlc], rstd = rowstat[2 * mlc + 1];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = rstd * (v[e] - mu * eo.cu[e]);
     }
     float xo[4];
 #pragma unroll
@@ -309,7 +349,7 @@ __global__ __launch_bounds__(256) void conv_gemm_wp_kernel(const ConvGemmArgs a,
 template <typename T, int BM, int BN, bool CAT, int NSET> hipError_t launch_wp3(const ConvGemmArgs &a, hipStream_t s) {
   constexpr int LD = BK + 16 / (int)sizeof(T);
   constexpr size_t stage_bytes = (size_t)4 * (BM + BN) * LD * sizeof(T);
-  constexpr size_t red_bytes = (size_t)4 * BM * (BN + 4) * sizeof(float);
+  constexpr size_t red_bytes = (size_t)4 * BM * (BN + 4) * sizeof(float) + (size_t)2 * BM * sizeof(float);   // + (mean, rstd) per row
   const size_t lds = stage_bytes > red_bytes ? stage_bytes : red_bytes;
   if (lds > 150 * 1024) return hipErrorInvalidValue;   // fp32 64-row tiles do not fit: the caller falls back
   const int mtiles = (a.M + BM - 1) / BM, ntiles = (a.n_store + BN - 1) / BN;

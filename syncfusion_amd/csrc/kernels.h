@@ -77,6 +77,7 @@ bool conv_gemm_emits_rowpart(int dt, const ConvGemmArgs &a);
 // GEMM whose first source is LayerNorm-modulated on the fly from producer-side row partials (see ConvGemmArgs)
 bool conv_gemm_ln_ok(int dt, const ConvGemmArgs &a);
 hipError_t launch_conv_gemm_ln(int dt, const ConvGemmArgs &a, hipStream_t s);
+const char *conv_gemm_ln_variant_name(int dt, const ConvGemmArgs &a);
 // Tuning hook (sf_bench_conv1d only; not thread-safe): force the kernel family / tile of launch_conv_gemm.
 //   path: 0 automatic, 1 classic (conv_gemm), 2 wave-split-K (sk / fast), 4 v2;  tile: -1 automatic else variant index;
 //   sk: reserved (was the grid split-K factor of v2; 64 selects the 256-wide chunk variant of conv_gemm_fast).

@@ -635,7 +635,7 @@ struct Exec {
     if (w.direct) timed("conv_direct", flops, bytes, [&] { SF_HIP(launch_conv_direct(dt_in, dt_out, a, s)); });
     else {
       if (dt_in != u.dt || (dt_out != u.dt && !a.out_f32)) fail(SF_ERR_INVALID, "internal: dtype mismatch on the MFMA path");
-      if (ln) timed(u.dt == F32 ? "conv_gemm_fast<f32,32x32>" : label_for_dtype(u.dt, "conv_gemm_fast<bf16,32x32>"), flops + 8.0 * a.M * a.cin, bytes,
+      if (ln) timed(conv_gemm_ln_variant_name(u.dt, a), flops + 8.0 * a.M * a.cin, bytes,
                     [&] { SF_HIP(launch_conv_gemm_ln(u.dt, a, s)); });
       else timed(conv_gemm_variant_name(u.dt, a), flops, bytes, [&] { SF_HIP(launch_conv_gemm(u.dt, a, s)); });
     }
