@@ -246,6 +246,11 @@ int sf_op_attention_bwd(const float *q, const float *kv, const float *out, const
 int sf_bench_conv1d(int dtype, int B, int L, int C, int N, int taps, int upsample, int path, int tile, int sk, int iters,
                     float *ms_out);
 /* y = layer_norm(x; eps, no affine) * (1 + scale[b]) + shift[b]   (scale/shift NULL -> plain normalise) */
+/* materialised SiLU(GroupNorm(x)) on channels-last rows (B, L, C), as the wide U-Net levels run it in front of their convolutions
+ * (a-unet ResnetItem).  ws (optional, >= B * 32 * groups * 2 floats): long sequences then take the
+ * chunked form (per-chunk statistics + one streaming pass) instead of one workgroup per (clip, group). */
+int sf_op_gn_silu(int dtype, const void *x, const float *gamma, const float *beta, int groups, float eps, int B, int L, int C, void *out,
+                  void *ws, int64_t ws_bytes, void *stream);
 int sf_op_ln_modulate(int dtype, const void *x, const float *scale_shift /* (B, 2C) or NULL */, float eps,
                       int B, int L, int C, void *out, void *stream);
 /* multi-head attention on packed projections: q:(B,L,H*D), kv:(B,L,2*H*D) -> out:(B,L,H*D) */

@@ -175,6 +175,17 @@ int sf_op_conv1d_cl(int dtype, const void *x, const float *w, const float *bias,
   SF_API_END
 }
 
+int sf_op_gn_silu(int dtype, const void *x, const float *gamma, const float *beta, int groups, float eps, int B, int L, int C, void *out,
+                  void *ws, int64_t ws_bytes, void *stream) {
+  SF_API_BEGIN
+  if (!x || !gamma || !beta || !out) fail(SF_ERR_INVALID, "null argument");
+  if (groups < 1 || C % groups) fail(SF_ERR_INVALID, "channels must be divisible by groups");
+  SF_HIP(launch_gn_silu_ws(dtype, x, C, B, L, C, groups, gamma, beta, eps, out, C, static_cast<float *>(ws), ws ? ws_bytes / 4 : 0,
+                           static_cast<hipStream_t>(stream)));
+  return SF_OK;
+  SF_API_END
+}
+
 int sf_bench_conv1d(int dtype, int B, int L, int C, int N, int taps, int upsample, int path, int tile, int sk, int iters, float *ms_out) {
   SF_API_BEGIN
   if (!ms_out || iters < 1) fail(SF_ERR_INVALID, "bad argument");

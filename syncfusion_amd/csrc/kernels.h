@@ -152,6 +152,8 @@ hipError_t launch_gn_stats(int dt, const void *x, int ld, int B, int L, int C, i
 // y = silu(GroupNorm_G(x; gamma, beta, eps)) materialised in one launch (statistics + apply, one workgroup per (clip, group))
 hipError_t launch_gn_silu(int dt, const void *x, int ld, int B, int L, int C, int G, const float *gamma, const float *beta, float eps,
                           void *out, int out_ld, hipStream_t s);
+hipError_t launch_gn_silu_ws(int dt, const void *x, int ld, int B, int L, int C, int G, const float *gamma, const float *beta, float eps, void *out,
+                             int out_ld, float *slab, int64_t slab_floats, hipStream_t s);
 
 // y = LN_C(x; eps) * (1 + scale[b][c]) + shift[b][c]   (ss == nullptr: plain normalise);  ss:(B, ss_ld) = [scale | shift]
 hipError_t launch_ln_modulate(int dt, const void *x, int ld, const float *ss, int ss_ld, float eps, int B, int L, int C,

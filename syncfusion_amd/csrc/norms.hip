@@ -3,6 +3,9 @@
 //                convolution merges the chunks (Chan) in its prologue -- deterministic, no atomics.
 //   ln_modulate  per-row LayerNorm over C fused with the a-unet Modulation  y = xhat*(1+s[b]) + t[b]
 // Both are pure streaming kernels (HBM/L2-bound): 16-byte loads, wave shuffles, one pass.
+#include <cstdlib>
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -361,6 +364,56 @@ __global__ __launch_bounds__(512) void gn_silu_reg_kernel(const T *__restrict__ 
   }
 }
 
+// Long sequences (the reference's 2^18-sample clips: 65 K elements per (clip, group) at depths 4-6): the one-workgroup-per-slab
+// kernel above leaves most CUs idle (80 workgroups at ten clips per branch) and walks each slab twice.  With the chunk statistics of
+// gn_stats in hand, the activation is ONE streaming pass over (clip, row chunk) workgroups that cover all channels: a thread keeps
+// its V channels (C / V divides 256), merges the chunk partials of their group (Chan, chunk order) once, then streams rows.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_silu_apply_kernel(const T *__restrict__ x, int ld, int L, int C, int G, const float *__restrict__ slab,
+                                                            int nch, int chunk_rows, const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta, float eps, int rows_per_wg, T *__restrict__ out,
+                                                            int out_ld) {
+  constexpr bool FAST = sizeof(T) == 2;
+  constexpr int V = Vec16<T>::N;
+  __shared__ float mean_s[64], rstd_s[64];
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const int cpg = C / G;
+  for (int g = tid; g < G; g += 256) {
+    const float *sb = slab + ((size_t)b * nch * G + g) * 2;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int ch = 0; ch < nch; ++ch) {
+      const float nb = (float)min(chunk_rows, L - ch * chunk_rows) * (float)cpg;
+      const float mb = sb[(size_t)ch * G * 2], qb = sb[(size_t)ch * G * 2 + 1];
+      const float delta = mb - mean, tot = n + nb;
+      mean += delta * (nb / tot);
+      m2 += qb + delta * delta * (n * nb / tot);
+      n = tot;
+    }
+    mean_s[g] = mean;
+    rstd_s[g] = rsqrtf(m2 / n + eps);
+  }
+  __syncthreads();
+  const int vpr = C / V, cv = tid % vpr, rstep = 256 / vpr;
+  float sc[V], sh[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    const int c = cv * V + j, g = c / cpg;
+    sc[j] = rstd_s[g] * gamma[c];
+    sh[j] = fmaf(-mean_s[g], sc[j], beta[c]);
+  }
+  const int r0 = blockIdx.x * rows_per_wg, r1 = min(L, r0 + rows_per_wg);
+  const T *xb = x + ((size_t)b * L) * ld + cv * V;
+  T *ob = out + ((size_t)b * L) * out_ld + cv * V;
+#pragma unroll 4
+  for (int r = r0 + tid / vpr; r < r1; r += rstep) {
+    const Vec16<T> v = ld16<T>(xb + (size_t)r * ld);
+    Vec16<T> o;
+#pragma unroll
+    for (int j = 0; j < V; ++j) o.set(j, silu_t<FAST>(fmaf(v.get(j), sc[j], sh[j])));
+    st16<T>(ob + (size_t)r * out_ld, o);
+  }
+}
+
 template <typename T>
 hipError_t gn_silu_go(const void *x, int ld, int B, int L, int C, int G, const float *gamma, const float *beta, float eps, void *out,
                       int out_ld, hipStream_t s) {
@@ -434,6 +487,42 @@ hipError_t gn_go(const void *x, int ld, int B, int L, int C, int G, int nch, int
 hipError_t launch_gn_stats(int dt, const void *x, int ld, int B, int L, int C, int G, int nch, int chunk_rows, float *slab,
                            hipStream_t s) {
   return SF_DISPATCH_T(dt, gn_go<T>(x, ld, B, L, C, G, nch, chunk_rows, slab, s));
+}
+
+// The same with a statistics slab at hand (>= B * 32 * G * 2 floats): slabs that do not fit one workgroup's registers take the
+// chunked two-launch path (gn_stats + gn_silu_apply); everything else goes to launch_gn_silu.
+template <typename T>
+static hipError_t gn_silu_ws_go(const void *x, int ld, int B, int L, int C, int G, const float *gamma, const float *beta, float eps, void *out,
+                                int out_ld, float *slab, int64_t slab_floats, hipStream_t s, bool &done) {
+  constexpr int V = Vec16<T>::N;
+  done = false;
+  if (C % G || G > 64 || C % V || (256 % (C / V)) || (ld % V) || (out_ld % V)) return hipSuccess;
+  const int cpg = C / G;
+  if (cpg % V == 0 && 512 % (cpg / V) == 0 && (int64_t)L * (cpg / V) <= 4 * 512) return hipSuccess;   // register-resident kernel applies
+  if ((int64_t)L * cpg < 32768) return hipSuccess;                                                       // short slabs: one launch wins
+  const GnPlan gp = gn_plan(B, L, C);
+  if ((int64_t)B * gp.nch * G * 2 > slab_floats) return hipSuccess;
+  hipError_t e = launch_gn_stats(std::is_same<T, float>::value ? F32 : (std::is_same<T, f16>::value ? F16 : BF16), x, ld, B, L, C, G, gp.nch,
+                                 gp.chunk_rows, slab, s);
+  if (e != hipSuccess) return e;
+  int nwg = (int)std::min<int64_t>(64, std::max<int64_t>(1, ((int64_t)L * C + 32767) / 32768));   // >= 32 K elements per workgroup
+  const int rows_per_wg = (L + nwg - 1) / nwg;
+  nwg = (L + rows_per_wg - 1) / rows_per_wg;
+  hipLaunchKernelGGL((gn_silu_apply_kernel<T>), dim3(nwg, B), dim3(256), 0, s, static_cast<const T *>(x), ld, L, C, G, slab, gp.nch, gp.chunk_rows, gamma,
+                     beta, eps, rows_per_wg, static_cast<T *>(out), out_ld);
+  done = true;
+  return hipGetLastError();
+}
+
+hipError_t launch_gn_silu_ws(int dt, const void *x, int ld, int B, int L, int C, int G, const float *gamma, const float *beta, float eps, void *out,
+                             int out_ld, float *slab, int64_t slab_floats, hipStream_t s) {
+  static const bool off = getenv("SF_NO_GN_CHUNKED") != nullptr;   // tuning hook
+  if (slab && !off) {
+    bool done = false;
+    hipError_t e = SF_DISPATCH_T(dt, gn_silu_ws_go<T>(x, ld, B, L, C, G, gamma, beta, eps, out, out_ld, slab, slab_floats, s, done));
+    if (e != hipSuccess || done) return e;
+  }
+  return launch_gn_silu(dt, x, ld, B, L, C, G, gamma, beta, eps, out, out_ld, s);
 }
 
 hipError_t launch_gn_silu(int dt, const void *x, int ld, int B, int L, int C, int G, const float *gamma, const float *beta, float eps,

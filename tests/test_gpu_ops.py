@@ -120,6 +120,31 @@ def test_ln_modulate(cuda, dtype, C, mod):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("B,L,C,with_ws", [
+    (3, 44, 1024, True),      # register-resident kernel (the deep levels of a 2 s clip)
+    (2, 2048, 256, False),    # slab of 65 K elements, one workgroup per (clip, group), two passes
+    (2, 2048, 256, True),     # the same through the chunked form (2^18-sample clips, depth 4)
+    (3, 1000, 512, True),     # ragged chunks
+    (1, 4096, 128, True),
+])
+def test_gn_silu_materialised(cuda, dtype, B, L, C, with_ws):
+    _l, lib = _lib()
+    G = 8
+    g = torch.Generator().manual_seed(L + C)
+    td = TD[dtype]
+    x = (torch.randn(B, L, C, generator=g) * 1.4 + 0.3).to(td)
+    gamma, beta = 1 + 0.2 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    ref = F.silu(F.group_norm(x.float().transpose(1, 2), G, gamma, beta, eps=1e-5)).transpose(1, 2)
+    xd, gd, bd = x.to(cuda), gamma.to(cuda), beta.to(cuda)
+    out = torch.empty_like(xd)
+    ws = torch.empty(B * 32 * G * 2, dtype=torch.float32, device=cuda) if with_ws else None
+    _l.check(lib.sf_op_gn_silu(_l.DTYPES[dtype], xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), G, 1e-5, B, L, C, out.data_ptr(),
+                               ws.data_ptr() if with_ws else None, ws.numel() * 4 if with_ws else 0, _l.stream_ptr(cuda)), "sf_op_gn_silu")
+    torch.cuda.synchronize()
+    assert rel_l2(out.float().cpu(), ref) < (2e-6 if dtype == "fp32" else 6e-3)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("L", [1, 44, 64, 100, 352])
 def test_attention(cuda, dtype, L):
     _l, lib = _lib()
