@@ -392,6 +392,24 @@ LOWP = ["bf16", "fp16"]
 LOWP_STEP_TOL = 5e-2     # stated tolerance of the 16-bit paths per evaluation (measured ~1e-2); fp32 is gated at 1e-4
 
 
+@pytest.mark.timeout(1500)
+def test_reference_length_eval_parity(cuda, full_model):
+    """The reference's own evaluation length (exp/evaluate_gh_gen.yaml:8, 2**18 samples; four clips so that the clip-parallel
+    branches are on, guidance 2.0 as :23): one evaluation against the oracle in fp32, bf16 and fp16.  This is where the
+    long-sequence kernels run: the 4-wave attention with hardware-transposed V reads (L = 2048 at depth 4), the macro-tile
+    GEMMs of the deep levels, the two-pass GroupNorm+SiLU on 65 K-element slabs."""
+    B, L0, scale = 4, 262144, 2.0
+    x, sigma, emb, chans = _full_inputs(full_model, B, L0, 91)
+    ref = _oracle_unet(full_model.model.net, x[:1], sigma[:1], emb[:1], [c[:1] for c in chans], scale)   # one clip on the CPU: 0.3 TFLOP
+    gx, gs, ge, gc = x.to(cuda), sigma.to(cuda), emb.to(cuda), [c.to(cuda) for c in chans]
+    for dtype, tol in (("fp32", FP32_TOL), ("bf16", LOWP_STEP_TOL), ("fp16", LOWP_STEP_TOL)):
+        with _compute_dtype(full_model, dtype) as net:
+            out = net(gx, gs, embedding=ge, channels=gc, embedding_scale=scale)
+        e = rel_l2(out[:1].cpu(), ref)
+        print(f"{dtype} L0=2**18 eval: rel-L2 {e:.3e}")
+        assert e < tol, f"{dtype}: {e:.3e}"
+
+
 @pytest.mark.parametrize("dtype", LOWP)
 def test_full_size_lowp_eval_parity_with_taps(cuda, full_model, dtype):
     """BASELINE configs[1] in its stated form (batch 8, L0 = 45056, 16-bit arithmetic): the BENCHMARKED kernels -- wave-private /
