@@ -295,6 +295,44 @@ def test_training_step_optimizer_loop_lowers_the_loss_and_the_engine_follows_the
         m.training_step(batch, 0)
 
 
+@pytest.mark.timeout(1500)
+def test_full_size_long_clip_gradients_against_oracle_autograd(cuda):
+    """The reference-size U-Net on ONE clip of 2**16 samples (self-attention over 512 / 256 / 128 / 64 positions, 65 K rows at the
+    thin levels): the loss and every parameter gradient against oracle autograd -- the chunked GroupNorm backward, the row-split
+    weight gradients and their reductions, LayerNorm backward over many chunks, the MFMA attention backward at real lengths."""
+    import syncfusion_amd as sa
+    from helpers import reference_model_config
+    from oracle import unet_ref
+
+    torch.manual_seed(4321)
+    net = sa.instantiate(reference_model_config()).model.net
+    cfg = dict(net.hparams)
+    P = {k: v.clone().requires_grad_() for k, v in oracle_params(net, "net.").items()}
+    B, L0 = 1, 65536
+    x, sigma, emb, chans = synth_inputs(cfg, B, L0, seed=53)
+    target = torch.randn(B, 1, L0, generator=torch.Generator().manual_seed(54))
+    v_ref = unet_ref.unet_forward(P, cfg, x, sigma, embedding=emb, channels=chans)
+    l_ref = F.mse_loss(v_ref, target)
+    l_ref.backward()
+    net = net.to(cuda)
+    v = net(x.to(cuda), sigma.to(cuda), embedding=emb.to(cuda), channels=[c.to(cuda) for c in chans])
+    loss = F.mse_loss(v, target.to(cuda))
+    assert abs(float(loss.detach()) - float(l_ref.detach())) < 1e-5 * float(l_ref.detach())
+    loss.backward()
+    typical = float(torch.cat([p.grad.reshape(-1) for p in P.values() if p.grad is not None]).abs().mean())
+    bad, n = [], 0
+    for name, p in net.named_parameters():
+        ref = P["net." + name].grad
+        if ref is None:
+            continue
+        n += 1
+        if _zero_by_construction(name, lambda parts: cfg["channels"][int(parts[1])], cfg["resnet_groups"]):
+            continue
+        if not _grad_close(p.grad.cpu(), ref, 5e-4, typical):
+            bad.append((name, rel_l2(p.grad.cpu(), ref)))
+    assert n > 400 and not bad, (n, bad[:8])
+
+
 @pytest.mark.timeout(900)
 def test_full_size_every_gradient_against_oracle_autograd(cuda):
     """The reference-size U-Net (215 M parameters, channels up to 1024, 8 heads) on two short clips: every parameter gradient of
