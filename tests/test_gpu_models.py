@@ -476,6 +476,28 @@ def test_config2_shape_lowp_parity(cuda, full_model, dtype):
     assert e < 2 * LOWP_STEP_TOL      # guidance doubles the difference of two evaluations: twice the per-evaluation tolerance
 
 
+@pytest.mark.parametrize("B,L0", [(3, 45056), (1, 262144)])
+def test_full_size_encoder1d_parity(cuda, full_model, B, L0):
+    """The reference's Encoder1d (exp/model/diffusion.yaml:35-43: 2 -> 256 channels, factors 1,4,4,4,2,2,2,2) at the benchmark and
+    at the reference evaluation length: every entry of info['xs'] against the oracle."""
+    from oracle import encoder1d_ref
+
+    enc = full_model.onsets_encoder
+    g = torch.Generator().manual_seed(L0 + B)
+    y = torch.zeros(B, 1, L0)
+    for b in range(B):
+        k = int(torch.randint(1, 9, (1,), generator=g))
+        y[b, 0, torch.randint(0, L0, (k,), generator=g)] = 1.0
+    with torch.no_grad():
+        z_ref, info_ref = encoder1d_ref.encoder1d_forward(oracle_params(enc), dict(enc.hparams), y)
+    z, info = enc(y.to(cuda), with_info=True)
+    assert len(info["xs"]) == len(info_ref["xs"]) == 11
+    for i, (a, b_) in enumerate(zip(info["xs"], info_ref["xs"])):
+        assert a.shape == b_.shape, i
+        assert rel_l2(a.cpu(), b_) < FP32_TOL, f"xs[{i}]: {rel_l2(a.cpu(), b_):.3e}"
+    assert rel_l2(z.cpu(), z_ref) < FP32_TOL
+
+
 def test_full_size_properties(cuda, full_model):
     """B = 8, L0 = 45056 (BASELINE configs[1] shape): determinism, clip independence, scale == 1 <=> single pass."""
     B, L0 = 8, 45056
