@@ -366,7 +366,7 @@ int conv_gemm_mt_variant(const ConvGemmArgs &a) {
     if (a.n_store <= 64) return 7;   // 128x64 tiles (three slots still fit twice)
     return wide ? 6 : 5;
   }
-  if (wide) return 2;
+  if (wide) return rule == 0 ? 2 : 6;   // in the U-Net step too the two-slot 128x192 tile wins on the qkv projections (28.6 vs 34.2 us)
   if (a.geom == 0) {
     // one workgroup per CU (the LDS ring fills it), each bound by its L2 -> LDS fill ~ (BM + BN) per K step: a launch costs
     // rounds x (BM + BN).  192-row tiles turn the 176-tile launches of the guidance batch (69 % of the CUs) into 235-240.
