@@ -12,7 +12,8 @@ built on the device where it is arithmetic and kept as plain host logic where it
 * ``PinnedPrefetcher``  double-buffered pinned-memory upload on a side stream, so that batch i+1 crosses PCIe while batch i
                         is being sampled (the reference relies on DataLoader(pin_memory=True), main/datamodule_diffusion.py:36-44)
 
-WebDataset tar decoding, JPEG decoding and torchaudio resampling of the SOURCE audio stay out of scope (host I/O).
+The tar shards themselves are read by ``syncfusion_amd/shards.py`` (standard library; PCM wav + the times csv files, source audio
+resampled by the HIP resampler).  JPEG / video decoding stays out of scope (host I/O through third-party codecs).
 """
 from __future__ import annotations
 

@@ -45,3 +45,38 @@ def test_pinned_prefetcher_feeds_generate_batch_inputs(cuda):
     for (x, y, z, text, fn), (gx, gy, gz, gtext, gfn) in zip(batches, got):
         torch.cuda.synchronize()
         assert gx.is_cuda and torch.equal(gx.cpu(), x) and torch.equal(gz.cpu(), z) and gtext == text and gfn == fn
+
+
+def test_shards_to_batches_with_device_resampling(cuda, tmp_path):
+    """Shard (8 kHz PCM) -> create_sfx_dataset's pipeline at 16 kHz: the source audio is resampled by the HIP sinc resampler
+    (torchaudio's algorithm, main/dataset_diffusion.py:15-16) and the chunks stay on the device."""
+    import io
+    import random
+    import tarfile
+    import wave
+
+    import numpy as np
+
+    from syncfusion_amd import resample, shards
+    from syncfusion_amd.input_pipeline import slice_chunks
+
+    sr, n = 8000, 6000
+    x = (np.random.RandomState(1).randn(1, n) * 4000).astype(np.int16)
+    buf = io.BytesIO()
+    with wave.open(buf, "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(sr)
+        w.writeframes(x.T.astype("<i2").tobytes())
+    path = tmp_path / "s-000.tar"
+    with tarfile.open(path, "w") as tf:
+        for name, data in (("k.resampled.wav", buf.getvalue()), ("k.times.csv", b"0.1,tap\n0.4,tap\n")):
+            ti = tarfile.TarInfo(name)
+            ti.size = len(data)
+            tf.addfile(ti, io.BytesIO(data))
+    got = list(shards.sfx_chunks(str(path), sample_rate=16000, chunk_size=4096, one_chunk_per_track=False, device=cuda, rng=random.Random(0)))
+    wav16 = resample(torch.from_numpy(x.astype(np.float32) / 32768.0).to(cuda)[None], orig_freq=sr, new_freq=16000)[0]
+    want = list(slice_chunks(wav16, 16000, {0.1: "tap", 0.4: "tap"}, None, "k", 4096, one_chunk_per_track=False, rng=random.Random(0)))
+    assert len(got) == len(want) == 2 and got[0][0].is_cuda and got[0][0].shape == (1, 4096)
+    for a, b in zip(got, want):
+        assert all(torch.equal(u, v) for u, v in zip(a[:3], b[:3])) and a[3:] == b[3:]
