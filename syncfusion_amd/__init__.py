@@ -6,7 +6,7 @@ Public surface = the reference's own: ``DiffusionModel`` 
 runs in ``lib/libsyncfusion_amd.so`` (hand-written HIP, C ABI in include/syncfusion_amd.h).
 """
 from . import _lib  # noqa: F401
-from . import autograd, shards, training  # noqa: F401
+from . import autograd, shards, training, video_chunks  # noqa: F401
 from .config import instantiate, instantiate_model_yaml
 from .diffusion import DiffusionModel, LinearSchedule, UNetV0, VDiffusion, VSampler
 from .encoder1d import Encoder1d

@@ -80,3 +80,32 @@ def test_shards_to_batches_with_device_resampling(cuda, tmp_path):
     assert len(got) == len(want) == 2 and got[0][0].is_cuda and got[0][0].shape == (1, 4096)
     for a, b in zip(got, want):
         assert all(torch.equal(u, v) for u, v in zip(a[:3], b[:3])) and a[3:] == b[3:]
+
+
+def test_frame_directory_chunks_to_onset_net_input(cuda, tmp_path):
+    """main/dataset_onset.py:121-165: frames of a chunk (naturally sorted files, PIL RGB decode) -> (3, T, 112, 112); the transform
+    chain against its restatement (oracle/frames_ref.py, pinned to the ATen antialias kernel)."""
+    import json
+
+    import numpy as np
+    from PIL import Image
+
+    from oracle import frames_ref
+    from syncfusion_amd import video_chunks as vc
+
+    d = tmp_path / "v1" / "frames"
+    d.mkdir(parents=True)
+    rs = np.random.RandomState(5)
+    imgs = []
+    for i in range(9):
+        a = rs.randint(0, 256, size=(60, 80, 3), dtype=np.uint8)
+        Image.fromarray(a).save(d / f"{i + 1}.jpg", quality=95)
+        imgs.append(np.asarray(Image.open(d / f"{i + 1}.jpg").convert("RGB")))     # what a JPEG decoder returns
+    (tmp_path / "v1" / "v1.metadata.json").write_text(json.dumps({"processed": {"video_frame_rate": 4.0, "video_duration": 2.1}}))
+    (tmp_path / "v1" / "v1.times.csv").write_text("0.3,hit\n1.6,hit\n")
+    table = vc.chunk_table(str(tmp_path), ["v1"], chunk_length_in_seconds=1.0)
+    assert len(table) == 2 and table[1]["labels"].tolist() == [0, 0, 1, 0]
+    clips, labels, part = next(vc.iter_clips(table, batch_size=2, device=cuda))
+    assert clips.shape == (2, 3, 4, 112, 112) and labels.shape == (2, 4) and len(part) == 2
+    want = frames_ref.frames_transform(torch.from_numpy(np.stack(imgs[4:8]))[None])[0]   # chunk 1 = frames 5..8
+    assert rel_l2(clips[1].cpu(), want) < 2e-5
