@@ -109,3 +109,47 @@ def test_frame_directory_chunks_to_onset_net_input(cuda, tmp_path):
     assert clips.shape == (2, 3, 4, 112, 112) and labels.shape == (2, 4) and len(part) == 2
     want = frames_ref.frames_transform(torch.from_numpy(np.stack(imgs[4:8]))[None])[0]   # chunk 1 = frames 5..8
     assert rel_l2(clips[1].cpu(), want) < 2e-5
+
+
+def test_shards_feed_generate_dataset(cuda, tmp_path):
+    """The reference's evaluation flow end to end on the small model: tar shard -> create_sfx_dataset's batches ->
+    generate_dataset (main/generation.py:12-122) -> one wav per chunk, named by the running chunk id."""
+    import functools
+    import io
+    import random
+    import tarfile
+    import wave
+
+    import numpy as np
+
+    import syncfusion_amd as sa
+    from helpers import SMALL_ENCODER, SMALL_UNET
+    from syncfusion_amd import shards
+
+    sr, L0 = 8000, 16 * 64
+    path = tmp_path / "eval-000.tar"
+    rs = np.random.RandomState(2)
+    with tarfile.open(path, "w") as tf:
+        for k in range(3):
+            x = (rs.randn(1, 3 * L0) * 5000).astype(np.int16)
+            buf = io.BytesIO()
+            with wave.open(buf, "wb") as w:
+                w.setnchannels(1)
+                w.setsampwidth(2)
+                w.setframerate(sr)
+                w.writeframes(x.T.astype("<i2").tobytes())
+            for name, data in ((f"clip{k}.resampled.wav", buf.getvalue()), (f"clip{k}.times.csv", b"0.01,hit\n0.2,hit\n")):
+                ti = tarfile.TarInfo(name)
+                ti.size = len(data)
+                tf.addfile(ti, io.BytesIO(data))
+    kw = dict(SMALL_UNET)
+    model = sa.Model(1e-4, 0.95, 0.999, 1e-6, 1e-3,
+                     sa.DiffusionModel(net_t=functools.partial(sa.UNetV0, seed=0), diffusion_t=sa.VDiffusion, sampler_t=sa.VSampler, use_embedding_cfg=True, **kw),
+                     sa.Encoder1d(seed=1, **SMALL_ENCODER), sa.RandomEmbedder(kw["embedding_features"]), None).to(cuda)
+    batches = list(shards.sfx_batches(str(path), batch_size=2, sample_rate=sr, chunk_size=L0, one_chunk_per_track=True, rng=random.Random(0)))
+    assert [b[0].shape[0] for b in batches] == [2, 1]
+    files = sa.generate_dataset(tmp_path / "gen", model, batches, device="cuda", sample_rate=sr, num_steps=3, length=L0, embedding_scale=2.0,
+                                cut_prefix=True, cut_length=L0 // 2)
+    assert [f.name for f in files] == ["0.wav", "1.wav", "2.wav"]
+    with wave.open(str(files[2]), "rb") as w:
+        assert w.getframerate() == sr and w.getnframes() == L0 // 2
