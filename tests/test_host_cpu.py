@@ -158,3 +158,44 @@ def test_committed_bench_line_follows_the_contract():
     cpu = line["cpu_baseline"]
     assert cpu["kind"] in ("port", "reference") and cpu["cores"] >= 1 and cpu["value"] > 0 and isinstance(cpu["sample"], str)
     assert abs(line["value"] - line["n_gpus"] * line["steps"] / (line["ms_per_step"] * line["steps"] / 1e3)) / line["value"] < 1e-2
+
+
+@pytest.mark.autograd
+def test_fit_batches_windows_on_a_cpu_stub():
+    """training.fit_batches (exp/train_diffusion_gh.yaml:91-92) is host logic: accumulation windows, the trailing partial window,
+    clip-by-global-norm and the on_step callback, on a stub module whose training_step is a plain torch expression."""
+    import torch
+
+    from syncfusion_amd.training import fit_batches
+
+    class Stub(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.tensor([1.0, -2.0, 3.0]))
+
+        def training_step(self, batch, idx):
+            return ((self.w * batch).sum()) ** 2
+
+    def run(acc, clip, n):
+        m = Stub()
+        opt = torch.optim.SGD(m.parameters(), lr=0.01)
+        seen = []
+        batches = [torch.tensor([0.1 * (i + 1), 0.2, -0.3]) for i in range(n)]
+        losses = fit_batches(m, opt, batches, accumulate_grad_batches=acc, gradient_clip_val=clip, on_step=lambda i, l: seen.append(i))
+        return m.w.detach().clone(), losses, seen, batches
+
+    w, losses, seen, batches = run(2, 0.5, 5)
+    assert len(losses) == 5 and seen == [1, 2, 3]                          # windows (2, 2, 1): the trailing batch is applied too
+    ref = Stub()
+    opt = torch.optim.SGD(ref.parameters(), lr=0.01)
+    for win in ([0, 1], [2, 3], [4]):
+        opt.zero_grad()
+        for i in win:
+            (ref.training_step(batches[i], i) / 2).backward()
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.5)
+        opt.step()
+    assert torch.allclose(w, ref.w.detach(), rtol=0, atol=1e-7)
+    w1, _, seen1, _ = run(1, None, 3)
+    assert seen1 == [1, 2, 3] and not torch.equal(w1, torch.tensor([1.0, -2.0, 3.0]))
+    with pytest.raises(ValueError):
+        run(0, None, 1)
