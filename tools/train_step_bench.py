@@ -73,6 +73,7 @@ def main() -> int:
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-optimizer", action="store_true")
+    ap.add_argument("--fused", action="store_true", help="torch.optim.AdamW(fused=True) with the reference's hyper-parameters")
     ap.add_argument("--graph", action="store_true", help="capture forward + backward in a torch CUDA graph (static batch buffers) and replay it")
     args = ap.parse_args()
     import torch
@@ -84,6 +85,9 @@ def main() -> int:
     torch.manual_seed(0)
     model = sa.instantiate(model_config()).to(dev)
     opt = model.configure_optimizers()
+    if args.fused:
+        opt = torch.optim.AdamW(list(model.model.parameters()) + list(model.onsets_encoder.parameters()), lr=model.lr, betas=(model.lr_beta1, model.lr_beta2),
+                                eps=model.lr_eps, weight_decay=model.lr_weight_decay, fused=True)
     g = torch.Generator().manual_seed(1)
     x = torch.randn(args.batch, 1, args.length, generator=g).to(dev)
     y = (torch.rand(args.batch, 1, args.length, generator=g) < 0.0005).float().to(dev)
