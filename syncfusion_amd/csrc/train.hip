@@ -709,7 +709,7 @@ int conv_wgrad_splits(int64_t rows, int C, int N, int taps) {
   const int64_t tiles = (int64_t)((N + T - 1) / T) * ((Q + T - 1) / T);
   int64_t S = std::max<int64_t>(1, (fam ? 512 : 2048) / std::max<int64_t>(tiles, 1));
   S = std::min<int64_t>(S, std::max<int64_t>(1, rows / 256));
-  return (int)std::min<int64_t>(S, 1024);
+  return (int)std::min<int64_t>(S, 512);   // >= 2 workgroups per CU; more splits only lengthen the reduction
 }
 
 hipError_t launch_conv_wgrad(const float *dy, const float *act, int B, int L, int C, int N, int taps, int pad, float *partial, int S, float *dw,
