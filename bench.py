@@ -195,6 +195,20 @@ def extra_workloads(model, device, args, noise, channels, emb) -> dict:
                     algorithmic_tflop_per_step=round(w["flops"] / 1e12, 3), tflops=round(w["flops"] / 1e12 / (ms * 1e-3), 1),
                     step_roofline_frac=round(roof_ms(B, 2, L0, args.dtype) / ms, 4))
 
+    def config3_leg():
+        # BASELINE configs[3]: 256 clips over 8 GPUs = 32 clips per GPU, no guidance: one GPU's share (the N-GPU run itself is the
+        # driver's `--gpus N` weak-scaling sweep of configs[1])
+        B, steps = 32, 10
+        nz = torch.randn(B, 1, L0, generator=torch.Generator().manual_seed(1000)).to(device)
+        ch, e = synthetic_conditioning(model, B, L0, device, real=True)
+        rate, o = timed_sample(model, device, nz, ch, e, 1.0, steps, warm=2)
+        assert torch.isfinite(o).all()
+        ms = 1e3 / rate
+        w = workmodel.unet_work(hp, L0, B, 1, ES[args.dtype])
+        return dict(workload="BASELINE configs[3], one GPU's share: batch=32 (256 clips / 8 GPUs), no guidance", steps_per_s=round(rate, 2),
+                    ms_per_step=round(ms, 3), clip_steps_per_s=round(rate * B, 1), dtype=args.dtype, timed_steps=steps,
+                    tflops=round(w["flops"] / 1e12 / (ms * 1e-3), 1), step_roofline_frac=round(roof_ms(B, 1, L0, args.dtype) / ms, 4))
+
     def reference_leg():
         B, L, scale, steps = 10, 262144, 2.0, 4      # exp/evaluate_gh_gen.yaml:8 (length), :21 (batch_size), :23 (embedding_scale)
         nz = torch.randn(B, 1, L, generator=torch.Generator().manual_seed(1000)).to(device)
@@ -296,6 +310,7 @@ def extra_workloads(model, device, args, noise, channels, emb) -> dict:
     if args.dtype != "fp32":
         leg("fp32_config1", fp32_leg)
     leg("config2_b32_cfg", config2_leg)
+    leg("config3_share_b32", config3_leg)
     leg("reference_eval_shape", reference_leg)
     leg("onset_net_n32", onset_leg)
     leg("e2e_config4_fp16", e2e_leg)
