@@ -442,7 +442,8 @@ bool conv_gemm_prefers_mt(const ConvGemmArgs &a) {
   static const int min_tiles = [] {   // tuning hook
     const char *e = getenv("SF_MT_TILES");
     const int v = e ? atoi(e) : 0;
-    return v > 0 ? v : 80;
+    return v > 0 ? v : 40;   // re-measured with the later tile variants: batch 32 without guidance 218 (80) -> 230 (40) steps/s, batch 16 335 -> 341,
+                             // batch 32 with guidance and batch 8 unchanged
   }();
   // outputs of <= 64 columns: half-empty 128-wide tiles lose to the 64x64 kernel (346 vs 259 TFLOP/s on the onset net's 192 -> 64
   // temporal convolution); the 128x64 tile with two workgroups per CU (video geometry) wins (542 vs 770 us on that shape)
