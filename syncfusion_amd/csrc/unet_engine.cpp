@@ -536,7 +536,9 @@ Plan make_plan(const sf_unet &u, Workspace &ws, int B, int L0, bool two, int num
     // chain length, not the rows per launch, sets the time); 16: 320 vs 262; from 32 evaluations on the launches are long enough
     // to fill the chip and ONE branch wins (32: 210 vs 203, 32 with guidance 211 vs 198, 64 with guidance 154 vs 151) -- it also
     // spares the two-stream step graph that guidance needs
-    int want = u.branches_override > 0 ? u.branches_override : ((p.Bt >= 4 && p.Bt < 32) ? 2 : 1);
+    // (re-measured with the later kernels: 32 evaluations 232 -> 253 steps/s with two branches, 16 clips with guidance 233 -> 243,
+    // 40 / 48 evaluations +1 ... 3 %, 64 evaluations 163 -> 153: two branches up to 48 evaluations)
+    int want = u.branches_override > 0 ? u.branches_override : ((p.Bt >= 4 && p.Bt <= 48) ? 2 : 1);
     if (want > sf_unet::kMaxBranches) want = sf_unet::kMaxBranches;
     while (want > 1 && p.Bt % want) --want;
     p.nbr = u.dbg.buf ? 1 : want;
