@@ -432,6 +432,15 @@ const char *conv_gemm_variant_name(int dt, const ConvGemmArgs &a) { return label
 // engine's second clip-parallel branch fills most of the rest (measured on BASELINE configs[2]: threshold 160 -> 138, 80 -> 145.5
 // steps/s; alone on the chip the 64x64 kernel still wins below ~160 tiles, tools/gemm_mt.py).  K >= 256: the three-slot ring
 // needs a few steps to reach steady state.
+static long short_act_tiles() {   // tuning hook: below this many 64x64 tiles a GEMM goes to the wave-split-K / wave-private kernels
+  static const long v = [] {
+    const char *e = getenv("SF_SHORT_TILES");
+    const long t = e ? atol(e) : 0;
+    return t > 0 ? t : 500L;
+  }();
+  return v;
+}
+
 bool conv_gemm_prefers_mt(const ConvGemmArgs &a) {
   static const int mode = [] {   // SF_MT=0 disables the kernel, SF_MT=2 prefers it wherever it is eligible (tuning / tests)
     const char *e = getenv("SF_MT");
@@ -461,7 +470,7 @@ static const char *variant_name_bf16(int dt, const ConvGemmArgs &a) {
   static const char *fast_names[2][3] = {{"conv_gemm_fast<f32,64x64>", "conv_gemm_fast<f32,64x32>", "conv_gemm_fast<f32,32x32>"},
                                          {"conv_gemm_fast<bf16,64x64>", "conv_gemm_fast<bf16,64x32>", "conv_gemm_fast<bf16,32x32>"}};
   const long t64 = (long)((a.M + 63) / 64) * ((a.n_store + 63) / 64);
-  const bool short_act = t64 < 500 && a.K >= 256 && (a.K % 32) == 0 && (a.cin % 32) == 0 && (a.cin2 % 32) == 0;
+  const bool short_act = t64 < short_act_tiles() && a.K >= 256 && (a.K % 32) == 0 && (a.cin % 32) == 0 && (a.cin2 % 32) == 0;
   if (!short_act) {
     V2Plan pl;
     if (conv_gemm_v2_plan(dt, a, pl)) return conv_gemm_v2_name(dt, pl);
@@ -485,7 +494,7 @@ bool conv_gemm_emits_rowpart(int dt, const ConvGemmArgs &a) {
   }
   if ((a.n_store % 32) || a.n_store != a.N) return false;
   const long t64 = (long)((a.M + 63) / 64) * ((a.n_store + 63) / 64);
-  const bool short_act = t64 < 500 && a.K >= 256 && (a.K % 32) == 0 && (a.cin % 32) == 0 && (a.cin2 % 32) == 0;
+  const bool short_act = t64 < short_act_tiles() && a.K >= 256 && (a.K % 32) == 0 && (a.cin % 32) == 0 && (a.cin2 % 32) == 0;
   if (!(short_act || use_sk(a))) return false;                 // would go to v2 / the classic tiles
   if ((a.cin % 32) || (a.cin2 % 32) || (a.K % 32)) return false;
   if (conv_gemm_sk_variant(a) != 2) return false;              // 32x32 tiles only
@@ -500,7 +509,7 @@ hipError_t launch_conv_gemm(int dt, const ConvGemmArgs &a, hipStream_t s) {
   if (f.path == 6) return launch_conv_gemm_mt(dt, a, s);
   if (f.path == 0 && conv_gemm_mt_ok(dt, a) && conv_gemm_prefers_mt(a)) return launch_conv_gemm_mt(dt, a, s);
   const long t64 = (long)((a.M + 63) / 64) * ((a.n_store + 63) / 64);
-  const bool short_act = t64 < 500 && a.K >= 256 && (a.K % 32) == 0 && (a.cin % 32) == 0 && (a.cin2 % 32) == 0;
+  const bool short_act = t64 < short_act_tiles() && a.K >= 256 && (a.K % 32) == 0 && (a.cin % 32) == 0 && (a.cin2 % 32) == 0;
   if (f.path == 4 || (f.path == 0 && !short_act)) {
     V2Plan pl;   // long activations: classic 2x2-wave tiles, channel counts that are multiples of 64, no prologue
     if (conv_gemm_v2_plan(dt, a, pl)) return launch_conv_gemm_v2(dt, a, pl, s);

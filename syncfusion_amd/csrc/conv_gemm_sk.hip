@@ -8,6 +8,8 @@
 // the four partial tiles are summed through LDS in the epilogue (deterministic order, no atomics, no second
 // launch).  Small tiles (32x32 .. 64x64) give 200-700 workgroups on those layers.  W tiles are re-read by
 // every row-tile, so the block->tile map keeps all row-tiles of one W panel on one XCD (shared L2).
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -381,8 +383,13 @@ hipError_t launch_conv_gemm_wp(int dt, const ConvGemmArgs &a, int variant, hipSt
 // at <= 512 tiles of 32x32 -- every GEMM of depths 3-7 at batch 4 except the widest qkv projections -- the staged
 // kernel's two barriers per chunk cost more than the operand sharing they buy.
 bool conv_gemm_prefers_wp(const ConvGemmArgs &a) {
+  static const long max_tiles = [] {   // tuning hook
+    const char *e = getenv("SF_WP_TILES");
+    const long v = e ? atol(e) : 0;
+    return v > 0 ? v : 512L;
+  }();
   const long tiles = (long)((a.M + 31) / 32) * ((a.n_store + 31) / 32);
-  return (tiles <= 512 && a.K >= 256) || (a.M <= 512 && a.K >= 2048);
+  return (tiles <= max_tiles && a.K >= 256) || (a.M <= 512 && a.K >= 2048);
 }
 
 hipError_t launch_conv_gemm_sk(int dt, const ConvGemmArgs &a, hipStream_t s) {
