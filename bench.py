@@ -392,7 +392,8 @@ def main() -> int:
     evals = 2 if args.scale != 1.0 else 1
     sigma = torch.full((B,), 0.5, device=device)
     net.engine().profile_forward(noise, sigma, channels, emb, args.scale)          # warm
-    recs = net.engine().profile_forward(noise, sigma, channels, emb, args.scale)
+    recs5 = net.engine().profile_forward(noise, sigma, channels, emb, args.scale, with_depth=True)
+    recs = [r[:4] for r in recs5]
     if args.dump_launches:
         with open(args.dump_launches, "w") as f:
             for i, (label, ms, fl, by) in enumerate(recs):
@@ -404,6 +405,12 @@ def main() -> int:
     # empty-kernel event time overlaps with a real kernel's own launch ramp, so half of it is subtracted.
     overhead_ms = 0.5 * max(0.0, (calib[len(calib) // 2] if calib else 0.0) - 1.5e-3)
     recs = [(label, max(ms - overhead_ms, 1e-4), fl, by) for label, ms, fl, by in recs if label != "calib_empty"]
+    depth_ms = defaultdict(float)      # device time of the instrumented evaluation by U-Net depth (-1: per-step features)
+    depth_n = defaultdict(int)
+    for label, ms, _, _, dep in recs5:
+        if label != "calib_empty":
+            depth_ms[dep] += max(ms - overhead_ms, 1e-4)
+            depth_n[dep] += 1
     agg = defaultdict(lambda: [0.0, 0.0, 0.0, 0])
     for label, ms, fl, by in recs:
         a = agg[label]
@@ -458,6 +465,30 @@ def main() -> int:
     roof["step_roofline_ms"] = round(t_roof, 4)
     roof["step_roofline_frac"] = round(t_roof / ms_per_step, 5)
     roof["step_hbm_gbs_algorithmic"] = round(work["bytes"] / 1e9 / (ms_per_step * 1e-3), 1)
+    # Per-depth-group roofline: depths 0-3 against the HBM peak, depths 4-7 against the dense MFMA peak.  Work = the
+    # closed-form algorithmic bytes / FLOPs of those depths for one step (weights once); time = the group's share of the TIMED step
+    # (ms_per_step apportioned by the device time of the group's launches in the instrumented evaluation, where the clip-parallel
+    # branches run one after another); `frac_serial` prices the same work against the un-overlapped device time itself.
+    nd = len(work["flops_by_depth"])
+    split = min(4, nd)
+    dev_total = sum(depth_ms.values())
+    groups = {}
+    for name, ds, bound in ((f"d0-{split - 1}", range(0, split), "hbm"), (f"d{split}-{nd - 1}", range(split, nd), "mfma")):
+        if len(ds) == 0:
+            continue
+        g_ms = sum(depth_ms.get(d, 0.0) for d in ds)
+        share_ms = ms_per_step * g_ms / max(dev_total, 1e-9)
+        fl = sum(work["flops_by_depth"][d] for d in ds)
+        by = sum(work["bytes_by_depth"][d] for d in ds)
+        if bound == "hbm":
+            a_step, a_ser, pk, unit = by / 1e9 / (share_ms * 1e-3), by / 1e9 / (g_ms * 1e-3), PEAK_HBM_GBS, "GB/s"
+        else:
+            a_step, a_ser, pk, unit = fl / 1e12 / (share_ms * 1e-3), fl / 1e12 / (g_ms * 1e-3), peak, "TFLOP/s"
+        groups[name] = dict(bound=bound, achieved=round(a_step, 3), peak=pk, unit=unit, frac=round(a_step / pk, 5),
+                            frac_serial=round(a_ser / pk, 5), step_share_ms=round(share_ms, 4), device_ms_serial=round(g_ms, 4),
+                            launches=sum(depth_n.get(d, 0) for d in ds), algorithmic_gb=round(by / 1e9, 4),
+                            algorithmic_tflop=round(fl / 1e12, 4))
+    roof["depth_groups"] = groups
 
     # ---------------- cpu_baseline: the oracle on this box's host cores, bounded sample ----------------
     cpu = None

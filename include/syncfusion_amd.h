@@ -127,6 +127,9 @@ int sf_unet_set_branches(sf_unet *h, int n);
 int sf_unet_profile_enable(sf_unet *h, int on);
 int sf_unet_profile_count(const sf_unet *h);
 int sf_unet_profile_get(const sf_unet *h, int i, char *name_out, int name_cap, float *ms, double *flops, double *bytes);
+/* U-Net depth (block index, 0 = outermost) of profile record i; -1 for per-step features, -2 for a bad index.  Feeds the
+ * per-depth-group roofline SURVEY.md section 8d asks for (HBM side for depths 0-3, MFMA side for depths 4-7). */
+int sf_unet_profile_depth(const sf_unet *h, int i);
 
 /* ------------------------------------------------------------------------------------------
  * Encoder1d (onset-track feature pyramid)

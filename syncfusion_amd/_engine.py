@@ -153,8 +153,9 @@ class UNetEngine(_Base):
     def graph_captures(self) -> int:
         return int(self.lib.sf_unet_graph_captures(self.handle))
 
-    def profile_forward(self, x, sigma, channels, embedding, embedding_scale=1.0):
-        """One evaluation with HIP events around every launch -> [(label, ms, algorithmic flops, algorithmic bytes)]."""
+    def profile_forward(self, x, sigma, channels, embedding, embedding_scale=1.0, with_depth: bool = False):
+        """One evaluation with HIP events around every launch -> [(label, ms, algorithmic flops, algorithmic bytes)]
+        (``with_depth``: a fifth member, the U-Net depth the launch belongs to, -1 for per-step features)."""
         check(self.lib.sf_unet_profile_enable(self.handle, 1), "sf_unet_profile_enable")
         try:
             self.forward(x, sigma, channels, embedding, embedding_scale)
@@ -163,7 +164,8 @@ class UNetEngine(_Base):
                 name = C.create_string_buffer(128)
                 ms, fl, by = C.c_float(), C.c_double(), C.c_double()
                 check(self.lib.sf_unet_profile_get(self.handle, i, name, 128, C.byref(ms), C.byref(fl), C.byref(by)), "profile_get")
-                recs.append((name.value.decode(), ms.value, fl.value, by.value))
+                rec = (name.value.decode(), ms.value, fl.value, by.value)
+                recs.append(rec + (self.lib.sf_unet_profile_depth(self.handle, i),) if with_depth else rec)
         finally:
             self.lib.sf_unet_profile_enable(self.handle, 0)
         return recs

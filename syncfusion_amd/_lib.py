@@ -69,6 +69,7 @@ SYMBOLS = {
     "sf_unet_profile_enable": (_I, [_P, _I]),
     "sf_unet_profile_count": (_I, [_P]),
     "sf_unet_profile_get": (_I, [_P, _I, C.c_char_p, _I, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "sf_unet_profile_depth": (_I, [_P, _I]),
     "sf_encoder1d_create": (_I, [C.POINTER(EncoderConfig), C.POINTER(SfTensor), _I, _P, C.POINTER(_P)]),
     "sf_encoder1d_destroy": (None, [_P]),
     "sf_encoder1d_workspace_bytes": (_L, [_P, _I, _I]),

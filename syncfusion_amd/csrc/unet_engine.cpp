@@ -97,6 +97,7 @@ struct sf_unet {
     double flops, bytes;
     hipEvent_t e0, e1;
     float ms;
+    int depth;   // U-Net depth the launch belongs to (-1: per-step features / sampler glue)
   };
   bool prof_on = false;
   std::vector<ProfRec> prof;
@@ -598,6 +599,7 @@ struct Exec {
   Plan &p;
   hipStream_t s;
   const void *stats_of = nullptr;   // thin levels: the activation whose GroupNorm partials currently sit in p.slab
+  int cur_depth = -1;               // depth tag of the launches being issued (profile records, roofline.depth_groups)
 
   template <class F> void timed(const char *label, double flops, double bytes, F &&f) {
     ++u.launches;
@@ -609,7 +611,7 @@ struct Exec {
     SF_HIP(hipEventRecord(e0, s));
     f();
     SF_HIP(hipEventRecord(e1, s));
-    u.prof.push_back({label, flops, bytes, e0, e1, 0.f});
+    u.prof.push_back({label, flops, bytes, e0, e1, 0.f, cur_depth});
   }
 
   ConvGemmArgs filled(const ConvW &w, ConvGemmArgs a) const {
@@ -1039,6 +1041,7 @@ struct Exec {
     const int Lprev = l.L * b.factor;
     void *cur = l.buf[0], *tA = l.buf[1], *tB = l.buf[2];
     stats_of = nullptr;
+    cur_depth = d;
     bool down_done = false;
     if (!b.down.direct && xin_dt == u.dt) {   // patchify conv on the (rows/f, f*cin) view as a thin-level kernel
       const ThinPlan tp = conv_thin_plan(p.Bt, l.L, l.C);
@@ -1095,6 +1098,7 @@ struct Exec {
     for (size_t j = 0; j < b.down_items.size(); ++j) group(b.down_items[j], d, cur, tA, tB, pre + ".items_down." + std::to_string(j));
     if (d + 1 < c.n_layers) {
       const bool have = block(d + 1, cur, u.dt, tA, u.dt);
+      cur_depth = d;
       void *o = cur;
       cur = tA;
       tA = o;
@@ -1685,6 +1689,10 @@ int sf_unet_profile_enable(sf_unet *h, int on) {
   return SF_OK;
 }
 int sf_unet_profile_count(const sf_unet *h) { return h ? (int)h->prof.size() : -1; }
+int sf_unet_profile_depth(const sf_unet *h, int i) {
+  if (!h || i < 0 || i >= (int)h->prof.size()) return -2;
+  return h->prof[i].depth;
+}
 int sf_unet_profile_get(const sf_unet *h, int i, char *name_out, int name_cap, float *ms, double *flops, double *bytes) {
   if (!h || i < 0 || i >= (int)h->prof.size()) return SF_ERR_INVALID;
   const auto &r = h->prof[i];

@@ -5,8 +5,12 @@ Reference loop body (main/generation.py:49-103): ``noise = randn(B,1,length)`` -
 zero everything before the first onset (``cut_prefix``), crop to ``cut_length``, resample, save.
 ``generate_batch`` is that body up to (not including) the CPU resample/save, with the same keyword
 names; the DataLoader / WebDataset / torchaudio.save plumbing around it is out of scope (SURVEY.md
-section 2 rows 5 and 8f-2) -- ``generate_dataset`` accepts any iterable of reference-shaped batches
-``(x, y, z, text, filenames)`` and writes 16-bit PCM wav files with the standard library.
+section 2 rows 5 and 8f-2).  ``generate_dataset`` takes what the reference passes it -- an UN-batched dataset of
+``(x, y, z, text, filename)`` chunks (``exp/evaluate_gh_gen.yaml:21,31-40``: ``create_sfx_dataset(...)`` + ``batch_size``) -- and
+batches it itself with ``batch_size`` / ``num_workers`` + ``collate_fn`` as main/generation.py:37-38 does; an iterable of
+already-collated batches is passed through.  Output files are 16-bit PCM wav written with the standard library
+(``torchaudio.save`` of a float tensor, :104-122, writes 32-bit float wav: same names, rate and sample count; readers such as
+the FAD / onset evaluation accept either).
 """
 from __future__ import annotations
 
@@ -17,6 +21,7 @@ from typing import Iterable, List, Optional, Sequence, Union
 import torch
 
 from . import _lib
+from .input_pipeline import collate_fn
 from .onset_glue import cut_prefix_crop
 from .resample import resample
 
@@ -58,13 +63,49 @@ def save_wav(path: Union[str, Path], audio: Tensor, sample_rate: int) -> None:
         f.writeframes(a.t().contiguous().numpy().tobytes())
 
 
+def _is_collated(elem) -> bool:
+    """A collated batch carries (B, C, T) waveforms and a sequence of filenames; a dataset element (C, T) and one filename."""
+    x = elem[0]
+    return isinstance(x, torch.Tensor) and x.dim() == 3 and not isinstance(elem[4], (str, bytes))
+
+
+def iter_batches(dataset: Iterable, batch_size: int, num_workers: int = 0) -> Iterable:
+    """What ``DataLoader(dataset, batch_size=batch_size, num_workers=num_workers, collate_fn=collate_fn)`` yields
+    (main/generation.py:37-38).  torch ``Dataset`` / ``IterableDataset`` objects go through that very DataLoader; any other
+    iterable of un-collated ``(x, y, z, text, filename)`` chunks is grouped here in order (last batch short, as the
+    DataLoader's ``drop_last=False``); an iterable whose elements already are collated batches is passed through."""
+    if batch_size < 1:
+        raise ValueError(f"batch_size must be >= 1, got {batch_size}")
+    if isinstance(dataset, (torch.utils.data.Dataset, torch.utils.data.IterableDataset)):
+        yield from torch.utils.data.DataLoader(dataset, batch_size=batch_size, num_workers=num_workers, collate_fn=collate_fn)
+        return
+    it = iter(dataset)
+    try:
+        first = next(it)
+    except StopIteration:
+        return
+    if _is_collated(first):
+        yield first
+        yield from it
+        return
+    buf = [first]
+    for elem in it:
+        if len(buf) == batch_size:
+            yield collate_fn(buf)
+            buf = []
+        buf.append(elem)
+    if buf:
+        yield collate_fn(buf)
+
+
 @torch.no_grad()
 def generate_dataset(experiment_path: Union[str, Path], model, dataset: Iterable, device: str = "cuda",
                      model_path: Optional[str] = None, batch_size: int = 16, num_workers: int = 4, sample_rate: int = 48000,
                      num_steps: int = 150, length: int = 2 ** 18, embedding_scale: float = 7.5, cut_prefix: bool = False,
                      cond_text: bool = False, one_chunk_per_track: bool = False, cut_length: Optional[int] = None,
                      downsample_rate: Optional[int] = None, save_cond: bool = False) -> List[Path]:
-    """Same signature as main/generation.py:12-30.  ``dataset`` yields already-collated batches."""
+    """Same signature as main/generation.py:12-30.  ``dataset``: the reference's un-batched chunk dataset (batched here with
+    ``batch_size`` / ``num_workers`` + ``collate_fn``, :37-38) or an iterable of already-collated batches (``iter_batches``)."""
     experiment_path = Path(experiment_path)
     experiment_path.mkdir(exist_ok=True, parents=True)
     if model_path:                                                                  # :40-44
@@ -73,7 +114,7 @@ def generate_dataset(experiment_path: Union[str, Path], model, dataset: Iterable
     model.to(device)
     written: List[Path] = []
     chunk_id = 0
-    for batch in dataset:
+    for batch in iter_batches(dataset, batch_size, num_workers):
         x, y, z, text, filenames = batch
         B = x.shape[0]
         if not one_chunk_per_track:

@@ -570,6 +570,81 @@ def test_e2e_frames_to_audio_shapes(cuda, full_model):
     assert float(gen[0, :, :first].abs().max()) == 0.0
 
 
+@pytest.mark.timeout(2400)
+def test_config4_chain_fp16_index_and_audio_parity(cuda, full_model):
+    """BASELINE configs[4] in its stated arithmetic: frames -> VideoOnsetNet(fp16) -> onset glue -> Encoder1d -> 10-step
+    guided sampling (fp16 U-Net) -> cut_prefix / crop, against the CPU oracle chain.
+
+    The reference thresholds RAW logits at 0.5 (main/module_onset.py:160-162) and turns frame indices into sample positions
+    through "%.4f" seconds (:176-183, main/dataset_diffusion.py:69-72), so a 16-bit logit on the wrong side of 0.5 would move an
+    onset: the fp16 chain's onset track must be INDEX-IDENTICAL to the fp32 engine's and to the oracle's
+    (oracle.onsetnet_ref + the "%.4f" restatement).  A random-init net puts every logit near 0.1, so the last bias is shifted
+    to put the threshold in the middle of the widest gap of the sorted fp32 logits around their median (about half of the 120
+    frames fire); the margin and the 16-bit logit error are printed.  Final audio of clip 0: stated 16-bit tolerance vs
+    encoder1d_ref -> sampler_ref (guidance 2.0) -> the reference's cut / crop."""
+    from oracle import encoder1d_ref, onsetnet_ref
+    from syncfusion_amd.generation import generate_batch
+    from syncfusion_amd.onset_glue import onsets_to_track
+    from syncfusion_amd.onset_net import VideoOnsetNet
+
+    B, L0, steps, scale, fps, sr, cut = 4, 45056, 10, 2.0, 15.0, 22528.0, 44100
+    frames = torch.randn(B, 3, 30, 112, 112, generator=torch.Generator().manual_seed(4100))
+    nets = {dt: VideoOnsetNet(False, dtype=dt) for dt in ("fp32", "fp16", "bf16")}
+    state = seeded_state(nets["fp32"], 7)
+    nets["fp32"].load_state_dict(state)
+    l0 = nets["fp32"].to(cuda).eval()(frames.to(cuda)).cpu().flatten().sort().values
+    mid = l0.numel() // 2
+    gaps = l0[mid - 20:mid + 21].diff()
+    k = int(gaps.argmax())
+    thr_at = 0.5 * float(l0[mid - 20 + k] + l0[mid - 20 + k + 1])
+    state["fc.2.bias"] = state["fc.2.bias"] + (0.5 - thr_at)
+    logits = {}
+    for dt, net in nets.items():
+        net.load_state_dict(state)
+        logits[dt] = net.to(cuda).eval()(frames.to(cuda))
+    with torch.no_grad():
+        lref = onsetnet_ref.onsetnet_forward({k_: v.float() for k_, v in state.items()}, frames)
+    assert rel_l2(logits["fp32"].cpu(), lref) < FP32_TOL
+    margin = float((lref - 0.5).abs().min())
+    err16 = {dt: float((logits[dt].cpu() - lref).abs().max()) for dt in ("fp16", "bf16")}
+    fired = int((lref > 0.5).sum())
+    print(f"configs[4] chain: {fired}/{lref.numel()} frames fire; threshold margin {margin:.3e}; max |logit error| fp16 {err16['fp16']:.3e} bf16 {err16['bf16']:.3e}")
+    assert 20 < fired < 100 and err16["fp16"] < margin
+    # oracle track: threshold, "%.4f" seconds, int(t * sr)
+    want = torch.zeros(B, 1, L0)
+    for i in range(B):
+        for idx in torch.nonzero(lref[i] > 0.5).flatten().tolist():
+            pos = int(float("%.4f" % (idx / fps)) * sr)
+            if pos < L0:
+                want[i, 0, pos] = 1.0
+    tracks = {dt: onsets_to_track(logits[dt], L0, frame_rate=fps, sample_rate=sr) for dt in ("fp32", "fp16")}
+    assert torch.equal(tracks["fp32"].cpu(), want)
+    assert torch.equal(tracks["fp16"].cpu(), want), "fp16 onset track differs from the fp32 / oracle track"
+    # diffusion half in fp16 on the fp16 chain's own track
+    z = torch.randn(B, 1, L0, generator=torch.Generator().manual_seed(1)) * 0.1
+    noise = torch.randn(B, 1, L0, generator=torch.Generator().manual_seed(1000))
+    emb = full_model.clap_encode_audio(z.to(cuda))
+    with _compute_dtype(full_model, "fp16"):
+        gen16 = generate_batch(full_model, tracks["fp16"], z, num_steps=steps, length=L0, embedding_scale=scale, cut_prefix=True, cut_length=cut,
+                               noise=noise.to(cuda))
+    gen32 = generate_batch(full_model, tracks["fp32"], z, num_steps=steps, length=L0, embedding_scale=scale, cut_prefix=True, cut_length=cut,
+                           noise=noise.to(cuda))
+    assert gen16.shape == (B, 1, cut) and torch.isfinite(gen16).all()
+    enc = full_model.onsets_encoder
+    with torch.no_grad():
+        _, info_ref = encoder1d_ref.encoder1d_forward(oracle_params(enc), dict(enc.hparams), want[:1])
+        ref = _oracle_sample(full_model.model, noise[:1], steps, emb[:1].cpu(), info_ref["xs"][2:-1], scale)
+    first = int(torch.nonzero(want[0, 0])[0])                      # main/generation.py:86-89,100
+    ref[0, :, :first] = 0.0
+    ref = ref[:, :, :cut]
+    e32, e16 = rel_l2(gen32[:1].cpu(), ref), rel_l2(gen16[:1].cpu(), ref)
+    e16_32 = rel_l2(gen16.cpu(), gen32.cpu())
+    print(f"configs[4] chain, {steps} guided steps: rel-L2 vs oracle fp32 {e32:.3e}, fp16 {e16:.3e}; fp16 vs fp32 engine (4 clips) {e16_32:.3e}")
+    assert float(gen16[0, :, :first].abs().max()) == 0.0
+    assert e32 < FP32_TOL
+    assert e16 < LOWP_STEP_TOL and e16_32 < LOWP_STEP_TOL
+
+
 def test_generate_dataset_writes_resampled_wavs(cuda, tmp_path):
     """main/generation.py:49-122 end to end on a small model: resume-skip, cut_prefix, crop, device resample, wav files."""
     import wave

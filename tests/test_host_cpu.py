@@ -199,3 +199,42 @@ def test_fit_batches_windows_on_a_cpu_stub():
     assert seen1 == [1, 2, 3] and not torch.equal(w1, torch.tensor([1.0, -2.0, 3.0]))
     with pytest.raises(ValueError):
         run(0, None, 1)
+
+
+def test_iter_batches_groups_an_uncollated_dataset_like_the_reference_dataloader():
+    """main/generation.py:37-38 wraps the UN-batched chunk dataset in DataLoader(batch_size, num_workers, collate_fn);
+    generate_dataset's batching must yield exactly what that DataLoader yields -- for a plain iterable of chunks, for a torch
+    Dataset, and must pass already-collated batches through unchanged."""
+    import torch
+
+    from syncfusion_amd.generation import iter_batches
+    from syncfusion_amd.input_pipeline import collate_fn
+
+    g = torch.Generator().manual_seed(3)
+    chunks = [(torch.randn(1, 64, generator=g), torch.randn(2, 64, generator=g), torch.randn(1, 40 + 7 * i, generator=g), f"text{i}", f"dir/clip{i}")
+              for i in range(5)]
+    want = list(torch.utils.data.DataLoader(chunks, batch_size=2, num_workers=0, collate_fn=collate_fn))
+    assert [b[0].shape[0] for b in want] == [2, 2, 1]
+
+    def same(got):
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            for i in range(3):
+                assert torch.equal(a[i], b[i])
+            assert tuple(a[3]) == tuple(b[3]) and tuple(a[4]) == tuple(b[4])
+
+    same(list(iter_batches(iter(chunks), 2)))                 # a generator of chunks (what shards.sfx_chunks is)
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return len(chunks)
+
+        def __getitem__(self, i):
+            return chunks[i]
+
+    same(list(iter_batches(DS(), 2, num_workers=0)))          # a map-style torch Dataset goes through the real DataLoader
+    same(list(iter_batches(want, 16)))                        # collated batches pass through, batch_size ignored
+    assert list(iter_batches([], 4)) == []
+    import pytest
+    with pytest.raises(ValueError):
+        list(iter_batches(chunks, 0))
