@@ -40,6 +40,28 @@ DEFAULT_CONFIG = dict(
 )
 
 
+# [RECALLED] facts about a-unet that neither shapes nor the reference's call sites can settle.  Each is a switch (cfg["variants"],
+# a dict overriding these defaults) so that tools/pin_upstream.py can decide it NUMERICALLY against the installed upstream packages
+# (SURVEY.md 8f-1), and tests/test_oracle_cpu.py checks that every switch changes the output (a wrong default cannot hide).
+RECALLED_DEFAULTS = dict(
+    skip_form="skip_plus_scaled_h",   # SkipModulate: skip + s*h (default) | "h_plus_scaled_skip": h + s*skip
+    mod_ln_eps=1e-6,                  # ModulationItem LayerNorm eps: 1e-6 (default) | 1e-5 (torch default)
+    mod_ln_affine=False,              # ModulationItem LayerNorm affine: off (default) | on (uses `<item>.mod.norm.weight/.bias` when present)
+    mod_act="silu",                   # features -> SiLU -> Linear (default) | "none": Linear on the raw features
+    attn_pos_embedding=False,         # Attention adds a learned positional embedding `<attn>.pos.weight` (max_length, C) to its input: off (default)
+    attn_scale="head",                # logits * head_features**-0.5 (default) | "none"
+    upsample_mode=None,               # None: cfg["upsample_mode"] (default "nearest" = UpsampleInterpolate) | "transpose" (Upsample)
+)
+
+
+def recalled_variants(cfg) -> Dict:
+    v = dict(RECALLED_DEFAULTS)
+    v.update(cfg.get("variants") or {})
+    unknown = set(v) - set(RECALLED_DEFAULTS)
+    assert not unknown, f"unknown oracle variant switches: {sorted(unknown)}"
+    return v
+
+
 def _lin(P: Dict[str, Tensor], name: str, x: Tensor) -> Tensor:
     return F.linear(x, P[name + ".weight"], P.get(name + ".bias"))
 
@@ -65,13 +87,14 @@ def _resnet(P, pre: str, x: Tensor, groups: int) -> Tensor:
     return x + h
 
 
-def _modulation(P, pre: str, x: Tensor, f: Tensor) -> Tensor:
+def _modulation(P, pre: str, x: Tensor, f: Tensor, var=RECALLED_DEFAULTS) -> Tensor:
     # ModulationItem (A.3 item 2): LN_C(x; eps 1e-6, no affine) * (1 + s) + t
     C = x.shape[1]
-    ss = _lin(P, pre + ".to_scale_shift", F.silu(f))
+    ss = _lin(P, pre + ".to_scale_shift", F.silu(f) if var["mod_act"] == "silu" else f)
     scale, shift = ss[:, None, :].chunk(2, dim=-1)
     xt = x.transpose(1, 2)
-    xt = F.layer_norm(xt, (C,), None, None, eps=1e-6) * (1.0 + scale) + shift
+    g, b = (P.get(pre + ".norm.weight"), P.get(pre + ".norm.bias")) if var["mod_ln_affine"] else (None, None)
+    xt = F.layer_norm(xt, (C,), g, b, eps=var["mod_ln_eps"]) * (1.0 + scale) + shift
     return xt.transpose(1, 2)
 
 
@@ -81,10 +104,12 @@ def _inject(P, pre: str, x: Tensor, ctx: Tensor) -> Tensor:
     return F.conv1d(torch.cat([x, ctx], dim=1), P[pre + ".conv.weight"], P[pre + ".conv.bias"]) + x
 
 
-def _attention(P, pre: str, x: Tensor, context: Optional[Tensor], heads: int, head_features: int) -> Tensor:
+def _attention(P, pre: str, x: Tensor, context: Optional[Tensor], heads: int, head_features: int, var=RECALLED_DEFAULTS) -> Tensor:
     # AttentionItem / CrossAttentionItem (A.3 items 4-5), channels-last internally.
     xt = x.transpose(1, 2)  # (B, L, C)
     C = xt.shape[-1]
+    if var["attn_pos_embedding"] and (pre + ".pos.weight") in P:
+        xt = xt + P[pre + ".pos.weight"][: xt.shape[1]][None]
     ctx = xt if context is None else context
     q_in = F.layer_norm(xt, (C,), P[pre + ".norm.weight"], P[pre + ".norm.bias"], eps=1e-5)
     c_in = F.layer_norm(ctx, (ctx.shape[-1],), P[pre + ".norm_context.weight"], P[pre + ".norm_context.bias"], eps=1e-5)
@@ -95,7 +120,7 @@ def _attention(P, pre: str, x: Tensor, context: Optional[Tensor], heads: int, he
     q = q.reshape(B, n, heads, head_features).transpose(1, 2)
     k = k.reshape(B, m, heads, head_features).transpose(1, 2)
     v = v.reshape(B, m, heads, head_features).transpose(1, 2)
-    sim = torch.einsum("bhnd,bhmd->bhnm", q, k) * (head_features ** -0.5)
+    sim = torch.einsum("bhnd,bhmd->bhnm", q, k) * ((head_features ** -0.5) if var["attn_scale"] == "head" else 1.0)
     attn = sim.softmax(dim=-1, dtype=torch.float32)
     out = torch.einsum("bhnm,bhmd->bhnd", attn, v)
     out = out.transpose(1, 2).reshape(B, n, heads * head_features)
@@ -104,14 +129,15 @@ def _attention(P, pre: str, x: Tensor, context: Optional[Tensor], heads: int, he
 
 
 def _item_group(P, cfg, pre: str, d: int, x, f, emb, ctx):
+    var = recalled_variants(cfg)
     x = _resnet(P, pre + ".resnet", x, cfg["resnet_groups"])
-    x = _modulation(P, pre + ".mod", x, f)
+    x = _modulation(P, pre + ".mod", x, f, var)
     if cfg["context_channels"][d] > 0:
         x = _inject(P, pre + ".inject", x, ctx[d])
     if cfg["attentions"][d]:
-        x = _attention(P, pre + ".attn", x, None, cfg["attention_heads"], cfg["attention_features"])
+        x = _attention(P, pre + ".attn", x, None, cfg["attention_heads"], cfg["attention_features"], var)
     if cfg["cross_attentions"][d]:
-        x = _attention(P, pre + ".cross", x, emb, cfg["attention_heads"], cfg["attention_features"])
+        x = _attention(P, pre + ".cross", x, emb, cfg["attention_heads"], cfg["attention_features"], var)
     return x
 
 
@@ -132,7 +158,8 @@ def _block(P, cfg, d: int, x, f, emb, ctx, taps=None):
         h = _item_group(P, cfg, f"{pre}.items_up.{j}", d, h, f, emb, ctx)
         if taps is not None:
             taps[f"d{d}.items_up.{j}"] = h
-    if cfg.get("upsample_mode", "nearest") == "transpose":
+    var = recalled_variants(cfg)
+    if (var["upsample_mode"] or cfg.get("upsample_mode", "nearest")) == "transpose":
         # a-unet `Upsample` (apex.py): ConvTranspose1d(C -> in, kernel_size=factor, stride=factor); weight (C, in, factor)
         h = F.conv_transpose1d(h, P[pre + ".up.weight"], P[pre + ".up.bias"], stride=fac)
     else:
@@ -140,8 +167,8 @@ def _block(P, cfg, d: int, x, f, emb, ctx, taps=None):
         h = F.interpolate(h, scale_factor=fac, mode="nearest")
         h = F.conv1d(h, P[pre + ".up.weight"], P[pre + ".up.bias"], padding=1)
     # SkipModulate: skip + Linear(SiLU(f))[:, :, None] * h
-    scale = _lin(P, pre + ".skip.to_scale", F.silu(f))
-    out = skip + scale[:, :, None] * h
+    scale = _lin(P, pre + ".skip.to_scale", F.silu(f) if var["mod_act"] == "silu" else f)
+    out = (skip + scale[:, :, None] * h) if var["skip_form"] == "skip_plus_scaled_h" else (h + scale[:, :, None] * skip)
     if taps is not None:
         taps[f"d{d}.out"] = out
     return out

@@ -22,17 +22,25 @@ networked machine.  Because of that the translation does not trust names more th
    reliably, but the ORDER of registration follows the forward order of the network, which the oracle restates:
    ``[time embedding] -> block_d( down, items_down..., block_{d+1}, items_up..., up ) -> skip scale``, and inside an item
    ``resnet(gn1, conv1, gn2, conv2) -> modulation -> inject -> attention(norm, norm_context, to_q, to_kv, to_out) ->
-   cross-attention(same)``.  Two placements cannot be settled by shapes alone and are explicit hypotheses
-   (``OrderHypothesis``): whether the time-embedding parameters are registered before or after the U-Net, and whether a
-   block's SkipModulate ``Linear`` comes before or after the block's items.  ``tools/pin_upstream.py`` decides them
-   numerically (the wrong choice changes the network's output).
+   cross-attention(same)``.  Three placements cannot be recalled and are explicit hypotheses (``OrderHypothesis``): whether the
+   time-embedding parameters are registered before or after the U-Net, whether a block's SkipModulate ``Linear`` comes before
+   or after the block's items, and whether the guidance plugin's fixed embedding precedes or follows the network it wraps.
+   They are NOT guessed when a checkpoint is loaded: a ``state_dict`` keeps registration order, so the checkpoint's own
+   SEQUENCE of (shape, weight/bias) pairs is compared position by position with the sequence each hypothesis predicts
+   (``infer_order``).  In the reference configuration several tensors have shapes that occur nowhere else (the 1024 x 1025
+   time projection, the 1 x 1024 and 8 x 1024 SkipModulate projections, the 8 x 1 x 1 first down-convolution), so exactly
+   one hypothesis fits and a wrong one cannot load permuted weights silently; if several fit and would pair tensors
+   differently a ``UnpinnedOrderWarning`` is raised, if none fits the load fails with the first position that differs.
+   ``tools/pin_upstream.py`` additionally confirms the choice numerically against the installed upstream packages.
 
 Every translation is verified: each local parameter receives exactly one tensor of its own shape, nothing is left over
 except ignorable subtrees, otherwise ``KeyMapError`` names what did not fit.
 """
 from __future__ import annotations
 
+import os
 import re
+import warnings
 from collections import OrderedDict, defaultdict
 from dataclasses import dataclass
 from typing import Dict, Iterable, List, Mapping, Optional, Tuple
@@ -46,15 +54,21 @@ class KeyMapError(RuntimeError):
     pass
 
 
+class UnpinnedOrderWarning(UserWarning):
+    """Several registration-order hypotheses fit a checkpoint and pair its tensors differently: the load is a guess."""
+
+
 @dataclass(frozen=True)
 class OrderHypothesis:
-    """The two registration-order facts about a-unet that shapes cannot settle ([RECALLED] defaults)."""
+    """The registration-order facts about a-unet that cannot be recalled ([RECALLED] defaults; decided per checkpoint by
+    ``infer_order`` from the checkpoint's own tensor sequence, confirmed numerically by tools/pin_upstream.py)."""
     time_first: bool = False     # TimeConditioningPlugin builds `net` first, then its embedding MLP ([RECALLED])
     skip_last: bool = True       # SkipModulate's Linear is registered after the wrapped items ([RECALLED])
+    cfg_last: bool = True        # ClassifierFreeGuidancePlugin registers `net` first, then its FixedEmbedding ([RECALLED])
 
     @staticmethod
     def all() -> List["OrderHypothesis"]:
-        return [OrderHypothesis(a, b) for a in (False, True) for b in (True, False)]
+        return [OrderHypothesis(a, b, c) for a in (False, True) for b in (True, False) for c in (True, False)]
 
 
 IGNORED_PREFIXES = ("clap.", "embedder.")
@@ -113,8 +127,35 @@ def unet_forward_order(hp: Mapping, hyp: OrderHypothesis = OrderHypothesis()) ->
         return out
 
     # ClassifierFreeGuidancePlugin wraps the XUNet and owns the fixed embedding; TimeConditioningPlugin wraps both
-    inner = block(0) + cfg
+    inner = (block(0) + cfg) if hyp.cfg_last else (cfg + block(0))
     return (time + inner) if hyp.time_first else (inner + time)
+
+
+def _seq(names: Iterable[str], shapes: Mapping[str, Tuple[int, ...]]) -> List[Tuple[Tuple[int, ...], str]]:
+    return [(tuple(shapes[k]), _kind(k)) for k in names]
+
+
+def infer_order(src: "Mapping[str, Tensor]", hp: Mapping, dst_shapes: Mapping[str, Tuple[int, ...]]) -> Tuple[List[OrderHypothesis], str]:
+    """Which hypotheses predict the checkpoint's own (shape, weight/bias) SEQUENCE, position by position?
+
+    Returns (matching hypotheses, diagnostic): the diagnostic names, for the best non-matching hypothesis, the first position
+    at which the checkpoint's sequence departs from the prediction."""
+    have = [(tuple(v.shape), _kind(k)) for k, v in src.items()]
+    fits, best = [], (-1, "")
+    for hyp in OrderHypothesis.all():
+        want = _seq(unet_forward_order(hp, hyp), dst_shapes)
+        n = 0
+        while n < min(len(have), len(want)) and have[n] == want[n]:
+            n += 1
+        if n == len(have) == len(want):
+            fits.append(hyp)
+        elif n > best[0]:
+            order = unet_forward_order(hp, hyp)
+            got = list(src)[n] if n < len(have) else "<end of checkpoint>"
+            exp = order[n] if n < len(want) else "<end of model>"
+            best = (n, f"under {hyp} the sequences agree for {n} of {len(want)} tensors; then the checkpoint has `{got}` "
+                       f"{have[n] if n < len(have) else ''} where the model expects `{exp}` {want[n] if n < len(want) else ''}")
+    return fits, best[1]
 
 
 def match_by_structure(src: "OrderedDict[str, Tensor]", dst_order: List[str], dst_shapes: Mapping[str, Tuple[int, ...]]) -> Dict[str, str]:
@@ -179,7 +220,32 @@ def translate_state_dict(sd: Mapping[str, Tensor], model: torch.nn.Module, hypot
     else:
         order = unet_forward_order(net.hparams, hyp)
         assert set(order) == set(net_own), "internal: forward-order list out of sync with UNetV0._build"
-        pairing = match_by_structure(src, order, net_own)
+        match_by_structure(src, order, net_own)          # per-class counts first: a clearer error for a wrong configuration
+        fits, why = infer_order(src, net.hparams, net_own)
+        if hypothesis is not None:
+            if fits and hypothesis not in fits:
+                raise KeyMapError(f"the checkpoint's tensor order contradicts the requested {hypothesis}: it fits {fits}")
+            chosen = hypothesis
+        elif len(fits) == 1:
+            chosen = fits[0]                               # pinned by the checkpoint's own registration order
+        elif fits:
+            pairs = {h: tuple(sorted(match_by_structure(src, unet_forward_order(net.hparams, h), net_own).items())) for h in fits}
+            chosen = hyp if hyp in fits else fits[0]
+            if len(set(pairs.values())) > 1:
+                warnings.warn(f"U-Net checkpoint: {len(fits)} registration-order hypotheses fit and pair tensors of equal shape "
+                              f"differently; loading under {chosen} is a guess (run tools/pin_upstream.py or pass hypothesis=)",
+                              UnpinnedOrderWarning, stacklevel=2)
+        else:
+            chosen = None
+        if chosen is None and not os.environ.get("SF_KEYMAP_ALLOW_CLASS_PAIRING"):
+            raise KeyMapError("the checkpoint's U-Net tensors are not in any modelled registration order, so tensors of equal shape "
+                              "(e.g. the 1024 x 1024 time-MLP / Modulation / SkipModulate projections) cannot be told apart: "
+                              + why + ".  Set SF_KEYMAP_ALLOW_CLASS_PAIRING=1 to pair them by (shape, kind) in checkpoint order anyway.")
+        if chosen is None:
+            chosen = hyp
+            warnings.warn("U-Net checkpoint paired by (shape, kind) only -- tensors of equal shape may be permuted: " + why,
+                          UnpinnedOrderWarning, stacklevel=2)
+        pairing = match_by_structure(src, unet_forward_order(net.hparams, chosen), net_own)
         for dst, s in pairing.items():
             out["model.net." + dst] = src[s]
     other = [k for k in sd if not k.startswith(("model.net.", "onsets_encoder."))]

@@ -94,19 +94,34 @@ class Model(_Base):
         for param in self.clap.parameters():
             param.requires_grad = False
 
-    def load_state_dict(self, state_dict, strict: bool = True, hypothesis=None, **kwargs):
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False, *, hypothesis=None):
         """``model.load_state_dict(checkpoint['state_dict'])`` as main/generation.py:43 calls it.  Accepts this build's key
         layout AND the upstream one (audio_diffusion_pytorch / a-unet / audio_encoders_pytorch module trees; see
         syncfusion_amd/keymap.py for how, and for what is [RECALLED] about it).  The frozen embedder's ``clap.*`` tensors
-        are loaded only when this model's embedder actually has those keys (the offline stub does not)."""
-        from .keymap import IGNORED_PREFIXES, translate_state_dict
+        are loaded only when this model's embedder actually has those keys (the offline stub does not).  Positional signature =
+        ``nn.Module.load_state_dict(state_dict, strict, assign)``; ``hypothesis`` (a ``keymap.OrderHypothesis``) is keyword-only.
+        ``strict=False`` tolerates what nn.Module tolerates: with this build's own key layout, missing keys keep their current
+        values and unexpected keys are reported in the returned ``_IncompatibleKeys`` instead of raising."""
+        from .keymap import IGNORED_PREFIXES, KeyMapError, translate_state_dict
 
-        mapped = translate_state_dict(state_dict, self, hypothesis)
         own = super().state_dict()
+        try:
+            mapped = translate_state_dict(state_dict, self, hypothesis)
+            extra = {}
+        except KeyMapError:
+            # strict=False on a partial checkpoint in this build's OWN layout: hand torch what matches, let it report the rest
+            if strict or not any(k in own for k in state_dict):
+                raise
+            mapped = {k: v for k, v in state_dict.items() if k in own}
+            extra = {k: v for k, v in state_dict.items() if k not in own and not k.startswith(IGNORED_PREFIXES)}
+        if not extra and all(k in state_dict for k in mapped):      # local layout: unexpected non-embedder keys are torch's to report
+            extra = {k: v for k, v in state_dict.items() if k not in own and not k.startswith(IGNORED_PREFIXES)
+                     and not k.startswith(("model.diffusion.net.", "model.sampler.net."))}
         for k in own:
             if k.startswith(IGNORED_PREFIXES):
                 mapped[k] = state_dict[k] if k in state_dict and tuple(state_dict[k].shape) == tuple(own[k].shape) else own[k]
-        return super().load_state_dict(mapped, strict=strict, **kwargs)
+        mapped.update(extra)
+        return super().load_state_dict(mapped, strict=strict, assign=assign)
 
     def configure_optimizers(self):
         """main/module_diffusion.py:53-61: AdamW over the U-Net and the onset encoder.  On the GPU the single-kernel (``fused``)

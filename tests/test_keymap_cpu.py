@@ -22,7 +22,7 @@ def _model(seed):
     return m
 
 
-@pytest.mark.parametrize("hyp_index", [0, 1, 2, 3])
+@pytest.mark.parametrize("hyp_index", list(range(8)))
 def test_upstream_layout_checkpoint_round_trip(tmp_path, hyp_index):
     from syncfusion_amd import keymap
 
@@ -36,26 +36,63 @@ def test_upstream_layout_checkpoint_round_trip(tmp_path, hyp_index):
     path = tmp_path / "epoch=784-valid_loss=0.008.ckpt"
     torch.save({"state_dict": up, "epoch": 784}, path)
     checkpoint = torch.load(path, map_location="cpu")
-    dst.load_state_dict(checkpoint["state_dict"], hypothesis=hyp)          # main/generation.py:42-43
+    dst.load_state_dict(checkpoint["state_dict"])          # main/generation.py:42-43 verbatim: the order is INFERRED from the checkpoint
     a, b = src.state_dict(), dst.state_dict()
     for k in a:
         if not k.startswith("clap."):
             assert torch.equal(a[k], b[k]), k
 
 
-def test_wrong_hypothesis_changes_the_assignment_or_is_harmless():
-    """The two registration-order hypotheses matter only for same-shaped tensors; where they matter the result differs
-    (which is what tools/pin_upstream.py detects numerically), and nothing is ever left unassigned."""
+def test_registration_order_is_inferred_from_the_checkpoint_not_guessed():
+    """the reference config has colliding 1024 x 1024 weights (time MLP, Modulation at C = 512, SkipModulate at
+    cin = 1024), so pairing tensors by shape under a GUESSED registration order could load permuted weights silently.  A state_dict
+    keeps registration order: the checkpoint's own (shape, kind) sequence decides the order hypothesis, a contradicting explicit
+    hypothesis is an error, and a checkpoint in NO modelled order fails with the first position that differs."""
+    import warnings
+
     from syncfusion_amd import keymap
 
     src, dst = _model(11), _model(22)
-    up = keymap.to_upstream_layout(src, keymap.OrderHypothesis(time_first=False, skip_last=True))
-    dst.load_state_dict(up, hypothesis=keymap.OrderHypothesis(time_first=True, skip_last=False))
-    a, b = src.state_dict(), dst.state_dict()
-    diff = [k for k in a if not k.startswith("clap.") and not torch.equal(a[k], b[k])]
-    assert 0 < len(diff) < len(a) // 2          # most tensors are pinned by shape alone; the rest is what the hypothesis decides
-    assert all(tuple(a[k].shape) == tuple(b[k].shape) for k in a)
-    assert all(("time." in k) or (".skip." in k) or k.endswith(".bias") or ".mod." in k or ".to_out." in k for k in diff), diff
+    net_own = {k[len("model.net."):]: tuple(v.shape) for k, v in dst.state_dict().items() if k.startswith("model.net.")}
+    for hyp in keymap.OrderHypothesis.all():
+        up = keymap.to_upstream_layout(src, hyp)
+        fits, _ = keymap.infer_order(keymap._strip(up, "model.net."), dst.model.net.hparams, net_own)
+        assert fits == [hyp], (hyp, fits)                     # exactly one hypothesis predicts this checkpoint's sequence
+        other = keymap.OrderHypothesis(not hyp.time_first, hyp.skip_last, hyp.cfg_last)
+        with pytest.raises(keymap.KeyMapError, match="contradicts"):
+            dst.load_state_dict(up, hypothesis=other)
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")                    # no UnpinnedOrderWarning: nothing was guessed
+            dst.load_state_dict(up)
+        a, b = src.state_dict(), dst.state_dict()
+        assert all(torch.equal(a[k], b[k]) for k in a if not k.startswith("clap."))
+    # a checkpoint whose tensors are in no modelled order: two same-kind tensors of different shape swapped
+    up = keymap.to_upstream_layout(src)
+    keys = [k for k in up if k.startswith("model.net.")]
+    i = next(n for n in range(len(keys) - 2) if keys[n].endswith("weight") and keys[n + 2].endswith("weight") and up[keys[n]].shape != up[keys[n + 2]].shape)
+    perm = list(up.items())
+    pos = {k: n for n, (k, _) in enumerate(perm)}
+    perm[pos[keys[i]]], perm[pos[keys[i + 2]]] = perm[pos[keys[i + 2]]], perm[pos[keys[i]]]
+    with pytest.raises(keymap.KeyMapError, match="not in any modelled registration order"):
+        dst.load_state_dict(dict(perm))
+
+
+def test_reference_config_order_is_pinned_by_unique_shapes():
+    """In the reference's 215 M-parameter configuration (exp/model/diffusion.yaml:11-33) the sequence test has anchors -- shapes that
+    occur once -- for every hypothesis bit, so an upstream checkpoint loads under exactly one order without any guess (checked on
+    shapes only: meta tensors, no 860 MB of weights)."""
+    import syncfusion_amd as sa
+    from helpers import reference_model_config
+    from syncfusion_amd import keymap
+
+    m = sa.instantiate(reference_model_config())
+    hp = m.model.net.hparams
+    net_own = {k[len("model.net."):]: tuple(v.shape) for k, v in m.state_dict().items() if k.startswith("model.net.")}
+    for hyp in keymap.OrderHypothesis.all():
+        order = keymap.unet_forward_order(hp, hyp)
+        fake = {f"p{i:04d}.{keymap._kind(k)}": torch.empty(net_own[k], device="meta") for i, k in enumerate(order)}
+        fits, _ = keymap.infer_order(fake, hp, net_own)
+        assert fits == [hyp]
 
 
 def test_local_layout_and_errors():
@@ -87,3 +124,24 @@ def test_forward_order_covers_the_reference_model():
     for hyp in keymap.OrderHypothesis.all():
         order = keymap.unet_forward_order(m.model.net.hparams, hyp)
         assert sorted(order) == sorted(own) and len(set(order)) == len(order)
+
+
+def test_load_state_dict_keeps_torch_strict_semantics():
+    """`hypothesis` is keyword-only (torch's third positional is `assign`); unexpected keys are reported by torch under
+    strict=True instead of being dropped; strict=False tolerates missing keys of the local layout."""
+    src, dst = _model(11), _model(22)
+    sd = dict(src.state_dict())
+    sd["model.net.blocks.0.bogus.weight"] = torch.zeros(2)
+    with pytest.raises(RuntimeError, match="Unexpected key"):
+        dst.load_state_dict(sd)
+    res = dst.load_state_dict(sd, strict=False)
+    assert "model.net.blocks.0.bogus.weight" in res.unexpected_keys
+    part = {k: v for k, v in src.state_dict().items() if not k.endswith("skip.to_scale.bias")}
+    with pytest.raises(Exception):
+        dst.load_state_dict(part)
+    before = {k: v.clone() for k, v in dst.state_dict().items() if k.endswith("skip.to_scale.bias")}
+    res = dst.load_state_dict(part, strict=False)
+    assert set(res.missing_keys) == set(before)
+    assert all(torch.equal(dst.state_dict()[k], v) for k, v in before.items())
+    with pytest.raises(TypeError):
+        dst.load_state_dict(src.state_dict(), True, False, None)       # hypothesis cannot be passed positionally

@@ -227,3 +227,94 @@ def test_oracle_selfcheck_frozen_outputs():
         z, info = encoder1d_ref.encoder1d_forward(oracle_params(enc), dict(enc.hparams), y)
         assert np.abs(z.numpy() - gold["enc_z"]).max() < 1e-5
         assert np.abs(np.array([float(t.double().mean()) for t in info["xs"]]) - gold["enc_xs_means"]).max() < 1e-6
+
+
+def test_every_recalled_switch_changes_the_oracle_output():
+    """the facts about a-unet / audio-encoders-pytorch that could only be RECALLED are explicit switches
+    (oracle.unet_ref.RECALLED_DEFAULTS, oracle.encoder1d_ref.RECALLED_DEFAULTS) that tools/pin_upstream.py decides numerically
+    against the real packages.  Each alternative must move the output well above the 1e-5 pinning threshold -- otherwise a wrong
+    default could reproduce upstream by accident and stay hidden -- and the defaults must be what the unparametrised call runs."""
+    net = small_unet_module()
+    P, cfg = oracle_params(net, "net."), dict(net.hparams)
+    x, sigma, emb, chans = synth_inputs(SMALL_UNET, 2, 16 * 6, seed=9)
+    g = torch.Generator().manual_seed(1)
+    # parameters only the alternatives read: a Modulation LayerNorm affine and an attention positional embedding
+    P2 = dict(P)
+    for k in list(P):
+        if k.endswith(".mod.to_scale_shift.weight"):
+            C = P[k].shape[0] // 2
+            P2[k.replace("to_scale_shift.weight", "norm.weight")] = 1.0 + 0.3 * torch.randn(C, generator=g)
+            P2[k.replace("to_scale_shift.weight", "norm.bias")] = 0.3 * torch.randn(C, generator=g)
+        if k.endswith(".attn.to_q.weight"):
+            P2[k.replace("to_q.weight", "pos.weight")] = 0.5 * torch.randn(64, P[k].shape[1], generator=g)
+
+    def run(variants, params=P2):
+        c = dict(cfg)
+        if variants is not None:
+            c["variants"] = variants
+        with torch.no_grad():
+            return unet_ref.unet_forward(params, c, x, sigma, embedding=emb, channels=chans, embedding_scale=1.0)
+
+    base = run(None, P)
+    assert torch.equal(base, run(dict(unet_ref.RECALLED_DEFAULTS)))       # the defaults ARE the unparametrised oracle; extra params unused
+    alternatives = dict(skip_form="h_plus_scaled_skip", mod_ln_eps=1e-5, mod_ln_affine=True, mod_act="none", attn_pos_embedding=True,
+                        attn_scale="none")
+    assert set(alternatives) | {"upsample_mode"} == set(unet_ref.RECALLED_DEFAULTS)
+    for key, alt in alternatives.items():
+        if key == "mod_ln_eps":
+            continue
+        d = rel_l2(run({key: alt}), base)
+        assert d > 1e-4, f"switch {key}={alt!r} moves the output by only {d:.2e}"     # >= 10x the 1e-5 pinning threshold
+    # eps 1e-5 against 1e-6 under a unit-variance LayerNorm moves a whole forward by ~1e-6 -- BELOW the pinning threshold -- so the
+    # pin tool reads this one from upstream's module attributes (nn.LayerNorm.eps) instead of deciding it numerically; the switch is
+    # live all the same: on a low-variance input it is a 4 % effect
+    pre = "net.blocks.1.items_down.0.mod"
+    xs_, f_ = 1e-2 * torch.randn(2, 32, 9, generator=g), torch.randn(2, SMALL_UNET["modulation_features"], generator=g)
+    m6 = unet_ref._modulation(P, pre, xs_, f_, unet_ref.recalled_variants({}))
+    m5 = unet_ref._modulation(P, pre, xs_, f_, unet_ref.recalled_variants(dict(variants=dict(mod_ln_eps=1e-5))))
+    assert rel_l2(m5, m6) > 1e-2
+    # the up-path switch needs the other weight layout (ConvTranspose1d): its own module
+    net_t = small_unet_module(upsample_mode="transpose")
+    Pt, cfgt = oracle_params(net_t, "net."), dict(net_t.hparams)
+    with torch.no_grad():
+        a = unet_ref.unet_forward(Pt, cfgt, x, sigma, embedding=emb, channels=chans)
+        cfgt2 = dict(cfgt, variants=dict(upsample_mode="transpose"), upsample_mode="nearest")
+        assert torch.equal(a, unet_ref.unet_forward(Pt, cfgt2, x, sigma, embedding=emb, channels=chans))   # the switch overrides the config
+    with pytest.raises(AssertionError):
+        run(dict(no_such_switch=1))
+    # Encoder1d
+    enc = small_encoder_module()
+    Pe, ecfg = oracle_params(enc), dict(enc.hparams)
+    y = torch.zeros(2, 1, 16 * 6)
+    y[:, 0, ::29] = 1.0
+    with torch.no_grad():
+        z0, _ = encoder1d_ref.encoder1d_forward(Pe, ecfg, y)
+        assert torch.equal(z0, encoder1d_ref.encoder1d_forward(Pe, dict(ecfg, variants=dict(encoder1d_ref.RECALLED_DEFAULTS)), y)[0])
+        for key, alt in dict(block_act="relu").items():
+            z1, _ = encoder1d_ref.encoder1d_forward(Pe, dict(ecfg, variants={key: alt}), y)
+            assert rel_l2(z1, z0) > 1e-3, key
+
+
+def test_pin_tool_search_identifies_a_hidden_combination():
+    """tools/pin_upstream.py cannot reach the real packages from here, but its decision procedure can be exercised: let the oracle
+    under a NON-default switch combination play upstream; the search over the numerically decided switches must single it out."""
+    import importlib.util
+    import os
+
+    from oracle import sampler_ref
+
+    spec = importlib.util.spec_from_file_location("pin_upstream", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "pin_upstream.py"))
+    pin = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pin)
+    net = small_unet_module()
+    P, hp = oracle_params(net, "net."), dict(net.hparams)
+    x, sigma, emb, chans = synth_inputs(SMALL_UNET, 2, 16 * 4, seed=12)
+    secret = dict(unet_ref.RECALLED_DEFAULTS, skip_form="h_plus_scaled_skip", attn_scale="none", mod_ln_eps=1e-5, upsample_mode="nearest")
+    cfg = dict(hp, variants=secret)
+    with torch.no_grad():
+        fwd = lambda xx, ss, sc: unet_ref.unet_forward(P, cfg, xx, ss, embedding=emb, channels=chans, embedding_scale=sc)
+        targets = (fwd(x, sigma, 1.0), fwd(x, sigma, 2.0), sampler_ref.vsample(lambda xx, ss: fwd(xx, ss, 2.0), x, 5))
+    space = list(pin.search_space(unet_ref, False, dict(eps=1e-5, affine=False), False))
+    assert len(space) == 8 and dict(unet_ref.RECALLED_DEFAULTS, mod_ln_eps=1e-5, upsample_mode="nearest") in space
+    winners = pin.find_combinations(P, hp, (x, sigma, emb, chans), targets, space, log=lambda *_: None)
+    assert winners == [secret]

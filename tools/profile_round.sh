@@ -17,5 +17,21 @@ python3 tools/pmc_traffic.py $(ls $O/fetch/*/*counter_collection.csv | head -1) 
 python3 tools/mfma_busy.py $O/mfma $O/pmc_mfma_by_kernel.csv > /dev/null
 python3 tools/mfma_busy.py $O/mfma_onset $O/pmc_mfma_onset_by_kernel.csv > /dev/null
 python3 bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
+# secondary workloads: kernel stats + matrix-core busy summaries of configs[2] (batch 32, guidance 2.0), one GPU's
+# share of configs[3] (batch 32, no guidance) and the reference's own evaluation shape (batch 10, 2^18 samples, guidance 2.0).
+# The program itself follows `--` (no env / shell hop under rocprofv3); SF_NO_GRAPH is exported for the eager counter passes.
+sec() {  # tag B scale steps L0
+  local T=$1; shift
+  ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_stats -- python3 $R/tools/sample_one.py "$@" > $O/${T}.txt 2> $O/${T}_stats.log )
+  cp $(ls $O/${T}_stats/*/*kernel_stats.csv | head -1) $O/${T}_kernel_stats.csv
+  ( cd /tmp && export SF_NO_GRAPH=1 && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $O/${T}_mfma -- python3 $R/tools/sample_one.py "$@" > /dev/null 2> $O/${T}_mfma.log )
+  python3 tools/mfma_busy.py $O/${T}_mfma $O/${T}_pmc_mfma_by_kernel.csv > /dev/null
+  rm -rf $O/${T}_stats $O/${T}_mfma
+}
+if [ "${SF_PROFILE_SECONDARY:-1}" = "1" ]; then
+  sec cfg2_b32_cfg 32 2.0 6 bf16 45056
+  sec cfg3share_b32 32 1.0 6 bf16 45056
+  sec refshape_b10_2p18 10 2.0 4 bf16 262144
+fi
 rm -rf $O/stats $O/fetch $O/write $O/mfma $O/mfma_onset
 ls -la $O
