@@ -125,7 +125,12 @@ def test_bench_gpus_flag_spawns_fresh_ranks(tmp_path, capfd):
 
     script = tmp_path / "fake_rank.py"
     script.write_text(_FAKE_RANK)
-    args = bench.parse_args(["--gpus", "2", "--master-port", "29641"])
+    import socket
+
+    with socket.socket() as sock:                     # a port that is free right now (a fixed one can sit in TIME_WAIT from an earlier run)
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    args = bench.parse_args(["--gpus", "2", "--master-port", str(port)])
     env_before = {k: os.environ.pop(k, None) for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     try:
         rc = bench.spawn_ranks(args, script=str(script), argv=["--gpus", "2", "--steps", "3"])
