@@ -68,6 +68,11 @@ def parse_args(argv=None):
     ap.add_argument("--dump-launches", default=None, help="write the per-launch event timings of one evaluation to this file")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank: exercises the N > 1 code path on a 1-GPU box")
     ap.add_argument("--master-port", type=int, default=29533)
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the N > 1 path (nccl = RCCL; gloo only for the share-GPU smoke run)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="map every local rank onto the visible GPUs round-robin (LOCAL_RANK %% device_count): the whole N-rank launcher -> "
+                         "broadcast -> timed loop -> gather -> JSON path on a 1-GPU box.  Throughput of such a run is meaningless.")
     return ap.parse_args(argv)
 
 
@@ -338,8 +343,13 @@ def main() -> int:
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(args.master_port))
+        if args.share_gpu:
+            local_rank %= max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
@@ -377,7 +387,7 @@ def main() -> int:
     fence()
     elapsed = time.perf_counter() - t0
     if dist_on:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     assert torch.isfinite(out).all()
@@ -543,7 +553,8 @@ def main() -> int:
                                "schedule length)",
                    "batch_per_gpu": B, "L0": L0, "evals_per_step": evals, "clip_steps_per_s": round(world * B * args.steps / elapsed, 2),
                    "params_M": round(sum(p.numel() for p in net.parameters()) / 1e6, 2), "hip_graph": not args.no_graph,
-                   "weights_broadcast_bytes": bcast_bytes, "gathered_clips": None if gathered is None else int(gathered.shape[0])},
+                   "weights_broadcast_bytes": bcast_bytes, "gathered_clips": None if gathered is None else int(gathered.shape[0]),
+                   **({"dist_backend": dist.get_backend(), "ranks_share_a_gpu": bool(args.share_gpu)} if dist_on else {})},
         "roofline": roof,
         "cpu_baseline": cpu,
         "extra": extra,

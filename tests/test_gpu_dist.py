@@ -97,6 +97,39 @@ def test_bench_force_dist_runs_the_rccl_path_with_one_rank(cuda):
     assert line["value"] > 0 and line["extra"] is None
 
 
+@pytest.mark.timeout(1500)
+def test_bench_two_ranks_end_to_end_on_one_gpu(cuda):
+    """`bench.py --gpus 2` exactly as a user types it -- the launcher starts two fresh ranks under
+    torch.distributed.run BEFORE anything touches the GPU, each rank builds the 215 M-parameter model, rank 0's weights are broadcast,
+    the timed loop runs bracketed by barriers, the clips are gathered, rank 0's JSON line is relayed -- with both ranks on cuda:0
+    (`--share-gpu`).  RCCL first (it refuses two ranks on one device on most builds: "Duplicate GPU detected"); if it does, the same
+    path over gloo.  The throughput of two processes time-slicing one GPU is meaningless and not asserted."""
+    import socket
+
+    def run(backend):
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--dist-backend", backend, "--steps", "3",
+                               "--warmup", "1", "--no-cpu-baseline", "--no-extra", "--master-port", str(port)], capture_output=True, text=True,
+                              timeout=700, env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+
+    r = run("nccl")
+    used = "nccl"
+    if r.returncode != 0:
+        print("RCCL with two ranks on one device failed as expected:", (r.stderr or "").strip().splitlines()[-1:] )
+        r = run("gloo")
+        used = "gloo"
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    print(f"two ranks on one GPU over {used}: {line['value']} steps/s aggregate (time-sliced, not a benchmark)")
+    assert line["n_gpus"] == 2 and line["config"]["gathered_clips"] == 16 and line["config"]["dist_backend"] == used
+    assert line["config"]["ranks_share_a_gpu"] is True and line["config"]["weights_broadcast_bytes"] > 4 * 214e6
+    assert line["value"] > 0 and line["scaling"] == "weak" and line["roofline"]["frac"] > 0
+
+
 def _train_batch(lo: int, hi: int):
     g = torch.Generator().manual_seed(77)
     x = torch.randn(B_TOTAL, 1, L0, generator=g)
