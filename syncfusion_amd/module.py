@@ -151,7 +151,10 @@ class Model(_Base):
         (syncfusion_amd/training.py: HIP forward + backward kernels), so the returned loss carries a graph onto the U-Net's and
         the onset encoder's parameters.  Called under ``torch.no_grad()`` or with every parameter frozen there is nothing to
         train, and returning a graph-less loss to a trainer would fail inside ``loss.backward()`` with an opaque message."""
-        loss = self.step(batch)
+        from .training import training_step_scope
+
+        with training_step_scope():
+            loss = self.step(batch)
         if not loss.requires_grad:
             raise RuntimeError("training_step: the loss carries no autograd graph (grad mode is off or every parameter is frozen)")
         self.log("train_loss", loss)

@@ -31,21 +31,42 @@ from . import autograd as sfa
 Tensor = torch.Tensor
 
 
-_warned_eval = False
+_warned_outside_step = False
+_in_training_step = 0
+
+
+class training_step_scope:
+    """Marks the calls made from ``Model.training_step`` / ``fit_batches``: there the differentiable composition is what the
+    caller asked for.  Anywhere else a forward call that records a graph gets ONE warning (see ``wants_grad``)."""
+
+    def __enter__(self):
+        global _in_training_step
+        _in_training_step += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _in_training_step
+        _in_training_step -= 1
 
 
 def wants_grad(module: torch.nn.Module, *tensors: Optional[Tensor]) -> bool:
-    """True when a forward call of ``module`` has to record an autograd graph."""
-    global _warned_eval
+    """True when a forward call of ``module`` has to record an autograd graph.
+
+    A freshly built module has trainable parameters and sits in train() mode, so ANY call outside ``torch.no_grad()`` lands
+    here -- and then leaves the 16-bit graph engine for the fp32 per-operation composition that keeps every activation (GBs at
+    2^18 samples).  That is right inside a training step and almost always an accident elsewhere, so the first such call made
+    outside ``Model.training_step`` / ``fit_batches`` warns (eval() or train() mode alike)."""
+    global _warned_outside_step
     if not torch.is_grad_enabled():
         return False
     want = any(t is not None and t.requires_grad for t in tensors) or any(p.requires_grad for p in module.parameters())
-    if want and not module.training and not _warned_eval:
-        _warned_eval = True
+    if want and not _in_training_step and not _warned_outside_step:
+        _warned_outside_step = True
         import warnings
 
-        warnings.warn(f"{type(module).__name__} is in eval() mode but autograd is recording: running the differentiable fp32 composition "
-                      "(syncfusion_amd.training), not the inference engine.  Wrap inference calls in torch.no_grad().", stacklevel=3)
+        warnings.warn(f"{type(module).__name__}: autograd is recording outside Model.training_step, so this call runs the differentiable fp32 "
+                      "composition (syncfusion_amd.training: every activation is kept for backward), not the inference engine.  Wrap "
+                      "inference calls in torch.no_grad().", stacklevel=3)
     return want
 
 
@@ -225,7 +246,14 @@ def allreduce_gradients(module: torch.nn.Module, bucket_bytes: int = 256 << 20) 
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return 0
     world = dist.get_world_size()
-    grads = [p.grad for p in module.parameters() if p.requires_grad and p.grad is not None]
+    # EVERY trainable parameter takes part, a missing gradient as zeros: the bucket boundaries (hence the number and the sizes of
+    # the collectives) must not depend on which parameters happened to receive a gradient on THIS rank
+    grads = []
+    for p in module.parameters():
+        if p.requires_grad:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            grads.append(p.grad)
     stage_host = dist.get_backend() == "gloo"
     calls, i = 0, 0
     while i < len(grads):
@@ -276,14 +304,38 @@ def fit_batches(model, optimizer, batches, *, accumulate_grad_batches: int = 2, 
             on_step(steps, sum(window) / len(window))
         window.clear()
 
+    def everyone_has(have: bool) -> bool:
+        """Ranks may see different batch counts (uneven shards): every rank takes a micro-batch only while ALL ranks still have
+        one, so the number of gradient all-reduces is the same everywhere (Lightning's DDP join does the same job)."""
+        import torch.distributed as dist
+
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return have
+        flag = torch.tensor([1 if have else 0], dtype=torch.int32)
+        if dist.get_backend() == "nccl":
+            flag = flag.to(params[0].device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(int(flag) == 1)
+
     optimizer.zero_grad(set_to_none=True)
-    for i, batch in enumerate(batches):
-        loss = model.training_step(batch, i)
-        (loss / accumulate_grad_batches).backward()
-        window.append(float(loss.detach()))
-        losses.append(window[-1])
-        if len(window) == accumulate_grad_batches:
+    it = iter(batches)
+    i = 0
+    with training_step_scope():
+        while True:
+            try:
+                batch = next(it)
+                have = True
+            except StopIteration:
+                batch, have = None, False
+            if not everyone_has(have):
+                break
+            loss = model.training_step(batch, i)
+            (loss / accumulate_grad_batches).backward()
+            window.append(float(loss.detach()))
+            losses.append(window[-1])
+            i += 1
+            if len(window) == accumulate_grad_batches:
+                apply()
+        if window:
             apply()
-    if window:
-        apply()
     return losses
