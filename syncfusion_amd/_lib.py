@@ -18,7 +18,7 @@ UPSAMPLE_MODES = {"nearest": 0, "transpose": 1}
 DTYPES = {"fp32": SF_F32, "float32": SF_F32, "f32": SF_F32, "bf16": SF_BF16, "bfloat16": SF_BF16, "fp16": SF_F16, "float16": SF_F16, "f16": SF_F16, "half": SF_F16}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsyncfusion_amd.so")
+LIB_PATH = os.environ.get("SF_LIB_PATH") or os.path.join(_HERE, "lib", "libsyncfusion_amd.so")   # SF_LIB_PATH: A/B builds of the HIP library (tuning aid)
 
 
 class SfTensor(C.Structure):

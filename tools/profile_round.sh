@@ -6,6 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
+if [ "${SF_PROFILE_PRIMARY:-1}" = "1" ]; then
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra > $O/bench_under_profiler.json 2> $O/stats.log
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- python3 $R/bench.py --no-cpu-baseline --no-extra --steps 3 --warmup 1 --no-graph > /dev/null 2> $O/fetch.log
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- python3 $R/bench.py --no-cpu-baseline --no-extra --steps 3 --warmup 1 --no-graph > /dev/null 2> $O/write.log
@@ -17,6 +18,8 @@ python3 tools/pmc_traffic.py $(ls $O/fetch/*/*counter_collection.csv | head -1) 
 python3 tools/mfma_busy.py $O/mfma $O/pmc_mfma_by_kernel.csv > /dev/null
 python3 tools/mfma_busy.py $O/mfma_onset $O/pmc_mfma_onset_by_kernel.csv > /dev/null
 python3 bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
+fi
+cd $R
 # secondary workloads: kernel stats + matrix-core busy summaries of configs[2] (batch 32, guidance 2.0), one GPU's
 # share of configs[3] (batch 32, no guidance) and the reference's own evaluation shape (batch 10, 2^18 samples, guidance 2.0).
 # The program itself follows `--` (no env / shell hop under rocprofv3); SF_NO_GRAPH is exported for the eager counter passes.
