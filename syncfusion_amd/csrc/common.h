@@ -135,6 +135,25 @@ __device__ __forceinline__ void welford_merge(float &n, float &mean, float &m2, 
   n = tot;
 }
 
+// The same with v_rcp_f32 (1 ulp) instead of two IEEE divisions (~10 VALU instructions each): the 16-bit engines' thin-level
+// kernels run ~18 divisions per wave in their statistics bookkeeping, 12 % of their instruction stream.
+template <bool FAST> __device__ __forceinline__ float div_t(float a, float b) {
+  if constexpr (FAST) return a * __builtin_amdgcn_rcpf(b);
+  else return a / b;
+}
+template <bool FAST> __device__ __forceinline__ void welford_merge_t(float &n, float &mean, float &m2, float nb, float mb, float m2b) {
+  if constexpr (!FAST) {
+    welford_merge(n, mean, m2, nb, mb, m2b);
+  } else {
+    if (nb <= 0.f) return;
+    const float tot = n + nb, r = __builtin_amdgcn_rcpf(tot);
+    const float delta = mb - mean;
+    mean += delta * (nb * r);
+    m2 += m2b + delta * delta * (n * nb * r);
+    n = tot;
+  }
+}
+
 // Final GroupNorm statistics of one (clip, group) from its <= 32 chunk partials (mean, M2): each of the 32 lanes of
 // a half-wave loads one chunk (all loads in flight together), then a fixed-shape shuffle tree merges them (Chan) --
 // deterministic, one memory latency.  Every lane of the half-wave must call it; every lane gets the result.

@@ -128,19 +128,20 @@ __device__ __forceinline__ float half_sum32(float v, int half) {
 
 // (mean, rstd) of one (clip, group) from its nch chunk partials, any nch: lane j of the half-wave folds partials
 // j, j+32, ... in order, then the fixed shuffle tree of gn_merge32 -- deterministic.
+template <bool FAST = false>
 __device__ __forceinline__ float2 gn_merge_n(const float *__restrict__ sl, int G, int nch, int chunk_rows, int L, int cpg, float eps,
                                              int lane32) {
   float n = 0.f, mean = 0.f, m2 = 0.f;
   for (int i = lane32; i < nch; i += 32) {
     const int rows = min(chunk_rows, L - i * chunk_rows);
-    welford_merge(n, mean, m2, (float)rows * (float)cpg, sl[(size_t)i * G * 2], sl[(size_t)i * G * 2 + 1]);
+    welford_merge_t<FAST>(n, mean, m2, (float)rows * (float)cpg, sl[(size_t)i * G * 2], sl[(size_t)i * G * 2 + 1]);
   }
 #pragma unroll
   for (int off = 16; off > 0; off >>= 1) {
     const float nb = __shfl_down(n, off, 32), mb = __shfl_down(mean, off, 32), qb = __shfl_down(m2, off, 32);
-    welford_merge(n, mean, m2, nb, mb, qb);
+    welford_merge_t<FAST>(n, mean, m2, nb, mb, qb);
   }
-  const float mu = __shfl(mean, 0, 32), var = __shfl(m2, 0, 32) / __shfl(n, 0, 32);
+  const float mu = __shfl(mean, 0, 32), var = div_t<FAST>(__shfl(m2, 0, 32), __shfl(n, 0, 32));
   return make_float2(mu, rsqrtf(var + eps));
 }
 
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(1024) void conv_thin_kernel(const ConvThinArgs a) {
   if constexpr (PRO == 0) __syncthreads();
   if constexpr (PRO == 1) {
     for (int g = tid >> 5; g < a.G; g += blockDim.x >> 5) {
-      const float2 st = gn_merge_n(a.stats_in + ((size_t)b * a.nch_in * a.G + g) * 2, a.G, a.nch_in, a.chunk_in, a.L, cpg, a.eps, l32);
+      const float2 st = gn_merge_n<FAST>(a.stats_in + ((size_t)b * a.nch_in * a.G + g) * 2, a.G, a.nch_in, a.chunk_in, a.L, cpg, a.eps, l32);
       if (l32 < cpg) {
         const int c = g * cpg + l32;
         const float s = st.y * a.gamma[c];
@@ -430,7 +431,7 @@ __global__ __launch_bounds__(1024) void conv_thin_kernel(const ConvThinArgs a) {
         const float cnt = (float)vrows;
         float m[4], q[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) m[e] = half_sum32(xs[0][e], half) / cnt;
+        for (int e = 0; e < 4; ++e) m[e] = div_t<FAST>(half_sum32(xs[0][e], half), cnt);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float d = rvalid ? xs[0][e] - m[e] : 0.f;
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(1024) void conv_thin_kernel(const ConvThinArgs a) {
         for (int v = 0; v < 4; ++v) {
           const float2 hs = half_sums((xs[v][0] + xs[v][1]) + (xs[v][2] + xs[v][3]));
           const float sum = cpg == 8 ? hs.x + hs.y : (half ? hs.y : hs.x);
-          gs[v] = sum / cnt;
+          gs[v] = div_t<FAST>(sum, cnt);
         }
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(1024) void conv_thin_kernel(const ConvThinArgs a) {
       const float n_t = on ? (float)min(32, rows - lane * 32) * (float)cpg : 0.f;
       const float m_t = on ? pp[0] : 0.f, q_t = on ? pp[1] : 0.f;
       const float2 sn = half_sums(n_t), sm = half_sums(n_t * m_t);
-      const float n = sn.x + sn.y, mean = (sm.x + sm.y) / n;
+      const float n = sn.x + sn.y, mean = div_t<FAST>(sm.x + sm.y, n);
       const float d = m_t - mean;
       const float2 sq = half_sums(fmaf(n_t * d, d, q_t));
       if (lane == 0) {
@@ -625,7 +626,7 @@ __global__ __launch_bounds__(1024) void thin_tail_kernel(const ThinTailArgs a) {
   }
   // GroupNorm statistics of h, modulation vectors
   for (int g = tid >> 5; g < a.G; g += blockDim.x >> 5) {
-    const float2 st = gn_merge_n(a.stats_in + ((size_t)b * a.nch_in * a.G + g) * 2, a.G, a.nch_in, a.chunk_in, a.L, cpg, a.eps_gn, l32);
+    const float2 st = gn_merge_n<FAST>(a.stats_in + ((size_t)b * a.nch_in * a.G + g) * 2, a.G, a.nch_in, a.chunk_in, a.L, cpg, a.eps_gn, l32);
     if (l32 < cpg) {
       const int c = g * cpg + l32;
       const float s = st.y * a.gamma[c];
@@ -814,7 +815,7 @@ __global__ __launch_bounds__(1024) void thin_tail_kernel(const ThinTailArgs a) {
         const float cnt = (float)vrows;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float m = half_sum32(xs[0][0][e], half) / cnt;
+          const float m = div_t<FAST>(half_sum32(xs[0][0][e], half), cnt);
           const float d = rvalid ? xs[0][0][e] - m : 0.f;
           const float q = half_sum32(d * d, half);
           if (l32 == 0) {
@@ -830,7 +831,7 @@ __global__ __launch_bounds__(1024) void thin_tail_kernel(const ThinTailArgs a) {
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
             const float2 hs = half_sums((xs[cb][v][0] + xs[cb][v][1]) + (xs[cb][v][2] + xs[cb][v][3]));
-            const float m = (cpg == 8 ? hs.x + hs.y : (half ? hs.y : hs.x)) / cnt;
+            const float m = div_t<FAST>(cpg == 8 ? hs.x + hs.y : (half ? hs.y : hs.x), cnt);
             float q = 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -856,7 +857,7 @@ __global__ __launch_bounds__(1024) void thin_tail_kernel(const ThinTailArgs a) {
       const float n_t = on ? (float)min(32, rows - lane * 32) * (float)cpg : 0.f;
       const float m_t = on ? pp[0] : 0.f, q_t = on ? pp[1] : 0.f;
       const float2 sn = half_sums(n_t), sm = half_sums(n_t * m_t);
-      const float n = sn.x + sn.y, mean = (sm.x + sm.y) / n;
+      const float n = sn.x + sn.y, mean = div_t<FAST>(sm.x + sm.y, n);
       const float d = m_t - mean;
       const float2 sq2 = half_sums(fmaf(n_t * d, d, q_t));
       if (lane == 0) {
