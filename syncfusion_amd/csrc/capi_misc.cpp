@@ -240,9 +240,14 @@ int sf_bench_conv1d(int dtype, int B, int L, int C, int N, int taps, int upsampl
   if (err == hipSuccess) {
     SF_HIP(hipDeviceSynchronize());
     SF_HIP(hipEventRecord(e0, nullptr));
+    // SF_BENCH_PREFETCH=n: a `touch` kernel of n workgroups reads this launch's weights right before it (1000 + n: the touch kernel
+    // alone) -- what an idle-CU prefetch in the PRECEDING kernel of the chain could buy
+    int pre = 0;
+    if (const char *e = getenv("SF_BENCH_PREFETCH")) pre = atoi(e);
     for (int i = 0; i < iters && err == hipSuccess; ++i) {
       a.w = static_cast<char *>(w) + (size_t)(i % ncopy) * wbytes;
-      err = launch_conv_gemm(dtype, a, nullptr);
+      if (pre > 0) err = launch_touch(a.w, wbytes, pre % 1000, reinterpret_cast<unsigned *>(bias), nullptr);
+      if (pre < 1000 && err == hipSuccess) err = launch_conv_gemm(dtype, a, nullptr);
     }
     SF_HIP(hipEventRecord(e1, nullptr));
     SF_HIP(hipEventSynchronize(e1));

@@ -66,6 +66,22 @@ template <typename T> __device__ __forceinline__ Vec16<T> zero16() {
 template <typename T> __device__ __forceinline__ float to_f(T x) { return (float)x; }
 template <typename T> __device__ __forceinline__ T from_f(float x) { return (T)x; }
 
+// Body of a hosted-prefetch workgroup (kernels.h, Prefetch): workgroup `w` of `pf.wgs` reads its slice of the range, all loads of a
+// thread in flight together, nothing kept.  The caller returns right after it.
+template <typename P> __device__ __forceinline__ void prefetch_slice(const P &pf, int w, int nthreads) {
+  const uint4 *base = static_cast<const uint4 *>(pf.ptr);
+  const unsigned n = pf.bytes >> 4, stride = (unsigned)pf.wgs * (unsigned)nthreads;
+  unsigned acc = 0;
+  for (unsigned i = (unsigned)w * (unsigned)nthreads + threadIdx.x; i < n; i += 4 * stride) {
+    uint4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = base[min(i + k * stride, n - 1)];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc ^= v[k].x;
+  }
+  asm volatile("" ::"v"(acc));   // keeps the loads alive without a store
+}
+
 // exp: accurate on the fp32 parity path, v_exp_f32 based on the bf16 path.
 template <bool FAST> __device__ __forceinline__ float exp_t(float x) {
   if constexpr (FAST) return __expf(x);

@@ -53,6 +53,10 @@ __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(const ConvGemmArgs 
   float *lntab = rowstat + 2 * BM;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if ((int)blockIdx.x >= mtiles * ntiles) {   // hosted weight prefetch for the next GEMM of the chain (kernels.h, Prefetch)
+    prefetch_slice(a.pf, (int)blockIdx.x - mtiles * ntiles, 256);
+    return;
+  }
   int bid = blockIdx.x, mt, nt;
   if (swz) {
     const int xcd = bid & 7, j = bid >> 3;
@@ -422,7 +426,7 @@ template <typename T, int BM, int BN, bool CAT, int KW, int NSET, bool LN = fals
     if (e != hipSuccess) return e;
     en = true;
   }
-  hipLaunchKernelGGL(kern, dim3(mtiles * ntiles), dim3(256), lds, s, a, mtiles, ntiles, swz, (unsigned)bA, (unsigned)bA2, (unsigned)bW);
+  hipLaunchKernelGGL(kern, dim3(mtiles * ntiles + (a.pf.ptr && a.pf.bytes >= 16 ? a.pf.wgs : 0)), dim3(256), lds, s, a, mtiles, ntiles, swz, (unsigned)bA, (unsigned)bA2, (unsigned)bW);
   return hipGetLastError();
 }
 

@@ -49,6 +49,10 @@ __global__ __launch_bounds__(256) void conv_gemm_wp_kernel(const ConvGemmArgs a,
   T *wlds = reinterpret_cast<T *>(smem) + (size_t)wave * WSTAGE;   // [A rows | W rows]
   float *red = reinterpret_cast<float *>(smem);
 
+  if ((int)blockIdx.x >= mtiles * ntiles) {   // hosted weight prefetch for the next GEMM of the chain (kernels.h, Prefetch)
+    prefetch_slice(a.pf, (int)blockIdx.x - mtiles * ntiles, 256);
+    return;
+  }
   int bid = blockIdx.x, mt, nt;
   if (swz) {
     const int xcd = bid & 7, j = bid >> 3;
@@ -365,7 +369,7 @@ template <typename T, int BM, int BN, bool CAT, int NSET> hipError_t launch_wp3(
     if (e != hipSuccess) return e;
     en = true;
   }
-  hipLaunchKernelGGL(kern, dim3(mtiles * ntiles), dim3(256), lds, s, a, mtiles, ntiles, swz, (unsigned)bA, (unsigned)bA2, (unsigned)bW);
+  hipLaunchKernelGGL(kern, dim3(mtiles * ntiles + (a.pf.ptr && a.pf.bytes >= 16 ? a.pf.wgs : 0)), dim3(256), lds, s, a, mtiles, ntiles, swz, (unsigned)bA, (unsigned)bA2, (unsigned)bW);
   return hipGetLastError();
 }
 

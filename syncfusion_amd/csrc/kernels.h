@@ -27,7 +27,17 @@ inline size_t dsize(int dt) { return dt == F32 ? 4 : 2; }
 //   A(m, tap*cin + ci)       = pro( src[row(m,tap)][ci] )       (0 outside the padding)
 //   A(m, taps*cin + ci2)     = src2[m][ci2]                      (channel concat, taps==1)
 // ---------------------------------------------------------------------------------------
+// Weight prefetch hosted by a kernel that leaves CUs idle: `wgs` extra workgroups appended to the host's grid read [ptr, ptr + bytes)
+// once (16 bytes per lane) and exit, so that the NEXT GEMM of the chain finds its weights in the Infinity Cache / L2 instead of HBM
+// (the 430 MB of bf16 weights of a step do not fit the 256 MB Infinity Cache: every GEMM streams its weights cold otherwise).
+struct Prefetch {
+  const void *ptr = nullptr;
+  unsigned bytes = 0;
+  int wgs = 0;
+};
+
 struct ConvGemmArgs {
+  Prefetch pf;   // hosted prefetch (conv_gemm_wp / conv_gemm_fast only; other kernels ignore it)
   const void *src = nullptr, *src2 = nullptr, *w = nullptr, *res = nullptr;
   void *out = nullptr;
   const float *bias = nullptr, *gamma = nullptr, *beta = nullptr, *stats = nullptr;
@@ -151,13 +161,13 @@ hipError_t launch_gn_stats(int dt, const void *x, int ld, int B, int L, int C, i
 
 // y = silu(GroupNorm_G(x; gamma, beta, eps)) materialised in one launch (statistics + apply, one workgroup per (clip, group))
 hipError_t launch_gn_silu(int dt, const void *x, int ld, int B, int L, int C, int G, const float *gamma, const float *beta, float eps,
-                          void *out, int out_ld, hipStream_t s);
+                          void *out, int out_ld, hipStream_t s, Prefetch pf = Prefetch());
 hipError_t launch_gn_silu_ws(int dt, const void *x, int ld, int B, int L, int C, int G, const float *gamma, const float *beta, float eps, void *out,
                              int out_ld, float *slab, int64_t slab_floats, hipStream_t s);
 
 // y = LN_C(x; eps) * (1 + scale[b][c]) + shift[b][c]   (ss == nullptr: plain normalise);  ss:(B, ss_ld) = [scale | shift]
 hipError_t launch_ln_modulate(int dt, const void *x, int ld, const float *ss, int ss_ld, float eps, int B, int L, int C,
-                              void *out, int out_ld, hipStream_t s);
+                              void *out, int out_ld, hipStream_t s, Prefetch pf = Prefetch());
 
 // Multi-head softmax attention on packed projections.  q row stride ldq, k/v inside kv with row stride ldkv
 // (k at column 0, v at column H*D).  out row stride ldo.
@@ -189,6 +199,7 @@ hipError_t launch_vsampler_update(float *x, const float *v, const float *v_uncon
 hipError_t launch_step_select(const float *table, int ld, int *step_idx, float *cur, hipStream_t s);
 // one wave busy-waits for `microseconds` (tuning aid)
 hipError_t launch_spin(double microseconds, hipStream_t s);
+hipError_t launch_touch(const void *p, size_t bytes, int wgs, unsigned *sink, hipStream_t s);
 // (*step_idx)++ -- its own 1-thread launch so that no kernel of a step races with the increment
 hipError_t launch_step_advance(int *step_idx, hipStream_t s);
 // out = v_u + (v_c - v_u) * scale   (single forward with CFG)

@@ -253,6 +253,20 @@ hipError_t launch_step_select(const float *table, int ld, int *step_idx, float *
   hipLaunchKernelGGL(step_select_kernel, dim3(1), dim3(1024), 0, s, table, ld, step_idx, cur);
   return hipGetLastError();
 }
+// Measurement aid (tools/prefetch_probe.py): read `bytes` once with `wgs` workgroups, 16 bytes per lane, so that they sit in the
+// L2s / the Infinity Cache when the next kernel streams them.
+__global__ __launch_bounds__(256) void touch_kernel(const uint4 *__restrict__ p, size_t n, unsigned *sink) {
+  unsigned acc = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const uint4 v = p[i];
+    acc ^= v.x ^ v.w;
+  }
+  if (acc == 0x9e3779b9u) *sink = acc;
+}
+hipError_t launch_touch(const void *p, size_t bytes, int wgs, unsigned *sink, hipStream_t s) {
+  hipLaunchKernelGGL(touch_kernel, dim3(wgs), dim3(256), 0, s, static_cast<const uint4 *>(p), bytes / 16, sink);
+  return hipGetLastError();
+}
 hipError_t launch_spin(double microseconds, hipStream_t s) {
   hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s, (unsigned long long)(microseconds * 100.0));
   return hipGetLastError();

@@ -157,9 +157,13 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T *__restrict__ x, 
 template <typename T, int VPT>
 __global__ __launch_bounds__(256) void ln_modulate_kernel(const T *__restrict__ x, int ld, const float *__restrict__ ss,
                                                           int ss_ld, float eps, int rows, int L, int C, int tpr,
-                                                          T *__restrict__ out, int out_ld) {
+                                                          T *__restrict__ out, int out_ld, const int nreal, const Prefetch pf) {
   constexpr int V = Vec16<T>::N;
   const int tid = threadIdx.x;
+  if ((int)blockIdx.x >= nreal) {   // hosted weight prefetch for the GEMM that follows (kernels.h, Prefetch)
+    prefetch_slice(pf, (int)blockIdx.x - nreal, 256);
+    return;
+  }
   const int rpb = 256 / tpr;
   const int row = blockIdx.x * rpb + tid / tpr;
   const int sub = tid % tpr;
@@ -288,10 +292,14 @@ __global__ __launch_bounds__(512) void gn_silu_kernel(const T *__restrict__ x, i
 template <typename T, int RV>
 __global__ __launch_bounds__(512) void gn_silu_reg_kernel(const T *__restrict__ x, int ld, int L, int C, int G,
                                                           const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
-                                                          T *__restrict__ out, int out_ld) {
+                                                          T *__restrict__ out, int out_ld, const int nslab, const Prefetch pf) {
   constexpr bool FAST = sizeof(T) == 2;
   constexpr int V = Vec16<T>::N;
   __shared__ float red[2][8];
+  if ((int)blockIdx.x >= nslab) {   // hosted weight prefetch for the convolution that follows (kernels.h, Prefetch)
+    prefetch_slice(pf, (int)blockIdx.x - nslab, 512);
+    return;
+  }
   const int tid = threadIdx.x, wave = tid >> 6;
   const int b = blockIdx.x / G, g = blockIdx.x - b * G;
   const int cpg = C / G;
@@ -416,7 +424,7 @@ __global__ __launch_bounds__(256) void gn_silu_apply_kernel(const T *__restrict_
 
 template <typename T>
 hipError_t gn_silu_go(const void *x, int ld, int B, int L, int C, int G, const float *gamma, const float *beta, float eps, void *out,
-                      int out_ld, hipStream_t s) {
+                      int out_ld, hipStream_t s, Prefetch pf = Prefetch()) {
   if (C % G) return hipErrorInvalidValue;
   const int cpg = C / G;
   constexpr int V = Vec16<T>::N;
@@ -427,8 +435,10 @@ hipError_t gn_silu_go(const void *x, int ld, int B, int L, int C, int G, const f
   const bool al = (ld % V == 0) && (out_ld % V == 0);
   if (al && cpg % V == 0 && 512 % (cpg / V) == 0 && (int64_t)L * (cpg / V) <= 4 * 512) {   // slab fits the registers of one workgroup
     const int64_t nv = (int64_t)L * (cpg / V);
-    if (nv <= 2 * 512) hipLaunchKernelGGL((gn_silu_reg_kernel<T, 2>), grid, dim3(512), 0, s, xp, ld, L, C, G, gamma, beta, eps, op, out_ld);
-    else hipLaunchKernelGGL((gn_silu_reg_kernel<T, 4>), grid, dim3(512), 0, s, xp, ld, L, C, G, gamma, beta, eps, op, out_ld);
+    const int nslab = B * G;
+    const dim3 gridp(nslab + (pf.ptr && pf.bytes >= 16 ? pf.wgs : 0));
+    if (nv <= 2 * 512) hipLaunchKernelGGL((gn_silu_reg_kernel<T, 2>), gridp, dim3(512), 0, s, xp, ld, L, C, G, gamma, beta, eps, op, out_ld, nslab, pf);
+    else hipLaunchKernelGGL((gn_silu_reg_kernel<T, 4>), gridp, dim3(512), 0, s, xp, ld, L, C, G, gamma, beta, eps, op, out_ld, nslab, pf);
     return hipGetLastError();
   }
   if (al && cpg % V == 0) SF_GNS(V);
@@ -441,7 +451,7 @@ hipError_t gn_silu_go(const void *x, int ld, int B, int L, int C, int G, const f
 
 template <typename T>
 hipError_t ln_go(const void *x, int ld, const float *ss, int ss_ld, float eps, int B, int L, int C, void *out, int out_ld,
-                 hipStream_t s) {
+                 hipStream_t s, Prefetch pf = Prefetch()) {
   constexpr int V = Vec16<T>::N;
   if (C % V) return hipErrorInvalidValue;
   if (ss && ((ss_ld % 4) || (reinterpret_cast<uintptr_t>(ss) % 16))) return hipErrorInvalidValue;   // 16-byte scale/shift loads
@@ -452,14 +462,15 @@ hipError_t ln_go(const void *x, int ld, const float *ss, int ss_ld, float eps, i
   int vpt = vpr / tpr;
   int rows = B * L;
   int rpb = 256 / tpr;
-  dim3 grid((rows + rpb - 1) / rpb);
+  const int nreal = (rows + rpb - 1) / rpb;
+  dim3 grid(nreal + (pf.ptr && pf.bytes >= 16 ? pf.wgs : 0));
   const T *xp = static_cast<const T *>(x);
   T *op = static_cast<T *>(out);
   switch (vpt) {
-    case 1: hipLaunchKernelGGL((ln_modulate_kernel<T, 1>), grid, dim3(256), 0, s, xp, ld, ss, ss_ld, eps, rows, L, C, tpr, op, out_ld); break;
-    case 2: hipLaunchKernelGGL((ln_modulate_kernel<T, 2>), grid, dim3(256), 0, s, xp, ld, ss, ss_ld, eps, rows, L, C, tpr, op, out_ld); break;
-    case 4: hipLaunchKernelGGL((ln_modulate_kernel<T, 4>), grid, dim3(256), 0, s, xp, ld, ss, ss_ld, eps, rows, L, C, tpr, op, out_ld); break;
-    case 8: hipLaunchKernelGGL((ln_modulate_kernel<T, 8>), grid, dim3(256), 0, s, xp, ld, ss, ss_ld, eps, rows, L, C, tpr, op, out_ld); break;
+    case 1: hipLaunchKernelGGL((ln_modulate_kernel<T, 1>), grid, dim3(256), 0, s, xp, ld, ss, ss_ld, eps, rows, L, C, tpr, op, out_ld, nreal, pf); break;
+    case 2: hipLaunchKernelGGL((ln_modulate_kernel<T, 2>), grid, dim3(256), 0, s, xp, ld, ss, ss_ld, eps, rows, L, C, tpr, op, out_ld, nreal, pf); break;
+    case 4: hipLaunchKernelGGL((ln_modulate_kernel<T, 4>), grid, dim3(256), 0, s, xp, ld, ss, ss_ld, eps, rows, L, C, tpr, op, out_ld, nreal, pf); break;
+    case 8: hipLaunchKernelGGL((ln_modulate_kernel<T, 8>), grid, dim3(256), 0, s, xp, ld, ss, ss_ld, eps, rows, L, C, tpr, op, out_ld, nreal, pf); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -526,13 +537,13 @@ hipError_t launch_gn_silu_ws(int dt, const void *x, int ld, int B, int L, int C,
 }
 
 hipError_t launch_gn_silu(int dt, const void *x, int ld, int B, int L, int C, int G, const float *gamma, const float *beta, float eps,
-                          void *out, int out_ld, hipStream_t s) {
-  return SF_DISPATCH_T(dt, gn_silu_go<T>(x, ld, B, L, C, G, gamma, beta, eps, out, out_ld, s));
+                          void *out, int out_ld, hipStream_t s, Prefetch pf) {
+  return SF_DISPATCH_T(dt, gn_silu_go<T>(x, ld, B, L, C, G, gamma, beta, eps, out, out_ld, s, pf));
 }
 
 hipError_t launch_ln_modulate(int dt, const void *x, int ld, const float *ss, int ss_ld, float eps, int B, int L, int C,
-                              void *out, int out_ld, hipStream_t s) {
-  return SF_DISPATCH_T(dt, ln_go<T>(x, ld, ss, ss_ld, eps, B, L, C, out, out_ld, s));
+                              void *out, int out_ld, hipStream_t s, Prefetch pf) {
+  return SF_DISPATCH_T(dt, ln_go<T>(x, ld, ss, ss_ld, eps, B, L, C, out, out_ld, s, pf));
 }
 
 }  // namespace sf

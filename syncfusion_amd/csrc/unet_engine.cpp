@@ -614,6 +614,30 @@ struct Exec {
     u.prof.push_back({label, flops, bytes, e0, e1, 0.f, cur_depth});
   }
 
+  // Hosted weight prefetch (kernels.h, Prefetch): the launch that PRECEDES a GEMM carries extra workgroups that read the GEMM's weights,
+  // so the GEMM streams them from the Infinity Cache instead of HBM (in the two-branch step: -1.0 us per GEMM launch, measured with a
+  // separate touch launch in front of every GEMM, profiles/r3_d_touch_*).  `host_wgs` = workgroups of the hosting launch: the
+  // prefetch takes the CUs it leaves idle.
+  Prefetch pf_for(const ConvW &w, int host_wgs) const {
+    static const bool off = getenv("SF_NO_PREFETCH") != nullptr;
+    Prefetch pf;
+    if (off || w.direct || !w.w || host_wgs > 208) return pf;   // a host that fills the chip has no idle CUs to lend
+    const size_t bytes = (size_t)w.N * w.K * dsize(u.dt);
+    if (bytes < (64u << 10) || bytes > 0x7FFFFFF0ull) return pf;   // small matrices: nothing to gain
+    pf.ptr = w.w;
+    pf.bytes = (unsigned)bytes;
+    static const int cap = [] {   // tuning hook: upper bound of prefetch workgroups per host launch
+      const char *e = getenv("SF_PF_WGS");
+      return e && atoi(e) > 0 ? atoi(e) : 224;
+    }();
+    static const int mult = [] {
+      const char *e = getenv("SF_PF_MULT");
+      return e && atoi(e) > 0 ? atoi(e) : 1;
+    }();
+    pf.wgs = std::max(std::min(48, cap), std::min(cap, mult * (256 - host_wgs)));
+    return pf;
+  }
+
   ConvGemmArgs filled(const ConvW &w, ConvGemmArgs a) const {
     a.w = w.w;
     a.bias = w.bias;
@@ -638,6 +662,13 @@ struct Exec {
                          (double)w.N * kreal * (w.direct ? 4.0 : (double)dsize(u.dt));
     if (w.direct) timed("conv_direct", flops, bytes, [&] { SF_HIP(launch_conv_direct(dt_in, dt_out, a, s)); });
     else {
+      // measurement aid: SF_TOUCH=n reads this GEMM's weights with an n-workgroup kernel right before it,
+      // to price what a weight prefetch hosted by the preceding kernel's idle CUs could save inside the real two-branch step
+      static const int touch = [] {
+        const char *e = getenv("SF_TOUCH");
+        return e ? atoi(e) : 0;
+      }();
+      if (touch > 0 && !u.prof_on) SF_HIP(launch_touch(w.w, (size_t)w.N * w.K * dsize(u.dt), touch, reinterpret_cast<unsigned *>(p.step + 8), s));
       if (dt_in != u.dt || (dt_out != u.dt && !a.out_f32)) fail(SF_ERR_INVALID, "internal: dtype mismatch on the MFMA path");
       if (ln) timed(conv_gemm_ln_variant_name(u.dt, a), flops + 8.0 * a.M * a.cin, bytes,
                     [&] { SF_HIP(launch_conv_gemm_ln(u.dt, a, s)); });
@@ -688,8 +719,10 @@ struct Exec {
     } else {
     const bool fuse_act = C <= 64;
     GnPlan gp = gn_plan(p.Bt, l.L, C);
-    auto conv3 = [&](const ConvW &w, const void *in, void *out, const float *gam, const float *bet, const void *res, float *rowpart) {
+    auto conv3 = [&](const ConvW &w, const void *in, void *out, const float *gam, const float *bet, const void *res, float *rowpart,
+                     const ConvW *next = nullptr) {
       ConvGemmArgs a;
+      if (next) a.pf = pf_for(*next, (int)((l.rows + 31) / 32) * ((C + 31) / 32));
       if (rowpart) {
         a.rowpart_out = rowpart;
         a.rowpart_nt = C / 32;
@@ -709,7 +742,7 @@ struct Exec {
         // (the chunked two-launch form of launch_gn_silu_ws was measured on the 2^18-sample shape: 97.4 vs 98.4 steps/s -- the second
         // launch costs what the better CU fill saves -- so the engine keeps the single launch)
         timed("gn_silu", 12.0 * l.rows * C, 3.0 * l.rows * C * dsize(u.dt),
-              [&] { SF_HIP(launch_gn_silu(u.dt, in, C, p.Bt, l.L, C, G, gam, bet, 1e-5f, l.act, C, s)); });
+              [&] { SF_HIP(launch_gn_silu(u.dt, in, C, p.Bt, l.L, C, G, gam, bet, 1e-5f, l.act, C, s, pf_for(w, p.Bt * G))); });
         a.src = l.act;
       }
       a.src_ld = C;
@@ -790,7 +823,7 @@ struct Exec {
       fuse_attn = inj_emits && conv_gemm_ln_ok(u.dt, filled(g.qkv, pq));
     }
     conv3(g.conv1, cur, tA, g.gn1_g, g.gn1_b, nullptr, nullptr);
-    conv3(g.conv2, tA, tB, g.gn2_g, g.gn2_b, cur, fuse_mod ? rp_y : nullptr);
+    conv3(g.conv2, tA, tB, g.gn2_g, g.gn2_b, cur, fuse_mod ? rp_y : nullptr, fuse_mod ? &g.inject : nullptr);
     if (fuse_mod) {
       // Modulation + InjectChannels in one GEMM: m = LN_C(y; 1e-6) * (1 + scale) + shift;  z = m + Conv1x1(cat[m, ctx]) (+ bias)
       ConvGemmArgs a = inject_args(tB, tA);
@@ -804,18 +837,21 @@ struct Exec {
         a.rowpart_out = rp_z;
         a.rowpart_nt = C / 32;
       }
+      if (g.attn) a.pf = pf_for(g.qkv, (int)((l.rows + 31) / 32) * (C / 32));
       conv(g.inject, a, u.dt, u.dt, /*ln=*/true);
       std::swap(tA, tB);   // z -> tB, as the code below expects
     } else {
       // Modulation: LN_C(x; eps 1e-6) * (1 + scale) + shift
       timed("ln_modulate", 8.0 * l.rows * C, 2.0 * l.rows * C * dsize(u.dt),
-            [&] { SF_HIP(launch_ln_modulate(u.dt, tB, C, p.mod_all + g.mod_off, p.mod_stride, 1e-6f, p.Bt, l.L, C, tA, C, s)); });
+            [&] { SF_HIP(launch_ln_modulate(u.dt, tB, C, p.mod_all + g.mod_off, p.mod_stride, 1e-6f, p.Bt, l.L, C, tA, C, s,
+                                            pf_for(g.inject, (int)(l.rows / 4)))); });
       // InjectChannels: Conv1x1(cat[x, ctx]) + x   (+ collapsed cross-attention bias when no self-attention follows)
       ConvGemmArgs a = inject_args(tA, tB);
       if (fuse_attn) {
         a.rowpart_out = rp_z;
         a.rowpart_nt = C / 32;
       }
+      if (g.attn) a.pf = pf_for(g.qkv, (int)((l.rows + 31) / 32) * (C / 32));
       conv(g.inject, a, u.dt, u.dt);
     }
     if (g.attn) {
@@ -826,6 +862,7 @@ struct Exec {
         a.ln_nt = C / 32;
         a.ln_eps = 1e-5f;
         a.ln_colsum = g.qkv_colsum;   // raw z through the MFMAs, rstd * (acc - mean * colsum) in the epilogue
+        a.pf = pf_for(g.attn_out, (int)((l.rows + 31) / 32) * (3 * u.hd / 32));
         conv(g.qkv, a, u.dt, u.dt, /*ln=*/true);
       } else {
         timed("ln_modulate", 6.0 * l.rows * C, 2.0 * l.rows * C * dsize(u.dt),
