@@ -28,7 +28,7 @@ struct BwdPlan {
 BwdPlan plan(Workspace &ws, int B, int L, int C, int N, int taps, int groups) {
   BwdPlan p;
   const int64_t rows = (int64_t)B * L;
-  p.ldn = (N % 32 == 0) ? N : N;   // dgrad reads dy rows of N channels: the MFMA path needs N % 32 == 0, else the direct kernel
+  p.ldn = N;   // dgrad reads dy rows of N channels (the MFMA path needs N % 32 == 0, else the direct kernel runs)
   if (groups > 0) p.act = ws.alloc_n<float>(rows * C);
   p.da = ws.alloc_n<float>(rows * C);
   p.wd = ws.alloc_n<float>((int64_t)C * taps * p.ldn);
