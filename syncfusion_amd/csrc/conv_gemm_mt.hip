@@ -371,6 +371,19 @@ int conv_gemm_mt_variant(const ConvGemmArgs &a) {
     // one workgroup per CU (the LDS ring fills it), each bound by its L2 -> LDS fill ~ (BM + BN) per K step: a launch costs
     // rounds x (BM + BN).  192-row tiles turn the 176-tile launches of the guidance batch (69 % of the CUs) into 235-240.
     const long nt = (a.n_store + 127) / 128;
+    {
+      // Launches that leave most of the CUs without a 128x128 tile (the deep levels at 16 evaluations per branch: 48-88 tiles) take
+      // 128x64 tiles, which fit twice on a CU: 1408 x 1024 x 3072 (depth 6) 32.7 -> 23.5 us alone (tools/mt_d7_variants.sh), batch 32
+      // without guidance 256.9 -> 263.2 steps/s (8 alternating runs, profiles/r3_f_ab_small_tiles.txt).  The 176-tile launches of
+      // the guidance batch gain 4 % alone (34.1 -> 32.6 us) and nothing in the step: the threshold stays at 100.  Long reductions
+      // only: on the K <= 1280 projections the deeper 192x128 / 128x128 rings measured better in the step.
+      static const int thr = [] {   // tuning hook: largest 128x128 tile count that still switches to 128x64 (0 = never)
+        const char *e = getenv("SF_MT_SMALL_TILES");
+        return e ? atoi(e) : 100;
+      }();
+      const long t128 = (long)((a.M + 127) / 128) * nt;
+      if (t128 <= thr && a.K >= 1536 && a.n_store % 64 == 0 && rule != 0) return 7;
+    }
     auto cost = [&](int bm) { return (((long)((a.M + bm - 1) / bm) * nt + 255) / 256) * (bm + 128); };
     const long c256 = cost(256), c192 = cost(192), c128 = cost(128);
     if (c192 < c256 && c192 <= c128) return 3;
