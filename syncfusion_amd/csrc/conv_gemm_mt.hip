@@ -372,17 +372,23 @@ int conv_gemm_mt_variant(const ConvGemmArgs &a) {
     // rounds x (BM + BN).  192-row tiles turn the 176-tile launches of the guidance batch (69 % of the CUs) into 235-240.
     const long nt = (a.n_store + 127) / 128;
     {
-      // Launches that leave most of the CUs without a 128x128 tile (the deep levels at 16 evaluations per branch: 48-88 tiles) take
-      // 128x64 tiles, which fit twice on a CU: 1408 x 1024 x 3072 (depth 6) 32.7 -> 23.5 us alone (tools/mt_d7_variants.sh), batch 32
-      // without guidance 256.9 -> 263.2 steps/s (8 alternating runs, profiles/r3_f_ab_small_tiles.txt).  The 176-tile launches of
-      // the guidance batch gain 4 % alone (34.1 -> 32.6 us) and nothing in the step: the threshold stays at 100.  Long reductions
-      // only: on the K <= 1280 projections the deeper 192x128 / 128x128 rings measured better in the step.
+      // Launches that leave half of the CUs or more without a 128x128 tile (the deep levels at 16 evaluations per branch: 48-132
+      // tiles) take 128x64 tiles, which fit twice on a CU.  Alone on the chip (tools/mt_d7_variants.sh, profiles/r3_f_mt_variants_*):
+      // 1408 x 1024 x 3072 32.7 -> 23.5 us, 704 x 1024 x 3072 31.9 -> 22.8, 2816 x 512 x 1536 18.7 -> 14.0, 5632 x 256 x 768 12.0 -> 9.0,
+      // 1408 x 1024 x 1280 17.0 -> 12.4, 1408 x 1536 x 1024 15.5 -> 14.0.  In the step: batch 32 without guidance 256.9 -> 263.2 steps/s
+      // with the K >= 1536 launches alone, 266.0 -> 268.6 with the shorter reductions and the 132-tile launches added (alternating
+      // runs, profiles/r3_f_ab_small_tiles*.txt).  The 176-tile launches of the guidance batch gain 4 % alone (34.1 -> 32.6 us) and
+      // nothing in the step: the threshold stays below them.
       static const int thr = [] {   // tuning hook: largest 128x128 tile count that still switches to 128x64 (0 = never)
         const char *e = getenv("SF_MT_SMALL_TILES");
-        return e ? atoi(e) : 100;
+        return e ? atoi(e) : 140;
       }();
       const long t128 = (long)((a.M + 127) / 128) * nt;
-      if (t128 <= thr && a.K >= 1536 && a.n_store % 64 == 0 && rule != 0) return 7;
+      static const int kmin = [] {   // tuning hook: shortest reduction that takes the rule
+        const char *e = getenv("SF_MT_SMALL_KMIN");
+        return e ? atoi(e) : 512;
+      }();
+      if (t128 <= thr && a.K >= kmin && a.n_store % 64 == 0 && rule != 0) return 7;
     }
     auto cost = [&](int bm) { return (((long)((a.M + bm - 1) / bm) * nt + 255) / 256) * (bm + 128); };
     const long c256 = cost(256), c192 = cost(192), c128 = cost(128);
