@@ -381,7 +381,7 @@ int conv_gemm_mt_variant(const ConvGemmArgs &a) {
       // nothing in the step: the threshold stays below them.
       static const int thr = [] {   // tuning hook: largest 128x128 tile count that still switches to 128x64 (0 = never)
         const char *e = getenv("SF_MT_SMALL_TILES");
-        return e ? atoi(e) : 140;
+        return e ? atoi(e) : 176;
       }();
       const long t128 = (long)((a.M + 127) / 128) * nt;
       static const int kmin = [] {   // tuning hook: shortest reduction that takes the rule

@@ -539,7 +539,14 @@ Plan make_plan(const sf_unet &u, Workspace &ws, int B, int L0, bool two, int num
     // spares the two-stream step graph that guidance needs
     // (re-measured with the later kernels: 32 evaluations 232 -> 253 steps/s with two branches, 16 clips with guidance 233 -> 243,
     // 40 / 48 evaluations +1 ... 3 %, 64 evaluations 163 -> 153: two branches up to 48 evaluations)
-    int want = u.branches_override > 0 ? u.branches_override : ((p.Bt >= 4 && p.Bt <= 48) ? 2 : 1);
+    // (round 3, after the hosted weight prefetch and the 128x64 rule for under-filled macro-tile launches: 64 evaluations -- batch 32
+    // with guidance, BASELINE configs[2] -- 168.2 -> 182.0 steps/s with two branches; 96 evaluations 113.7 -> 131.6; 128 evaluations
+    // 101.5 -> 108.3; four branches at 64 evaluations 166: profiles/r3_g_ab_branches.txt)
+    static const int two_max = [] {   // tuning hook: largest number of evaluations per step that still runs as two branches
+      const char *e = getenv("SF_TWO_BRANCH_MAX");
+      return e ? atoi(e) : 128;
+    }();
+    int want = u.branches_override > 0 ? u.branches_override : ((p.Bt >= 4 && p.Bt <= two_max) ? 2 : 1);
     if (want > sf_unet::kMaxBranches) want = sf_unet::kMaxBranches;
     while (want > 1 && p.Bt % want) --want;
     p.nbr = u.dbg.buf ? 1 : want;
