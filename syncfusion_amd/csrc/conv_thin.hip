@@ -928,14 +928,14 @@ ThinPlan conv_thin_plan(int B, int L, int C) {
   static const int rows8 = [] {   // tuning hook: positions per workgroup on the 8-channel level
     const char *e = getenv("SF_THIN_ROWS8");
     const int v = e ? atoi(e) : 0;
-    return v > 0 ? v : 1024;
+    return v > 0 ? v : 2048;
   }();
   // a wave's fixed cost (weights, prologue table, epilogue bookkeeping) is amortised over 32 positions x C channels
   // per tile: the 8-channel level gives each wave several tiles
   static const int rows_cap = [] {   // tuning hook: upper bound of positions per workgroup above 8 channels
     const char *e = getenv("SF_THIN_MAXROWS");
     const int v = e ? atoi(e) : 0;
-    return v > 0 ? v : 512;
+    return v > 0 ? v : 1024;   // (512 until round 3: with two branches at the guidance batch 1024 / 2048 measured +3.6 % on configs[2], +3 % at batch 32, +4.4 % on the 2^18-sample shape, profiles/r3_g_ab_thin_rows.txt)
   }();
   const int max_rows = C <= 8 ? rows8 : rows_cap;
   static const int wgs = [] {   // tuning hook: workgroups a launch aims for
