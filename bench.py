@@ -188,7 +188,7 @@ def extra_workloads(model, device, args, noise, channels, emb) -> dict:
                     lowp_vs_fp32_final_sample_rel_l2=round(rel, 6), lowp_dtype=args.dtype, rel_l2_steps=ref_steps)
 
     def config2_leg():
-        B, scale, steps = 32, 2.0, 10
+        B, scale, steps = 32, 2.0, BASELINE_STEPS      # the configuration's own 50 steps: the per-call conditioning is amortised as in a real run
         nz = torch.randn(B, 1, L0, generator=torch.Generator().manual_seed(1000)).to(device)
         ch, e = synthetic_conditioning(model, B, L0, device, real=True)
         rate, o = timed_sample(model, device, nz, ch, e, scale, steps, warm=2)
@@ -203,7 +203,7 @@ def extra_workloads(model, device, args, noise, channels, emb) -> dict:
     def config3_leg():
         # BASELINE configs[3]: 256 clips over 8 GPUs = 32 clips per GPU, no guidance: one GPU's share (the N-GPU run itself is the
         # driver's `--gpus N` weak-scaling sweep of configs[1])
-        B, steps = 32, 10
+        B, steps = 32, BASELINE_STEPS
         nz = torch.randn(B, 1, L0, generator=torch.Generator().manual_seed(1000)).to(device)
         ch, e = synthetic_conditioning(model, B, L0, device, real=True)
         rate, o = timed_sample(model, device, nz, ch, e, 1.0, steps, warm=2)
@@ -215,10 +215,10 @@ def extra_workloads(model, device, args, noise, channels, emb) -> dict:
                     tflops=round(w["flops"] / 1e12 / (ms * 1e-3), 1), step_roofline_frac=round(roof_ms(B, 1, L0, args.dtype) / ms, 4))
 
     def reference_leg():
-        B, L, scale, steps = 10, 262144, 2.0, 4      # exp/evaluate_gh_gen.yaml:8 (length), :21 (batch_size), :23 (embedding_scale)
+        B, L, scale, steps = 10, 262144, 2.0, 20     # exp/evaluate_gh_gen.yaml:8 (length), :21 (batch_size), :23 (embedding_scale)
         nz = torch.randn(B, 1, L, generator=torch.Generator().manual_seed(1000)).to(device)
         ch, e = synthetic_conditioning(model, B, L, device, real=True)
-        rate, o = timed_sample(model, device, nz, ch, e, scale, steps, warm=0)
+        rate, o = timed_sample(model, device, nz, ch, e, scale, steps, warm=2)
         assert torch.isfinite(o).all()
         ms = 1e3 / rate
         w = workmodel.unet_work(hp, L, B, 2, ES[args.dtype])
