@@ -85,8 +85,19 @@ def spawn_ranks(args, script: str = os.path.abspath(__file__), argv=None) -> int
     proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
     line = None
     for ln in proc.stdout.splitlines():
-        if ln.startswith("{") and '"metric"' in ln:
-            line = ln
+        # rank 0's JSON line, wherever it starts: the ranks share one pipe and the C++ side of torch.distributed (gloo / RCCL banners)
+        # writes to it unbuffered, so a partial banner can precede the object on the same line
+        at = ln.find('{"metric"')
+        obj = None
+        if at >= 0:
+            try:
+                obj, _ = json.JSONDecoder().raw_decode(ln[at:])
+            except ValueError:
+                obj = None
+        if isinstance(obj, dict):
+            line = json.dumps(obj)
+            if at > 0:
+                print(ln[:at], file=sys.stderr)
         else:
             print(ln, file=sys.stderr)
     if proc.returncode != 0 or line is None:

@@ -109,6 +109,7 @@ t = torch.tensor([float(dist.get_rank() + 1)])
 dist.all_reduce(t)
 print("noise on stdout from rank", dist.get_rank())
 if dist.get_rank() == 0:
+    sys.stdout.write("[partial banner without a newline] ")      # what an unbuffered C++ writer on the shared pipe can do to the line
     print(json.dumps({"metric": "fake", "n_gpus": dist.get_world_size(), "sum": float(t), "argv": sys.argv[1:]}))
 dist.destroy_process_group()
 '''
