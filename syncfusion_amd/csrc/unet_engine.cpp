@@ -798,7 +798,11 @@ struct Exec {
     };
     bool fuse_mod = false;
     // (measured: normalising the operand while staging costs more than the separate launch once the row is 1024 wide)
-    if (!fuse_act && C % 32 == 0 && C <= 512 && !u.no_ln_fusion) {
+    static const int ln_fuse_maxc = [] {   // tuning hook: widest level whose Modulation LayerNorm is folded into the InjectChannels GEMM
+      const char *e = getenv("SF_LN_FUSE_MAXC");
+      return e ? atoi(e) : 512;
+    }();
+    if (!fuse_act && C % 32 == 0 && C <= ln_fuse_maxc && !u.no_ln_fusion) {
       ConvGemmArgs pc;   // conv2 as it will be launched
       pc.src = l.act;
       pc.src_ld = C;
