@@ -231,7 +231,8 @@ int sf_op_conv1d_cl(int dtype, const void *x, const float *w, const float *bias,
  * exp/train_diffusion_gh.yaml:84-96, fp32): gradients of  y = conv1d(act(x)) + bias  with  act = silu(groupnorm(x)) when
  * groups > 0 (a ResnetItem convolution) or the identity when groups == 0 (the 1x1 InjectChannels convolution), stride 1,
  * 2 * pad == taps - 1, everything fp32 channels-last: x, dx:(B,L,C); dy:(B,L,N); w, dw:(N,C,taps) PyTorch layout; db:(N) or NULL;
- * dgb:(2C) = [dgamma | dbeta] (groups > 0).  No atomics: results are bit-reproducible. */
+ * dgb:(2C) = [dgamma | dbeta] (groups > 0).  dx may be NULL when groups == 0 and dw may be NULL (the caller needs no such gradient:
+ * that part of the work is skipped).  No atomics: results are bit-reproducible. */
 int64_t sf_op_conv1d_bwd_workspace_bytes(int B, int L, int C, int N, int taps, int groups);
 int sf_op_conv1d_bwd_cl(const float *x, const float *w, const float *gamma, const float *beta, int groups, float eps, const float *dy,
                         int B, int L, int C, int N, int taps, int pad, float *dx, float *dw, float *db, float *dgb, void *ws,

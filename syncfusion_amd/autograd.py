@@ -91,8 +91,12 @@ class _ConvBlockFn(torch.autograd.Function):
             dy_cl = _lib.f32c(dy) if channels_last else _cl(_lib.f32c(dy))
             if n_real != N:
                 dy_cl = torch.nn.functional.pad(dy_cl, (0, N - n_real))
-            dx = torch.empty_like(x_cl)
-            dw = torch.empty_like(w)
+            # ctx.needs_input_grad: (x, weight, bias, gamma, beta, ...).  The data gradient of a convolution without a GroupNorm in
+            # front and the weight gradient of a frozen layer are not computed at all (the C ABI takes NULL for them).
+            need_dx = ctx.needs_input_grad[0] or groups > 0
+            need_dw = ctx.needs_input_grad[1]
+            dx = torch.empty_like(x_cl) if need_dx else None
+            dw = torch.empty_like(w) if need_dw else None
             db = torch.empty(N, dtype=torch.float32, device=dev) if has_bias else None
             dgb = torch.empty(2 * Cc, dtype=torch.float32, device=dev) if groups > 0 else None
             n = lib.sf_op_conv1d_bwd_workspace_bytes(B, L, Cc, N, taps, groups)
@@ -100,14 +104,20 @@ class _ConvBlockFn(torch.autograd.Function):
                 raise _lib.SyncFusionAmdError(lib.sf_last_error().decode())
             ws = torch.empty(max(int(n), 256), dtype=torch.uint8, device=dev)
             _lib.check(lib.sf_op_conv1d_bwd_cl(x_cl.data_ptr(), w.data_ptr(), g.data_ptr() if groups > 0 else None, be.data_ptr() if groups > 0 else None,
-                                               groups, eps, dy_cl.data_ptr(), B, L, Cc, N, taps, pad, dx.data_ptr(), dw.data_ptr(),
+                                               groups, eps, dy_cl.data_ptr(), B, L, Cc, N, taps, pad, dx.data_ptr() if dx is not None else None,
+                                               dw.data_ptr() if dw is not None else None,
                                                db.data_ptr() if db is not None else None, dgb.data_ptr() if dgb is not None else None,
                                                ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)), "sf_op_conv1d_bwd_cl")
         if c_real != Cc:
-            dx, dw = dx[:, :, :c_real], dw[:, :c_real]
+            dx = dx[:, :, :c_real] if dx is not None else None
+            dw = dw[:, :c_real] if dw is not None else None
         if n_real != N:
-            dw, db = dw[:n_real], (db[:n_real] if db is not None else None)
-        return (dx if channels_last else dx.transpose(1, 2), dw, db, dgb[:Cc] if dgb is not None else None, dgb[Cc:] if dgb is not None else None,
+            dw, db = (dw[:n_real] if dw is not None else None), (db[:n_real] if db is not None else None)
+        if dx is not None and not channels_last:
+            dx = dx.transpose(1, 2)
+        if not ctx.needs_input_grad[0]:
+            dx = None
+        return (dx, dw, db, dgb[:Cc] if dgb is not None else None, dgb[Cc:] if dgb is not None else None,
                 None, None, None)
 
 

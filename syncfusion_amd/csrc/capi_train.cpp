@@ -58,8 +58,9 @@ int64_t sf_op_conv1d_bwd_workspace_bytes(int B, int L, int C, int N, int taps, i
 int sf_op_conv1d_bwd_cl(const float *x, const float *w, const float *gamma, const float *beta, int groups, float eps, const float *dy, int B, int L,
                         int C, int N, int taps, int pad, float *dx, float *dw, float *db, float *dgb, void *ws, int64_t ws_bytes, void *stream) {
   SF_API_BEGIN
-  if (!x || !w || !dy || !dx || !dw || !ws) fail(SF_ERR_INVALID, "null argument");
-  if (groups > 0 && (!gamma || !beta || !dgb)) fail(SF_ERR_INVALID, "GroupNorm backward needs gamma, beta and dgb");
+  if (!x || !w || !dy || !ws) fail(SF_ERR_INVALID, "null argument");
+  if (!dx && !dw && !db && !dgb) fail(SF_ERR_INVALID, "nothing to compute: dx, dw, db and dgb are all null");
+  if (groups > 0 && (!gamma || !beta || !dgb || !dx)) fail(SF_ERR_INVALID, "GroupNorm backward needs gamma, beta, dgb and dx");
   if (taps < 1 || pad < 0 || pad >= taps || 2 * pad != taps - 1) fail(SF_ERR_UNSUPPORTED, "stride-1 'same' convolutions only (2 * pad == taps - 1)");
   hipStream_t s = static_cast<hipStream_t>(stream);
   Workspace wk(ws, ws_bytes);
@@ -70,7 +71,9 @@ int sf_op_conv1d_bwd_cl(const float *x, const float *w, const float *gamma, cons
     act = p.act;
   }
   // ---- dgrad: da = conv(dy; W flipped and transposed), same padding -------------------------------------------
-  {
+  // (dx == NULL: the input needs no gradient -- the first convolution on the raw waveform, a frozen trunk -- and without a GroupNorm
+  // in front nothing else depends on da: the whole data gradient is skipped; likewise dw == NULL skips the weight gradient)
+  if (dx || groups > 0) {
     SF_HIP(launch_pack_dgrad(w, N, C, taps, p.ldn, p.wd, s));
     ConvGemmArgs a;
     a.src = dy;
@@ -93,7 +96,7 @@ int sf_op_conv1d_bwd_cl(const float *x, const float *w, const float *gamma, cons
     else SF_HIP(launch_conv_gemm(F32, a, s));
   }
   // ---- wgrad / bias grad ------------------------------------------------------------------------------------------
-  SF_HIP(launch_conv_wgrad(dy, act, B, L, C, N, taps, pad, p.wpart, p.S, dw, s));
+  if (dw) SF_HIP(launch_conv_wgrad(dy, act, B, L, C, N, taps, pad, p.wpart, p.S, dw, s));
   if (db) SF_HIP(launch_col_sums(dy, (int64_t)B * L, N, p.bpart, p.Sb, db, s));
   // ---- GroupNorm + SiLU ----------------------------------------------------------------------------------------------
   if (groups > 0) SF_HIP(launch_gn_silu_bwd(x, p.da, gamma, beta, B, L, C, groups, eps, dx, p.gpart, dgb, s));

@@ -49,6 +49,35 @@ def test_conv_block_gradients(cuda, B, L, C, N, taps, groups):
     assert torch.equal(leaves2[1].grad, ws.grad) and torch.equal(leaves2[0].grad, xs.grad)
 
 
+@pytest.mark.parametrize("groups", [0, 8])
+def test_conv_block_skips_gradients_nobody_asked_for(cuda, groups):
+    """backward honours ctx.needs_input_grad -- an input that needs no gradient (the raw waveform in front of the first
+    convolution) or a frozen weight is passed to the C ABI as NULL and that part of the work is skipped; what IS computed is bit-equal
+    to the full backward."""
+    from syncfusion_amd import autograd as sfa
+
+    B, L, C, N, taps = 2, 176, 64, 64, 3
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, C, L, generator=g).to(cuda)
+    w = (torch.randn(N, C, taps, generator=g) / (C * taps) ** 0.5).to(cuda)
+    b = (torch.randn(N, generator=g) * 0.1).to(cuda)
+    gamma, beta = (1 + 0.2 * torch.randn(C, generator=g)).to(cuda), (0.1 * torch.randn(C, generator=g)).to(cuda)
+    dy = torch.randn(B, N, L, generator=g).to(cuda)
+
+    def run(x_grad, w_grad):
+        xs, ws, bs = x.clone().requires_grad_(x_grad), w.clone().requires_grad_(w_grad), b.clone().requires_grad_()
+        gs, bes = gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+        y = sfa.gn_silu_conv1d(xs, ws, bs, gs, bes, groups) if groups else sfa.conv1d(xs, ws, bs)
+        y.backward(dy)
+        return xs.grad, ws.grad, bs.grad
+
+    dx, dw, db = run(True, True)
+    dx1, dw1, db1 = run(False, True)           # no data gradient wanted
+    assert dx1 is None and torch.equal(dw1, dw) and torch.equal(db1, db)
+    dx2, dw2, db2 = run(True, False)           # frozen weight
+    assert dw2 is None and torch.equal(dx2, dx) and torch.equal(db2, db)
+
+
 def test_resnet_item_and_inject_chain_against_oracle_autograd(cuda):
     """x -> ResnetItem -> InjectChannels with the SMALL_UNET parameters of depth 2: loss = mse(out, target); every parameter
     gradient and the input gradient against autograd through the oracle's own functions (oracle/unet_ref.py)."""
