@@ -237,7 +237,8 @@ int64_t sf_op_conv1d_bwd_workspace_bytes(int B, int L, int C, int N, int taps, i
 int sf_op_conv1d_bwd_cl(const float *x, const float *w, const float *gamma, const float *beta, int groups, float eps, const float *dy,
                         int B, int L, int C, int N, int taps, int pad, float *dx, float *dw, float *db, float *dgb, void *ws,
                         int64_t ws_bytes, void *stream);
-/* backward of sf_op_ln_modulate (fp32): dx:(B,L,C); dss:(B,2C) = [dscale | dshift] or NULL; ws >= B * min(64, ceil(L/64)) * 2C floats */
+/* backward of sf_op_ln_modulate (fp32): dx:(B,L,C); dss:(B,2C) = [dscale | dshift] or NULL; ws >= sf_op_ln_modulate_bwd_workspace_bytes */
+int64_t sf_op_ln_modulate_bwd_workspace_bytes(int B, int L, int C);
 int sf_op_ln_modulate_bwd(const float *x, const float *scale_shift, const float *dy, float eps, int B, int L, int C, float *dx, float *dss,
                           void *ws, int64_t ws_bytes, void *stream);
 /* backward of sf_op_attention (fp32 matrix cores, head_dim 64): out = the forward result; dq:(B,L,H*D), dkv:(B,L,2*H*D);

@@ -161,7 +161,7 @@ class _LnModulateFn(torch.autograd.Function):
             dyc = _lib.f32c(dy)
             dx = torch.empty_like(xc)
             dss = torch.empty(B, 2 * Cc, dtype=torch.float32, device=dev) if has_ss else None
-            ws = torch.empty(B * 64 * 2 * Cc * 4 + 256, dtype=torch.uint8, device=dev)
+            ws = torch.empty(max(int(lib.sf_op_ln_modulate_bwd_workspace_bytes(B, L, Cc)), 256), dtype=torch.uint8, device=dev)
             _lib.check(lib.sf_op_ln_modulate_bwd(xc.data_ptr(), sc.data_ptr() if has_ss else None, dyc.data_ptr(), eps, B, L, Cc, dx.data_ptr(),
                                                  dss.data_ptr() if dss is not None else None, ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)),
                        "sf_op_ln_modulate_bwd")

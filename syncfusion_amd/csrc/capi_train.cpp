@@ -104,12 +104,17 @@ int sf_op_conv1d_bwd_cl(const float *x, const float *w, const float *gamma, cons
   SF_API_END
 }
 
+int64_t sf_op_ln_modulate_bwd_workspace_bytes(int B, int L, int C) {
+  if (B < 1 || L < 1 || C < 1) return -1;
+  return (int64_t)B * ln_mod_bwd_chunks(L) * 2 * C * (int64_t)sizeof(float);
+}
+
 int sf_op_ln_modulate_bwd(const float *x, const float *scale_shift, const float *dy, float eps, int B, int L, int C, float *dx, float *dss, void *ws,
                           int64_t ws_bytes, void *stream) {
   SF_API_BEGIN
   if (!x || !dy || !dx || !ws) fail(SF_ERR_INVALID, "null argument");
   if (C < 4 || C > 1024 || (C & (C - 1))) fail(SF_ERR_UNSUPPORTED, "C must be a power of two in [4, 1024] (got %d)", C);
-  const int64_t need = (int64_t)B * ln_mod_bwd_chunks(L) * 2 * C * (int64_t)sizeof(float);
+  const int64_t need = sf_op_ln_modulate_bwd_workspace_bytes(B, L, C);
   if (ws_bytes < need) fail(SF_ERR_WORKSPACE, "workspace too small: need %lld bytes", (long long)need);
   SF_HIP(launch_ln_modulate_bwd(x, scale_shift, dy, eps, B, L, C, dx, static_cast<float *>(ws), dss, static_cast<hipStream_t>(stream)));
   return SF_OK;
