@@ -137,7 +137,8 @@ def synthetic_conditioning(model, B, L, device, real: bool):
     else:
         track[:, 0, 0] = 1.0
         emb = torch.zeros(B, 1, 512, device=device)
-    _, info = model.onsets_encoder(track, with_info=True)
+    with torch.no_grad():      # the inference engine (with autograd recording Encoder1d runs the differentiable fp32 composition)
+        _, info = model.onsets_encoder(track, with_info=True)
     return info["xs"][2:-1], emb
 
 
