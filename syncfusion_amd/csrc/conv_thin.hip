@@ -920,6 +920,7 @@ bool thin_tail_supported(int dt, const ThinTailArgs &a) {
 
 hipError_t launch_thin_tail(int dt, const ThinTailArgs &a, hipStream_t s) {
   if (!thin_tail_supported(dt, a)) return hipErrorInvalidValue;
+  if (d0_tail_supported(a)) return launch_d0_tail(dt, a, s);
   return SF_DISPATCH_T(dt, tail_dispatch<T>(a, s));
 }
 
@@ -928,7 +929,7 @@ ThinPlan conv_thin_plan(int B, int L, int C) {
   static const int rows8 = [] {   // tuning hook: positions per workgroup on the 8-channel level
     const char *e = getenv("SF_THIN_ROWS8");
     const int v = e ? atoi(e) : 0;
-    return v > 0 ? v : 2048;
+    return v > 0 ? v : 0;
   }();
   // a wave's fixed cost (weights, prologue table, epilogue bookkeeping) is amortised over 32 positions x C channels
   // per tile: the 8-channel level gives each wave several tiles
@@ -937,7 +938,10 @@ ThinPlan conv_thin_plan(int B, int L, int C) {
     const int v = e ? atoi(e) : 0;
     return v > 0 ? v : 1024;   // (512 until round 3: with two branches at the guidance batch 1024 / 2048 measured +3.6 % on configs[2], +3 % at batch 32, +4.4 % on the 2^18-sample shape, profiles/r3_g_ab_thin_rows.txt)
   }();
-  const int max_rows = C <= 8 ? rows8 : rows_cap;
+  // 8-channel level: 992 = 16 x 62 where the vector kernels run (conv_d0.hip) -- whole passes for them, 31 MFMA tiles for the up
+  // convolution that shares the chunking; against 2048 it measured +1.6 % on 32 evaluations per step and no change on 64
+  // (profiles/r3_j_ab_d0.txt).  The MFMA formulation prefers the long chunk.
+  const int max_rows = C <= 8 ? (rows8 > 0 ? rows8 : (d0_enabled(B, L) ? 992 : 2048)) : rows_cap;
   static const int wgs = [] {   // tuning hook: workgroups a launch aims for
     const char *e = getenv("SF_THIN_WGS");
     const int v = e ? atoi(e) : 0;
@@ -977,6 +981,7 @@ bool conv_thin_supported(int dt, const ConvThinArgs &a) {
 
 hipError_t launch_conv_thin(int dt, const ConvThinArgs &a, hipStream_t s) {
   if (!conv_thin_supported(dt, a)) return hipErrorInvalidValue;
+  if (d0_conv_supported(a)) return launch_d0_conv(dt, a, s);
   return SF_DISPATCH_T(dt, thin_dispatch<T>(a, s));
 }
 

@@ -39,6 +39,7 @@ struct Prefetch {
 struct ConvGemmArgs {
   Prefetch pf;   // hosted prefetch (conv_gemm_wp / conv_gemm_fast only; other kernels ignore it)
   const void *src = nullptr, *src2 = nullptr, *w = nullptr, *res = nullptr;
+  const float *w32 = nullptr;   // the same weights in fp32, [N][taps*C] (8-channel level: conv_d0.hip reads these as scalar operands)
   void *out = nullptr;
   const float *bias = nullptr, *gamma = nullptr, *beta = nullptr, *stats = nullptr;
   const float *badd = nullptr, *bscale = nullptr;
@@ -113,6 +114,7 @@ bool conv_gemm_supported(int dt, const ConvGemmArgs &a);
 // ---------------------------------------------------------------------------------------
 struct ConvThinArgs {
   const void *src = nullptr, *src2 = nullptr, *w = nullptr, *res = nullptr;
+  const float *w32 = nullptr;   // the same weights in fp32, [N][taps*C] (8-channel level: conv_d0.hip reads these as scalar operands)
   void *out = nullptr;
   const float *bias = nullptr, *gamma = nullptr, *beta = nullptr, *stats_in = nullptr, *ss = nullptr, *badd = nullptr, *bscale = nullptr;
   float *stats_out = nullptr;
@@ -133,6 +135,8 @@ ThinPlan conv_thin_plan(int B, int L, int C);
 //   y = x + Conv3(SiLU(GroupNorm(h)));  m = LayerNorm_C(y; eps_ln) * (1 + ss[b][c]) + ss[b][C + c];  out = m + W3 . [m | ctx] + bias3 (+ badd[b])
 struct ThinTailArgs {
   const void *h = nullptr, *x = nullptr, *ctx = nullptr, *w2 = nullptr, *w3 = nullptr;
+  const float *w2_32 = nullptr, *w3_32 = nullptr;   // fp32 [C][3*C] and [C][C + c2real] (8-channel level, conv_d0.hip)
+  int c2real = 0;
   void *out = nullptr;
   const float *bias2 = nullptr, *bias3 = nullptr, *gamma = nullptr, *beta = nullptr, *stats_in = nullptr, *ss = nullptr, *badd = nullptr;
   float *stats_out = nullptr;
@@ -144,6 +148,13 @@ bool thin_tail_supported(int dt, const ThinTailArgs &a);
 hipError_t launch_thin_tail(int dt, const ThinTailArgs &a, hipStream_t s);
 bool conv_thin_supported(int dt, const ConvThinArgs &a);
 hipError_t launch_conv_thin(int dt, const ConvThinArgs &a, hipStream_t s);
+// The 8-channel level on the vector units, one position per lane (conv_d0.hip): launch_conv_thin / launch_thin_tail route
+// C = N = 8 shapes here (same argument blocks, chunking and statistics layout); SF_NO_D0=1 keeps the MFMA formulation.
+bool d0_enabled(int B, int L);
+bool d0_conv_supported(const ConvThinArgs &a);
+bool d0_tail_supported(const ThinTailArgs &a);
+hipError_t launch_d0_conv(int dt, const ConvThinArgs &a, hipStream_t s);
+hipError_t launch_d0_tail(int dt, const ThinTailArgs &a, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------
 // Direct (VALU) convolution for thin layers (Cin*taps small, N <= 32): one output row per thread.

@@ -985,6 +985,7 @@ struct Exec {
       ConvThinArgs a = a1;
       a.src = cur;
       a.w = w1;
+      if (g.conv1.direct) a.w32 = static_cast<const float *>(g.conv1.w);
       a.bias = g.conv1.bias;
       a.gamma = g.gn1_g;
       a.beta = g.gn1_b;
@@ -1001,6 +1002,11 @@ struct Exec {
       t.ctx = l.ctx;
       t.ctx_ld = b.ctx_ld;
       t.w2 = w2;
+      if (g.conv2.direct && g.inject.direct) {
+        t.w2_32 = static_cast<const float *>(g.conv2.w);
+        t.w3_32 = static_cast<const float *>(g.inject.w);
+        t.c2real = g.inject.cin2;
+      }
       t.bias2 = g.conv2.bias;
       t.gamma = g.gn2_g;
       t.beta = g.gn2_b;
@@ -1043,6 +1049,7 @@ struct Exec {
       ConvThinArgs a = a1;
       a.src = tA;
       a.w = w2;
+      if (g.conv2.direct) a.w32 = static_cast<const float *>(g.conv2.w);
       a.bias = g.conv2.bias;
       a.gamma = g.gn2_g;
       a.beta = g.gn2_b;

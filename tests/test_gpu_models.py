@@ -347,6 +347,26 @@ def test_unet_edge_shapes(cuda, dtype, B, mult):
         assert rel_l2(out.cpu(), ref) < (FP32_TOL if dtype == "fp32" else 5e-2)
 
 
+def test_unet_edge_shapes_on_the_vector_level0_kernels(cuda):
+    """The 8-channel level switches to the vector kernels (csrc/conv_d0.hip) from 256 K positions per launch, so the small shapes
+    above run its MFMA formulation.  The same edge grid (clips shorter than a 62-position pass, ragged chunks, odd batches; fp32
+    and bf16, 120 combinations) with the vector kernels forced on -- the switch is read once per process, hence the child."""
+    import os, subprocess, sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SF_D0_MIN_ROWS="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "edge_sweep.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "FAIL" not in r.stdout, r.stdout[-2000:]
+    assert "worst rel-L2" in r.stdout
+    # and the switch did something: the same process with the kernels off must report different bf16 digits
+    worst = r.stdout.strip().splitlines()[-1]
+    r2 = subprocess.run([sys.executable, os.path.join(root, "tools", "edge_sweep.py")], env=dict(os.environ, SF_NO_D0="1"), capture_output=True,
+                        text=True, timeout=900)
+    assert r2.returncode == 0 and "FAIL" not in r2.stdout
+    assert r2.stdout.strip().splitlines()[-1] != worst
+
+
 # ----------------------------------------------------------------------------------------------------------
 # BASELINE-size checks (full 215 M-parameter U-Net, L0 = 45056): one evaluation against the oracle, then
 # size-independent properties of the sampler at batch 8.
