@@ -315,6 +315,8 @@ template <typename T, int GEOM, bool CAT> hipError_t launch_mt_v(const ConvGemmA
     case 5: return launch_mt<T, 128, 128, 2, 4, GEOM, CAT, 2, 2>(a, s);   // two-slot ring, 64 KB of LDS: two workgroups per CU
     case 6: return launch_mt<T, 128, 192, 4, 2, GEOM, CAT, 2, 2>(a, s);   // the same for 192-wide column tiles (80 KB)
     case 7: return launch_mt<T, 128, 64, 4, 2, GEOM, CAT, 3, 1>(a, s);    // three-slot ring of a 128x64 tile (72 KB): two workgroups per CU
+    case 8: return launch_mt<T, 192, 128, 2, 4, GEOM, CAT, 2, 2>(a, s);   // two-slot 192x128 (80 KB): two workgroups per CU, 5/6 of the fill of 128x128
+    case 9: return launch_mt<T, 256, 64, 8, 1, GEOM, CAT, 2, 2>(a, s);    // two-slot 256x64 (80 KB): the same for outputs of <= 64 columns
     default: return launch_mt<T, 256, 128, 4, 2, GEOM, CAT>(a, s);
   }
 }
@@ -340,13 +342,14 @@ bool conv_gemm_mt_ok(int dt, const ConvGemmArgs &a) {
 }
 
 // tile variant: 0 = 256x128, 1 = 128x128, 2 = 128x192, 3 = 192x128, 4 = 256x64 (three-slot ring, one workgroup per CU);
-//               5 = 128x128, 6 = 128x192 with a two-slot ring and a two-pass epilogue (two workgroups per CU)
+//               5 = 128x128, 6 = 128x192, 8 = 192x128, 9 = 256x64 with a two-slot ring and a two-pass epilogue (two workgroups per CU);
+//               7 = 128x64 with three slots (two workgroups per CU)
 int conv_gemm_mt_variant(const ConvGemmArgs &a) {
   static const int forced = [] {   // tuning hook
     const char *e = getenv("SF_MT_VARIANT");
     return e ? atoi(e) : -1;
   }();
-  if (forced >= 0 && forced <= 7) return forced;
+  if (forced >= 0 && forced <= 9) return forced;
   auto cols = [&](int bn) { return (long)((a.n_store + bn - 1) / bn) * bn; };
   static const int rule = [] {   // tuning hook: 0 = three-slot rings only, 1 = two-slot rings for every geometry, default: video geometry only
     const char *e = getenv("SF_MT_RULE");
@@ -363,8 +366,15 @@ int conv_gemm_mt_variant(const ConvGemmArgs &a) {
     // 12 U-Net guidance-batch shapes (tools/mt_variants.py, up to 30 % on the K = 256-512 projections), but inside the U-Net
     // step, where every GEMM starts on cold operands, the deeper three-slot ring holds its own (154 vs 162 steps/s at batch 32
     // with guidance), so the 1-D geometry keeps the rule below.
-    if (a.n_store <= 64) return 7;   // 128x64 tiles (three slots still fit twice)
-    return wide ? 6 : 5;
+    // Taller tiles with the same two-slot ring (80 KB, still two workgroups per CU) move 5/6 of the bytes per FLOP through the
+    // L2 -> LDS fill: 192x128 for 128x128 (+2.8 % on the whole net), 256x64 for 128x64 (+1 %), profiles/r3_j_onset_variants.txt --
+    // where the launch still has two rounds of them (the 7x7 and 14x14 stages keep the smaller tiles).
+    static const int v_thin = [] { const char *e = getenv("SF_MT_VIDEO_THIN"); return e ? atoi(e) : 9; }();   // tuning hooks
+    static const int v_sq = [] { const char *e = getenv("SF_MT_VIDEO_SQ"); return e ? atoi(e) : 8; }();
+    static const long tall_min = [] { const char *e = getenv("SF_MT_VIDEO_TALL_MIN"); return e ? atol(e) : 1024L; }();
+    if (a.n_store <= 64) return (long)((a.M + 255) / 256) >= tall_min ? v_thin : 7;   // 128x64 tiles (three slots still fit twice)
+    if (wide) return 6;
+    return (long)((a.M + 191) / 192) * ((a.n_store + 127) / 128) >= tall_min ? v_sq : 5;
   }
   if (wide) return rule == 0 ? 2 : 6;   // in the U-Net step too the two-slot 128x192 tile wins on the qkv projections (28.6 vs 34.2 us)
   if (a.geom == 0) {
@@ -399,8 +409,9 @@ int conv_gemm_mt_variant(const ConvGemmArgs &a) {
 }
 
 const char *conv_gemm_mt_name(const ConvGemmArgs &a) {
-  static const char *n[8] = {"conv_gemm_mt<bf16,256x128>", "conv_gemm_mt<bf16,128x128>", "conv_gemm_mt<bf16,128x192>", "conv_gemm_mt<bf16,192x128>",
-                             "conv_gemm_mt<bf16,256x64>", "conv_gemm_mt<bf16,128x128,2wg>", "conv_gemm_mt<bf16,128x192,2wg>", "conv_gemm_mt<bf16,128x64,2wg>"};
+  static const char *n[10] = {"conv_gemm_mt<bf16,256x128>", "conv_gemm_mt<bf16,128x128>", "conv_gemm_mt<bf16,128x192>", "conv_gemm_mt<bf16,192x128>",
+                             "conv_gemm_mt<bf16,256x64>", "conv_gemm_mt<bf16,128x128,2wg>", "conv_gemm_mt<bf16,128x192,2wg>", "conv_gemm_mt<bf16,128x64,2wg>",
+                             "conv_gemm_mt<bf16,192x128,2wg>", "conv_gemm_mt<bf16,256x64,2wg>"};
   return n[conv_gemm_mt_variant(a)];
 }
 
