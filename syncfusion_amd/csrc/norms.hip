@@ -433,12 +433,24 @@ hipError_t gn_silu_go(const void *x, int ld, int B, int L, int C, int G, const f
   dim3 grid(B * G);
 #define SF_GNS(VW) hipLaunchKernelGGL((gn_silu_kernel<T, VW>), grid, dim3(512), 0, s, xp, ld, L, C, G, gamma, beta, eps, op, out_ld)
   const bool al = (ld % V == 0) && (out_ld % V == 0);
-  if (al && cpg % V == 0 && 512 % (cpg / V) == 0 && (int64_t)L * (cpg / V) <= 4 * 512) {   // slab fits the registers of one workgroup
+  // slab fits the registers of one workgroup: up to 16 vectors of 16 bytes per thread (64 data registers of the 256 a wave of a
+  // 512-thread workgroup may hold).  8 and 16 cover the 2^18-sample clips (65 K elements per slab at depths 3-6), which the two-pass
+  // kernel below walked twice with four loads in flight: 16.4 us per launch, 10.6 % of that step (profiles/r3_h_refshape_*).
+  static const int max_rv = [] {   // tuning hook
+    const char *e = getenv("SF_GN_REG_MAXV");
+    const int v = e ? atoi(e) : 16;
+    return v >= 16 ? 16 : (v >= 8 ? 8 : 4);
+  }();
+  if (al && cpg % V == 0 && 512 % (cpg / V) == 0 && (int64_t)L * (cpg / V) <= (int64_t)max_rv * 512) {
     const int64_t nv = (int64_t)L * (cpg / V);
     const int nslab = B * G;
     const dim3 gridp(nslab + (pf.ptr && pf.bytes >= 16 ? pf.wgs : 0));
-    if (nv <= 2 * 512) hipLaunchKernelGGL((gn_silu_reg_kernel<T, 2>), gridp, dim3(512), 0, s, xp, ld, L, C, G, gamma, beta, eps, op, out_ld, nslab, pf);
-    else hipLaunchKernelGGL((gn_silu_reg_kernel<T, 4>), gridp, dim3(512), 0, s, xp, ld, L, C, G, gamma, beta, eps, op, out_ld, nslab, pf);
+#define SF_GNR(RV) hipLaunchKernelGGL((gn_silu_reg_kernel<T, RV>), gridp, dim3(512), 0, s, xp, ld, L, C, G, gamma, beta, eps, op, out_ld, nslab, pf)
+    if (nv <= 2 * 512) SF_GNR(2);
+    else if (nv <= 4 * 512) SF_GNR(4);
+    else if (nv <= 8 * 512) SF_GNR(8);
+    else SF_GNR(16);
+#undef SF_GNR
     return hipGetLastError();
   }
   if (al && cpg % V == 0) SF_GNS(V);
@@ -509,7 +521,7 @@ static hipError_t gn_silu_ws_go(const void *x, int ld, int B, int L, int C, int 
   done = false;
   if (C % G || G > 64 || C % V || (256 % (C / V)) || (ld % V) || (out_ld % V)) return hipSuccess;
   const int cpg = C / G;
-  if (cpg % V == 0 && 512 % (cpg / V) == 0 && (int64_t)L * (cpg / V) <= 4 * 512) return hipSuccess;   // register-resident kernel applies
+  if (cpg % V == 0 && 512 % (cpg / V) == 0 && (int64_t)L * (cpg / V) <= 16 * 512) return hipSuccess;   // register-resident kernel applies
   if ((int64_t)L * cpg < 32768) return hipSuccess;                                                       // short slabs: one launch wins
   const GnPlan gp = gn_plan(B, L, C);
   if ((int64_t)B * gp.nch * G * 2 > slab_floats) return hipSuccess;

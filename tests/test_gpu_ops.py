@@ -122,7 +122,9 @@ def test_ln_modulate(cuda, dtype, C, mod):
 @pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("B,L,C,with_ws", [
     (3, 44, 1024, True),      # register-resident kernel (the deep levels of a 2 s clip)
-    (2, 2048, 256, False),    # slab of 65 K elements, one workgroup per (clip, group), two passes
+    (2, 2048, 256, False),    # slab of 65 K elements: 16 vectors per thread in registers (16-bit), two passes in fp32
+    (2, 1024, 256, False),    # 8 vectors per thread (16-bit) / 16 (fp32)
+    (1, 4096, 256, False),    # 131 K elements: beyond the registers of a workgroup, two passes in every type
     (2, 2048, 256, True),     # the same through the chunked form (2^18-sample clips, depth 4)
     (3, 1000, 512, True),     # ragged chunks
     (1, 4096, 128, True),
