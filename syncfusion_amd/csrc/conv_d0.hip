@@ -260,8 +260,11 @@ __global__ __launch_bounds__(1024) void d0_conv_kernel(const ConvThinArgs a) {
     for (int j = 0; j < CH; ++j) {
       float y = fmaf(x[j], sc[j], sh[j]);
       if (a.pro == 1) y = silu_t<FAST>(y);
-      if constexpr (FAST) y = to_f(from_f<T>(y));   // the MFMA kernels feed the matrix cores 16-bit activations: same operand here
-      act[j] = in ? y : 0.f;                         // the convolution pads the ACTIVATED tensor with zeros
+      act[j] = y;   // kept in fp32 (the MFMA kernels round their operand to the 16-bit type: the vector path has no reason to)
+    }
+    if (base <= 0 || base + SPAN >= a.L) {   // wave-uniform: only a wave at a clip edge has lanes outside, and the convolution pads the
+#pragma unroll                              // ACTIVATED tensor with zeros
+      for (int j = 0; j < CH; ++j) act[j] = in ? act[j] : 0.f;
     }
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
@@ -274,7 +277,15 @@ __global__ __launch_bounds__(1024) void d0_conv_kernel(const ConvThinArgs a) {
       for (int j = 0; j < CH; ++j) rv[j] = act[j];
     }
 #pragma unroll
-    for (int j = 0; j < CH; ++j) o[j] = (o[j] + prm[2][j]) * prm[3][j] + rv[j] + prm[4][j];
+    for (int j = 0; j < CH; ++j) o[j] = o[j] + prm[2][j] + rv[j];
+    if (a.bscale) {   // SkipModulate-style per-clip scale: not on the item convolutions
+#pragma unroll
+      for (int j = 0; j < CH; ++j) o[j] = (o[j] - rv[j]) * prm[3][j] + rv[j];
+    }
+    if (a.badd) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) o[j] += prm[4][j];
+    }
     round8<T>(o);
     if (owner) store8<T>(out + (clip + p) * a.out_ld, o);
     if (a.stats_out) stats_add(st, o, owner, lane);
@@ -344,8 +355,11 @@ __global__ __launch_bounds__(1024) void d0_tail_kernel(const ThinTailArgs a) {
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
       float v = silu_t<FAST>(fmaf(hv[j], sc[j], sh[j]));
-      if constexpr (FAST) v = to_f(from_f<T>(v));
-      act[j] = in ? v : 0.f;
+      act[j] = v;
+    }
+    if (base <= 0 || base + SPAN >= a.L) {   // wave-uniform: a wave at a clip edge (zero padding of the activated tensor)
+#pragma unroll
+      for (int j = 0; j < CH; ++j) act[j] = in ? act[j] : 0.f;
     }
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
@@ -353,12 +367,11 @@ __global__ __launch_bounds__(1024) void d0_tail_kernel(const ThinTailArgs a) {
       nx[j] = from_next(act[j]);
     }
     conv3_8(w2, pv, act, nx, y);
-    // y = conv2 + bias + x, rounded as the unfused path stores it; LayerNorm over the 8 channels of the position; modulate
+    // y = conv2 + bias + x; LayerNorm over the 8 channels of the position; modulate
     float sum = 0.f;
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
-      y[j] += prm[2][j] + xv[j];
-      if constexpr (FAST) y[j] = to_f(from_f<T>(y[j]));
+      y[j] += prm[2][j] + xv[j];   // (y and m stay in fp32: the unfused path rounds them to the 16-bit type because it stores them)
       sum += y[j];
     }
     const float mean = sum * 0.125f;
@@ -373,7 +386,6 @@ __global__ __launch_bounds__(1024) void d0_tail_kernel(const ThinTailArgs a) {
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
       m[j] = fmaf((y[j] - mean) * rstd, prm[3][j], prm[4][j]);
-      if constexpr (FAST) m[j] = to_f(from_f<T>(m[j]));   // m is both the operand and the residual of the 1x1 convolution
     }
     float dep = m[0];
 #pragma unroll
