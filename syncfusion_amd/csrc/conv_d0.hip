@@ -53,21 +53,7 @@ template <typename T> struct Raw8 {
     }
   }
 };
-template <typename T> __device__ __forceinline__ void load8(const T *p, float (&v)[CH]) {
-  if constexpr (sizeof(T) == 2) {
-    const Vec16<T> r = ld16<T>(p);
-#pragma unroll
-    for (int j = 0; j < CH; ++j) v[j] = r.get(j);
-  } else {
-    const f32x4 a = *reinterpret_cast<const f32x4 *>(p), b = *reinterpret_cast<const f32x4 *>(p + 4);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      v[j] = a[j];
-      v[4 + j] = b[j];
-    }
-  }
-}
-// stores v rounded to T and returns the rounded values in v (the statistics see what was stored)
+// rounds v to T in place (the statistics see what is stored)
 template <typename T> __device__ __forceinline__ void round8(float (&v)[CH]) {
   if constexpr (sizeof(T) == 2) {
 #pragma unroll

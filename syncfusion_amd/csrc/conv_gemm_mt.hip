@@ -402,8 +402,10 @@ int conv_gemm_mt_variant(const ConvGemmArgs &a) {
     }
     auto cost = [&](int bm) { return (((long)((a.M + bm - 1) / bm) * nt + 255) / 256) * (bm + 128); };
     const long c256 = cost(256), c192 = cost(192), c128 = cost(128);
-    if (c192 < c256 && c192 <= c128) return 3;
-    return c128 < c256 ? 1 : 0;
+    static const int v192 = [] { const char *e = getenv("SF_MT_V192"); return e ? atoi(e) : 3; }();   // tuning hooks: 8 / 5 = the two-slot forms
+    static const int v128 = [] { const char *e = getenv("SF_MT_V128"); return e ? atoi(e) : 1; }();
+    if (c192 < c256 && c192 <= c128) return v192;
+    return c128 < c256 ? v128 : 0;
   }
   return t256 < 160 ? 1 : 0;                                   // few row bands: halve the tile so that more CUs get one
 }
