@@ -182,7 +182,7 @@ def extra_workloads(model, device, args, noise, channels, emb) -> dict:
 
     def fp32_leg():
         # the same torch module, engine repacked in fp32 (identical weights): the path gated at 1e-4 against the oracle
-        steps = 10
+        steps = 40   # (10 timed steps gave 179-209 steps/s from run to run on boxes where 30 give 216 three times in a row)
         ref_steps = min(args.steps, 20)
         lo = model.model.sample(x_noisy=noise, num_steps=ref_steps, channels=channels, embedding=emb, embedding_scale=args.scale)
         prev = net.compute_dtype
