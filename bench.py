@@ -295,7 +295,7 @@ def extra_workloads(model, device, args, noise, channels, emb) -> dict:
     def train_leg():
         # the reference's training configuration (exp/train_diffusion_gh.yaml:8,38,87): fp32, batch 4 per device, clips of 2^18
         # samples; Model.training_step -> loss.backward() (HIP forward + backward kernels) -> AdamW over U-Net + onset encoder
-        B, L, iters = 4, 262144, 3
+        B, L, iters = 4, 262144, 5
         g = torch.Generator().manual_seed(5)
         x = torch.randn(B, 1, L, generator=g).to(device)
         y = (torch.rand(B, 1, L, generator=g) < 0.0005).float().to(device)
@@ -312,9 +312,11 @@ def extra_workloads(model, device, args, noise, channels, emb) -> dict:
                     opt.zero_grad(set_to_none=True)
                     loss.backward()
                     opt.step()
-                    losses.append(round(float(loss.detach()), 5))
+                    losses.append(loss.detach())   # read back after the timed region: a host read per step would serialise the
+                                                   # Python-issued forward of step i+1 behind the backward of step i
                 torch.cuda.synchronize(device)
                 dt = (time.perf_counter() - t0) / iters
+                losses = [round(float(v), 5) for v in losses]
         finally:
             del opt
             model.zero_grad(set_to_none=True)
