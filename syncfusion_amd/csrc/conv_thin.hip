@@ -29,6 +29,22 @@
 namespace sf {
 namespace {
 
+// waves per workgroup at most, by the channel count of the level (tuning hooks SF_THIN_WAVES32 / SF_THIN_WAVES64: 8 lets two workgroups
+// of 512-position chunks share a CU -- the kernels hold ~100 registers, so a CU takes 16-20 waves of them)
+static int thin_max_waves(int C) {
+  static const int v32 = [] {
+    const char *e = getenv("SF_THIN_WAVES32");
+    const int w = e ? atoi(e) : 8;
+    return w >= 16 ? 16 : (w >= 8 ? 8 : 4);
+  }();
+  static const int v64 = [] {
+    const char *e = getenv("SF_THIN_WAVES64");
+    const int w = e ? atoi(e) : 8;
+    return w >= 16 ? 16 : (w >= 8 ? 8 : 4);
+  }();
+  return C == 32 ? v32 : (C == 64 ? v64 : 16);
+}
+
 constexpr int kThinMaxTiles = 64;   // 32-position tiles per workgroup (RW <= 2048; 512 above 8 channels)
 constexpr int kThinMaxG = 16;
 
@@ -519,7 +535,7 @@ template <typename T, int CIN, int TAPS, int C2, int PRO, int NOUT> hipError_t t
   }
   constexpr int NCB = (NOUT + 31) / 32;
   int nw = ((a.rw + 31) / 32) * NCB;
-  if (nw > 16) nw = 16;
+  if (nw > thin_max_waves(NOUT)) nw = thin_max_waves(NOUT);
   nw = (nw / NCB) * NCB;
   // staging registers: the source rows of a workgroup (<= rw + 2) * CIN/8 vectors must fit NV = 6 per thread
   if (((a.rw >> a.up_shift) + 3) * (CIN / 8) > 6 * nw * 64) return hipErrorInvalidValue;
@@ -886,7 +902,7 @@ template <typename T, int C, int C2> hipError_t tail_go(const ThinTailArgs &a, h
     }
   }
   int nw = (a.rw + 31) / 32;
-  if (nw > 16) nw = 16;
+  if (nw > thin_max_waves(C)) nw = thin_max_waves(C);
   if ((a.rw + 2) * (C / 8) > 6 * nw * 64) return hipErrorInvalidValue;
   hipLaunchKernelGGL(kern, dim3(a.B * a.nchw), dim3(nw * 64), lds, s, a);
   return hipGetLastError();
@@ -911,7 +927,7 @@ bool thin_tail_supported(int dt, const ThinTailArgs &a) {
   if (!a.ss || !a.stats_in) return false;
   {
     int nw = (a.rw + 31) / 32;
-    if (nw > 16) nw = 16;
+    if (nw > thin_max_waves(a.C)) nw = thin_max_waves(a.C);
     if ((a.rw + 2) * (a.C / 8) > 6 * nw * 64) return false;
   }
   const size_t lds = dt == F32 ? tail_lds_bytes<float>(a.C, a.C2, a.rw) : tail_lds_bytes<bf16>(a.C, a.C2, a.rw);
@@ -936,12 +952,19 @@ ThinPlan conv_thin_plan(int B, int L, int C) {
   static const int rows_cap = [] {   // tuning hook: upper bound of positions per workgroup above 8 channels
     const char *e = getenv("SF_THIN_MAXROWS");
     const int v = e ? atoi(e) : 0;
-    return v > 0 ? v : 1024;   // (512 until round 3: with two branches at the guidance batch 1024 / 2048 measured +3.6 % on configs[2], +3 % at batch 32, +4.4 % on the 2^18-sample shape, profiles/r3_g_ab_thin_rows.txt)
+    return v > 0 ? v : 352;   // 64 channels: 352 positions x 8 waves (two workgroups per CU; 6 staged vectors per thread bound the chunk);
+                               // one workgroup of 16 waves x 1024 positions measured 1.4 % slower on configs[2] and the 2^18-sample shape
+                               // (profiles/r3_k_ab_thin_waves.txt).  (512 until round 3: with two branches at the guidance batch 1024 / 2048 measured +3.6 % on configs[2], +3 % at batch 32, +4.4 % on the 2^18-sample shape, profiles/r3_g_ab_thin_rows.txt)
   }();
   // 8-channel level: 992 = 16 x 62 where the vector kernels run (conv_d0.hip) -- whole passes for them, 31 MFMA tiles for the up
   // convolution that shares the chunking; against 2048 it measured +1.6 % on 32 evaluations per step and no change on 64
   // (profiles/r3_j_ab_d0.txt).  The MFMA formulation prefers the long chunk.
-  const int max_rows = C <= 8 ? (rows8 > 0 ? rows8 : (d0_enabled(B, L) ? 992 : 2048)) : rows_cap;
+  static const int rows32 = [] {   // tuning hook: the same bound on the 32-channel level alone
+    const char *e = getenv("SF_THIN_MAXROWS32");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 512;
+  }();
+  const int max_rows = C <= 8 ? (rows8 > 0 ? rows8 : (d0_enabled(B, L) ? 992 : 2048)) : (C == 32 && rows32 > 0 ? rows32 : rows_cap);
   static const int wgs = [] {   // tuning hook: workgroups a launch aims for
     const char *e = getenv("SF_THIN_WGS");
     const int v = e ? atoi(e) : 0;
@@ -971,7 +994,7 @@ bool conv_thin_supported(int dt, const ConvThinArgs &a) {
   {   // staging registers: the source rows of a workgroup must fit 6 vectors per thread (see thin_go)
     const int ncb = (a.N + 31) / 32;
     int nw = ((a.rw + 31) / 32) * ncb;
-    if (nw > 16) nw = 16;
+    if (nw > thin_max_waves(a.N)) nw = thin_max_waves(a.N);
     nw = (nw / ncb) * ncb;
     if (((a.rw >> a.up_shift) + 3) * (a.C / 8) > 6 * nw * 64) return false;
   }
