@@ -32,6 +32,14 @@ constexpr int NSTAGE = 3;
 
 typedef __attribute__((address_space(3))) void lds_void;
 
+// -DSF_MT_STAMPS: workgroup 0 accumulates, per wave, the shader-clock cycles (s_memtime) its K loop spends in each part of a K step --
+// counted wait | barrier | DMA issue | fragment reads + MFMA issue -- plus prologue and epilogue, into g_mt_stamps[wave][6]
+// (tools/mt_stamps.hip reads them back).  Off in the product build.
+#ifdef SF_MT_STAMPS
+__device__ unsigned long long g_mt_stamps[8][8];
+#define SF_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#endif
+
 // CAT: K = taps * cin + cin2, the last cin2 columns read row m of a second source (InjectChannels: Conv1x1 over cat[x, ctx])
 // WM x WN = 8 waves; a wave owns (BM / WM) x (BN / WN) = (32 TM) x (32 TN) of the block tile
 template <typename T, int BM, int BN, int WM, int WN, int GEOM, bool CAT, int NST = NSTAGE, int EP = 1>
@@ -177,22 +185,59 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
   const unsigned sw = (unsigned)(fr & 7);   // rows of a fragment: (row & 7) == (fr & 7) since every row base is a multiple of 8
 
   // ---- prologue: two K steps in flight ---------------------------------------------------------------------------
+#ifdef SF_MT_STAMPS
+  SF_STAMP(t_begin);
+  unsigned long long c_wait = 0, c_bar = 0, c_issue = 0, c_mma = 0;
+#endif
   issue(0);
   if (NST == 3 && nk > 1) issue(1);
+#ifdef SF_MT_STAMPS
+  SF_STAMP(t_loop);
+#endif
 
   for (int k = 0; k < nk; ++k) {
+#ifdef SF_MT_STAMPS
+    SF_STAMP(t0);
+#endif
     if constexpr (NST == 3) {
       // own DMA of step k has landed when at most the NLD loads of step k+1 are still outstanding
       if (k + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef SF_MT_STAMPS
+      SF_STAMP(t1);
+#endif
       __builtin_amdgcn_s_barrier();   // every wave's step-k data is in LDS; every wave is done reading step k-1's slot
+#ifdef SF_MT_STAMPS
+      SF_STAMP(t2);
+#endif
       if (k + 2 < nk) issue((k + 2) % 3);
+#ifdef SF_MT_STAMPS
+      SF_STAMP(t3);
+      c_wait += t1 - t0;
+      c_bar += t2 - t1;
+      c_issue += t3 - t2;
+#endif
     } else {
       // two slots (half the LDS: two workgroups share a CU and cover each other's prologue / epilogue): one step ahead only
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef SF_MT_STAMPS
+      SF_STAMP(t1);
+#endif
       __builtin_amdgcn_s_barrier();
+#ifdef SF_MT_STAMPS
+      SF_STAMP(t2);
+#endif
       if (k + 1 < nk) issue((k + 1) % 2);
+#ifdef SF_MT_STAMPS
+      SF_STAMP(t3);
+      c_wait += t1 - t0;
+      c_bar += t2 - t1;
+      c_issue += t3 - t2;
+#endif
     }
+#ifdef SF_MT_STAMPS
+    SF_STAMP(t4);
+#endif
     const unsigned char *slot = smem + (k % NST) * STAGE;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -207,7 +252,15 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = mfma32x16(af[i], bf[j], acc[i][j]);
     }
+#ifdef SF_MT_STAMPS
+    asm volatile("s_nop 0" ::"v"(acc[0][0][0]));   // the last MFMA of the step has written its accumulator
+    SF_STAMP(t5);
+    c_mma += t5 - t4;
+#endif
   }
+#ifdef SF_MT_STAMPS
+  SF_STAMP(t_loop_end);
+#endif
 
   // ---- epilogue through LDS: each wave parks its RM x RN fp32 tile (EP = 2: half of the rows of every 32-row MFMA tile at a time, so
   // that the parking area fits inside a two-slot ring), then streams it out row-major ----------------------------------------------
@@ -282,6 +335,20 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
     if (live) st16<T>(out + (size_t)m * a.out_ld + n, o);
   }
   }
+#ifdef SF_MT_STAMPS
+  if (blockIdx.x == 0 && lane == 0) {
+    SF_STAMP(t_end);
+    unsigned long long *o = g_mt_stamps[wave];
+    o[0] = c_wait;
+    o[1] = c_bar;
+    o[2] = c_issue;
+    o[3] = c_mma;
+    o[4] = t_loop - t_begin;
+    o[5] = t_end - t_loop_end;
+    o[6] = t_end - t_begin;
+    o[7] = (unsigned long long)nk;
+  }
+#endif
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int GEOM, bool CAT, int NST = NSTAGE, int EP = 1> hipError_t launch_mt(const ConvGemmArgs &a, hipStream_t s) {
