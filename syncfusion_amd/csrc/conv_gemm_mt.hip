@@ -76,7 +76,12 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
 
   // ---- DMA lane geometry: a wave-instruction fills 8 rows x 128 B; lane -> (row lane>>3, LDS chunk lane&7), source chunk swizzled
   const int lrow = lane >> 3;
-  const unsigned gchunk_b = (unsigned)(((lane & 7) ^ lrow) * 16);
+  // Swizzle key of a staged row = (row >> 1) & 7.  A ds_read_b128 is serviced in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}
+  // (+ 32 for the upper half-wave), 16 lanes per LDS cycle over 64 banks of 4 bytes: a fragment read takes 16 rows whose bank quad is
+  // 8 (row & 1) + chunk, so the eight even (odd) rows of a group need eight different chunks -- (row >> 1) & 7 gives exactly that for both
+  // groups, where the row & 7 used until round 3 put two rows on every quad (SQ_LDS_BANK_CONFLICT = 49 % of SQ_LDS_IDX_ACTIVE,
+  // profiles/r3_l_cfg2_lds.csv).  A DMA piece is rows (i * 8 + wave) * 8 + lrow, i.e. key (4 wave + (lrow >> 1)) & 7.
+  const unsigned gchunk_b = (unsigned)(((lane & 7) ^ ((4 * (wave & 1) + (lrow >> 1)) & 7)) * 16);
   int rbase[PA], rp0[PA], rh[PA], rw_[PA];
   unsigned vmask[PA], woff[PB], roff2[PA];
 #pragma unroll
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
     const int row = wn * RN + j * 32 + fr;
     offB[j] = (unsigned)(BM * ROWB + row * ROWB);
   }
-  const unsigned sw = (unsigned)(fr & 7);   // rows of a fragment: (row & 7) == (fr & 7) since every row base is a multiple of 8
+  const unsigned sw = (unsigned)((fr >> 1) & 7);   // rows of a fragment: every row base is a multiple of 32, so (row >> 1) & 7 == (fr >> 1) & 7
 
   // ---- prologue: two K steps in flight ---------------------------------------------------------------------------
 #ifdef SF_MT_STAMPS
