@@ -331,12 +331,15 @@ template <typename T> __global__ __launch_bounds__(256) void attention_mfma4_ker
 // layouts and operand permutation as above with TK = 32.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int KS = 4, TK2 = 32;
-constexpr int LDK2 = D + 8, LDV2 = TK2 + 8;
-constexpr int WSTG = TK2 * LDK2 + D * LDV2;   // bf16 elements of one wave's staging area (K tile | V^T tile)
+constexpr int LDK2 = D + 8;
+constexpr int LDVR = 96;                         // row pitch of the ROW-major V tile (192 B, as in the 4-wave kernel below)
+constexpr int WSTG = TK2 * LDK2 + TK2 * LDVR;   // bf16 elements of one wave's staging area (K tile | V tile)
+typedef short v4i16k __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4i16k lds_v4i16k;
 
 template <typename T> __global__ __launch_bounds__(256) void attention_ksplit_kernel(const T *__restrict__ q, int ldq, const T *__restrict__ kv, int ldkv,
                                                                int L, int H, T *__restrict__ out, int ldo, float scale) {
-  // staging: KS x WSTG bf16 (39 KB); merge (aliases it after a barrier): KS x 32 x (D + 1) floats + KS x 32 x 2
+  // staging: KS x WSTG bf16 (43 KB); merge (aliases it after a barrier): KS x 32 x (D + 1) floats + KS x 32 x 2
   __shared__ __attribute__((aligned(16))) unsigned char smem[KS * WSTG * 2 > KS * 32 * (D + 4) * 4 ? KS * WSTG * 2 : KS * 32 * (D + 4) * 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
@@ -346,7 +349,7 @@ template <typename T> __global__ __launch_bounds__(256) void attention_ksplit_ke
   const int qi = q0 + fr;
   const bool qvalid = qi < L;
   T *Ks = reinterpret_cast<T *>(smem) + (size_t)wave * WSTG;
-  T *Vt = Ks + TK2 * LDK2;
+  T *Vs = Ks + TK2 * LDK2;
 
   typename Frag16<T>::type qf[4];
   {
@@ -388,10 +391,11 @@ template <typename T> __global__ __launch_bounds__(256) void attention_ksplit_ke
     for (int i = 0; i < 4; ++i) {
       const int kr = i * 8 + srow;
       st16<T>(Ks + kr * LDK2 + svec * 8, rk[i]);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) Vt[(svec * 8 + j) * LDV2 + kr] = rv[i].v[j];
-    }
+      st16<T>(Vs + kr * LDVR + svec * 8, rv[i]);   // row-major: the transposed fragments are gathered by ds_read_b64_tr_b16 (until round 3
+    }                                              // 32 two-byte stores per thread wrote V^T: 65 % of this kernel's LDS cycles were bank conflicts)
   };
+  // transposed-read lane geometry (see attention_mfma4_kernel): lane 4 q + p of a 16-lane group addresses key row q, head dims 4 p ... 4 p + 3
+  const int tr_off = (4 * fh + ((lane & 15) >> 2)) * LDVR + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
 
   if (wave < ntk) prefetch(wave * TK2);
   for (int t = wave; t < ntk; t += KS) {
@@ -439,17 +443,12 @@ template <typename T> __global__ __launch_bounds__(256) void attention_ksplit_ke
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        const T *vp = Vt + (32 * i + fr) * LDV2 + 16 * ks + 4 * fh;
-        typedef __attribute__((ext_vector_type(4))) T x4_t;
-        x4_t lo = *reinterpret_cast<const x4_t *>(vp);
-        x4_t hi = *reinterpret_cast<const x4_t *>(vp + 8);
-        typename Frag16<T>::type vf;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          vf[j] = lo[j];
-          vf[4 + j] = hi[j];
-        }
-        o[i] = mfma32x16(vf, pf[ks], o[i]);
+        const T *vp = Vs + tr_off + (16 * ks) * LDVR + 32 * i;
+        const v4i16k lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16k *)(vp));
+        const v4i16k hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16k *)(vp + 8 * LDVR));
+        typedef short v8i16k __attribute__((ext_vector_type(8)));
+        const v8i16k both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        o[i] = mfma32x16(__builtin_bit_cast(typename Frag16<T>::type, both), pf[ks], o[i]);
       }
   }
   lrun += __shfl_xor(lrun, 32, 64);
