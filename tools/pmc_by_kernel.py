@@ -30,7 +30,7 @@ def main():
             seen.add((cn, key))
             if cn not in names:
                 names.append(cn)
-            a = agg[r["Kernel_Name"].split("(")[0][:110]]
+            a = agg[r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("\"", "")[:110]]
             if key not in a["n"]:
                 a["n"].add(key)
                 a["t"] += dur.get(key, 0)
