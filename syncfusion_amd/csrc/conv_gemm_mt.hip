@@ -10,7 +10,7 @@
 //   * operands go global -> LDS DIRECTLY (`buffer_load_dwordx4 ... lds`, 16 B per lane, out-of-range offsets return zero, so
 //     padding rows / taps outside the clip / M and N tails need no predication) into a 3-slot LDS ring of 64-deep K steps;
 //     the LDS image is lane-linear, so the bank-conflict swizzle sits on the SOURCE side (16-byte chunk c of row r is fetched
-//     from chunk c ^ (r & 7)) and on the fragment reads (rule 21 of the guide);
+//     from chunk c ^ ((r >> 1) & 7), the key that is conflict-free for the lane groups of ds_read_b128, see the kernel) and on the fragment reads (rule 21 of the guide);
 //   * one raw s_barrier per K step and a COUNTED s_waitcnt vmcnt(N): the loads of step k+1 stay in flight across the barrier
 //     while step k is multiplied, those of step k+2 are issued right after the barrier (the slot they overwrite was read during
 //     step k-1, which every wave has finished when it passes the barrier);
