@@ -63,6 +63,7 @@ def parse_args(argv=None):
     ap.add_argument("--scale", type=float, default=1.0, help="embedding_scale (!= 1 -> classifier-free guidance, 2 evals/step)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config0", action="store_true", help="skip cpu_baseline.config0_full (the oracle's whole 10-step guided sample)")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads of the `extra` object")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--dump-launches", default=None, help="write the per-launch event timings of one evaluation to this file")
@@ -107,7 +108,7 @@ def spawn_ranks(args, script: str = os.path.abspath(__file__), argv=None) -> int
     return 0
 
 
-def build_model(dtype: str, device):
+def build_model(dtype: str, device, upsample_mode: str = "nearest"):
     import contextlib
 
     import torch
@@ -118,6 +119,8 @@ def build_model(dtype: str, device):
     torch.manual_seed(1234)
     cfg = model_config()
     cfg["model"]["net_t"]["dtype"] = dtype
+    if upsample_mode != "nearest":
+        cfg["model"]["upsample_mode"] = upsample_mode
     with contextlib.redirect_stdout(sys.stderr):   # the Model constructor prints like the reference's; stdout carries ONE JSON line
         model = sa.instantiate(cfg)
     return model.to(device)
@@ -326,9 +329,52 @@ def extra_workloads(model, device, args, noise, channels, emb) -> dict:
         return dict(workload="training step (exp/train_diffusion_gh.yaml): fp32, batch 4 x 2**18 samples, v-objective loss -> backward -> AdamW",
                     ms_per_step=round(1e3 * dt, 2), clips_per_s=round(B / dt, 2), dtype="fp32", timed_steps=iters, losses=losses)
 
+    def transpose_up_legs():
+        # The OTHER candidate network (SURVEY 8f-1 cannot be settled offline): upsample_mode="transpose", a-unet's `Upsample` =
+        # ConvTranspose1d(kernel = stride = factor), north_star's "transposed-conv blocks".  Same seed, same inputs, same timing
+        # protocol as the headline (configs[1]) and as config2_b32_cfg, so both candidate networks are driver-timed.
+        mt = build_model(args.dtype, device, upsample_mode="transpose")
+        mt.model.sampler.use_graph = not args.no_graph
+        hpt = dict(mt.model.net.hparams)
+        res = {}
+        try:
+            B1 = noise.shape[0]
+            ch1, e1 = synthetic_conditioning(mt, B1, L0, device, real=False)
+            rate, o = timed_sample(mt, device, noise, ch1, e1, 1.0, BASELINE_STEPS, warm=5)
+            assert torch.isfinite(o).all()
+            w = workmodel.unet_work(hpt, L0, B1, 1, ES[args.dtype], upsample_mode="transpose")
+            peak = (PEAK_F32_TFLOPS if args.dtype == "fp32" else PEAK_BF16_TFLOPS) * 1e12
+            ms = 1e3 / rate
+            res["config1_transpose_up"] = dict(
+                workload=f"BASELINE configs[1] on the transposed-up network: batch={B1}, {BASELINE_STEPS} steps, scale 1.0, dummy cond",
+                steps_per_s=round(rate, 2), ms_per_step=round(ms, 3), dtype=args.dtype, timed_steps=BASELINE_STEPS,
+                params_M=round(sum(p.numel() for p in mt.model.net.parameters()) / 1e6, 2),
+                step_roofline_frac=round(workmodel.step_roofline_ms(w, peak, PEAK_HBM_GBS * 1e9) / ms, 4))
+            B2, scale = 32, 2.0
+            nz = torch.randn(B2, 1, L0, generator=torch.Generator().manual_seed(1000)).to(device)
+            ch2, e2 = synthetic_conditioning(mt, B2, L0, device, real=True)
+            rate, o = timed_sample(mt, device, nz, ch2, e2, scale, BASELINE_STEPS, warm=2)
+            assert torch.isfinite(o).all()
+            w = workmodel.unet_work(hpt, L0, B2, 2, ES[args.dtype], upsample_mode="transpose")
+            ms = 1e3 / rate
+            res["config2_transpose_up"] = dict(
+                workload="BASELINE configs[2] on the transposed-up network: batch=32, guidance scale 2.0, real conditioning",
+                steps_per_s=round(rate, 2), ms_per_step=round(ms, 3), dtype=args.dtype, timed_steps=BASELINE_STEPS,
+                tflops=round(w["flops"] / 1e12 / (ms * 1e-3), 1),
+                step_roofline_frac=round(workmodel.step_roofline_ms(w, peak, PEAK_HBM_GBS * 1e9) / ms, 4))
+        finally:
+            del mt
+            torch.cuda.empty_cache()
+        return res
+
     if args.dtype != "fp32":
         leg("fp32_config1", fp32_leg)
     leg("config2_b32_cfg", config2_leg)
+    try:
+        out.update(transpose_up_legs())
+    except Exception as e:  # noqa: BLE001
+        out["config1_transpose_up"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    torch.cuda.synchronize(device)
     leg("config3_share_b32", config3_leg)
     leg("reference_eval_shape", reference_leg)
     leg("onset_net_n32", onset_leg)
@@ -543,6 +589,39 @@ def main() -> int:
         cpu = dict(value=round(n / dt, 4), unit="steps/s", cores=torch.get_num_threads(), kind="port",
                    sample=f"{n} timed denoise steps (U-Net evaluation, batch {B}, L0 {L0}, fp32) after 1 warm-up; "
                           "the sampler's element-wise update is excluded (<0.01% of a step)")
+        # BASELINE configs[0] IN FULL: 1 clip, 10 sampler steps, guidance scale 2.0, L0 = 45056, the call
+        # shape of main/module_diffusion.py:200-206 -- the oracle's whole sample() on the host cores, and the SAME call on the HIP
+        # fp32 engine next to it (identical noise), with the distance between the two final samples.
+        if not args.no_config0:
+            from oracle import sampler_ref
+
+            steps0, scale0 = 10, 2.0
+            nz0 = torch.randn(1, 1, L0, generator=torch.Generator().manual_seed(1000))
+            ch0 = [c[:1].cpu() for c in channels]
+            e0 = torch.nn.functional.normalize(torch.randn(1, 1, 512, generator=torch.Generator().manual_seed(2000)), dim=-1)
+            with torch.no_grad():
+                t1 = time.perf_counter()
+                ref0 = sampler_ref.vsample(lambda x, s_: unet_ref.unet_forward(P, cfg, x, s_, embedding=e0, channels=ch0, embedding_scale=scale0), nz0, steps0)
+                cpu_s = time.perf_counter() - t1
+            prev = net.compute_dtype
+            net.compute_dtype = "fp32"
+            try:
+                gch0 = [c.to(device) for c in ch0]
+                kw0 = dict(x_noisy=nz0.to(device), num_steps=steps0, channels=gch0, embedding=e0.to(device), embedding_scale=scale0)
+                model.model.sample(**kw0)
+                torch.cuda.synchronize(device)
+                t1 = time.perf_counter()
+                got0 = model.model.sample(**kw0)
+                torch.cuda.synchronize(device)
+                gpu_s = time.perf_counter() - t1
+            finally:
+                net.compute_dtype = prev
+                net.engine()
+            rel0 = float((got0.cpu().double() - ref0.double()).norm() / ref0.double().norm())
+            cpu["config0_full"] = dict(workload="BASELINE configs[0]: 1 clip, 10 steps, scale 2.0 (20 U-Net evaluations), L0 45056, fp32",
+                                       seconds=round(cpu_s, 3), steps_per_s=round(steps0 / cpu_s, 4), cores=torch.get_num_threads(), kind="port",
+                                       hip_fp32_engine_seconds=round(gpu_s, 4), hip_fp32_steps_per_s=round(steps0 / gpu_s, 2),
+                                       rel_l2_hip_fp32_vs_cpu=float(f"{rel0:.3e}"))
 
     extra = None
     if not args.no_extra and world == 1 and not args.force_dist:

@@ -236,6 +236,7 @@ int sf_bench_conv1d(int dtype, int B, int L, int C, int N, int taps, int upsampl
   SF_HIP(hipEventCreate(&e0));
   SF_HIP(hipEventCreate(&e1));
   hipError_t err = hipSuccess;
+  unsigned *sink = nullptr;   // the touch kernel's dedicated write sink (never a live buffer)
   for (int i = 0; i < 3 && err == hipSuccess; ++i) err = launch_conv_gemm(dtype, a, nullptr);
   if (err == hipSuccess) {
     SF_HIP(hipDeviceSynchronize());
@@ -244,9 +245,11 @@ int sf_bench_conv1d(int dtype, int B, int L, int C, int N, int taps, int upsampl
     // alone) -- what an idle-CU prefetch in the PRECEDING kernel of the chain could buy
     int pre = 0;
     if (const char *e = getenv("SF_BENCH_PREFETCH")) pre = atoi(e);
+    if (pre > 0 && pre % 1000 == 0) fail(SF_ERR_INVALID, "SF_BENCH_PREFETCH=%d: the workgroup count (value mod 1000) must be >= 1", pre);
+    if (pre > 0) SF_HIP(hipMalloc(reinterpret_cast<void **>(&sink), 64));
     for (int i = 0; i < iters && err == hipSuccess; ++i) {
       a.w = static_cast<char *>(w) + (size_t)(i % ncopy) * wbytes;
-      if (pre > 0) err = launch_touch(a.w, wbytes, pre % 1000, reinterpret_cast<unsigned *>(bias), nullptr);
+      if (pre > 0) err = launch_touch(a.w, wbytes, pre % 1000, sink, nullptr);
       if (pre < 1000 && err == hipSuccess) err = launch_conv_gemm(dtype, a, nullptr);
     }
     SF_HIP(hipEventRecord(e1, nullptr));
@@ -258,6 +261,7 @@ int sf_bench_conv1d(int dtype, int B, int L, int C, int N, int taps, int upsampl
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   for (void *p : {x, w, out, res, (void *)bias}) (void)hipFree(p);
+  if (sink) (void)hipFree(sink);
   if (err != hipSuccess) fail(SF_ERR_UNSUPPORTED, "variant not applicable: %s", hipGetErrorString(err));
   return SF_OK;
   SF_API_END

@@ -178,8 +178,11 @@ __device__ __forceinline__ void conv3_8(cfloat_p w, const float (&pv)[CH], const
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(1024) void d0_conv_kernel(const ConvThinArgs a) {
+// MAXT: the launch bound the kernel is compiled for -- 256 for the default four waves (the compiler may then use up to 256 VGPRs per
+// lane: with a 1024-thread bound it is capped at 128, which cost 2-12 SGPR spills on every instantiation and scratch on d0_tail<float,2>),
+// 1024 for the SF_D0_WAVES tuning hook.
+template <typename T, int MAXT>
+__global__ __launch_bounds__(MAXT) void d0_conv_kernel(const ConvThinArgs a) {
   constexpr bool FAST = sizeof(T) == 2;
   __shared__ __attribute__((aligned(16))) float prm[5][CH];        // GroupNorm scale, shift | bias | per-clip scale | per-clip add
   __shared__ float part[16][CH][3];
@@ -280,8 +283,8 @@ __global__ __launch_bounds__(1024) void d0_conv_kernel(const ConvThinArgs a) {
 }
 
 // C2R: the REAL context channels (the context rows are padded to 8; the fp32 1x1 weights are not: rows of 8 + C2R)
-template <typename T, int C2R>
-__global__ __launch_bounds__(1024) void d0_tail_kernel(const ThinTailArgs a) {
+template <typename T, int C2R, int MAXT>
+__global__ __launch_bounds__(MAXT) void d0_tail_kernel(const ThinTailArgs a) {
   constexpr bool FAST = sizeof(T) == 2;
   __shared__ __attribute__((aligned(16))) float prm[6][CH];        // GroupNorm scale, shift | bias2 | 1 + modulation scale | modulation shift | bias3 + per-clip add
   __shared__ float part[16][CH][3];
@@ -436,17 +439,24 @@ bool d0_tail_supported(const ThinTailArgs &a) {
   return a.C == CH && a.C2 == CH && a.G == CH && a.ctx_ld >= CH && (a.ctx_ld % CH) == 0 && a.ss && a.stats_in && a.bias2 && a.bias3 && a.rw >= 1;
 }
 hipError_t launch_d0_conv(int dt, const ConvThinArgs &a, hipStream_t s) {
-  SF_DISPATCH_STMT(dt, hipLaunchKernelGGL((d0_conv_kernel<T>), dim3(a.B * a.nchw), dim3(d0_threads()), 0, s, a));
+  if (d0_threads() <= 256) SF_DISPATCH_STMT(dt, hipLaunchKernelGGL((d0_conv_kernel<T, 256>), dim3(a.B * a.nchw), dim3(d0_threads()), 0, s, a));
+  else SF_DISPATCH_STMT(dt, hipLaunchKernelGGL((d0_conv_kernel<T, 1024>), dim3(a.B * a.nchw), dim3(d0_threads()), 0, s, a));
   return hipGetLastError();
 }
 hipError_t launch_d0_tail(int dt, const ThinTailArgs &a, hipStream_t s) {
+#define SF_D0_TAIL(C2R)                                                                                                                  \
+  do {                                                                                                                                   \
+    if (d0_threads() <= 256) SF_DISPATCH_STMT(dt, hipLaunchKernelGGL((d0_tail_kernel<T, C2R, 256>), dim3(a.B * a.nchw), dim3(d0_threads()), 0, s, a)); \
+    else SF_DISPATCH_STMT(dt, hipLaunchKernelGGL((d0_tail_kernel<T, C2R, 1024>), dim3(a.B * a.nchw), dim3(d0_threads()), 0, s, a));      \
+  } while (0)
   switch (a.c2real) {
-    case 1: SF_DISPATCH_STMT(dt, hipLaunchKernelGGL((d0_tail_kernel<T, 1>), dim3(a.B * a.nchw), dim3(d0_threads()), 0, s, a)); break;
-    case 2: SF_DISPATCH_STMT(dt, hipLaunchKernelGGL((d0_tail_kernel<T, 2>), dim3(a.B * a.nchw), dim3(d0_threads()), 0, s, a)); break;
-    case 4: SF_DISPATCH_STMT(dt, hipLaunchKernelGGL((d0_tail_kernel<T, 4>), dim3(a.B * a.nchw), dim3(d0_threads()), 0, s, a)); break;
-    case 8: SF_DISPATCH_STMT(dt, hipLaunchKernelGGL((d0_tail_kernel<T, 8>), dim3(a.B * a.nchw), dim3(d0_threads()), 0, s, a)); break;
+    case 1: SF_D0_TAIL(1); break;
+    case 2: SF_D0_TAIL(2); break;
+    case 4: SF_D0_TAIL(4); break;
+    case 8: SF_D0_TAIL(8); break;
     default: return hipErrorInvalidValue;
   }
+#undef SF_D0_TAIL
   return hipGetLastError();
 }
 

@@ -27,6 +27,17 @@ GnPlan gn_plan(int B, int L, int C) {
 
 namespace {
 
+// largest number of 16-byte vectors per thread the register-resident GroupNorm+SiLU kernel is used for (tuning hook SF_GN_REG_MAXV:
+// 4 / 8 / 16); shared by gn_silu_go and gn_silu_ws_go so that an A/B with the hook compares exactly two paths
+int gn_reg_max_rv() {
+  static const int v = [] {
+    const char *e = getenv("SF_GN_REG_MAXV");
+    const int x = e ? atoi(e) : 16;
+    return x >= 16 ? 16 : (x >= 8 ? 8 : 4);
+  }();
+  return v;
+}
+
 // One block = one (clip, chunk).  V = elements per access (16 bytes, or 1 for C < 16 bytes).
 template <typename T, int V>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const T *__restrict__ x, int ld, int L, int C, int G, int nch,
@@ -436,11 +447,7 @@ hipError_t gn_silu_go(const void *x, int ld, int B, int L, int C, int G, const f
   // slab fits the registers of one workgroup: up to 16 vectors of 16 bytes per thread (64 data registers of the 256 a wave of a
   // 512-thread workgroup may hold).  8 and 16 cover the 2^18-sample clips (65 K elements per slab at depths 3-6), which the two-pass
   // kernel below walked twice with four loads in flight: 16.4 us per launch, 10.6 % of that step (profiles/r3_h_refshape_*).
-  static const int max_rv = [] {   // tuning hook
-    const char *e = getenv("SF_GN_REG_MAXV");
-    const int v = e ? atoi(e) : 16;
-    return v >= 16 ? 16 : (v >= 8 ? 8 : 4);
-  }();
+  const int max_rv = gn_reg_max_rv();
   if (al && cpg % V == 0 && 512 % (cpg / V) == 0 && (int64_t)L * (cpg / V) <= (int64_t)max_rv * 512) {
     const int64_t nv = (int64_t)L * (cpg / V);
     const int nslab = B * G;
@@ -521,7 +528,7 @@ static hipError_t gn_silu_ws_go(const void *x, int ld, int B, int L, int C, int 
   done = false;
   if (C % G || G > 64 || C % V || (256 % (C / V)) || (ld % V) || (out_ld % V)) return hipSuccess;
   const int cpg = C / G;
-  if (cpg % V == 0 && 512 % (cpg / V) == 0 && (int64_t)L * (cpg / V) <= 16 * 512) return hipSuccess;   // register-resident kernel applies
+  if (cpg % V == 0 && 512 % (cpg / V) == 0 && (int64_t)L * (cpg / V) <= (int64_t)gn_reg_max_rv() * 512) return hipSuccess;   // register-resident kernel applies
   if ((int64_t)L * cpg < 32768) return hipSuccess;                                                       // short slabs: one launch wins
   const GnPlan gp = gn_plan(B, L, C);
   if ((int64_t)B * gp.nch * G * 2 > slab_floats) return hipSuccess;

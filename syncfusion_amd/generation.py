@@ -8,13 +8,13 @@ names; the DataLoader / WebDataset / torchaudio.save plumbing around it is out o
 section 2 rows 5 and 8f-2).  ``generate_dataset`` takes what the reference passes it -- an UN-batched dataset of
 ``(x, y, z, text, filename)`` chunks (``exp/evaluate_gh_gen.yaml:21,31-40``: ``create_sfx_dataset(...)`` + ``batch_size``) -- and
 batches it itself with ``batch_size`` / ``num_workers`` + ``collate_fn`` as main/generation.py:37-38 does; an iterable of
-already-collated batches is passed through.  Output files are 16-bit PCM wav written with the standard library
-(``torchaudio.save`` of a float tensor, :104-122, writes 32-bit float wav: same names, rate and sample count; readers such as
-the FAD / onset evaluation accept either).
+already-collated batches is passed through.  Output files are 32-bit IEEE-float wav (RIFF format tag 3) written with the
+standard library: what ``torchaudio.save`` of a float32 tensor (:104-122) produces -- samples are stored bit-exactly, nothing is
+clamped or quantised.
 """
 from __future__ import annotations
 
-import wave
+import struct
 from pathlib import Path
 from typing import Iterable, List, Optional, Sequence, Union
 
@@ -54,13 +54,48 @@ def generate_batch(model, y: Tensor, z: Optional[Tensor] = None, text: Optional[
 
 
 def save_wav(path: Union[str, Path], audio: Tensor, sample_rate: int) -> None:
-    """(channels, n) float tensor in [-1, 1] -> 16-bit PCM wav (stand-in for torchaudio.save, :104-122)."""
-    a = (audio.detach().cpu().clamp(-1.0, 1.0) * 32767.0).round().to(torch.int16)
-    with wave.open(str(path), "wb") as f:
-        f.setnchannels(a.shape[0])
-        f.setsampwidth(2)
-        f.setframerate(int(sample_rate))
-        f.writeframes(a.t().contiguous().numpy().tobytes())
+    """(channels, n) float tensor -> 32-bit IEEE-float wav, the file ``torchaudio.save(path, float32 tensor, rate)`` writes
+    (main/generation.py:104-122): RIFF/WAVE, ``fmt `` with format tag 3 (WAVE_FORMAT_IEEE_FLOAT), the ``fact`` chunk non-PCM
+    formats carry, interleaved little-endian float32 frames.  Samples keep their bits: no clamp, no rounding."""
+    a = audio.detach().to(torch.float32).cpu()
+    if a.dim() != 2:
+        raise ValueError(f"save_wav expects (channels, samples), got shape {tuple(a.shape)}")
+    ch, n = int(a.shape[0]), int(a.shape[1])
+    data = a.t().contiguous().numpy().astype("<f4", copy=False).tobytes()
+    rate = int(sample_rate)
+    fmt = struct.pack("<HHIIHH", 3, ch, rate, rate * ch * 4, ch * 4, 32)
+    body = (b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"fact" + struct.pack("<II", 4, n) +
+            b"data" + struct.pack("<I", len(data)) + data)
+    with open(str(path), "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", len(body)) + body)
+
+
+def load_wav(path: Union[str, Path]):
+    """Reader for the files ``save_wav`` writes (and 16-bit PCM wav): -> ((channels, n) float32 tensor, sample_rate).
+    The standard library's ``wave`` module rejects format tag 3."""
+    raw = Path(path).read_bytes()
+    if raw[:4] != b"RIFF" or raw[8:12] != b"WAVE":
+        raise ValueError(f"{path}: not a RIFF/WAVE file")
+    pos, fmt, data = 12, None, None
+    while pos + 8 <= len(raw):
+        cid, size = raw[pos:pos + 4], struct.unpack("<I", raw[pos + 4:pos + 8])[0]
+        if cid == b"fmt ":
+            fmt = struct.unpack("<HHIIHH", raw[pos + 8:pos + 24])
+        elif cid == b"data":
+            data = raw[pos + 8:pos + 8 + size]
+        pos += 8 + size + (size & 1)
+    if fmt is None or data is None:
+        raise ValueError(f"{path}: missing fmt / data chunk")
+    tag, ch, rate, _, _, bits = fmt
+    import numpy as np
+
+    if tag == 3 and bits == 32:
+        a = torch.from_numpy(np.frombuffer(data, dtype="<f4").astype(np.float32))
+    elif tag == 1 and bits == 16:
+        a = torch.from_numpy(np.frombuffer(data, dtype="<i2").astype(np.float32) / 32768.0)
+    else:
+        raise ValueError(f"{path}: unsupported wav encoding (format tag {tag}, {bits} bits)")
+    return a.reshape(-1, ch).t().contiguous(), int(rate)
 
 
 def _is_collated(elem) -> bool:

@@ -246,29 +246,42 @@ def allreduce_gradients(module: torch.nn.Module, bucket_bytes: int = 256 << 20) 
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return 0
     world = dist.get_world_size()
-    # EVERY trainable parameter takes part, a missing gradient as zeros: the bucket boundaries (hence the number and the sizes of
-    # the collectives) must not depend on which parameters happened to receive a gradient on THIS rank
-    grads = []
-    for p in module.parameters():
-        if p.requires_grad:
-            if p.grad is None:
-                p.grad = torch.zeros_like(p)
-            grads.append(p.grad)
+    # EVERY trainable parameter takes part, a missing gradient as zeros INSIDE THE FLAT BUCKET only: the bucket boundaries (hence the
+    # number and the sizes of the collectives) must not depend on which parameters happened to receive a gradient on THIS rank.
+    # A presence flag per parameter rides with the first bucket: a parameter that no rank had a gradient for keeps `grad = None`
+    # afterwards, exactly as on a single rank (the fused AdamW step skips it: no weight decay, no moment update).
+    params = [p for p in module.parameters() if p.requires_grad]
+    if not params:
+        return 0
+    dev = params[0].device
+    present = torch.tensor([0.0 if p.grad is None else 1.0 for p in params], dtype=torch.float32, device=dev)
     stage_host = dist.get_backend() == "gloo"
     calls, i = 0, 0
-    while i < len(grads):
+    while i < len(params):
         j, size = i, 0
-        while j < len(grads) and (j == i or size + grads[j].numel() * 4 <= bucket_bytes):
-            size += grads[j].numel() * 4
+        while j < len(params) and (j == i or size + params[j].numel() * 4 <= bucket_bytes):
+            size += params[j].numel() * 4
             j += 1
-        flat = torch.cat([g.reshape(-1) for g in grads[i:j]])
+        parts = [(p.grad if p.grad is not None else torch.zeros(p.numel(), dtype=torch.float32, device=p.device)).reshape(-1).to(torch.float32)
+                 for p in params[i:j]]
+        if i == 0:
+            parts.append(present)
+        flat = torch.cat(parts)
         buf = flat.cpu() if stage_host and flat.is_cuda else flat
         dist.all_reduce(buf)
-        buf = buf.to(flat.device) / world
+        buf = buf.to(flat.device)
+        if i == 0:
+            present = buf[-len(params):].cpu().tolist()   # one host read per call, not one per parameter
+            buf = buf[:-len(params)]
+        buf = buf / world
         off = 0
-        for g in grads[i:j]:
-            g.copy_(buf[off: off + g.numel()].view_as(g))
-            off += g.numel()
+        for k, p in enumerate(params[i:j]):
+            n = p.numel()
+            if present[i + k] > 0.0:      # some rank had a gradient: the average (missing ranks count as zeros)
+                if p.grad is None:
+                    p.grad = torch.empty_like(p)
+                p.grad.copy_(buf[off: off + n].view_as(p))
+            off += n
         calls += 1
         i = j
     return calls

@@ -64,10 +64,16 @@ def _grad_worker(rank: int, world: int, port: int, q):
         torch.manual_seed(7)                                # same weights everywhere, DIFFERENT data per rank
         net = torch.nn.Sequential(torch.nn.Linear(6, 9), torch.nn.Tanh(), torch.nn.Linear(9, 3))
         net[2].bias.requires_grad_(False)                   # frozen tensors are skipped
+        net.add_module("unused", torch.nn.Linear(2, 2))     # trainable, never in the graph: no gradient on any rank
+        net.add_module("rank1_only", torch.nn.Linear(3, 3, bias=False))   # in the graph of rank 1 only
         x = torch.randn(4, 6, generator=torch.Generator().manual_seed(50 + rank))
-        net(x).square().mean().backward()
+        y = net[2](net[1](net[0](x)))
+        if rank == 1:
+            y = y + net.rank1_only(y.detach())
+        y.square().mean().backward()
         calls = allreduce_gradients(net, bucket_bytes=200)  # tiny buckets: several collectives, one oversize tensor alone in its own
-        q.put((rank, calls, torch.cat([p.grad.reshape(-1) for p in net.parameters() if p.grad is not None]).tolist()))
+        none = sorted(n for n, p in net.named_parameters() if p.requires_grad and p.grad is None)
+        q.put((rank, calls, torch.cat([p.grad.reshape(-1) for p in net.parameters() if p.grad is not None]).tolist(), none))
     finally:
         dist.destroy_process_group()
 
@@ -87,13 +93,20 @@ def test_gradient_allreduce_world2_equals_the_full_batch_gradient():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (_, calls0, g0), (_, calls1, g1) = res
+    (_, calls0, g0, none0), (_, calls1, g1, none1) = res
     assert g0 == g1 and calls0 == calls1 >= 2
+    # a parameter without a gradient on EVERY rank keeps grad = None (as a single-rank run leaves it: the optimizer skips it);
+    # one with a gradient on some rank gets the average on all of them
+    assert none0 == none1 == ["unused.bias", "unused.weight"]
     torch.manual_seed(7)
     net = torch.nn.Sequential(torch.nn.Linear(6, 9), torch.nn.Tanh(), torch.nn.Linear(9, 3))
     net[2].bias.requires_grad_(False)
+    net.add_module("unused", torch.nn.Linear(2, 2))
+    net.add_module("rank1_only", torch.nn.Linear(3, 3, bias=False))
     xs = [torch.randn(4, 6, generator=torch.Generator().manual_seed(50 + r)) for r in range(world)]
-    (sum(net(x).square().mean() for x in xs) / world).backward()
+    ys = [net[2](net[1](net[0](x))) for x in xs]
+    ys[1] = ys[1] + net.rank1_only(ys[1].detach())
+    (sum(y.square().mean() for y in ys) / world).backward()
     ref = torch.cat([p.grad.reshape(-1) for p in net.parameters() if p.grad is not None])
     assert torch.allclose(torch.tensor(g0), ref, rtol=1e-5, atol=1e-7)
     from syncfusion_amd.training import allreduce_gradients

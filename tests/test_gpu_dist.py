@@ -189,9 +189,9 @@ def test_two_rank_data_parallel_gradients_equal_the_full_batch_gradient(cuda):
     assert calls0 == calls1 >= 2 and torch.equal(g0, g1)
     model = _build(seed_weights=200)
     _loss_and_grads(model, 0, B_TOTAL)
-    # (allreduce_gradients gives EVERY trainable parameter a gradient -- zeros where a rank produced none -- so that the bucket layout
-    # cannot differ between ranks; a parameter without a gradient here is one without a gradient there: zeros)
-    want = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in model.parameters() if p.requires_grad]).cpu()
+    # (allreduce_gradients zero-fills a missing gradient only inside its flat buckets, so that the bucket layout cannot differ between
+    # ranks; a parameter without a gradient on EVERY rank keeps grad = None, as in this single process)
+    want = torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.requires_grad and p.grad is not None]).cpu()
     assert g0.shape == want.shape
     err = float((g0 - want).norm() / want.norm())
     assert err < 1e-5, err

@@ -1,7 +1,8 @@
 """Model-level parity on the MI355X: HIP engines (through the C ABI and the Python boundary) vs the CPU oracle.
 
 Gate (BASELINE.json north_star): samples within 1e-4 rel-L2 of the CPU reference on identical noise
-seeds on the fp32 path; the bf16 path is reported against a stated tolerance of 5e-2 per evaluation.
+seeds on the fp32 path.  16-bit engines: full-size OUTPUTS are gated at about 5x their measured error (LOWP_EVAL_TOL,
+LOWP_SAMPLE5_TOL, LOWP_CHAIN_TOL below); block-level taps inside an evaluation and the small test models at 5e-2.
 """
 import os
 
@@ -409,7 +410,21 @@ class _compute_dtype:
 
 
 LOWP = ["bf16", "fp16"]
-LOWP_STEP_TOL = 5e-2     # stated tolerance of the 16-bit paths per evaluation (measured ~1e-2); fp32 is gated at 1e-4
+LOWP_TAP_TOL = 5e-2      # 16-bit engines, block-level activations INSIDE one evaluation (worst measured tap: 1.1e-2 bf16, 1.3e-3 fp16)
+# 16-bit engines, OUTPUTS: about 5x the error measured on MI355X, so that a kernel change that costs a
+# decimal digit fails.  fp32 is gated at the north-star 1e-4 everywhere.
+LOWP_EVAL_TOL = {"bf16": 1e-3, "fp16": 1.5e-4}      # one evaluation (measured 1.8e-4 / 2.1e-5; configs[2] shape 2.0e-4 / 2.3e-5)
+LOWP_SAMPLE5_TOL = {"bf16": 1.2e-2, "fp16": 1.5e-3}   # 5-step sample (measured 2.4e-3 / 3.0e-4)
+LOWP_CHAIN_TOL = {"fp16": 1e-3}                       # configs[4] chain, 10 guided steps (measured 1.4e-4)
+
+_MEMO = {}
+
+
+def _memo(key, fn):
+    """Oracle results shared by the parametrisations of a test (the CPU oracle of the full model is the slow part)."""
+    if key not in _MEMO:
+        _MEMO[key] = fn()
+    return _MEMO[key]
 
 
 @pytest.mark.timeout(1500)
@@ -422,7 +437,7 @@ def test_reference_length_eval_parity(cuda, full_model):
     x, sigma, emb, chans = _full_inputs(full_model, B, L0, 91)
     ref = _oracle_unet(full_model.model.net, x[:1], sigma[:1], emb[:1], [c[:1] for c in chans], scale)   # one clip on the CPU: 0.3 TFLOP
     gx, gs, ge, gc = x.to(cuda), sigma.to(cuda), emb.to(cuda), [c.to(cuda) for c in chans]
-    for dtype, tol in (("fp32", FP32_TOL), ("bf16", LOWP_STEP_TOL), ("fp16", LOWP_STEP_TOL)):
+    for dtype, tol in (("fp32", FP32_TOL), ("bf16", LOWP_EVAL_TOL["bf16"]), ("fp16", LOWP_EVAL_TOL["fp16"])):
         with _compute_dtype(full_model, dtype) as net:
             out = net(gx, gs, embedding=ge, channels=gc, embedding_scale=scale)
         e = rel_l2(out[:1].cpu(), ref)
@@ -437,8 +452,11 @@ def test_full_size_lowp_eval_parity_with_taps(cuda, full_model, dtype):
     block-level activation included so that a wrong dispatch variant is localised."""
     B, L0 = 8, 45056
     x, sigma, emb, chans = _full_inputs(full_model, B, L0, 81)
-    taps_ref = {}
-    ref = _oracle_unet(full_model.model.net, x, sigma, emb, chans, 1.0, taps_ref)
+    def oracle():
+        taps_ref = {}
+        return _oracle_unet(full_model.model.net, x, sigma, emb, chans, 1.0, taps_ref), taps_ref
+
+    ref, taps_ref = _memo("cfg1_b8_taps", oracle)
     with _compute_dtype(full_model, dtype) as net:
         gx, gs, ge, gc = x.to(cuda), sigma.to(cuda), emb.to(cuda), [c.to(cuda) for c in chans]
         out_t, taps = net.engine().forward_with_taps(gx, gs, gc, ge, 1.0, cap_floats=1 << 27)
@@ -449,25 +467,105 @@ def test_full_size_lowp_eval_parity_with_taps(cuda, full_model, dtype):
         got = taps[name].cpu().reshape(B, -1, t.shape[1]).transpose(1, 2)
         e = rel_l2(got, t)
         worst = max(worst, (name, e), key=lambda p: p[1])
-        assert e < LOWP_STEP_TOL, f"{dtype} tap {name}: rel-L2 {e:.3e}"
+        assert e < LOWP_TAP_TOL, f"{dtype} tap {name}: rel-L2 {e:.3e}"
     e_t, e_o = rel_l2(out_t.cpu(), ref), rel_l2(out.cpu(), ref)
     print(f"{dtype} full-size B=8 eval: rel-L2 {e_o:.3e} (taps run {e_t:.3e}); worst tap {worst[0]} {worst[1]:.3e}")
-    assert e_t < LOWP_STEP_TOL and e_o < LOWP_STEP_TOL
+    assert e_t < LOWP_EVAL_TOL[dtype] and e_o < LOWP_EVAL_TOL[dtype]
 
 
-@pytest.mark.parametrize("dtype,tol", [("fp32", FP32_TOL), ("bf16", LOWP_STEP_TOL), ("fp16", LOWP_STEP_TOL)])
+@pytest.mark.parametrize("dtype,tol", [("fp32", FP32_TOL), ("bf16", LOWP_SAMPLE5_TOL["bf16"]), ("fp16", LOWP_SAMPLE5_TOL["fp16"])])
 def test_full_size_multistep_sample_parity(cuda, full_model, dtype, tol):
     """5 sampler steps of the full 215 M-parameter model at B = 2, L0 = 45056 against sampler_ref on identical noise:
     the north-star gate (1e-4) on the fp32 engine, the stated tolerance on the 16-bit engines; graph replay on."""
     B, L0, steps = 2, 45056, 5
     _, _, emb, chans = _full_inputs(full_model, B, L0, 82)
     noise = torch.randn(B, 1, L0, generator=torch.Generator().manual_seed(1000))
-    ref = _oracle_sample(full_model.model, noise, steps, emb, chans, 1.0)
+    ref = _memo("cfg1_b2_sample5", lambda: _oracle_sample(full_model.model, noise, steps, emb, chans, 1.0))
     with _compute_dtype(full_model, dtype):
         out = full_model.model.sample(x_noisy=noise.to(cuda), num_steps=steps, channels=[c.to(cuda) for c in chans], embedding=emb.to(cuda),
                                       embedding_scale=1.0)
     e = rel_l2(out.cpu(), ref)
     print(f"{dtype} full-size 5-step sample: rel-L2 {e:.3e}")
+    assert e < tol
+
+
+def test_config0_exact_one_clip_ten_guided_steps_fp32(cuda, full_model):
+    """BASELINE configs[0] in its stated form -- 1 clip, the full 215 M-parameter U-Net, 10 sampler steps, guidance scale
+    2.0, L0 = 45056 -- on the fp32 engine against sampler_ref: the call shape of main/module_diffusion.py:200-206
+    (`sample(x_noisy, num_steps, channels=xs[2:-1], embedding, embedding_scale)`).  Gate: the north-star 1e-4."""
+    B, L0, steps, scale = 1, 45056, 10, 2.0
+    _, _, emb, chans = _full_inputs(full_model, B, L0, 83)
+    noise = torch.randn(B, 1, L0, generator=torch.Generator().manual_seed(1000))
+    ref = _oracle_sample(full_model.model, noise, steps, emb, chans, scale)
+    out = full_model.model.sample(x_noisy=noise.to(cuda), num_steps=steps, channels=[c.to(cuda) for c in chans], embedding=emb.to(cuda),
+                                  embedding_scale=scale)
+    e = rel_l2(out.cpu(), ref)
+    print(f"configs[0] (1 clip, 10 steps, scale 2.0, full model, fp32 engine): rel-L2 {e:.3e}")
+    assert out.shape == (B, 1, L0) and e < FP32_TOL
+
+
+# ----------------------------------------------------------------------------------------------------------
+# The OTHER candidate up path at full size: upsample_mode="transpose" (a-unet `Upsample` = ConvTranspose1d(kernel = stride =
+# factor); north_star's "transposed-conv blocks").  Which of the two upstream's default is cannot be checked offline
+# (SURVEY 8f-1), so both networks carry the same full-size parity and are both timed by bench.py.
+# ----------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def full_model_transposed(cuda):
+    from helpers import reference_model_config
+    import syncfusion_amd as sa
+
+    cfg = reference_model_config()
+    cfg["model"]["upsample_mode"] = "transpose"
+    torch.manual_seed(1234)
+    m = sa.instantiate(cfg).to(cuda)
+    assert m.model.net.hparams["upsample_mode"] == "transpose"
+    return m
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
+def test_full_size_transposed_up_eval_parity_with_taps(cuda, full_model_transposed, dtype):
+    """configs[1] shape (batch 8, L0 = 45056) on the transposed-up network: every block-level activation and the output against
+    the oracle; fp32 at 1e-4, the 16-bit engines at the same bounds as the nearest+conv3 network.  The un-patchify GEMM
+    (N = factor * C_in columns, SkipModulate scale and bias tiled `factor` times) runs at the 215 M model's sizes here."""
+    model = full_model_transposed
+    B, L0 = 8, 45056
+    x, sigma, emb, chans = _full_inputs(model, B, L0, 84)
+
+    def oracle():
+        taps_ref = {}
+        return _oracle_unet(model.model.net, x, sigma, emb, chans, 1.0, taps_ref), taps_ref
+
+    ref, taps_ref = _memo("cfg1T_b8_taps", oracle)
+    tap_tol, out_tol = (FP32_TOL, FP32_TOL) if dtype == "fp32" else (LOWP_TAP_TOL, LOWP_EVAL_TOL[dtype])
+    with _compute_dtype(model, dtype) as net:
+        gx, gs, ge, gc = x.to(cuda), sigma.to(cuda), emb.to(cuda), [c.to(cuda) for c in chans]
+        out_t, taps = net.engine().forward_with_taps(gx, gs, gc, ge, 1.0, cap_floats=1 << 27)
+        out = net(gx, gs, embedding=ge, channels=gc)
+    assert set(taps) == set(taps_ref)
+    worst = ("", 0.0)
+    for name, t in taps_ref.items():
+        got = taps[name].cpu().reshape(B, -1, t.shape[1]).transpose(1, 2)
+        e = rel_l2(got, t)
+        worst = max(worst, (name, e), key=lambda p: p[1])
+        assert e < tap_tol, f"{dtype} tap {name}: rel-L2 {e:.3e}"
+    e_t, e_o = rel_l2(out_t.cpu(), ref), rel_l2(out.cpu(), ref)
+    print(f"{dtype} transposed-up full-size B=8 eval: rel-L2 {e_o:.3e} (taps run {e_t:.3e}); worst tap {worst[0]} {worst[1]:.3e}")
+    assert e_t < out_tol and e_o < out_tol
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", FP32_TOL), ("bf16", LOWP_SAMPLE5_TOL["bf16"]), ("fp16", LOWP_SAMPLE5_TOL["fp16"])])
+def test_full_size_transposed_up_multistep_sample_parity(cuda, full_model_transposed, dtype, tol):
+    """5 sampler steps of the transposed-up 215 M-parameter model (B = 2, L0 = 45056, graph replay) against sampler_ref."""
+    model = full_model_transposed
+    B, L0, steps = 2, 45056, 5
+    _, _, emb, chans = _full_inputs(model, B, L0, 85)
+    noise = torch.randn(B, 1, L0, generator=torch.Generator().manual_seed(1000))
+    ref = _memo("cfg1T_b2_sample5", lambda: _oracle_sample(model.model, noise, steps, emb, chans, 1.0))
+    with _compute_dtype(model, dtype):
+        out = model.model.sample(x_noisy=noise.to(cuda), num_steps=steps, channels=[c.to(cuda) for c in chans], embedding=emb.to(cuda),
+                                 embedding_scale=1.0)
+    e = rel_l2(out.cpu(), ref)
+    print(f"{dtype} transposed-up full-size 5-step sample: rel-L2 {e:.3e}")
     assert e < tol
 
 
@@ -487,13 +585,13 @@ def test_config2_shape_lowp_parity(cuda, full_model, dtype):
     x = torch.randn(B, 1, L0, generator=torch.Generator().manual_seed(1000))
     sigma = torch.rand(B, generator=torch.Generator().manual_seed(5))
     emb = torch.nn.functional.normalize(torch.randn(B, 1, 512, generator=torch.Generator().manual_seed(2000)), dim=-1)
-    ref = _oracle_unet(full_model.model.net, x[:2], sigma[:2], emb[:2], [c[:2] for c in chans], scale)
+    ref = _memo("cfg2_b32_clips01", lambda: _oracle_unet(full_model.model.net, x[:2], sigma[:2], emb[:2], [c[:2] for c in chans], scale))
     with _compute_dtype(full_model, dtype) as net:
         out = net(x.to(cuda), sigma.to(cuda), embedding=emb.to(cuda), channels=[c.to(cuda) for c in chans], embedding_scale=scale)
     assert torch.isfinite(out).all()
     e = rel_l2(out[:2].cpu(), ref)
     print(f"{dtype} configs[2] shape (B=32, CFG 2.0): rel-L2 of clips 0-1 = {e:.3e}")
-    assert e < 2 * LOWP_STEP_TOL      # guidance doubles the difference of two evaluations: twice the per-evaluation tolerance
+    assert e < LOWP_EVAL_TOL[dtype]      # measured 2.0e-4 (bf16) / 2.3e-5 (fp16)
 
 
 @pytest.mark.parametrize("B,L0", [(3, 45056), (1, 262144)])
@@ -662,15 +760,13 @@ def test_config4_chain_fp16_index_and_audio_parity(cuda, full_model):
     print(f"configs[4] chain, {steps} guided steps: rel-L2 vs oracle fp32 {e32:.3e}, fp16 {e16:.3e}; fp16 vs fp32 engine (4 clips) {e16_32:.3e}")
     assert float(gen16[0, :, :first].abs().max()) == 0.0
     assert e32 < FP32_TOL
-    assert e16 < LOWP_STEP_TOL and e16_32 < LOWP_STEP_TOL
+    assert e16 < LOWP_CHAIN_TOL["fp16"] and e16_32 < LOWP_CHAIN_TOL["fp16"]
 
 
 def test_generate_dataset_writes_resampled_wavs(cuda, tmp_path):
     """main/generation.py:49-122 end to end on a small model: resume-skip, cut_prefix, crop, device resample, wav files."""
-    import wave
-
     from syncfusion_amd import Model, RandomEmbedder
-    from syncfusion_amd.generation import generate_dataset
+    from syncfusion_amd.generation import generate_dataset, load_wav
 
     dm = _small_diffusion(cuda)
     enc = small_encoder_module().to(cuda)
@@ -687,7 +783,7 @@ def test_generate_dataset_writes_resampled_wavs(cuda, tmp_path):
     kw = dict(num_steps=3, length=L, embedding_scale=2.0, cut_prefix=True, cut_length=800, sample_rate=48000, downsample_rate=22050)
     files = generate_dataset(tmp_path, model, batches(), **kw)
     assert [f.name for f in files] == ["0.wav", "1.wav", "2.wav", "3.wav"]
-    with wave.open(str(files[0])) as w:
-        assert w.getframerate() == 22050 and w.getnframes() == -(-147 * 800 // 320) and w.getnchannels() == 1
+    got, rate = load_wav(files[0])
+    assert rate == 22050 and got.shape == (1, -(-147 * 800 // 320)) and got.dtype == torch.float32
     # second call: every batch's last file exists -> everything is skipped (the reference's crude resume, :52-59)
     assert generate_dataset(tmp_path, model, batches(), **kw) == []

@@ -464,11 +464,7 @@ def test_train_checkpoint_generate_round_trip(cuda, tmp_path):
     """The reference's life cycle on the small model: a few optimizer steps (fit_batches), a Lightning-style checkpoint
     ({'state_dict': ...}), then main/generation.py's `generate_dataset(model_path=...)` with a FRESH model: the wavs it writes
     equal what the trained instance generates -- the trained fp32 masters reach the inference engine through the checkpoint."""
-    import wave
-
-    import numpy as np
-
-    from syncfusion_amd.generation import generate_batch, generate_dataset
+    from syncfusion_amd.generation import generate_batch, generate_dataset, load_wav
     from syncfusion_amd.training import fit_batches
 
     L0 = 16 * 16
@@ -497,7 +493,5 @@ def test_train_checkpoint_generate_round_trip(cuda, tmp_path):
                                  embedding_scale=2.0)
     assert [f.name for f in files] == ["0.wav", "1.wav"]
     for i, f in enumerate(files):
-        with wave.open(str(f), "rb") as w:
-            pcm = np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16)
-        ref = (want[i, 0].clamp(-1, 1) * 32767.0).to(torch.int16).cpu().numpy()
-        assert pcm.shape == ref.shape and np.abs(pcm.astype(np.int32) - ref.astype(np.int32)).max() <= 1
+        got, rate = load_wav(f)              # 32-bit float wav, as torchaudio.save writes it: the samples keep their bits
+        assert rate == 22050 and torch.equal(got, want[i].cpu())

@@ -238,3 +238,27 @@ def test_iter_batches_groups_an_uncollated_dataset_like_the_reference_dataloader
     import pytest
     with pytest.raises(ValueError):
         list(iter_batches(chunks, 0))
+
+
+def test_save_wav_writes_ieee_float_like_torchaudio_save(tmp_path):
+    """main/generation.py:104-122 saves float32 tensors with torchaudio.save, i.e. 32-bit IEEE-float wav (RIFF format tag 3):
+    header fields by byte offset, the `fact` chunk, and bit-exact samples -- values beyond +-1 included (nothing is clamped)."""
+    import struct
+
+    import torch
+
+    from syncfusion_amd.generation import load_wav, save_wav
+
+    a = torch.tensor([[0.0, 0.25, -1.5, 3.0e-5, 1.0], [1e-9, -0.75, 2.0, -3.0e-5, -1.0]], dtype=torch.float32)
+    p = tmp_path / "x.wav"
+    save_wav(p, a, 22050)
+    raw = p.read_bytes()
+    assert raw[:4] == b"RIFF" and raw[8:16] == b"WAVEfmt " and struct.unpack("<I", raw[4:8])[0] == len(raw) - 8
+    size, tag, ch, rate, brate, align, bits = struct.unpack("<IHHIIHH", raw[16:36])
+    assert (size, tag, ch, rate, brate, align, bits) == (16, 3, 2, 22050, 22050 * 8, 8, 32)
+    assert raw[36:40] == b"fact" and struct.unpack("<II", raw[40:48]) == (4, 5)
+    assert raw[48:52] == b"data" and struct.unpack("<I", raw[52:56])[0] == 5 * 2 * 4
+    got, r = load_wav(p)
+    assert r == 22050 and got.dtype == torch.float32 and torch.equal(got, a)
+    with pytest.raises(ValueError):
+        save_wav(p, a[0], 22050)

@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 run() {  # name counters...
   local N=$1; shift
   rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/$N -- python3 $R/bench.py --no-cpu-baseline --no-extra --steps 3 --warmup 1 --no-graph > /dev/null 2> $O/$N.log
-  python3 $R/tools/pmc_by_kernel.py $O/$N > $O/$N.txt 2>&1
+  python3 $R/tools/pmc_by_kernel.py $O/$N $O/$N.csv > $O/$N.txt 2>&1
   python3 - "$O/$N" >> $O/$N.txt <<'PY'
 import csv, glob, os, sys, collections
 d = sys.argv[1]
