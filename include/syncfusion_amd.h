@@ -250,6 +250,20 @@ int sf_op_attention_bwd(const float *q, const float *kv, const float *out, const
  * (path 0 auto, 1 classic, 2 wave-split-K, 4 v2), tile variant (-1 auto) and grid split-K factor (-1 auto). */
 int sf_bench_conv1d(int dtype, int B, int L, int C, int N, int taps, int upsample, int path, int tile, int sk, int iters,
                     float *ms_out);
+/* The deep-level item head as the small-batch engine runs it (conv_cb.hip; a-unet ResnetItem + ModulationItem, SURVEY appendix A.3
+ * items 1-2), 16-bit dtypes, C a multiple of 128, L >= 44:
+ *   h = conv3(silu(groupnorm(x; gn1)), w1) + b1;  y = x + conv3(silu(groupnorm(h; gn2)), w2) + b2;
+ *   m = layer_norm(y; eps_ln, no affine) * (1 + scale[b]) + shift[b]          (scale_shift (B, 2C) or NULL -> plain normalise)
+ * as: gn_silu -> channel-block split-K convolution (fp32 partial slabs) -> slab reduction + bias + GroupNorm chunk sums -> the same
+ * convolution with the GroupNorm+SiLU panel prologue -> slab reduction + bias + residual + LayerNorm + Modulation.
+ * x, h_out (optional), m_out: (B, L, C) channels-last in `dtype`; w1, w2: (C, C, 3) fp32 PyTorch layout. */
+int64_t sf_op_resnet_mod_cb_workspace_bytes(int B, int L, int C);
+int sf_op_resnet_mod_cb(int dtype, const void *x, const float *w1, const float *b1, const float *w2, const float *b2, const float *gn1_g,
+                        const float *gn1_b, const float *gn2_g, const float *gn2_b, int groups, float eps_gn, const float *scale_shift,
+                        float eps_ln, int B, int L, int C, void *h_out, void *m_out, void *ws, int64_t ws_bytes, void *stream);
+/* Kernel tuning aid: average milliseconds of the four launches of that chain on random data (ms[0] convolution, ms[1] reduction +
+ * GroupNorm sums, ms[2] convolution with prologue, ms[3] reduction + LayerNorm); cold != 0 streams the weights from HBM. */
+int sf_bench_conv_cb(int dtype, int B, int L, int C, int groups, int cold, int iters, float *ms /* [4] */);
 /* y = layer_norm(x; eps, no affine) * (1 + scale[b]) + shift[b]   (scale/shift NULL -> plain normalise) */
 /* materialised SiLU(GroupNorm(x)) on channels-last rows (B, L, C), as the wide U-Net levels run it in front of their convolutions
  * (a-unet ResnetItem).  ws (optional, >= B * 32 * groups * 2 floats): long sequences then take the

@@ -267,6 +267,132 @@ int sf_bench_conv1d(int dtype, int B, int L, int C, int N, int taps, int upsampl
   SF_API_END
 }
 
+int64_t sf_op_resnet_mod_cb_workspace_bytes(int B, int L, int C) {
+  Workspace dry(nullptr, 0);
+  const int64_t M = (int64_t)B * L;
+  dry.alloc(2 * (int64_t)C * C * 3 * 2);
+  dry.alloc(M * C * 2);
+  dry.alloc(M * C * 2);
+  dry.alloc((int64_t)(C / 128) * M * C * 4);
+  dry.alloc((int64_t)B * 32 * 64 * 2 * 4);
+  return dry.used();
+}
+
+int sf_op_resnet_mod_cb(int dtype, const void *x, const float *w1, const float *b1, const float *w2, const float *b2, const float *gn1_g,
+                        const float *gn1_b, const float *gn2_g, const float *gn2_b, int groups, float eps_gn, const float *scale_shift, float eps_ln,
+                        int B, int L, int C, void *h_out, void *m_out, void *ws, int64_t ws_bytes, void *stream) {
+  SF_API_BEGIN
+  if (!x || !w1 || !b1 || !w2 || !b2 || !gn1_g || !gn1_b || !gn2_g || !gn2_b || !m_out || !ws) fail(SF_ERR_INVALID, "null argument");
+  if (!conv_cb_shape_ok(dtype, B, L, C, C, groups) || groups > 64) fail(SF_ERR_UNSUPPORTED, "shape outside the channel-block convolution's coverage");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  Workspace wk(ws, ws_bytes);
+  const int64_t M = (int64_t)B * L;
+  const int S = C / 128;
+  char *wp = static_cast<char *>(wk.alloc(2 * (int64_t)C * C * 3 * 2));
+  void *wp1 = wp, *wp2 = wp + (int64_t)C * C * 3 * 2;
+  void *act = wk.alloc(M * C * 2);
+  void *h = h_out ? h_out : wk.alloc(M * C * 2);
+  float *slab = static_cast<float *>(wk.alloc((int64_t)S * M * C * 4));
+  float *stats = static_cast<float *>(wk.alloc((int64_t)B * 32 * 64 * 2 * 4));
+  SF_HIP(launch_pack_conv_cb(dtype, w1, C, C, wp1, s));
+  SF_HIP(launch_pack_conv_cb(dtype, w2, C, C, wp2, s));
+  SF_HIP(launch_gn_silu(dtype, x, C, B, L, C, groups, gn1_g, gn1_b, eps_gn, act, C, s));
+  ConvCbArgs a;
+  a.src = act;
+  a.src_ld = C;
+  a.wp = wp1;
+  a.slab = slab;
+  a.B = B;
+  a.L = L;
+  a.C = a.N = C;
+  SF_HIP(launch_conv_cb(dtype, a, s));
+  const CbGnPlan gp = cb_gn_plan(L);
+  SF_HIP(launch_cb_reduce_gn(dtype, slab, S, B, L, C, b1, h, C, groups, stats, gp, s));
+  a.src = h;
+  a.wp = wp2;
+  a.pro = 1;
+  a.G = groups;
+  a.nch = gp.nch;
+  a.chunk_rows = gp.chunk_rows;
+  a.stats = stats;
+  a.gamma = gn2_g;
+  a.beta = gn2_b;
+  a.eps = eps_gn;
+  SF_HIP(launch_conv_cb(dtype, a, s));
+  SF_HIP(launch_cb_reduce_ln(dtype, slab, S, B, L, C, b2, x, C, scale_shift, 2 * C, eps_ln, m_out, C, s));
+  return SF_OK;
+  SF_API_END
+}
+
+// Timing aid: the four launches of the channel-block chain, each averaged over `iters` back-to-back launches on random data
+// (ms[0] conv_cb without prologue, ms[1] cb_reduce_gn, ms[2] conv_cb with the GroupNorm+SiLU prologue, ms[3] cb_reduce_ln).
+// cold != 0: rotate through enough weight copies that every launch streams its weights from HBM.
+int sf_bench_conv_cb(int dtype, int B, int L, int C, int groups, int cold, int iters, float *ms) {
+  SF_API_BEGIN
+  if (!ms || iters < 1) fail(SF_ERR_INVALID, "bad argument");
+  if (!conv_cb_shape_ok(dtype, B, L, C, C, groups)) fail(SF_ERR_UNSUPPORTED, "shape outside the channel-block convolution's coverage");
+  const int64_t M = (int64_t)B * L;
+  const int S = C / 128;
+  const size_t wbytes = (size_t)C * C * 3 * 2;
+  int ncopy = 1;
+  if (cold) ncopy = (int)std::min<size_t>(256, (768u << 20) / wbytes + 1);
+  void *w = nullptr, *x = nullptr, *h = nullptr;
+  float *slab = nullptr, *stats = nullptr, *vec = nullptr;
+  SF_HIP(hipMalloc(&w, wbytes * ncopy));
+  SF_HIP(hipMalloc(&x, M * C * 2));
+  SF_HIP(hipMalloc(&h, M * C * 2));
+  SF_HIP(hipMalloc(reinterpret_cast<void **>(&slab), (size_t)S * M * C * 4));
+  SF_HIP(hipMalloc(reinterpret_cast<void **>(&stats), (size_t)B * 32 * 64 * 2 * 4));
+  SF_HIP(hipMalloc(reinterpret_cast<void **>(&vec), (size_t)(4 * C + (size_t)B * 2 * C) * 4));
+  SF_HIP(hipMemset(w, 0x11, wbytes * ncopy));     // small finite 16-bit patterns (bf16 / fp16 alike)
+  SF_HIP(hipMemset(x, 0x3c, M * C * 2));
+  SF_HIP(hipMemset(vec, 0, (size_t)(4 * C + (size_t)B * 2 * C) * 4));
+  const CbGnPlan gp = cb_gn_plan(L);
+  ConvCbArgs a;
+  a.src = x;
+  a.src_ld = C;
+  a.slab = slab;
+  a.B = B;
+  a.L = L;
+  a.C = a.N = C;
+  a.G = groups;
+  a.nch = gp.nch;
+  a.chunk_rows = gp.chunk_rows;
+  a.stats = stats;
+  a.gamma = vec;
+  a.beta = vec + C;
+  hipEvent_t e0, e1;
+  SF_HIP(hipEventCreate(&e0));
+  SF_HIP(hipEventCreate(&e1));
+  hipError_t err = hipSuccess;
+  for (int which = 0; which < 4 && err == hipSuccess; ++which) {
+    auto one = [&](int i) -> hipError_t {
+      a.wp = static_cast<char *>(w) + (size_t)(i % ncopy) * wbytes;
+      switch (which) {
+        case 0: a.pro = 0; return launch_conv_cb(dtype, a, nullptr);
+        case 1: return launch_cb_reduce_gn(dtype, slab, S, B, L, C, vec + 2 * C, h, C, groups, stats, gp, nullptr);
+        case 2: a.pro = 1; return launch_conv_cb(dtype, a, nullptr);
+        default: return launch_cb_reduce_ln(dtype, slab, S, B, L, C, vec + 2 * C, x, C, vec + 4 * C, 2 * C, 1e-6f, h, C, nullptr);
+      }
+    };
+    for (int i = 0; i < 3 && err == hipSuccess; ++i) err = one(i);
+    if (err != hipSuccess) break;
+    SF_HIP(hipDeviceSynchronize());
+    SF_HIP(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters && err == hipSuccess; ++i) err = one(i);
+    SF_HIP(hipEventRecord(e1, nullptr));
+    SF_HIP(hipEventSynchronize(e1));
+    SF_HIP(hipEventElapsedTime(&ms[which], e0, e1));
+    ms[which] /= (float)iters;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  for (void *p : {w, x, h, (void *)slab, (void *)stats, (void *)vec}) (void)hipFree(p);
+  if (err != hipSuccess) fail(SF_ERR_HIP, "launch failed: %s", hipGetErrorString(err));
+  return SF_OK;
+  SF_API_END
+}
+
 int sf_op_ln_modulate(int dtype, const void *x, const float *scale_shift, float eps, int B, int L, int C, void *out, void *stream) {
   SF_API_BEGIN
   if (!x || !out) fail(SF_ERR_INVALID, "null argument");

@@ -503,6 +503,13 @@ bool conv_gemm_emits_rowpart(int dt, const ConvGemmArgs &a) {
   return conv_gemm_fast_ok(dt, a);
 }
 
+bool conv_gemm_emits_gnpart(int dt, const ConvGemmArgs &a) {
+  ConvGemmArgs plain = a;
+  plain.gnpart_out = nullptr;
+  if (a.geom != 0 || a.Lout < 32 || !conv_gemm_emits_rowpart(dt, plain)) return false;
+  return conv_gemm_prefers_wp(a) && conv_gemm_wp_ok(dt, a);   // the wave-private 32x32 kernel is the one that writes them
+}
+
 hipError_t launch_conv_gemm(int dt, const ConvGemmArgs &a, hipStream_t s) {
   if (!conv_gemm_supported(dt, a)) return hipErrorInvalidValue;
   const ConvGemmForce &f = g_conv_gemm_force;

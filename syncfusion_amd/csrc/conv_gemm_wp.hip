@@ -271,6 +271,7 @@ __global__ __launch_bounds__(256) void conv_gemm_wp_kernel(const ConvGemmArgs a,
   // ---- the four partial tiles meet here --------------------------------------------------------------------
   __syncthreads();   // every wave is done with its staging buffers (red aliases them)
   float *rowstat = red + (size_t)4 * BM * LDR;   // (mean, rstd) per row, behind the four partial tiles
+  float *gsum = rowstat + 2 * BM;                // (sum, sum of squares) per row of the stored tile (gnpart_out)
   if (ln_epi) {
     const int t8 = tid & 7;
     const float mean = sum8_dpp((ln_mp[0] + ln_mp[1]) + (ln_mp[2] + ln_mp[3])) / (float)a.ln_nt;   // every partial covers 32 channels
@@ -346,6 +347,25 @@ __global__ __launch_bounds__(256) void conv_gemm_wp_kernel(const ConvGemmArgs a,
         q = sum8_dpp(q);
         if (nq == 0 && live) *reinterpret_cast<float2 *>(a.rowpart_out + ((size_t)m * a.rowpart_nt + nt) * 2) = make_float2(mean, q);
       }
+      if (a.gnpart_out) {   // GroupNorm tile sums of the stored values for the channel-block convolution that follows (kernels.h)
+        const float s1 = sum8_dpp((xo[0] + xo[1]) + (xo[2] + xo[3]));
+        const float s2 = sum8_dpp(fmaf(xo[0], xo[0], xo[1] * xo[1]) + fmaf(xo[2], xo[2], xo[3] * xo[3]));
+        if (nq == 0) {
+          gsum[2 * ml] = live ? s1 : 0.f;
+          gsum[2 * ml + 1] = live ? s2 : 0.f;
+        }
+        __syncthreads();
+        if (tid < 2) {   // segment 0: rows of the first row's clip; segment 1: rows of the next clip.  Fixed order: deterministic
+          const int rb = min((m0 / a.Lout + 1) * a.Lout - m0, BM);
+          const int lo = tid == 0 ? 0 : rb, hi = tid == 0 ? rb : BM;
+          float t1 = 0.f, t2 = 0.f;
+          for (int r = lo; r < hi; ++r) {
+            t1 += gsum[2 * r];
+            t2 += gsum[2 * r + 1];
+          }
+          *reinterpret_cast<float2 *>(a.gnpart_out + (((size_t)mt * ntiles + nt) * 2 + tid) * 2) = make_float2(t1, t2);
+        }
+      }
     }
   }
 }
@@ -353,7 +373,7 @@ __global__ __launch_bounds__(256) void conv_gemm_wp_kernel(const ConvGemmArgs a,
 template <typename T, int BM, int BN, bool CAT, int NSET> hipError_t launch_wp3(const ConvGemmArgs &a, hipStream_t s) {
   constexpr int LD = BK + 16 / (int)sizeof(T);
   constexpr size_t stage_bytes = (size_t)4 * (BM + BN) * LD * sizeof(T);
-  constexpr size_t red_bytes = (size_t)4 * BM * (BN + 4) * sizeof(float) + (size_t)2 * BM * sizeof(float);   // + (mean, rstd) per row
+  constexpr size_t red_bytes = (size_t)4 * BM * (BN + 4) * sizeof(float) + (size_t)4 * BM * sizeof(float);   // + (mean, rstd) and (sum, sumsq) per row
   const size_t lds = stage_bytes > red_bytes ? stage_bytes : red_bytes;
   if (lds > 150 * 1024) return hipErrorInvalidValue;   // fp32 64-row tiles do not fit: the caller falls back
   const int mtiles = (a.M + BM - 1) / BM, ntiles = (a.n_store + BN - 1) / BN;

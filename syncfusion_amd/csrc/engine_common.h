@@ -104,6 +104,7 @@ struct ConvW {
   int kreal = 0;           // un-padded reduction length (algorithmic FLOP accounting)
   bool direct = false;     // thin layer -> conv_direct (fp32 weights)
   void *wt = nullptr;      // direct layers only: the same [N][K] matrix in the compute type (conv_thin's MFMA operand)
+  void *wcb = nullptr;     // k = 3 convolutions of the deep levels: the same weights in MFMA fragment order (conv_cb.hip)
 };
 
 // Name lookup + packing helper shared by the Encoder1d and VideoOnsetNet engines.

@@ -64,6 +64,10 @@ struct ConvGemmArgs {
   //     statistics pooled from ln_part (ln_nt = cin / 32 partials per row); res_ln: the residual rows get the same transform.
   float *rowpart_out = nullptr;
   int rowpart_nt = 0;
+  // GroupNorm partials of the STORED output for the channel-block convolution that consumes it (conv_gemm_wp, 32x32 tiles, 1-D,
+  // Lout >= 32 so that a tile touches at most two clips): gnpart_out[((m_tile * (n_store / 32) + n_tile) * 2 + seg) * 2 + {0,1}] =
+  // (sum, sum of squares) over the tile's rows of the clip of its first row (seg 0) and of the next clip (seg 1).
+  float *gnpart_out = nullptr;
   //     ln_colsum != nullptr (plain normalisation, no second source): the source is multiplied RAW and the LayerNorm is
   //     applied to the accumulator instead,  rstd_m * (acc[m][n] - mean_m * ln_colsum[n]),  ln_colsum[n] = sum_k w[n][k].
   const float *ln_colsum = nullptr;
@@ -85,6 +89,8 @@ hipError_t launch_conv_gemm_mt(int dt, const ConvGemmArgs &a, hipStream_t s);
 const char *conv_gemm_mt_name(const ConvGemmArgs &a);   // label of the tile variant it picks (bf16 spelling)
 // true when launch_conv_gemm would run `a` on a kernel that honours rowpart_out (fast / wp, 32x32 tiles)
 bool conv_gemm_emits_rowpart(int dt, const ConvGemmArgs &a);
+// true when launch_conv_gemm would run `a` on the kernel that honours gnpart_out (wp, 32x32 tiles)
+bool conv_gemm_emits_gnpart(int dt, const ConvGemmArgs &a);
 // GEMM whose first source is LayerNorm-modulated on the fly from producer-side row partials (see ConvGemmArgs)
 bool conv_gemm_ln_ok(int dt, const ConvGemmArgs &a);
 hipError_t launch_conv_gemm_ln(int dt, const ConvGemmArgs &a, hipStream_t s);
@@ -155,6 +161,44 @@ bool d0_conv_supported(const ConvThinArgs &a);
 bool d0_tail_supported(const ThinTailArgs &a);
 hipError_t launch_d0_conv(int dt, const ConvThinArgs &a, hipStream_t s);
 hipError_t launch_d0_tail(int dt, const ThinTailArgs &a, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------
+// Channel-block split-K convolution for the deep levels at small batch (conv_cb.hip): k = 3, stride 1, padding 1, 16-bit types.
+//   slab[cb][m][n] = sum_{tap, c in block cb} W[n][c][tap] * pro(src)[m + tap - 1][c]      (fp32, no bias; cb = 0 .. C / 128 - 1)
+//   pro 1: SiLU(GroupNorm(src)) from the chunk sums stats [B][nch][G][2] = (sum, sum of squares) that cb_reduce_gn leaves
+//          (nch <= 32 chunks per clip), applied while the (rows + 2) x 128 activation panel is staged in LDS
+//   pro 2: the same from the TILE sums the producing GEMM's epilogue leaves (ConvGemmArgs::gnpart_out: per 32-row x 32-column
+//          tile and clip segment); needs C / G >= 32 and at most 32 tiles per (clip, group)
+// The launches that follow sum the slabs: cb_reduce_gn (+ bias -> 16-bit h and its GroupNorm chunk partials) and cb_reduce_ln
+// (+ bias + residual, LayerNorm over the row, Modulation -> 16-bit m).
+// ---------------------------------------------------------------------------------------
+struct ConvCbArgs {
+  Prefetch pf;
+  const void *src = nullptr;   // (B * L, src_ld) activations
+  const void *wp = nullptr;    // weights in fragment order (launch_pack_conv_cb)
+  float *slab = nullptr;       // [C / 128][B * L][N]
+  int B = 0, L = 0, C = 0, N = 0, src_ld = 0;
+  int pro = 0, G = 1, nch = 1, chunk_rows = 1;
+  const float *gamma = nullptr, *beta = nullptr, *stats = nullptr;
+  float eps = 1e-5f;
+  // filled by the launcher: log2(C / 128), log2(C / G), ceil(2^32 / L)
+  int log2S = 0, log2cpg = 7;
+  unsigned magicL = 0;
+};
+struct CbGnPlan {
+  int nch = 1, chunk_rows = 8;
+};
+bool conv_cb_shape_ok(int dt, int B, int L, int C, int N, int G);
+bool conv_cb_tile_stats_ok(int L, int C, int G);   // pro 2 applicable
+int conv_cb_mt(int M, int N, int C);            // 32-row tiles per workgroup the launcher picks
+size_t conv_cb_weight_elems(int N, int C);
+hipError_t launch_pack_conv_cb(int dt, const float *w /* (N, C, 3) fp32 */, int N, int C, void *out, hipStream_t s);
+hipError_t launch_conv_cb(int dt, const ConvCbArgs &a, hipStream_t s);
+CbGnPlan cb_gn_plan(int L);
+hipError_t launch_cb_reduce_gn(int dt, const float *slab, int S, int B, int L, int N, const float *bias, void *out, int out_ld, int G, float *stats,
+                               const CbGnPlan &gp, hipStream_t s, Prefetch pf = Prefetch());
+hipError_t launch_cb_reduce_ln(int dt, const float *slab, int S, int B, int L, int C, const float *bias, const void *res, int res_ld, const float *ss,
+                               int ss_ld, float eps, void *out, int out_ld, hipStream_t s, Prefetch pf = Prefetch());
 
 // ---------------------------------------------------------------------------------------
 // Direct (VALU) convolution for thin layers (Cin*taps small, N <= 32): one output row per thread.

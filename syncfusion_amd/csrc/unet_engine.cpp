@@ -50,6 +50,7 @@ struct Level {
   int64_t rows = 0;
   void *buf[3] = {nullptr, nullptr, nullptr};
   void *qkv = nullptr, *ao = nullptr, *ctx = nullptr, *act = nullptr;
+  bool cb = false;   // the item heads of this level run as the channel-block split-K chain (conv_cb.hip)
 };
 
 struct Plan {  // everything carved out of the caller's workspace for one (B, L0, two_pass)
@@ -67,6 +68,10 @@ struct Plan {  // everything carved out of the caller's workspace for one (B, L0
   int64_t slab_half = 0;       // second statistics slab of a branch starts here
   float *rowpart = nullptr;    // per-row LayerNorm partials of the wide levels: two buffers per branch (y and z of an item)
   int64_t rowpart_half = 0, rowpart_stride = 0;
+  float *cbslab = nullptr;     // fp32 partial slabs of the channel-block convolutions: one buffer per branch
+  int64_t cbslab_stride = 0;
+  float *gnpart = nullptr;     // GroupNorm tile sums a producing GEMM leaves for the next item's first convolution: one buffer per branch
+  int64_t gnpart_stride = 0;
   // modulation vectors: per clip ([Bt][mod_ld], mod_stride = mod_ld) for a single forward, or ONE row shared by all
   // clips (mod_stride = 0) inside the sampler, where sigma is the same for every clip and the rows of all steps are
   // computed once per call (mod_steps [steps][mod_ld])
@@ -251,7 +256,7 @@ struct Builder {
   }
 
   // Conv1d weight (N, C1 + C2, taps); channels [0,C1) -> taps x cin_pad block, [C1, C1+C2) -> cin2_pad block (taps == 1)
-  ConvW conv(const std::string &pre, int N, int C1, int taps, int C2, bool bias, bool direct, int cin_pad, int cin2_pad) {
+  ConvW conv(const std::string &pre, int N, int C1, int taps, int C2, bool bias, bool direct, int cin_pad, int cin2_pad, bool cb = false) {
     ConvW c;
     c.N = N;
     c.taps = taps;
@@ -274,6 +279,12 @@ struct Builder {
       c.wt = u.arena.alloc(N * kt * dsize(u.dt));
       SF_HIP(launch_pack_conv(u.dt, w, N, Ctot, 0, C1, taps, C1, nullptr, c.wt, kt, 0, s));
       if (C2) SF_HIP(launch_pack_conv(u.dt, w, N, Ctot, C1, C2, 1, c2p, nullptr, c.wt, kt, (int64_t)taps * C1, s));
+    }
+    static const bool no_cb = getenv("SF_NO_CB") != nullptr;   // debugging / A-B aid: keep the wave-private GEMM chain everywhere
+    if (cb && !no_cb && !direct && taps == 3 && C2 == 0 && cin_pad == C1 && conv_cb_shape_ok(u.dt, 1, 64, C1, N, 0)) {
+      // second copy in MFMA fragment order for the channel-block split-K kernel (the small-batch engine of the deep levels)
+      c.wcb = u.arena.alloc((int64_t)conv_cb_weight_elems(N, C1) * dsize(u.dt));
+      SF_HIP(launch_pack_conv_cb(u.dt, w, N, C1, c.wcb, s));
     }
     if (b) {
       c.bias = u.arena.alloc_n<float>(N);
@@ -321,10 +332,10 @@ void build_group(Builder &bd, Group &g, const std::string &pre, int d, int &mod_
   const bool thin = (C % 32) != 0;
   g.gn1_g = bd.copy_f32(pre + ".resnet.gn1.weight", C);
   g.gn1_b = bd.copy_f32(pre + ".resnet.gn1.bias", C);
-  g.conv1 = bd.conv(pre + ".resnet.conv1", C, C, 3, 0, true, thin, C, 0);
+  g.conv1 = bd.conv(pre + ".resnet.conv1", C, C, 3, 0, true, thin, C, 0, /*cb=*/true);
   g.gn2_g = bd.copy_f32(pre + ".resnet.gn2.weight", C);
   g.gn2_b = bd.copy_f32(pre + ".resnet.gn2.bias", C);
-  g.conv2 = bd.conv(pre + ".resnet.conv2", C, C, 3, 0, true, thin, C, 0);
+  g.conv2 = bd.conv(pre + ".resnet.conv2", C, C, 3, 0, true, thin, C, 0, /*cb=*/true);
   // Modulation Linear -> rows of the shared per-step GEMM (filled by build())
   g.mod_off = mod_cols;
   mod_cols = pad_to(mod_cols + 2 * C, 4);
@@ -578,6 +589,34 @@ Plan make_plan(const sf_unet &u, Workspace &ws, int B, int L0, bool two, int num
     p.rowpart_stride = 2 * p.rowpart_half;
     p.rowpart = ws.alloc_n<float>(p.rowpart_stride * p.nbr);
   }
+  {
+    // Channel-block split-K chain (conv_cb.hip) for the levels whose per-branch activations are short: below ~1.4 K rows the
+    // wave-private GEMMs stream 4-12x their operands through single CUs; the partial slabs cost S * rows * C floats per branch.
+    static const int cb_max_rows = [] {   // tuning hook: most rows per branch a level may have and still take the chain (0: never)
+      const char *e = getenv("SF_CB_MAX_ROWS");
+      return e ? atoi(e) : 1408;
+    }();
+    static const int cb_min_c = [] {      // tuning hook: narrowest level that takes the chain
+      const char *e = getenv("SF_CB_MIN_C");
+      return e ? atoi(e) : 256;
+    }();
+    int64_t need = 0, need_gp = 0;
+    for (int d = 0; d < c.n_layers; ++d) {
+      Level &l = p.lv[d];
+      const int bt = p.Bt / p.nbr;
+      const int64_t rows = (int64_t)bt * l.L;
+      const Block &b = u.blocks[d];
+      const bool have_w = !b.down_items.empty() && b.down_items[0].conv1.wcb != nullptr;
+      l.cb = have_w && l.C >= cb_min_c && rows <= cb_max_rows && conv_cb_shape_ok(u.dt, bt, l.L, l.C, l.C, c.resnet_groups) &&
+             cb_gn_plan(l.L).nch <= 32 && (int64_t)bt * 32 * c.resnet_groups * 2 <= p.slab_half;
+      if (l.cb) need = std::max<int64_t>(need, (int64_t)(l.C / 128) * rows * l.C);
+      if (l.cb) need_gp = std::max<int64_t>(need_gp, ((rows + 31) / 32) * (l.C / 32) * 4);
+    }
+    p.cbslab_stride = align_up(need, 64);
+    p.cbslab = need ? ws.alloc_n<float>(p.cbslab_stride * p.nbr) : nullptr;
+    p.gnpart_stride = align_up(need_gp, 64);
+    p.gnpart = need_gp ? ws.alloc_n<float>(p.gnpart_stride * p.nbr) : nullptr;
+  }
   p.emb2 = ws.alloc_n<float>((int64_t)p.Bt * c.embedding_features);
   p.emb_t = ws.alloc((int64_t)p.Bt * c.embedding_features * es);
   p.xhat_e = ws.alloc((int64_t)p.Bt * c.embedding_features * es);
@@ -606,6 +645,8 @@ struct Exec {
   Plan &p;
   hipStream_t s;
   const void *stats_of = nullptr;   // thin levels: the activation whose GroupNorm partials currently sit in p.slab
+  const void *gnpart_of = nullptr;  // channel-block levels: the activation whose GroupNorm tile sums currently sit in p.gnpart
+  bool up_gnpart = false;           // block(d + 1) left the tile sums of its output (level d's next item input) in p.gnpart
   int cur_depth = -1;               // depth tag of the launches being issued (profile records, roofline.depth_groups)
 
   template <class F> void timed(const char *label, double flops, double bytes, F &&f) {
@@ -625,17 +666,18 @@ struct Exec {
   // so the GEMM streams them from the Infinity Cache instead of HBM (in the two-branch step: -1.0 us per GEMM launch, measured with a
   // separate touch launch in front of every GEMM, profiles/r3_d_touch_*).  `host_wgs` = workgroups of the hosting launch: the
   // prefetch takes the CUs it leaves idle.
-  Prefetch pf_for(const ConvW &w, int host_wgs) const {
+  Prefetch pf_for(const ConvW &w, int host_wgs) const { return pf_bytes(w.direct ? nullptr : w.w, (size_t)w.N * w.K * dsize(u.dt), host_wgs); }
+  Prefetch pf_cb(const ConvW &w, int host_wgs) const { return pf_bytes(w.wcb, conv_cb_weight_elems(w.N, w.cin) * dsize(u.dt), host_wgs); }
+  Prefetch pf_bytes(const void *ptr, size_t bytes, int host_wgs) const {
     static const bool off = getenv("SF_NO_PREFETCH") != nullptr;
     Prefetch pf;
     static const int host_max = [] {   // tuning hook: hosts with more workgroups than this lend nothing
       const char *e = getenv("SF_PF_HOST_MAX");
       return e ? atoi(e) : 1024;   // (208 at first: batch 32 without guidance 277.2 -> 281.1 steps/s with 1024, configs[2] unchanged)
     }();
-    if (off || w.direct || !w.w || host_wgs > host_max) return pf;   // a host that fills the chip has no idle CUs to lend
-    const size_t bytes = (size_t)w.N * w.K * dsize(u.dt);
+    if (off || !ptr || host_wgs > host_max) return pf;   // a host that fills the chip has no idle CUs to lend
     if (bytes < (64u << 10) || bytes > 0x7FFFFFF0ull) return pf;   // small matrices: nothing to gain
-    pf.ptr = w.w;
+    pf.ptr = ptr;
     pf.bytes = (unsigned)bytes;
     static const int cap = [] {   // tuning hook: upper bound of prefetch workgroups per host launch
       const char *e = getenv("SF_PF_WGS");
@@ -647,6 +689,22 @@ struct Exec {
     }();
     pf.wgs = std::max(std::min(48, cap), std::min(cap, mult * (256 - host_wgs)));
     return pf;
+  }
+
+  // the producer of an item input of level d should leave GroupNorm tile sums (ConvGemmArgs::gnpart_out) for conv_cb's prologue
+  bool wants_gnpart(int d) const {
+    static const bool off = getenv("SF_NO_CB_TILESTATS") != nullptr;   // A/B aid: keep the gn_silu launch in front of conv1
+    if (off || d < 0 || d >= (int)p.lv.size()) return false;
+    const Level &l = p.lv[d];
+    return l.cb && p.gnpart && conv_cb_tile_stats_ok(l.L, l.C, u.cfg.resnet_groups);
+  }
+  // arm `a` (a GEMM whose output is the next item's input at level d) when the kernel it will run on can write them
+  bool arm_gnpart(const ConvW &w, ConvGemmArgs &a, int d) const {
+    if (!wants_gnpart(d)) return false;
+    a.gnpart_out = p.gnpart;
+    if (conv_gemm_emits_gnpart(u.dt, filled(w, a))) return true;
+    a.gnpart_out = nullptr;
+    return false;
   }
 
   ConvGemmArgs filled(const ConvW &w, ConvGemmArgs a) const {
@@ -713,7 +771,8 @@ struct Exec {
 
   // One item-group: Resnet -> Modulation -> InjectChannels -> [Attention] -> [CrossAttention]
   // cur is consumed; returns the buffer that holds the result.  tA / tB are the two free buffers.
-  void group(const Group &g, int d, void *&cur, void *&tA, void *&tB, const std::string &tapname) {
+  // next: the item group that consumes this one's output at the same level (nullptr: a down / up convolution follows)
+  void group(const Group &g, int d, void *&cur, void *&tA, void *&tB, const std::string &tapname, const Group *next = nullptr) {
     const Level &l = p.lv[d];
     const Block &b = u.blocks[d];
     const int C = l.C, G = u.cfg.resnet_groups;
@@ -837,6 +896,68 @@ struct Exec {
       const bool inj_emits = fuse_mod ? true : conv_gemm_emits_rowpart(u.dt, filled(g.inject, pi));
       fuse_attn = inj_emits && conv_gemm_ln_ok(u.dt, filled(g.qkv, pq));
     }
+    const bool use_cb = l.cb && !fuse_act && g.conv1.wcb && g.conv2.wcb && g.conv1.bias && g.conv2.bias && p.cbslab;
+    if (use_cb) {
+      // Channel-block split-K chain (conv_cb.hip): the two launches that followed the convolutions anyway (GroupNorm+SiLU, LayerNorm +
+      // Modulation) sum the fp32 partial slabs; the second convolution applies GroupNorm+SiLU while staging its activation panel.
+      const int bt = p.Bt, S = C / 128;
+      const double es = dsize(u.dt), rc = (double)l.rows * C;
+      const double cflops = 2.0 * rc * 3 * C, cbytes = 2.0 * rc * es + 3.0 * C * C * es;
+      const int mt = conv_cb_mt((int)l.rows, C, C);
+      const int cwgs = (int)((l.rows + 32 * mt - 1) / (32 * mt)) * (C / 128) * S;
+      const CbGnPlan cgp = cb_gn_plan(l.L);
+      ConvCbArgs a;
+      a.src_ld = C;
+      a.wp = g.conv1.wcb;
+      a.slab = p.cbslab;
+      a.B = bt;
+      a.L = l.L;
+      a.C = a.N = C;
+      a.G = G;
+      a.eps = 1e-5f;
+      a.pf = pf_cb(g.conv2, cwgs);
+      if (gnpart_of == cur && wants_gnpart(d)) {
+        // the GEMM that produced `cur` left its GroupNorm tile sums: GroupNorm+SiLU rides in conv1's panel prologue, no gn_silu launch
+        a.src = cur;
+        a.pro = 2;
+        a.stats = p.gnpart;
+        a.gamma = g.gn1_g;
+        a.beta = g.gn1_b;
+        timed("conv_cb", cflops + 12.0 * rc, cbytes, [&] { SF_HIP(launch_conv_cb(u.dt, a, s)); });
+      } else {
+        timed("gn_silu", 12.0 * rc, 3.0 * rc * es,
+              [&] { SF_HIP(launch_gn_silu(u.dt, cur, C, bt, l.L, C, G, g.gn1_g, g.gn1_b, 1e-5f, l.act, C, s, pf_cb(g.conv1, bt * G))); });
+        a.src = l.act;
+        timed("conv_cb", cflops, cbytes, [&] { SF_HIP(launch_conv_cb(u.dt, a, s)); });
+      }
+      gnpart_of = nullptr;
+      timed("cb_reduce_gn", 4.0 * rc, 2.0 * rc * es, [&] {
+        SF_HIP(launch_cb_reduce_gn(u.dt, p.cbslab, S, bt, l.L, C, g.conv1.bias, tA, C, G, p.slab, cgp, s, pf_cb(g.conv2, bt * cgp.nch * (C / 128))));
+      });
+      a.src = tA;
+      a.wp = g.conv2.wcb;
+      a.pro = 1;
+      a.nch = cgp.nch;
+      a.chunk_rows = cgp.chunk_rows;
+      a.stats = p.slab;
+      a.gamma = g.gn2_g;
+      a.beta = g.gn2_b;
+      a.pf = pf_for(g.inject, cwgs);
+      timed("conv_cb", cflops + 12.0 * rc, cbytes, [&] { SF_HIP(launch_conv_cb(u.dt, a, s)); });
+      timed("cb_reduce_ln", 12.0 * rc, 3.0 * rc * es, [&] {
+        SF_HIP(launch_cb_reduce_ln(u.dt, p.cbslab, S, bt, l.L, C, g.conv2.bias, cur, C, p.mod_all + g.mod_off, p.mod_stride, 1e-6f, tA, C, s,
+                                   pf_for(g.inject, (int)(l.rows * (C / 4) / 256))));
+      });
+      stats_of = nullptr;
+      ConvGemmArgs ai = inject_args(tA, tB);   // InjectChannels on the modulated rows (+ collapsed cross-attention bias when no attention follows)
+      if (fuse_attn) {
+        ai.rowpart_out = rp_z;
+        ai.rowpart_nt = C / 32;
+      }
+      if (g.attn) ai.pf = pf_for(g.qkv, (int)((l.rows + 31) / 32) * (C / 32));
+      else if (next && arm_gnpart(g.inject, ai, d)) gnpart_of = tB;   // tB becomes `cur` below
+      conv(g.inject, ai, u.dt, u.dt);
+    } else {
     conv3(g.conv1, cur, tA, g.gn1_g, g.gn1_b, nullptr, nullptr);
     conv3(g.conv2, tA, tB, g.gn2_g, g.gn2_b, cur, fuse_mod ? rp_y : nullptr, fuse_mod ? &g.inject : nullptr);
     if (fuse_mod) {
@@ -869,6 +990,7 @@ struct Exec {
       if (g.attn) a.pf = pf_for(g.qkv, (int)((l.rows + 31) / 32) * (C / 32));
       conv(g.inject, a, u.dt, u.dt);
     }
+    }   // !use_cb
     if (g.attn) {
       // x + W_o MHA(W_q LN_a(x), W_kv LN_b(x)): the two LayerNorms share (mean, rstd); their affines are folded.
       if (fuse_attn) {
@@ -884,7 +1006,7 @@ struct Exec {
               [&] { SF_HIP(launch_ln_modulate(u.dt, tB, C, nullptr, 0, 1e-5f, p.Bt, l.L, C, tA, C, s)); });
         conv(g.qkv, qkv_args(tA), u.dt, u.dt);
       }
-      attention_tail(g, d, cur, tB);
+      attention_tail(g, d, cur, tB, next);
       u.dbg.tap(tapname, u.dt, cur, C, l.rows, C, s);
       return;
     } else {
@@ -910,7 +1032,7 @@ struct Exec {
         a.out_ld = 3 * u.hd;
         conv(g.qkv, a, u.dt, u.dt);
       }
-      attention_tail(g, d, cur, tB);
+      attention_tail(g, d, cur, tB, next);
       // result in cur's buffer; tA, tB free again
     } else {
       void *o = cur;
@@ -922,7 +1044,7 @@ struct Exec {
   }
 
   // softmax attention on the packed q | k | v projections, then x' = z + W_o ao (+ collapsed cross-attention bias) -> `out`
-  void attention_tail(const Group &g, int d, void *out, const void *z) {
+  void attention_tail(const Group &g, int d, void *out, const void *z, const Group *next = nullptr) {
     const Level &l = p.lv[d];
     const int C = l.C;
     const size_t es = dsize(u.dt);
@@ -942,6 +1064,11 @@ struct Exec {
     if (g.cross) {
       a.badd = p.ca_all + g.ca_off;
       a.badd_ld = u.ca_ld;
+    }
+    gnpart_of = nullptr;
+    if (next && arm_gnpart(g.attn_out, a, d)) {
+      gnpart_of = out;
+      if (next->conv1.wcb) a.pf = pf_cb(next->conv1, (int)((l.rows + 31) / 32) * (C / 32));   // the next item starts with conv1 right away
     }
     conv(g.attn_out, a, u.dt, u.dt);
   }
@@ -1150,20 +1277,31 @@ struct Exec {
         w.cin = b.factor * b.cin;
         w.taps = 1;
       }
+      gnpart_of = nullptr;
+      if (!w.direct && !b.down_items.empty() && arm_gnpart(w, a, d)) gnpart_of = cur;
       conv(w, a, xin_dt, u.dt);
     }
     const std::string pre = "d" + std::to_string(d);
     u.dbg.tap(pre + ".down", u.dt, cur, l.C, l.rows, l.C, s);
-    for (size_t j = 0; j < b.down_items.size(); ++j) group(b.down_items[j], d, cur, tA, tB, pre + ".items_down." + std::to_string(j));
+    const bool innermost = d + 1 >= c.n_layers;
+    for (size_t j = 0; j < b.down_items.size(); ++j) {
+      // the consumer of this item's output: the next down item; at the innermost level the first up item; else the next level's down conv
+      const Group *nx = j + 1 < b.down_items.size() ? &b.down_items[j + 1] : ((innermost && !b.up_items.empty()) ? &b.up_items[0] : nullptr);
+      group(b.down_items[j], d, cur, tA, tB, pre + ".items_down." + std::to_string(j), nx);
+    }
     if (d + 1 < c.n_layers) {
+      up_gnpart = false;
       const bool have = block(d + 1, cur, u.dt, tA, u.dt);
       cur_depth = d;
       void *o = cur;
       cur = tA;
       tA = o;
       stats_of = have ? cur : nullptr;   // deeper levels share the statistics slabs
-    }
-    for (size_t j = 0; j < b.up_items.size(); ++j) group(b.up_items[j], d, cur, tA, tB, pre + ".items_up." + std::to_string(j));
+      gnpart_of = (up_gnpart && !b.up_items.empty()) ? cur : nullptr;
+      up_gnpart = false;
+    }   // (innermost level: the last down item feeds the first up item directly; its tile sums are still valid)
+    for (size_t j = 0; j < b.up_items.size(); ++j)
+      group(b.up_items[j], d, cur, tA, tB, pre + ".items_up." + std::to_string(j), j + 1 < b.up_items.size() ? &b.up_items[j + 1] : nullptr);
     bool up_stats = false, up_done = false;
     if (b.up_transposed) {   // x_out = skip + scale * ConvTranspose(h): one GEMM onto the (rows, f * cin) view of the outer level
       ConvGemmArgs a;
@@ -1231,6 +1369,7 @@ struct Exec {
       a.bscale = p.mod_all + b.skip_off;
       a.bscale_ld = p.mod_stride;
       if (xout_dt != u.dt && !b.up.direct) fail(SF_ERR_UNSUPPORTED, "depth 0 must be a thin level (channels[0] %% 32 != 0)");
+      if (d > 0 && xout_dt == u.dt && !b.up.direct && arm_gnpart(b.up, a, d - 1)) up_gnpart = true;
       conv(b.up, a, u.dt, xout_dt);
     }
     u.dbg.tap(pre + ".out", xout_dt, xout, b.cin, l.rows * b.factor, b.cin, s);
@@ -1307,6 +1446,8 @@ struct Exec {
     v.ca_all = p.ca_all + (int64_t)br * bt * u.ca_ld;
     v.slab = p.slab + (int64_t)br * p.slab_stride;
     v.rowpart = p.rowpart + (int64_t)br * p.rowpart_stride;
+    v.cbslab = p.cbslab ? p.cbslab + (int64_t)br * p.cbslab_stride : nullptr;
+    v.gnpart = p.gnpart ? p.gnpart + (int64_t)br * p.gnpart_stride : nullptr;
     return v;
   }
 

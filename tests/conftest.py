@@ -10,6 +10,11 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def pytest_configure(config):
+    # The CPU oracle's convolutions (2 .. 1024 channels) crawl when torch's intra-op pool oversubscribes a 256-thread GPU host (bench.py
+    # caps its cpu_baseline leg the same way): at most 32 threads for everything the suite computes on the host.
+    import torch
+
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), 32)))
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
     config.addinivalue_line("markers", "autograd: the test records an autograd graph (everything else runs under torch.no_grad())")
 

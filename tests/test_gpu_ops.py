@@ -249,3 +249,73 @@ def test_cut_prefix_crop_matches_reference_loop(cuda):
     y[3] = 0.0
     with pytest.raises(IndexError):
         cut_prefix_crop(gen.to(cuda), y.to(cuda), Lc)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# Channel-block split-K convolution chain of the deep levels (conv_cb.hip): gn_silu -> conv_cb -> slab reduction + GroupNorm sums ->
+# conv_cb with the GroupNorm+SiLU panel prologue -> slab reduction + residual + LayerNorm + Modulation.
+# ----------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", [
+    # B, L, C, modulated
+    (4, 44, 1024, True),     # depth 7 of configs[1] per branch: 176 rows, 8 channel blocks, one group per block
+    (4, 88, 1024, True),     # depth 6
+    (4, 176, 512, True),     # depth 5: two groups per channel block
+    (4, 352, 256, True),     # depth 4: four groups per block, 16-row statistics chunks
+    (3, 45, 128, False),     # one channel block, ragged rows, eight groups per block, plain LayerNorm (no modulation)
+    (1, 256, 256, True),     # a single clip
+    (5, 61, 512, True),      # row tiles that start and end inside clips, odd clip length
+])
+def test_conv_cb_chain(cuda, dtype, shape):
+    """a-unet ResnetItem + ModulationItem through the channel-block chain against fp32 torch on the
+    CPU from the same 16-bit-rounded inputs: the intermediate h (after the first reduction) and the modulated output m."""
+    _l, lib = _lib()
+    B, L, C, mod = shape
+    G = 8
+    td = TD[dtype]
+    g = torch.Generator().manual_seed(B * 1000 + L + C)
+    x = torch.randn(B, C, L, generator=g) * 1.3 + 0.2
+    w1 = torch.randn(C, C, 3, generator=g) / (3 * C) ** 0.5
+    w2 = torch.randn(C, C, 3, generator=g) / (3 * C) ** 0.5
+    b1, b2 = torch.randn(C, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1
+    gam = [1 + 0.2 * torch.randn(C, generator=g) for _ in range(2)]
+    bet = [0.1 * torch.randn(C, generator=g) for _ in range(2)]
+    ss = torch.randn(B, 2 * C, generator=g) * 0.3 if mod else None
+    xr = x.to(td).float()
+    w1r, w2r = w1.to(td).float(), w2.to(td).float()
+    h_ref = F.conv1d(F.silu(F.group_norm(xr, G, gam[0], bet[0], eps=1e-5)), w1r, b1, padding=1)
+    y = xr + F.conv1d(F.silu(F.group_norm(h_ref, G, gam[1], bet[1], eps=1e-5)), w2r, b2, padding=1)
+    m_ref = F.layer_norm(y.transpose(1, 2), (C,), eps=1e-6)
+    if mod:
+        m_ref = m_ref * (1 + ss[:, None, :C]) + ss[:, None, C:]
+    dev = lambda t: t.to(cuda)   # noqa: E731
+    x_cl = dev(x.transpose(1, 2).contiguous().to(td))
+    h = torch.empty(B, L, C, dtype=td, device=cuda)
+    m = torch.empty(B, L, C, dtype=td, device=cuda)
+    nbytes = lib.sf_op_resnet_mod_cb_workspace_bytes(B, L, C)
+    assert nbytes > 0
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=cuda)
+    keep = [dev(t) for t in (w1, b1, w2, b2, gam[0], bet[0], gam[1], bet[1])]
+    ssd = dev(ss) if mod else None
+    rc = lib.sf_op_resnet_mod_cb(_l.DTYPES[dtype], x_cl.data_ptr(), *[t.data_ptr() for t in keep], G, 1e-5,
+                                 ssd.data_ptr() if mod else None, 1e-6, B, L, C, h.data_ptr(), m.data_ptr(), ws.data_ptr(), ws.numel(),
+                                 _l.stream_ptr(cuda))
+    _l.check(rc, "sf_op_resnet_mod_cb")
+    torch.cuda.synchronize()
+    e_h = rel_l2(h.float().cpu().transpose(1, 2), h_ref)
+    e_m = rel_l2(m.float().cpu(), m_ref)
+    print(f"conv_cb chain {dtype} B={B} L={L} C={C}: h {e_h:.3e}  m {e_m:.3e}")
+    assert e_h < TOL[dtype] and e_m < TOL[dtype]
+
+
+def test_conv_cb_rejects_shapes_outside_its_coverage(cuda):
+    """fp32, channel counts that are not multiples of 128 and clips shorter than 44 positions are refused (the engine keeps the
+    wave-private GEMM chain there): an error code, not a wrong result."""
+    _l, lib = _lib()
+    for dtype, B, L, C in (("fp32", 2, 64, 256), ("bf16", 2, 64, 192), ("bf16", 2, 40, 256)):
+        t = torch.zeros(B, L, C, dtype=TD[dtype], device=cuda)
+        f = torch.zeros(3 * C * C + 2 * B * C, device=cuda)
+        ws = torch.empty(1 << 20, dtype=torch.uint8, device=cuda)
+        rc = lib.sf_op_resnet_mod_cb(_l.DTYPES[dtype], t.data_ptr(), *[f.data_ptr()] * 8, 8, 1e-5, None, 1e-6, B, L, C, None, t.data_ptr(),
+                                     ws.data_ptr(), ws.numel(), _l.stream_ptr(cuda))
+        assert rc != 0
