@@ -137,6 +137,11 @@ int sf_op_conv1d_cl(int dtype, const void *x, const float *w, const float *bias,
   void *wp = wk.alloc((int64_t)N * K * dsize(wdt));
   SF_HIP(launch_pack_conv(wdt, w, N, C, 0, C, taps, C, nullptr, wp, K, 0, s));
   ConvGemmArgs a;
+  if (!direct && dtype != F32 && (K % 64) == 0 && K <= 1536 && (N % 32) == 0 && (C % 16) == 0) {   // as the engine packs it (conv_gemm_rs.hip)
+    void *wfr = wk.alloc((int64_t)N * K * dsize(wdt));
+    SF_HIP(launch_pack_wfr(dtype, wp, N, K, wfr, s));
+    a.wfr = wfr;
+  }
   a.src = x;
   a.src_ld = C;
   a.w = wp;
@@ -237,6 +242,12 @@ int sf_bench_conv1d(int dtype, int B, int L, int C, int N, int taps, int upsampl
   SF_HIP(hipEventCreate(&e1));
   hipError_t err = hipSuccess;
   unsigned *sink = nullptr;   // the touch kernel's dedicated write sink (never a live buffer)
+  void *wfr = nullptr;
+  if (dtype != F32 && (K % 64) == 0 && K <= 1536 && (N % 32) == 0 && (C % 16) == 0 && !getenv("SF_BENCH_NO_WFR")) {
+    SF_HIP(hipMalloc(&wfr, wbytes * ncopy));   // fragment-ordered copies, same rotation (the values are random either way)
+    SF_HIP(hipMemcpy(wfr, w, wbytes * ncopy, hipMemcpyDeviceToDevice));
+    a.wfr = wfr;
+  }
   for (int i = 0; i < 3 && err == hipSuccess; ++i) err = launch_conv_gemm(dtype, a, nullptr);
   if (err == hipSuccess) {
     SF_HIP(hipDeviceSynchronize());
@@ -249,6 +260,7 @@ int sf_bench_conv1d(int dtype, int B, int L, int C, int N, int taps, int upsampl
     if (pre > 0) SF_HIP(hipMalloc(reinterpret_cast<void **>(&sink), 64));
     for (int i = 0; i < iters && err == hipSuccess; ++i) {
       a.w = static_cast<char *>(w) + (size_t)(i % ncopy) * wbytes;
+      if (wfr) a.wfr = static_cast<char *>(wfr) + (size_t)(i % ncopy) * wbytes;
       if (pre > 0) err = launch_touch(a.w, wbytes, pre % 1000, sink, nullptr);
       if (pre < 1000 && err == hipSuccess) err = launch_conv_gemm(dtype, a, nullptr);
     }
@@ -262,6 +274,7 @@ int sf_bench_conv1d(int dtype, int B, int L, int C, int N, int taps, int upsampl
   (void)hipEventDestroy(e1);
   for (void *p : {x, w, out, res, (void *)bias}) (void)hipFree(p);
   if (sink) (void)hipFree(sink);
+  if (wfr) (void)hipFree(wfr);
   if (err != hipSuccess) fail(SF_ERR_UNSUPPORTED, "variant not applicable: %s", hipGetErrorString(err));
   return SF_OK;
   SF_API_END

@@ -480,13 +480,23 @@ static bool ln_goes_wp(int dt, const ConvGemmArgs &a) {
   return use_wp && a.ln_colsum && !a.ln_ss && !a.res_ln && !a.rowpart_out && conv_gemm_wp_ok(dt, a);
 }
 
+static bool ln_goes_rs(int dt, const ConvGemmArgs &a);
 const char *conv_gemm_ln_variant_name(int dt, const ConvGemmArgs &a) {
+  if (ln_goes_rs(dt, a)) return label_for_dtype(dt, "conv_gemm_rs<bf16,32x32>");
   if (dt == F32) return ln_goes_wp(dt, a) ? "conv_gemm_wp<f32,32x32>" : "conv_gemm_fast<f32,32x32>";
   return label_for_dtype(dt, ln_goes_wp(dt, a) ? "conv_gemm_wp<bf16,32x32>" : "conv_gemm_fast<bf16,32x32>");
 }
 
+// the accumulator-side LayerNorm (raw rows through the matrix cores, rstd * (acc - mean * colsum) in the epilogue) on the register-staged
+// kernel when the fragment-ordered weights are at hand and the launch has few tiles
+bool conv_gemm_prefers_wp(const ConvGemmArgs &a);
+static bool ln_goes_rs(int dt, const ConvGemmArgs &a) {
+  return a.ln_colsum && !a.ln_ss && !a.res_ln && g_conv_gemm_force.path == 0 && conv_gemm_prefers_wp(a) && conv_gemm_rs_ok(dt, a);
+}
+
 hipError_t launch_conv_gemm_ln(int dt, const ConvGemmArgs &a, hipStream_t s) {
   if (!conv_gemm_ln_ok(dt, a)) return hipErrorInvalidValue;
+  if (ln_goes_rs(dt, a)) return launch_conv_gemm_rs(dt, a, s);
   if (ln_goes_wp(dt, a)) return launch_conv_gemm_wp(dt, a, 2, s);
   return SF_DISPATCH_T(dt, (a.cin2 ? launch_fast3<T, 32, 32, true, 32, 2, true>(a, s) : launch_fast3<T, 32, 32, false, 32, 2, true>(a, s)));
 }

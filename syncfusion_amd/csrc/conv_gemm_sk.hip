@@ -379,6 +379,15 @@ hipError_t launch_conv_gemm_fast(int dt, const ConvGemmArgs &a, int variant, hip
 bool conv_gemm_wp_ok(int dt, const ConvGemmArgs &a);
 hipError_t launch_conv_gemm_wp(int dt, const ConvGemmArgs &a, int variant, hipStream_t s);
 
+bool conv_gemm_prefers_wp(const ConvGemmArgs &a);
+bool conv_gemm_rs_rows_ok(int64_t rows, int N) {
+  ConvGemmArgs a;
+  a.M = (int)rows;
+  a.N = a.n_store = N;
+  a.K = 1024;
+  return conv_gemm_prefers_wp(a) && conv_gemm_sk_variant(a) == 2;
+}
+
 // Barrier-free wave-private pipelines (conv_gemm_wp.hip) win where few workgroups exist (cold weights, tools/gemm_cold.py):
 // at <= 512 tiles of 32x32 -- every GEMM of depths 3-7 at batch 4 except the widest qkv projections -- the staged
 // kernel's two barriers per chunk cost more than the operand sharing they buy.
@@ -398,6 +407,8 @@ hipError_t launch_conv_gemm_sk(int dt, const ConvGemmArgs &a, hipStream_t s) {
   // barrier-free wave-private pipelines where few tiles exist (conv_gemm_prefers_wp); with many tiles the staged kernel
   // wins because its loads are shared by more MFMA work per byte
   const bool prefer_wp = g_conv_gemm_force.path == 5 || (g_conv_gemm_force.path == 0 && conv_gemm_prefers_wp(a));
+  // few 32x32 tiles and fragment-ordered weights at hand: the register-staged kernel (all loads of a wave up front)
+  if (g_conv_gemm_force.path == 0 && prefer_wp && v == 2 && conv_gemm_rs_ok(dt, a)) return launch_conv_gemm_rs(dt, a, s);
   if (prefer_wp && conv_gemm_wp_ok(dt, a)) {
     hipError_t e = launch_conv_gemm_wp(dt, a, dt == F32 ? 2 : v, s);
     if (e != hipErrorInvalidValue) return e;

@@ -39,6 +39,7 @@ struct Prefetch {
 struct ConvGemmArgs {
   Prefetch pf;   // hosted prefetch (conv_gemm_wp / conv_gemm_fast only; other kernels ignore it)
   const void *src = nullptr, *src2 = nullptr, *w = nullptr, *res = nullptr;
+  const void *wfr = nullptr;    // optional: the same [N][K] matrix in MFMA fragment order [N / 32][K / 16][64][8] (conv_gemm_rs.hip)
   const float *w32 = nullptr;   // the same weights in fp32, [N][taps*C] (8-channel level: conv_d0.hip reads these as scalar operands)
   void *out = nullptr;
   const float *bias = nullptr, *gamma = nullptr, *beta = nullptr, *stats = nullptr;
@@ -89,6 +90,11 @@ hipError_t launch_conv_gemm_mt(int dt, const ConvGemmArgs &a, hipStream_t s);
 const char *conv_gemm_mt_name(const ConvGemmArgs &a);   // label of the tile variant it picks (bf16 spelling)
 // true when launch_conv_gemm would run `a` on a kernel that honours rowpart_out (fast / wp, 32x32 tiles)
 bool conv_gemm_emits_rowpart(int dt, const ConvGemmArgs &a);
+// register-staged kernel (conv_gemm_rs.hip): 32x32 tiles, all operand fragments of a wave in flight, fragment-ordered weights
+bool conv_gemm_rs_ok(int dt, const ConvGemmArgs &a);
+bool conv_gemm_rs_rows_ok(int64_t rows, int N);   // few enough 32x32 tiles for the small-batch kernels (the rule launch_conv_gemm applies)
+hipError_t launch_conv_gemm_rs(int dt, const ConvGemmArgs &a, hipStream_t s);
+hipError_t launch_pack_wfr(int dt, const void *w /* [N][K], compute type */, int N, int K, void *out, hipStream_t s);
 // true when launch_conv_gemm would run `a` on the kernel that honours gnpart_out (wp, 32x32 tiles)
 bool conv_gemm_emits_gnpart(int dt, const ConvGemmArgs &a);
 // GEMM whose first source is LayerNorm-modulated on the fly from producer-side row partials (see ConvGemmArgs)

@@ -286,11 +286,20 @@ struct Builder {
       c.wcb = u.arena.alloc((int64_t)conv_cb_weight_elems(N, C1) * dsize(u.dt));
       SF_HIP(launch_pack_conv_cb(u.dt, w, N, C1, c.wcb, s));
     }
+    pack_wfr(c);
     if (b) {
       c.bias = u.arena.alloc_n<float>(N);
       SF_HIP(hipMemcpyAsync(c.bias, b, N * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
     return c;
+  }
+
+  // second copy of a packed [N][K] matrix in MFMA fragment order for the register-staged small-batch GEMM (conv_gemm_rs.hip)
+  void pack_wfr(ConvW &c) {
+    static const bool off = getenv("SF_NO_RS") != nullptr;
+    if (off || u.listing || c.direct || u.dt == F32 || !c.w || (c.K % 64) || c.K > 1536 || (c.N % 32) || (c.cin % 16) || (c.cin2 % 16)) return;
+    c.wfr = u.arena.alloc((int64_t)c.N * c.K * dsize(u.dt));
+    SF_HIP(launch_pack_wfr(u.dt, c.w, c.N, c.K, c.wfr, s));
   }
 
   // Linear weight (N, K) [+ per-column scale] -> [N][Kpad] in the compute type, rows appended at row0 of dst
@@ -363,6 +372,8 @@ void build_group(Builder &bd, Group &g, const std::string &pre, int d, int &mod_
       bd.linear_into(g.attn_out, 0, wo, C, hd, nullptr);
       g.qkv_colsum = u.arena.alloc_n<float>(3 * hd);
       SF_HIP(launch_row_sums(u.dt, g.qkv.w, 3 * hd, g.qkv.K, g.qkv_colsum, bd.s));
+      bd.pack_wfr(g.qkv);
+      bd.pack_wfr(g.attn_out);
     }
   }
   if (g.cross) {
@@ -666,7 +677,12 @@ struct Exec {
   // so the GEMM streams them from the Infinity Cache instead of HBM (in the two-branch step: -1.0 us per GEMM launch, measured with a
   // separate touch launch in front of every GEMM, profiles/r3_d_touch_*).  `host_wgs` = workgroups of the hosting launch: the
   // prefetch takes the CUs it leaves idle.
-  Prefetch pf_for(const ConvW &w, int host_wgs) const { return pf_bytes(w.direct ? nullptr : w.w, (size_t)w.N * w.K * dsize(u.dt), host_wgs); }
+  // `rows` = output rows of the GEMM that will read the weights: short activations run on the register-staged kernel, which reads
+  // the fragment-ordered copy (conv_gemm_rs.hip)
+  Prefetch pf_for(const ConvW &w, int host_wgs, int64_t rows = -1) const {
+    const bool rs = w.wfr && rows >= 0 && conv_gemm_rs_rows_ok(rows, w.N);
+    return pf_bytes(w.direct ? nullptr : (rs ? w.wfr : w.w), (size_t)w.N * w.K * dsize(u.dt), host_wgs);
+  }
   Prefetch pf_cb(const ConvW &w, int host_wgs) const { return pf_bytes(w.wcb, conv_cb_weight_elems(w.N, w.cin) * dsize(u.dt), host_wgs); }
   Prefetch pf_bytes(const void *ptr, size_t bytes, int host_wgs) const {
     static const bool off = getenv("SF_NO_PREFETCH") != nullptr;
@@ -709,6 +725,7 @@ struct Exec {
 
   ConvGemmArgs filled(const ConvW &w, ConvGemmArgs a) const {
     a.w = w.w;
+    a.wfr = w.wfr;
     a.bias = w.bias;
     a.N = w.N;
     a.K = w.K;
@@ -792,7 +809,7 @@ struct Exec {
     auto conv3 = [&](const ConvW &w, const void *in, void *out, const float *gam, const float *bet, const void *res, float *rowpart,
                      const ConvW *next = nullptr) {
       ConvGemmArgs a;
-      if (next) a.pf = pf_for(*next, (int)((l.rows + 31) / 32) * ((C + 31) / 32));
+      if (next) a.pf = pf_for(*next, (int)((l.rows + 31) / 32) * ((C + 31) / 32), l.rows);
       if (rowpart) {
         a.rowpart_out = rowpart;
         a.rowpart_nt = C / 32;
@@ -942,11 +959,11 @@ struct Exec {
       a.stats = p.slab;
       a.gamma = g.gn2_g;
       a.beta = g.gn2_b;
-      a.pf = pf_for(g.inject, cwgs);
+      a.pf = pf_for(g.inject, cwgs, l.rows);
       timed("conv_cb", cflops + 12.0 * rc, cbytes, [&] { SF_HIP(launch_conv_cb(u.dt, a, s)); });
       timed("cb_reduce_ln", 12.0 * rc, 3.0 * rc * es, [&] {
         SF_HIP(launch_cb_reduce_ln(u.dt, p.cbslab, S, bt, l.L, C, g.conv2.bias, cur, C, p.mod_all + g.mod_off, p.mod_stride, 1e-6f, tA, C, s,
-                                   pf_for(g.inject, (int)(l.rows * (C / 4) / 256))));
+                                   pf_for(g.inject, (int)(l.rows * (C / 4) / 256), l.rows)));
       });
       stats_of = nullptr;
       ConvGemmArgs ai = inject_args(tA, tB);   // InjectChannels on the modulated rows (+ collapsed cross-attention bias when no attention follows)
@@ -954,7 +971,7 @@ struct Exec {
         ai.rowpart_out = rp_z;
         ai.rowpart_nt = C / 32;
       }
-      if (g.attn) ai.pf = pf_for(g.qkv, (int)((l.rows + 31) / 32) * (C / 32));
+      if (g.attn) ai.pf = pf_for(g.qkv, (int)((l.rows + 31) / 32) * (C / 32), l.rows);
       else if (next && arm_gnpart(g.inject, ai, d)) gnpart_of = tB;   // tB becomes `cur` below
       conv(g.inject, ai, u.dt, u.dt);
     } else {
@@ -973,21 +990,21 @@ struct Exec {
         a.rowpart_out = rp_z;
         a.rowpart_nt = C / 32;
       }
-      if (g.attn) a.pf = pf_for(g.qkv, (int)((l.rows + 31) / 32) * (C / 32));
+      if (g.attn) a.pf = pf_for(g.qkv, (int)((l.rows + 31) / 32) * (C / 32), l.rows);
       conv(g.inject, a, u.dt, u.dt, /*ln=*/true);
       std::swap(tA, tB);   // z -> tB, as the code below expects
     } else {
       // Modulation: LN_C(x; eps 1e-6) * (1 + scale) + shift
       timed("ln_modulate", 8.0 * l.rows * C, 2.0 * l.rows * C * dsize(u.dt),
             [&] { SF_HIP(launch_ln_modulate(u.dt, tB, C, p.mod_all + g.mod_off, p.mod_stride, 1e-6f, p.Bt, l.L, C, tA, C, s,
-                                            pf_for(g.inject, (int)(l.rows / 4)))); });
+                                            pf_for(g.inject, (int)(l.rows / 4), l.rows))); });
       // InjectChannels: Conv1x1(cat[x, ctx]) + x   (+ collapsed cross-attention bias when no self-attention follows)
       ConvGemmArgs a = inject_args(tA, tB);
       if (fuse_attn) {
         a.rowpart_out = rp_z;
         a.rowpart_nt = C / 32;
       }
-      if (g.attn) a.pf = pf_for(g.qkv, (int)((l.rows + 31) / 32) * (C / 32));
+      if (g.attn) a.pf = pf_for(g.qkv, (int)((l.rows + 31) / 32) * (C / 32), l.rows);
       conv(g.inject, a, u.dt, u.dt);
     }
     }   // !use_cb
@@ -999,7 +1016,7 @@ struct Exec {
         a.ln_nt = C / 32;
         a.ln_eps = 1e-5f;
         a.ln_colsum = g.qkv_colsum;   // raw z through the MFMAs, rstd * (acc - mean * colsum) in the epilogue
-        a.pf = pf_for(g.attn_out, (int)((l.rows + 31) / 32) * (3 * u.hd / 32));
+        a.pf = pf_for(g.attn_out, (int)((l.rows + 31) / 32) * (3 * u.hd / 32), l.rows);
         conv(g.qkv, a, u.dt, u.dt, /*ln=*/true);
       } else {
         timed("ln_modulate", 6.0 * l.rows * C, 2.0 * l.rows * C * dsize(u.dt),

@@ -251,6 +251,23 @@ def test_cut_prefix_crop_matches_reference_loop(cuda):
         cut_prefix_crop(gen.to(cuda), y.to(cuda), Lc)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", [
+    # B, L, C, N, taps, stride, pad, up, groups, residual -- few 32x32 tiles, K = taps * C a multiple of 64 up to 1536, N a multiple of 32:
+    # the register-staged kernel (conv_gemm_rs.hip: fragment-ordered weights, all fragments of a wave in flight)
+    (4, 44, 512, 1024, 1, 1, 0, 1, 0, True),    # attention output projection at depth 7 (K = 512: 8 fragments per wave)
+    (4, 44, 1024, 1536, 1, 1, 0, 1, 0, False),  # qkv projection (K = 1024: 16 per wave)
+    (4, 88, 1280, 1024, 1, 1, 0, 1, 0, True),   # InjectChannels width (K = 1280: 20 of 24)
+    (4, 176, 512, 256, 3, 1, 1, 1, 0, True),    # k = 3 with padding, K = 1536 (24 per wave), taps cross the waves' ranges
+    (3, 45, 128, 96, 3, 1, 1, 1, 0, False),     # ragged rows and clips, K = 384: a wave's range ends inside a tap
+    (2, 88, 256, 128, 3, 1, 1, 2, 0, True),     # nearest x2 upsample + conv3 (up path), K = 768
+    (5, 7, 64, 32, 1, 1, 0, 1, 0, False),       # clips shorter than a tile, one fragment per wave
+])
+def test_conv1d_register_staged_shapes(cuda, dtype, shape):
+    e = _conv_case(cuda, dtype, *shape, seed=11)
+    assert e < TOL[dtype], f"{dtype} {shape}: rel-L2 {e:.3e}"
+
+
 # ----------------------------------------------------------------------------------------------------------
 # Channel-block split-K convolution chain of the deep levels (conv_cb.hip): gn_silu -> conv_cb -> slab reduction + GroupNorm sums ->
 # conv_cb with the GroupNorm+SiLU panel prologue -> slab reduction + residual + LayerNorm + Modulation.
