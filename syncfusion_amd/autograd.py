@@ -36,7 +36,7 @@ def _cl(x: Tensor) -> Tensor:
 class _ConvBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], gamma: Optional[Tensor], beta: Optional[Tensor], groups: int, eps: float,
-                channels_last: bool = False):
+                channels_last: bool = False, residual: Optional[Tensor] = None):
         _lib.require_gpu_tensor(x, "syncfusion_amd.autograd")
         lib = _lib.load()
         if channels_last:
@@ -71,14 +71,25 @@ class _ConvBlockFn(torch.autograd.Function):
             be = _lib.f32c(beta) if groups > 0 else None
             out = torch.empty(B, L, N, dtype=torch.float32, device=x.device)
             ws = torch.empty(max(256, 4 * N * Cc * taps + 8 * B * 64 * groups + (1 << 16)), dtype=torch.uint8, device=x.device)
+            # residual: added in the convolution's epilogue (one pass less over the tensor than a separate add); its gradient is dy itself
+            res_cl, res_late = None, None
+            if residual is not None:
+                res_cl = _lib.f32c(residual) if channels_last else _cl(_lib.f32c(residual))
+                if tuple(res_cl.shape) != (B, L, n_real):
+                    raise ValueError(f"residual shape {tuple(residual.shape)} does not match the output")
+                if n_real != N:   # zero-padded output width: the kernel's rows are wider than the residual's; add afterwards
+                    res_cl, res_late = None, res_cl
             _lib.check(lib.sf_op_conv1d_cl(_lib.SF_F32, x_cl.data_ptr(), w.data_ptr(), b.data_ptr() if b is not None else None,
                                            g.data_ptr() if g is not None else None, be.data_ptr() if be is not None else None, int(groups), float(eps),
-                                           None, B, L, Cc, N, taps, 1, pad, 1, out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr(x.device)),
+                                           res_cl.data_ptr() if res_cl is not None else None, B, L, Cc, N, taps, 1, pad, 1, out.data_ptr(), ws.data_ptr(),
+                                           ws.numel(), _lib.stream_ptr(x.device)),
                        "sf_op_conv1d_cl")
         ctx.save_for_backward(x_cl, w, g if g is not None else x_cl.new_empty(0), be if be is not None else x_cl.new_empty(0))
         ctx.meta = (B, L, Cc, N, taps, pad, int(groups), float(eps), bias is not None, c_real, n_real, bool(channels_last))
         if n_real != N:
             out = out[:, :, :n_real]
+            if res_late is not None:
+                out = out + res_late
         return out if channels_last else out.transpose(1, 2)
 
     @staticmethod
@@ -118,19 +129,19 @@ class _ConvBlockFn(torch.autograd.Function):
         if not ctx.needs_input_grad[0]:
             dx = None
         return (dx, dw, db, dgb[:Cc] if dgb is not None else None, dgb[Cc:] if dgb is not None else None,
-                None, None, None)
+                None, None, None, dy if ctx.needs_input_grad[8] else None)
 
 
 def gn_silu_conv1d(x: Tensor, weight: Tensor, bias: Optional[Tensor], gamma: Tensor, beta: Tensor, groups: int, eps: float = 1e-5,
-                   channels_last: bool = False) -> Tensor:
-    """``F.conv1d(F.silu(F.group_norm(x, groups, gamma, beta, eps)), weight, bias, padding=k//2)`` with HIP forward and backward.
-    ``channels_last``: x and the result are ``(B, L, C)`` instead of ``(B, C, L)`` (no transposes around the kernels)."""
-    return _ConvBlockFn.apply(x, weight, bias, gamma, beta, int(groups), float(eps), bool(channels_last))
+                   channels_last: bool = False, residual: Optional[Tensor] = None) -> Tensor:
+    """``F.conv1d(F.silu(F.group_norm(x, groups, gamma, beta, eps)), weight, bias, padding=k//2) (+ residual)`` with HIP forward and
+    backward.  ``channels_last``: x, residual and the result are ``(B, L, C)`` instead of ``(B, C, L)`` (no transposes around the kernels)."""
+    return _ConvBlockFn.apply(x, weight, bias, gamma, beta, int(groups), float(eps), bool(channels_last), residual)
 
 
-def conv1d(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, channels_last: bool = False) -> Tensor:
-    """``F.conv1d(x, weight, bias, padding=k//2)`` (stride 1) with HIP forward and backward."""
-    return _ConvBlockFn.apply(x, weight, bias, None, None, 0, 0.0, bool(channels_last))
+def conv1d(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, channels_last: bool = False, residual: Optional[Tensor] = None) -> Tensor:
+    """``F.conv1d(x, weight, bias, padding=k//2) (+ residual)`` (stride 1) with HIP forward and backward."""
+    return _ConvBlockFn.apply(x, weight, bias, None, None, 0, 0.0, bool(channels_last), residual)
 
 
 class _LnModulateFn(torch.autograd.Function):

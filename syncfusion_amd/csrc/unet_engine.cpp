@@ -601,11 +601,20 @@ Plan make_plan(const sf_unet &u, Workspace &ws, int B, int L0, bool two, int num
     p.rowpart = ws.alloc_n<float>(p.rowpart_stride * p.nbr);
   }
   {
-    // Channel-block split-K chain (conv_cb.hip) for the levels whose per-branch activations are short: below ~1.4 K rows the
-    // wave-private GEMMs stream 4-12x their operands through single CUs; the partial slabs cost S * rows * C floats per branch.
+    // Channel-block split-K chain (conv_cb.hip) for the levels whose per-branch activations are short: there the wave-private GEMMs
+    // stream 4-12x their operands through single CUs and every launch is latency-bound.  The price is the fp32 partial slabs,
+    // S * rows * C * 4 bytes written and read back per convolution: 5.8 MB per level at four clips per branch, 46 MB at 32 -- where
+    // the step is bandwidth- / MFMA-bound and the slab traffic costs more than the operand amplification it removes (configs[2]
+    // 191 vs 200 steps/s, one GPU's share of configs[3] 271 vs 285 with the chain on at 704-1408 rows: profiles/r4_d_ab_cb_rows.txt).
+    // Footprint limit swept at batch 12 / 16 / 32 with and without guidance (profiles/r4_d_ab_cb_slab.txt): 12 MB is never behind "off"
+    // beyond run-to-run noise and +1.5 % at batch 12-16.
     static const int cb_max_rows = [] {   // tuning hook: most rows per branch a level may have and still take the chain (0: never)
       const char *e = getenv("SF_CB_MAX_ROWS");
       return e ? atoi(e) : 1408;
+    }();
+    static const double cb_max_slab_mb = [] {   // tuning hook: largest partial-slab footprint (MB per branch and level)
+      const char *e = getenv("SF_CB_MAX_SLAB_MB");
+      return e ? atof(e) : 12.0;
     }();
     static const int cb_min_c = [] {      // tuning hook: narrowest level that takes the chain
       const char *e = getenv("SF_CB_MIN_C");
@@ -618,7 +627,8 @@ Plan make_plan(const sf_unet &u, Workspace &ws, int B, int L0, bool two, int num
       const int64_t rows = (int64_t)bt * l.L;
       const Block &b = u.blocks[d];
       const bool have_w = !b.down_items.empty() && b.down_items[0].conv1.wcb != nullptr;
-      l.cb = have_w && l.C >= cb_min_c && rows <= cb_max_rows && conv_cb_shape_ok(u.dt, bt, l.L, l.C, l.C, c.resnet_groups) &&
+      l.cb = have_w && l.C >= cb_min_c && rows <= cb_max_rows && (double)(l.C / 128) * rows * l.C * 4.0 <= cb_max_slab_mb * 1048576.0 &&
+             conv_cb_shape_ok(u.dt, bt, l.L, l.C, l.C, c.resnet_groups) &&
              cb_gn_plan(l.L).nch <= 32 && (int64_t)bt * 32 * c.resnet_groups * 2 <= p.slab_half;
       if (l.cb) need = std::max<int64_t>(need, (int64_t)(l.C / 128) * rows * l.C);
       if (l.cb) need_gp = std::max<int64_t>(need_gp, ((rows + 31) / 32) * (l.C / 32) * 4);

@@ -29,7 +29,9 @@ def main():
             if key in seen:
                 continue
             seen.add(key)
-            a = agg[r["Kernel_Name"].split("(")[0][:110]]
+            # full kernel name with its template arguments: demangled names start with "void sf::(anonymous namespace)::", so cutting at the
+            # first "(" merged every kernel into one row
+            a = agg[r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("\"", "").split("(sf::")[0].split("(float")[0].split("(int")[0][:120]]
             a[0] += 1
             a[1] += float(r["Counter_Value"])
             a[2] += dur.get(key, 0)

@@ -16,7 +16,8 @@ import re
 import sys
 
 LABELS = [  # (regex on the kernel name, bench.py label prefix)
-    (r"conv_gemm_fast_kernel", "conv_gemm_fast"), (r"conv_gemm_wp_kernel", "conv_gemm_wp"), (r"conv_gemm_v2_kernel", "conv_gemm_v2"),
+    (r"conv_cb_kernel", "conv_cb"), (r"cb_reduce_gn_kernel", "cb_reduce_gn"), (r"cb_reduce_ln_kernel", "cb_reduce_ln"),
+    (r"conv_gemm_rs_kernel", "conv_gemm_rs"), (r"conv_gemm_fast_kernel", "conv_gemm_fast"), (r"conv_gemm_wp_kernel", "conv_gemm_wp"), (r"conv_gemm_v2_kernel", "conv_gemm_v2"),
     (r"conv_gemm_mt_kernel", "conv_gemm_mt"), (r"thin_tail_kernel", "conv_thin"), (r"attention_ksplit_kernel", "attention"),
     (r"conv_gemm_sk_kernel", "conv_gemm_sk"), (r"conv_gemm_kernel", "conv_gemm"), (r"conv_thin_kernel", "conv_thin"),
     (r"conv_direct_kernel", "conv_direct"), (r"gn_silu_kernel", "gn_silu"), (r"gn_stats_kernel", "gn_stats"),
