@@ -260,10 +260,11 @@ int sf_bench_conv1d(int dtype, int B, int L, int C, int N, int taps, int upsampl
 int64_t sf_op_resnet_mod_cb_workspace_bytes(int B, int L, int C);
 int sf_op_resnet_mod_cb(int dtype, const void *x, const float *w1, const float *b1, const float *w2, const float *b2, const float *gn1_g,
                         const float *gn1_b, const float *gn2_g, const float *gn2_b, int groups, float eps_gn, const float *scale_shift,
-                        float eps_ln, int B, int L, int C, void *h_out, void *m_out, void *ws, int64_t ws_bytes, void *stream);
+                        float eps_ln, int B, int L, int C, int kb /* 128-channel blocks per workgroup: 1 or 2 */, void *h_out, void *m_out,
+                        void *ws, int64_t ws_bytes, void *stream);
 /* Kernel tuning aid: average milliseconds of the four launches of that chain on random data (ms[0] convolution, ms[1] reduction +
  * GroupNorm sums, ms[2] convolution with prologue, ms[3] reduction + LayerNorm); cold != 0 streams the weights from HBM. */
-int sf_bench_conv_cb(int dtype, int B, int L, int C, int groups, int cold, int iters, float *ms /* [4] */);
+int sf_bench_conv_cb(int dtype, int B, int L, int C, int groups, int kb, int cold, int iters, float *ms /* [4] */);
 /* y = layer_norm(x; eps, no affine) * (1 + scale[b]) + shift[b]   (scale/shift NULL -> plain normalise) */
 /* materialised SiLU(GroupNorm(x)) on channels-last rows (B, L, C), as the wide U-Net levels run it in front of their convolutions
  * (a-unet ResnetItem).  ws (optional, >= B * 32 * groups * 2 floats): long sequences then take the

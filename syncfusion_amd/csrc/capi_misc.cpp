@@ -137,7 +137,7 @@ int sf_op_conv1d_cl(int dtype, const void *x, const float *w, const float *bias,
   void *wp = wk.alloc((int64_t)N * K * dsize(wdt));
   SF_HIP(launch_pack_conv(wdt, w, N, C, 0, C, taps, C, nullptr, wp, K, 0, s));
   ConvGemmArgs a;
-  if (!direct && dtype != F32 && (K % 64) == 0 && K <= 1536 && (N % 32) == 0 && (C % 16) == 0) {   // as the engine packs it (conv_gemm_rs.hip)
+  if (!direct && dtype != F32 && (K % 64) == 0 && K <= 2048 && (N % 32) == 0 && (C % 16) == 0) {   // as the engine packs it (conv_gemm_rs.hip)
     void *wfr = wk.alloc((int64_t)N * K * dsize(wdt));
     SF_HIP(launch_pack_wfr(dtype, wp, N, K, wfr, s));
     a.wfr = wfr;
@@ -243,7 +243,7 @@ int sf_bench_conv1d(int dtype, int B, int L, int C, int N, int taps, int upsampl
   hipError_t err = hipSuccess;
   unsigned *sink = nullptr;   // the touch kernel's dedicated write sink (never a live buffer)
   void *wfr = nullptr;
-  if (dtype != F32 && (K % 64) == 0 && K <= 1536 && (N % 32) == 0 && (C % 16) == 0 && !getenv("SF_BENCH_NO_WFR")) {
+  if (dtype != F32 && (K % 64) == 0 && K <= 2048 && (N % 32) == 0 && (C % 16) == 0 && !getenv("SF_BENCH_NO_WFR")) {
     SF_HIP(hipMalloc(&wfr, wbytes * ncopy));   // fragment-ordered copies, same rotation (the values are random either way)
     SF_HIP(hipMemcpy(wfr, w, wbytes * ncopy, hipMemcpyDeviceToDevice));
     a.wfr = wfr;
@@ -293,14 +293,16 @@ int64_t sf_op_resnet_mod_cb_workspace_bytes(int B, int L, int C) {
 
 int sf_op_resnet_mod_cb(int dtype, const void *x, const float *w1, const float *b1, const float *w2, const float *b2, const float *gn1_g,
                         const float *gn1_b, const float *gn2_g, const float *gn2_b, int groups, float eps_gn, const float *scale_shift, float eps_ln,
-                        int B, int L, int C, void *h_out, void *m_out, void *ws, int64_t ws_bytes, void *stream) {
+                        int B, int L, int C, int kb, void *h_out, void *m_out, void *ws, int64_t ws_bytes, void *stream) {
   SF_API_BEGIN
+  if (kb != 1 && kb != 2) fail(SF_ERR_INVALID, "kb must be 1 or 2");
   if (!x || !w1 || !b1 || !w2 || !b2 || !gn1_g || !gn1_b || !gn2_g || !gn2_b || !m_out || !ws) fail(SF_ERR_INVALID, "null argument");
   if (!conv_cb_shape_ok(dtype, B, L, C, C, groups) || groups > 64) fail(SF_ERR_UNSUPPORTED, "shape outside the channel-block convolution's coverage");
   hipStream_t s = static_cast<hipStream_t>(stream);
   Workspace wk(ws, ws_bytes);
   const int64_t M = (int64_t)B * L;
-  const int S = C / 128;
+  const int S = C / 128 / kb;
+  if (kb == 2 && ((C / 128) % 2 || C / groups < 32)) fail(SF_ERR_UNSUPPORTED, "two channel blocks per workgroup need C a multiple of 256 and >= 32 channels per group");
   char *wp = static_cast<char *>(wk.alloc(2 * (int64_t)C * C * 3 * 2));
   void *wp1 = wp, *wp2 = wp + (int64_t)C * C * 3 * 2;
   void *act = wk.alloc(M * C * 2);
@@ -318,6 +320,7 @@ int sf_op_resnet_mod_cb(int dtype, const void *x, const float *w1, const float *
   a.B = B;
   a.L = L;
   a.C = a.N = C;
+  a.kb = kb;
   SF_HIP(launch_conv_cb(dtype, a, s));
   const CbGnPlan gp = cb_gn_plan(L);
   SF_HIP(launch_cb_reduce_gn(dtype, slab, S, B, L, C, b1, h, C, groups, stats, gp, s));
@@ -340,12 +343,12 @@ int sf_op_resnet_mod_cb(int dtype, const void *x, const float *w1, const float *
 // Timing aid: the four launches of the channel-block chain, each averaged over `iters` back-to-back launches on random data
 // (ms[0] conv_cb without prologue, ms[1] cb_reduce_gn, ms[2] conv_cb with the GroupNorm+SiLU prologue, ms[3] cb_reduce_ln).
 // cold != 0: rotate through enough weight copies that every launch streams its weights from HBM.
-int sf_bench_conv_cb(int dtype, int B, int L, int C, int groups, int cold, int iters, float *ms) {
+int sf_bench_conv_cb(int dtype, int B, int L, int C, int groups, int kb, int cold, int iters, float *ms) {
   SF_API_BEGIN
-  if (!ms || iters < 1) fail(SF_ERR_INVALID, "bad argument");
+  if (!ms || iters < 1 || (kb != 1 && kb != 2)) fail(SF_ERR_INVALID, "bad argument");
   if (!conv_cb_shape_ok(dtype, B, L, C, C, groups)) fail(SF_ERR_UNSUPPORTED, "shape outside the channel-block convolution's coverage");
   const int64_t M = (int64_t)B * L;
-  const int S = C / 128;
+  const int S = C / 128 / kb;
   const size_t wbytes = (size_t)C * C * 3 * 2;
   int ncopy = 1;
   if (cold) ncopy = (int)std::min<size_t>(256, (768u << 20) / wbytes + 1);
@@ -368,6 +371,7 @@ int sf_bench_conv_cb(int dtype, int B, int L, int C, int groups, int cold, int i
   a.B = B;
   a.L = L;
   a.C = a.N = C;
+  a.kb = kb;
   a.G = groups;
   a.nch = gp.nch;
   a.chunk_rows = gp.chunk_rows;

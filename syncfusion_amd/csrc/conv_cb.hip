@@ -48,11 +48,14 @@ template <typename T> __device__ __forceinline__ Vec16<T> buf_ld16(__amdgpu_buff
 // Grid: x = weight slice (column block, channel block), y = row tile (rows y >= mtiles: hosted prefetch).  Every division of the index
 // arithmetic is a shift (S, channels per group, groups per block are powers of two) or a multiply-high by ceil(2^32 / L) (exact for
 // x * L < 2^32): the weight loads are issued ~100 instructions into the kernel, not ~400.
-template <typename T, int MT, bool PRO>
+// KB = 128-channel blocks per workgroup (1 or 2): two blocks halve the number of partial slabs (their traffic is what limits the chain at
+// 8-16 clips per branch) for twice the weight stream per workgroup (48 fragments per wave).
+template <typename T, int MT, bool PRO, int KB>
 __global__ __launch_bounds__(256) void conv_cb_kernel(const ConvCbArgs a, const int mtiles, const unsigned bytes_src) {
   using frag = typename Frag16<T>::type;
-  constexpr int BM = 32 * MT, PR = BM + 2, NV = (PR + 15) / 16;
-  __shared__ __attribute__((aligned(16))) T panel[PR * PITCH];
+  constexpr int KCW = KC * KB, PITCHW = KCW + 8, TPR = KCW / 8, RPP = 256 / TPR;   // channels per workgroup, LDS pitch, threads per row, rows per pass
+  constexpr int BM = 32 * MT, PR = BM + 2, NV = (PR + RPP - 1) / RPP;
+  __shared__ __attribute__((aligned(16))) T panel[PR * PITCHW];
   __shared__ float2 gstat[NSLOT][8];   // (mean, rstd) per (clip slot, group inside the channel block)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -69,19 +72,19 @@ __global__ __launch_bounds__(256) void conv_cb_kernel(const ConvCbArgs a, const 
 
   // ---- 1. activation panel: rows r0 - 1 .. r0 + BM of channel block cb (16 threads per row, 16 rows per pass) ----------------
   const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.src), 0, bytes_src, 0x00020000);
-  const int cv = tid & 15, pr = tid >> 4;
+  const int cv = tid % TPR, pr = tid / TPR;
   Vec16<T> pv[NV];
-  const unsigned col_b = (unsigned)((cb * KC + cv * 8) * sizeof(T)), row_b = (unsigned)(a.src_ld * sizeof(T));
+  const unsigned col_b = (unsigned)((cb * KCW + cv * 8) * sizeof(T)), row_b = (unsigned)(a.src_ld * sizeof(T));
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const int j = pr + 16 * i, r = r0 - 1 + j;
+    const int j = pr + RPP * i, r = r0 - 1 + j;
     const bool ok = j < PR && r >= 0 && r < M;
     pv[i] = buf_ld16<T>(rS, ok ? (unsigned)r * row_b + col_b : OOB);
   }
   // ---- 2. GroupNorm operands: gamma / beta of this thread's channel octet, chunk sums of the clips the panel touches ----------
   //         (8 lanes per (clip, group) pair, 4 chunks each; every address is clamped so that the loads are branch-free and all in
   //         flight together, behind the panel loads and in front of the weight loads: the first wait must not cover the weights)
-  const int gshift = KC_LOG2 - a.log2cpg;                      // log2(groups inside one channel block)
+  const int gshift = KC_LOG2 + (KB == 2 ? 1 : 0) - a.log2cpg;   // log2(groups inside the workgroup's channel range)
   const int clip0 = divL(max(r0 - 1, 0));
   const int nclip = PRO ? (divL(min(r0 + BM, M - 1)) - clip0 + 1) : 0;
   const int npair = nclip << gshift;                           // <= NSLOT * 8 = 32: one pair per 8 lanes
@@ -94,8 +97,8 @@ __global__ __launch_bounds__(256) void conv_cb_kernel(const ConvCbArgs a, const 
     const int G = a.C >> a.log2cpg;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      ga[q] = *reinterpret_cast<const f32x4 *>(a.gamma + cb * KC + cv * 8 + 4 * q);
-      be[q] = *reinterpret_cast<const f32x4 *>(a.beta + cb * KC + cv * 8 + 4 * q);
+      ga[q] = *reinterpret_cast<const f32x4 *>(a.gamma + cb * KCW + cv * 8 + 4 * q);
+      be[q] = *reinterpret_cast<const f32x4 *>(a.beta + cb * KCW + cv * 8 + 4 * q);
     }
     // pro 1: chunk sums [clip][nch][G]; pro 2: tile sums [m tile][C / 32][segment] of the producing GEMM (kernels.h).  One address
     // select per load instead of two code paths: loaded values that meet at a join cost a wait in front of the weight loads.
@@ -121,11 +124,12 @@ __global__ __launch_bounds__(256) void conv_cb_kernel(const ConvCbArgs a, const 
   }
   // ---- 3. the wave's weight slice, fragment order: 24 x 1 KB contiguous, independent of the producer kernel -----------------
   __builtin_amdgcn_sched_barrier(0);   // issue order = wait order (vmcnt counts in issue order): panel, GroupNorm operands, THEN weights
-  frag wf[24];
-  {
-    const frag *wp = reinterpret_cast<const frag *>(a.wp) + ((size_t)(cb * (a.N >> 5) + (nt * 4 + wave)) * 24) * 64;   // uniform
+  frag wf[24 * KB];
 #pragma unroll
-    for (int s = 0; s < 24; ++s) wf[s] = wp[s * 64 + lane];
+  for (int blk = 0; blk < KB; ++blk) {
+    const frag *wp = reinterpret_cast<const frag *>(a.wp) + ((size_t)((cb * KB + blk) * (a.N >> 5) + (nt * 4 + wave)) * 24) * 64;   // uniform
+#pragma unroll
+    for (int s = 0; s < 24; ++s) wf[blk * 24 + s] = wp[s * 64 + lane];
   }
   __builtin_amdgcn_sched_barrier(0);
   // (the compiler otherwise hoists the first use of a chunk sum in front of the weight loads, and its wait with it)
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(256) void conv_cb_kernel(const ConvCbArgs a, const 
   // ---- 5. panel -> LDS, GroupNorm + SiLU applied on the way -------------------------------------------------------------------
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const int j = pr + 16 * i, r = r0 - 1 + j;
+    const int j = pr + RPP * i, r = r0 - 1 + j;
     if (j < PR) {
       Vec16<T> o = pv[i];
       if (PRO && r >= 0 && r < M) {
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(256) void conv_cb_kernel(const ConvCbArgs a, const 
           o.set(e, silu_t<true>(fmaf(pv[i].get(e), sc, sh)));
         }
       }
-      st16<T>(panel + j * PITCH + cv * 8, o);
+      st16<T>(panel + j * PITCHW + cv * 8, o);
     }
   }
   __syncthreads();
@@ -193,16 +197,18 @@ __global__ __launch_bounds__(256) void conv_cb_kernel(const ConvCbArgs a, const 
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   const frag zf = __builtin_bit_cast(frag, u32x4{0u, 0u, 0u, 0u});
 #pragma unroll
-  for (int tap = 0; tap < 3; ++tap)
+  for (int blk = 0; blk < KB; ++blk)
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks)
+    for (int tap = 0; tap < 3; ++tap)
 #pragma unroll
-      for (int t = 0; t < MT; ++t) {
-        frag af = *reinterpret_cast<const frag *>(panel + (t * 32 + fr + tap) * PITCH + ks * 16 + fh * 8);
-        if (tap == 0) af = ok0[t] ? af : zf;
-        if (tap == 2) af = ok2[t] ? af : zf;
-        acc[t] = mfma32x16(wf[tap * 8 + ks], af, acc[t]);
-      }
+      for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          frag af = *reinterpret_cast<const frag *>(panel + (t * 32 + fr + tap) * PITCHW + blk * KC + ks * 16 + fh * 8);
+          if (tap == 0) af = ok0[t] ? af : zf;
+          if (tap == 2) af = ok2[t] ? af : zf;
+          acc[t] = mfma32x16(wf[blk * 24 + tap * 8 + ks], af, acc[t]);
+        }
   // ---- 7. partial slab ---------------------------------------------------------------------------------------------------------
   float *sl = a.slab + (size_t)cb * M * a.N + nt * 128 + wave * 32 + 4 * fh;
 #pragma unroll
@@ -439,7 +445,9 @@ hipError_t launch_conv_cb(int dt, const ConvCbArgs &a0, hipStream_t s) {
   if (a0.pro == 1 && a0.nch > 32) return hipErrorInvalidValue;
   if (a0.pro == 2 && !conv_cb_tile_stats_ok(a0.L, a0.C, a0.G)) return hipErrorInvalidValue;
   ConvCbArgs a = a0;
-  const int M = a.B * a.L, S = a.C / KC;
+  const int kb = a.kb == 2 ? 2 : 1;
+  const int M = a.B * a.L, S = a.C / KC / kb;   // partial slabs = workgroups along the input channels
+  if (kb == 2 && ((a.C / KC) % 2 || (a.pro && a.C / a.G < 32))) return hipErrorInvalidValue;   // <= 8 groups inside a 256-channel range
   a.log2S = 0;
   while ((1 << a.log2S) < S) ++a.log2S;
   const int cpg = a.pro ? a.C / a.G : KC;
@@ -447,27 +455,33 @@ hipError_t launch_conv_cb(int dt, const ConvCbArgs &a0, hipStream_t s) {
   while ((1 << a.log2cpg) < cpg) ++a.log2cpg;
   if ((1 << a.log2S) != S || (1 << a.log2cpg) != cpg) return hipErrorInvalidValue;
   a.magicL = (unsigned)((0x100000000ull + (unsigned)a.L - 1) / (unsigned)a.L);   // x / L == mulhi(x, magicL) while x * L < 2^32
-  const int mt = conv_cb_mt(M, a.N, a.C);
+  const int mt = kb == 2 ? std::min(2, conv_cb_mt(M, a.N, a.C / 2)) : conv_cb_mt(M, a.N, a.C);
   const int mtiles = (M + 32 * mt - 1) / (32 * mt), nws = (a.N / 128) * S;
   const int pf_rows = (a.pf.ptr && a.pf.bytes >= 16 && a.pf.wgs > 0) ? (a.pf.wgs + nws - 1) / nws : 0;
   a.pf.wgs = pf_rows * nws;
   const dim3 grid(nws, mtiles + pf_rows);
   const unsigned bytes_src = (unsigned)((size_t)M * a.src_ld * 2);
-#define SF_CB(T, MT)                                                                                                  \
-  do {                                                                                                                \
-    if (a.pro) hipLaunchKernelGGL((conv_cb_kernel<T, MT, true>), grid, dim3(256), 0, s, a, mtiles, bytes_src);        \
-    else hipLaunchKernelGGL((conv_cb_kernel<T, MT, false>), grid, dim3(256), 0, s, a, mtiles, bytes_src);             \
+#define SF_CB2(T, MT, KB_)                                                                                                \
+  do {                                                                                                                    \
+    if (a.pro) hipLaunchKernelGGL((conv_cb_kernel<T, MT, true, KB_>), grid, dim3(256), 0, s, a, mtiles, bytes_src);       \
+    else hipLaunchKernelGGL((conv_cb_kernel<T, MT, false, KB_>), grid, dim3(256), 0, s, a, mtiles, bytes_src);            \
+  } while (0)
+#define SF_CB(T, MT)                 \
+  do {                               \
+    if (kb == 2) SF_CB2(T, MT, 2);   \
+    else SF_CB2(T, MT, 1);           \
   } while (0)
 #define SF_CB_T(T)            \
   switch (mt) {               \
     case 1: SF_CB(T, 1); break; \
     case 2: SF_CB(T, 2); break; \
-    case 3: SF_CB(T, 3); break; \
-    default: SF_CB(T, 4); break; \
+    case 3: if (kb == 2) { SF_CB2(T, 2, 2); } else { SF_CB2(T, 3, 1); } break; \
+    default: if (kb == 2) { SF_CB2(T, 2, 2); } else { SF_CB2(T, 4, 1); } break; \
   }
   if (dt == BF16) { SF_CB_T(bf16) } else { SF_CB_T(f16) }
 #undef SF_CB_T
 #undef SF_CB
+#undef SF_CB2
   return hipGetLastError();
 }
 

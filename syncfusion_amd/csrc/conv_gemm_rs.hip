@@ -1,12 +1,12 @@
 // Register-staged ("rs") implicit GEMM for the SHORT activations of the deep U-Net levels at small batch: 32x32 tiles, 16-bit types,
-// K <= 1536.  Same tiling, wave-split K and epilogue as the wave-private kernel (conv_gemm_wp.hip), but NO staging and no pipeline:
+// K <= 2048.  Same tiling, wave-split K and epilogue as the wave-private kernel (conv_gemm_wp.hip), but NO staging and no pipeline:
 //
 //   * the weights come from a second, FRAGMENT-ORDERED copy of the matrix (ConvGemmArgs::wfr = [N / 32][K / 16][64 lanes][8]): the
 //     16 bytes a lane needs for one 32x32x16 MFMA are where its load finds them, a wave's load is 1 KB contiguous, nothing passes
 //     through LDS;
 //   * the activations are loaded in fragment order too, straight from the rows (lane = row, 16 bytes = 8 consecutive k; the 128-byte
 //     line of a row serves four consecutive fragments from the vector L1);
-//   * every wave issues ALL loads of its K quarter up front (<= 24 + 24 fragments = 192 registers), weights interleaved with
+//   * every wave issues ALL loads of its K quarter up front (<= 32 + 32 fragments = 256 registers), weights interleaved with
 //     activations, and multiplies as they land (counted vmcnt).
 //
 // The wave-private kernel keeps two 16 KB register sets per wave in flight and so pays one memory round trip per 128 of K per wave
@@ -265,7 +265,8 @@ template <typename T, bool CAT> hipError_t launch_rs(const ConvGemmArgs &a, hipS
   } while (0)
   if (nf <= 8) SF_RS(8);
   else if (nf <= 16) SF_RS(16);
-  else SF_RS(24);
+  else if (nf <= 24) SF_RS(24);
+  else SF_RS(32);
 #undef SF_RS
   return hipGetLastError();
 }
@@ -273,11 +274,11 @@ template <typename T, bool CAT> hipError_t launch_rs(const ConvGemmArgs &a, hipS
 }  // namespace
 
 // the launch takes the register-staged kernel: fragment-ordered weights at hand, a 16-bit type, 1-D geometry, no prologue, 32x32
-// tiles (the caller has decided that), K a multiple of 64 up to 1536, channel counts that are multiples of 16, whole 32-column tiles
+// tiles (the caller has decided that), K a multiple of 64 up to 2048, channel counts that are multiples of 16, whole 32-column tiles
 bool conv_gemm_rs_ok(int dt, const ConvGemmArgs &a) {
   static const bool off = getenv("SF_NO_RS") != nullptr;   // A/B aid
   if (off || dt == F32 || !a.wfr || a.geom != 0 || a.pro != 0 || a.taps < 1) return false;
-  if ((a.K % 64) || a.K > 1536 || (a.cin % 16) || (a.cin2 % 16) || (a.N % 32) || a.n_store != a.N) return false;
+  if ((a.K % 64) || a.K > 2048 || (a.cin % 16) || (a.cin2 % 16) || (a.N % 32) || a.n_store != a.N) return false;
   if ((a.res && (a.res_ld % 4)) || (a.bscale && (a.bscale_ld % 4)) || (a.badd && (a.badd_ld % 4)) || (a.out_ld % 4)) return false;   // vector epilogue loads
   if (a.ln_ss || a.res_ln) return false;   // the operand-side LayerNorm (Modulation folded into InjectChannels) stays on conv_gemm_fast
   if (a.ln_colsum && (!a.ln_part || a.ln_nt * 32 != a.cin || a.ln_nt > 32 || a.cin2)) return false;

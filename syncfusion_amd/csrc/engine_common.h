@@ -105,7 +105,7 @@ struct ConvW {
   bool direct = false;     // thin layer -> conv_direct (fp32 weights)
   void *wt = nullptr;      // direct layers only: the same [N][K] matrix in the compute type (conv_thin's MFMA operand)
   void *wcb = nullptr;     // k = 3 convolutions of the deep levels: the same weights in MFMA fragment order (conv_cb.hip)
-  void *wfr = nullptr;     // the [N][K] matrix in MFMA fragment order [N / 32][K / 16][64][8] (conv_gemm_rs.hip), K <= 1536
+  void *wfr = nullptr;     // the [N][K] matrix in MFMA fragment order [N / 32][K / 16][64][8] (conv_gemm_rs.hip), K <= 2048
 };
 
 // Name lookup + packing helper shared by the Encoder1d and VideoOnsetNet engines.

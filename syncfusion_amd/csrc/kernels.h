@@ -187,6 +187,7 @@ struct ConvCbArgs {
   int pro = 0, G = 1, nch = 1, chunk_rows = 1;
   const float *gamma = nullptr, *beta = nullptr, *stats = nullptr;
   float eps = 1e-5f;
+  int kb = 1;   // 128-channel blocks per workgroup: 1, or 2 (slab[C / 256][M][N]: half the partial slabs, twice the weight stream per workgroup)
   // filled by the launcher: log2(C / 128), log2(C / G), ceil(2^32 / L)
   int log2S = 0, log2cpg = 7;
   unsigned magicL = 0;

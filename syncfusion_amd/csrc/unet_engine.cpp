@@ -51,6 +51,7 @@ struct Level {
   void *buf[3] = {nullptr, nullptr, nullptr};
   void *qkv = nullptr, *ao = nullptr, *ctx = nullptr, *act = nullptr;
   bool cb = false;   // the item heads of this level run as the channel-block split-K chain (conv_cb.hip)
+  int cb_kb = 1;     // ... with this many 128-channel blocks per workgroup (2 halves the partial slabs)
 };
 
 struct Plan {  // everything carved out of the caller's workspace for one (B, L0, two_pass)
@@ -297,7 +298,7 @@ struct Builder {
   // second copy of a packed [N][K] matrix in MFMA fragment order for the register-staged small-batch GEMM (conv_gemm_rs.hip)
   void pack_wfr(ConvW &c) {
     static const bool off = getenv("SF_NO_RS") != nullptr;
-    if (off || u.listing || c.direct || u.dt == F32 || !c.w || (c.K % 64) || c.K > 1536 || (c.N % 32) || (c.cin % 16) || (c.cin2 % 16)) return;
+    if (off || u.listing || c.direct || u.dt == F32 || !c.w || (c.K % 64) || c.K > 2048 || (c.N % 32) || (c.cin % 16) || (c.cin2 % 16)) return;
     c.wfr = u.arena.alloc((int64_t)c.N * c.K * dsize(u.dt));
     SF_HIP(launch_pack_wfr(u.dt, c.w, c.N, c.K, c.wfr, s));
   }
@@ -627,10 +628,22 @@ Plan make_plan(const sf_unet &u, Workspace &ws, int B, int L0, bool two, int num
       const int64_t rows = (int64_t)bt * l.L;
       const Block &b = u.blocks[d];
       const bool have_w = !b.down_items.empty() && b.down_items[0].conv1.wcb != nullptr;
-      l.cb = have_w && l.C >= cb_min_c && rows <= cb_max_rows && (double)(l.C / 128) * rows * l.C * 4.0 <= cb_max_slab_mb * 1048576.0 &&
-             conv_cb_shape_ok(u.dt, bt, l.L, l.C, l.C, c.resnet_groups) &&
-             cb_gn_plan(l.L).nch <= 32 && (int64_t)bt * 32 * c.resnet_groups * 2 <= p.slab_half;
-      if (l.cb) need = std::max<int64_t>(need, (int64_t)(l.C / 128) * rows * l.C);
+      const bool shape_ok = have_w && l.C >= cb_min_c && rows <= cb_max_rows && conv_cb_shape_ok(u.dt, bt, l.L, l.C, l.C, c.resnet_groups) &&
+                            cb_gn_plan(l.L).nch <= 32 && (int64_t)bt * 32 * c.resnet_groups * 2 <= p.slab_half;
+      const double slab1 = (double)(l.C / 128) * rows * l.C * 4.0;   // bytes of the partial slabs with one channel block per workgroup
+      static const bool no_kb2 = getenv("SF_CB_NO_KB2") != nullptr;   // A/B aid
+      static const double cb_max_slab2_mb = [] {   // tuning hook: the same limit for the two-block form
+        const char *e = getenv("SF_CB_MAX_SLAB2_MB");
+        return e ? atof(e) : 12.0;
+      }();
+      l.cb = false;
+      l.cb_kb = 1;
+      if (shape_ok && slab1 <= cb_max_slab_mb * 1048576.0) l.cb = true;
+      else if (shape_ok && !no_kb2 && (l.C / 128) % 2 == 0 && l.C / c.resnet_groups >= 32 && slab1 * 0.5 <= cb_max_slab2_mb * 1048576.0) {
+        l.cb = true;   // two channel blocks per workgroup: half the slabs (8-16 clips per branch at the 1024-channel levels)
+        l.cb_kb = 2;
+      }
+      if (l.cb) need = std::max<int64_t>(need, (int64_t)(l.C / 128 / l.cb_kb) * rows * l.C);
       if (l.cb) need_gp = std::max<int64_t>(need_gp, ((rows + 31) / 32) * (l.C / 32) * 4);
     }
     p.cbslab_stride = align_up(need, 64);
@@ -927,10 +940,10 @@ struct Exec {
     if (use_cb) {
       // Channel-block split-K chain (conv_cb.hip): the two launches that followed the convolutions anyway (GroupNorm+SiLU, LayerNorm +
       // Modulation) sum the fp32 partial slabs; the second convolution applies GroupNorm+SiLU while staging its activation panel.
-      const int bt = p.Bt, S = C / 128;
+      const int bt = p.Bt, kb = l.cb_kb, S = C / 128 / kb;
       const double es = dsize(u.dt), rc = (double)l.rows * C;
       const double cflops = 2.0 * rc * 3 * C, cbytes = 2.0 * rc * es + 3.0 * C * C * es;
-      const int mt = conv_cb_mt((int)l.rows, C, C);
+      const int mt = kb == 2 ? std::min(2, conv_cb_mt((int)l.rows, C, C / 2)) : conv_cb_mt((int)l.rows, C, C);
       const int cwgs = (int)((l.rows + 32 * mt - 1) / (32 * mt)) * (C / 128) * S;
       const CbGnPlan cgp = cb_gn_plan(l.L);
       ConvCbArgs a;
@@ -940,6 +953,7 @@ struct Exec {
       a.B = bt;
       a.L = l.L;
       a.C = a.N = C;
+      a.kb = kb;
       a.G = G;
       a.eps = 1e-5f;
       a.pf = pf_cb(g.conv2, cwgs);

@@ -258,6 +258,7 @@ def test_cut_prefix_crop_matches_reference_loop(cuda):
     (4, 44, 512, 1024, 1, 1, 0, 1, 0, True),    # attention output projection at depth 7 (K = 512: 8 fragments per wave)
     (4, 44, 1024, 1536, 1, 1, 0, 1, 0, False),  # qkv projection (K = 1024: 16 per wave)
     (4, 88, 1280, 1024, 1, 1, 0, 1, 0, True),   # InjectChannels width (K = 1280: 20 of 24)
+    (4, 44, 2048, 1024, 1, 1, 0, 1, 0, False),  # patchify down-conv of depth 7 as a plain GEMM (K = 2048: 32 per wave)
     (4, 176, 512, 256, 3, 1, 1, 1, 0, True),    # k = 3 with padding, K = 1536 (24 per wave), taps cross the waves' ranges
     (3, 45, 128, 96, 3, 1, 1, 1, 0, False),     # ragged rows and clips, K = 384: a wave's range ends inside a tap
     (2, 88, 256, 128, 3, 1, 1, 2, 0, True),     # nearest x2 upsample + conv3 (up path), K = 768
@@ -274,20 +275,23 @@ def test_conv1d_register_staged_shapes(cuda, dtype, shape):
 # ----------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("shape", [
-    # B, L, C, modulated
-    (4, 44, 1024, True),     # depth 7 of configs[1] per branch: 176 rows, 8 channel blocks, one group per block
-    (4, 88, 1024, True),     # depth 6
-    (4, 176, 512, True),     # depth 5: two groups per channel block
-    (4, 352, 256, True),     # depth 4: four groups per block, 16-row statistics chunks
-    (3, 45, 128, False),     # one channel block, ragged rows, eight groups per block, plain LayerNorm (no modulation)
-    (1, 256, 256, True),     # a single clip
-    (5, 61, 512, True),      # row tiles that start and end inside clips, odd clip length
+    # B, L, C, modulated, channel blocks per workgroup
+    (4, 44, 1024, True, 1),     # depth 7 of configs[1] per branch: 176 rows, 8 channel blocks, one group per block
+    (4, 88, 1024, True, 1),     # depth 6
+    (4, 176, 512, True, 1),     # depth 5: two groups per channel block
+    (4, 352, 256, True, 1),     # depth 4: four groups per block, 16-row statistics chunks
+    (3, 45, 128, False, 1),     # one channel block, ragged rows, eight groups per block, plain LayerNorm (no modulation)
+    (1, 256, 256, True, 1),     # a single clip
+    (5, 61, 512, True, 1),      # row tiles that start and end inside clips, odd clip length
+    (16, 44, 1024, True, 2),    # two channel blocks per workgroup (4 partial slabs): depth 7 at 16 clips per branch
+    (3, 61, 512, True, 2),      # ... eight groups inside the 256-channel range (64 channels per group halved: 2 x 4)
+    (2, 100, 256, False, 2),    # ... a single slab (C = 256), 32 channels per group
 ])
 def test_conv_cb_chain(cuda, dtype, shape):
     """a-unet ResnetItem + ModulationItem through the channel-block chain against fp32 torch on the
     CPU from the same 16-bit-rounded inputs: the intermediate h (after the first reduction) and the modulated output m."""
     _l, lib = _lib()
-    B, L, C, mod = shape
+    B, L, C, mod, kb = shape
     G = 8
     td = TD[dtype]
     g = torch.Generator().manual_seed(B * 1000 + L + C)
@@ -315,7 +319,7 @@ def test_conv_cb_chain(cuda, dtype, shape):
     keep = [dev(t) for t in (w1, b1, w2, b2, gam[0], bet[0], gam[1], bet[1])]
     ssd = dev(ss) if mod else None
     rc = lib.sf_op_resnet_mod_cb(_l.DTYPES[dtype], x_cl.data_ptr(), *[t.data_ptr() for t in keep], G, 1e-5,
-                                 ssd.data_ptr() if mod else None, 1e-6, B, L, C, h.data_ptr(), m.data_ptr(), ws.data_ptr(), ws.numel(),
+                                 ssd.data_ptr() if mod else None, 1e-6, B, L, C, kb, h.data_ptr(), m.data_ptr(), ws.data_ptr(), ws.numel(),
                                  _l.stream_ptr(cuda))
     _l.check(rc, "sf_op_resnet_mod_cb")
     torch.cuda.synchronize()
@@ -333,6 +337,6 @@ def test_conv_cb_rejects_shapes_outside_its_coverage(cuda):
         t = torch.zeros(B, L, C, dtype=TD[dtype], device=cuda)
         f = torch.zeros(3 * C * C + 2 * B * C, device=cuda)
         ws = torch.empty(1 << 20, dtype=torch.uint8, device=cuda)
-        rc = lib.sf_op_resnet_mod_cb(_l.DTYPES[dtype], t.data_ptr(), *[f.data_ptr()] * 8, 8, 1e-5, None, 1e-6, B, L, C, None, t.data_ptr(),
+        rc = lib.sf_op_resnet_mod_cb(_l.DTYPES[dtype], t.data_ptr(), *[f.data_ptr()] * 8, 8, 1e-5, None, 1e-6, B, L, C, 1, None, t.data_ptr(),
                                      ws.data_ptr(), ws.numel(), _l.stream_ptr(cuda))
         assert rc != 0

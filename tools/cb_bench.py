@@ -18,7 +18,7 @@ shapes = [("d7", 4, 44, 1024), ("d6", 4, 88, 1024), ("d5", 4, 176, 512), ("d4", 
           ("d7 B32", 32, 44, 1024), ("d6 B32", 32, 88, 1024)]
 for name, B, L, Cc in shapes:
     ms = (C.c_float * 4)()
-    rc = lib.sf_bench_conv_cb(1, B, L, Cc, 8, cold, 200, ms)
+    rc = lib.sf_bench_conv_cb(1, B, L, Cc, 8, int(os.environ.get("SF_CB_KB", "1")), cold, 200, ms)
     old = C.c_float()
     rc2 = lib.sf_bench_conv1d(1, B, L, Cc, Cc, 3, 1, 0, -1, -1, 200, C.byref(old))
     cb = "conv %%.1f  reduce_gn %%.1f  conv+gn %%.1f  reduce_ln %%.1f us" %% tuple(v * 1e3 for v in ms) if rc == 0 else "n/a"
