@@ -306,6 +306,16 @@ hipError_t launch_onset_stem(int dt, const void *in, int NT, int H, int W, const
                              hipStream_t s);
 
 // ---------------------------------------------------------------------------------------
+// Temporal-walk (3,1,1) convolution, 64 output channels, 16-bit types (conv_tw.hip): a workgroup owns 128 positions of one clip and walks
+// the frames with a three-frame LDS ring and register-stationary weights (VideoOnsetNet stem / layer 1).
+// ---------------------------------------------------------------------------------------
+bool conv_tw_ok(int dt, int cin_real, int cin_ld, int cout, int out_ld, int res_ld);
+size_t conv_tw_weight_elems(int cin_real);
+hipError_t launch_pack_conv_tw(int dt, const void *w /* [64][3 * cin_ld], compute type */, int cin_real, int cin_ld, void *out, hipStream_t s);
+hipError_t launch_conv_tw(int dt, const void *in, int in_ld, int cin_real, const void *wfr, const float *bias, const void *res, int res_ld, void *out,
+                          int out_ld, int N, int T, int HW, int relu, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------
 // Input side (input.hip)
 // ---------------------------------------------------------------------------------------
 // uint8 RGB frames (N, T, H, W, 3) -> (N, 3, T, oh, ow) fp32: /255, antialiased bilinear resize (ATen semantics), (x - mean) / std

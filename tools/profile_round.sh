@@ -8,8 +8,12 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 if [ "${SF_PROFILE_PRIMARY:-1}" = "1" ]; then
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra > $O/bench_under_profiler.json 2> $O/stats.log
+# traffic passes WITHOUT the hosted weight prefetch: a prefetch workgroup's reads are charged to the launch that hosts it (the NEXT GEMM's
+# weights), which would triple the apparent traffic of the small-batch GEMMs; the timed runs keep the prefetch on
+export SF_NO_PREFETCH=1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- python3 $R/bench.py --no-cpu-baseline --no-extra --steps 3 --warmup 1 --no-graph > /dev/null 2> $O/fetch.log
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- python3 $R/bench.py --no-cpu-baseline --no-extra --steps 3 --warmup 1 --no-graph > /dev/null 2> $O/write.log
+unset SF_NO_PREFETCH
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $O/mfma -- python3 $R/bench.py --no-cpu-baseline --no-extra --steps 3 --warmup 1 --no-graph > /dev/null 2> $O/mfma.log
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $O/mfma_onset -- python3 $R/tools/onset_one.py 32 bf16 3 > /dev/null 2> $O/mfma_onset.log
 cd $R
