@@ -49,14 +49,15 @@ const char *kStageName[4] = {"layer1", "layer2", "layer3", "layer4"};
 int midplanes(int in, int planes) { return (in * planes * 27) / (in * 9 + 3 * planes); }  // main/resnet.py:86-87
 
 // conv (+ the BatchNorm that follows it, folded)
+// cin_ld / cout_ld: row lengths of the input / output tensors when they are narrower than the default padding (0 = default)
 Conv3 make_conv(sf_onsetnet &o, Packer &pk, const std::string &conv_name, const std::string &bn_name, int cin, int cout, int kt,
-                int kh, int kw, int sh, int pt, int ph) {
+                int kh, int kw, int sh, int pt, int ph, int cin_ld = 0, int cout_ld = 0) {
   Conv3 c;
   c.cin_real = cin;
   c.cout = cout;
   // multiples of 64 so that every layer but the RGB stem runs on the main (v2) MFMA kernel
-  c.cin_ld = cin < 32 ? pad_to(cin, 4) : pad_to(cin, 64);
-  c.cout_ld = pad_to(cout, 64);
+  c.cin_ld = cin_ld ? cin_ld : (cin < 32 ? pad_to(cin, 4) : pad_to(cin, 64));
+  c.cout_ld = cout_ld ? cout_ld : pad_to(cout, 64);
   c.kt = kt;
   c.kh = kh;
   c.kw = kw;
@@ -197,10 +198,14 @@ int sf_onsetnet_create(const sf_tensor *weights, int n_weights, int dtype, void 
       const std::string pre = m + kStageName[st] + "." + std::to_string(bi);
       ResBlk b;
       const int mid1 = midplanes(inp, planes), mid2 = mid1;  // one midplanes per BasicBlock (main/resnet.py:86-98)
-      b.s1 = make_conv(*o, pk, pre + ".conv1.0.0", pre + ".conv1.0.1", inp, mid1, 1, 3, 3, stride, 0, 1);
-      b.t1 = make_conv(*o, pk, pre + ".conv1.0.3", pre + ".conv1.1", mid1, planes, 3, 1, 1, 1, 1, 0);
-      b.s2 = make_conv(*o, pk, pre + ".conv2.0.0", pre + ".conv2.0.1", planes, mid2, 1, 3, 3, 1, 0, 1);
-      b.t2 = make_conv(*o, pk, pre + ".conv2.0.3", pre + ".conv2.1", mid2, planes, 3, 1, 1, 1, 1, 0);
+      // Where the temporal convolution runs as the frame walk (conv_tw.hip: 64 outputs, 16-bit types) it is HBM-bound on the mid tensor,
+      // and that kernel has no use for rows padded to a multiple of 64: 144 channels travel as 160 instead of 192 (-17 % of the 1.16 GB
+      // written by the spatial convolution and read back by the temporal one, per pair, at 32 clips).
+      const int mid_ld = conv_tw_ok(dtype, mid1, pad_to(mid1, 32), planes, pad_to(planes, 64), pad_to(planes, 64)) ? pad_to(mid1, 32) : 0;
+      b.s1 = make_conv(*o, pk, pre + ".conv1.0.0", pre + ".conv1.0.1", inp, mid1, 1, 3, 3, stride, 0, 1, 0, mid_ld);
+      b.t1 = make_conv(*o, pk, pre + ".conv1.0.3", pre + ".conv1.1", mid1, planes, 3, 1, 1, 1, 1, 0, mid_ld, 0);
+      b.s2 = make_conv(*o, pk, pre + ".conv2.0.0", pre + ".conv2.0.1", planes, mid2, 1, 3, 3, 1, 0, 1, 0, mid_ld);
+      b.t2 = make_conv(*o, pk, pre + ".conv2.0.3", pre + ".conv2.1", mid2, planes, 3, 1, 1, 1, 1, 0, mid_ld, 0);
       b.has_ds = bi == 0 && (stride != 1 || inp != planes);
       if (b.has_ds) b.ds = make_conv(*o, pk, pre + ".downsample.0", pre + ".downsample.1", inp, planes, 1, 1, 1, stride, 0, 0);
       o->blocks.push_back(b);
