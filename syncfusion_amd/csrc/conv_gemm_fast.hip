@@ -491,7 +491,12 @@ const char *conv_gemm_ln_variant_name(int dt, const ConvGemmArgs &a) {
 // kernel when the fragment-ordered weights are at hand and the launch has few tiles
 bool conv_gemm_prefers_wp(const ConvGemmArgs &a);
 static bool ln_goes_rs(int dt, const ConvGemmArgs &a) {
-  return a.ln_colsum && !a.ln_ss && !a.res_ln && g_conv_gemm_force.path == 0 && conv_gemm_prefers_wp(a) && conv_gemm_rs_ok(dt, a);
+  static const long max_tiles = [] {   // tuning hook: most 32x32 tiles a LayerNorm-folded projection may have and still take the register-staged kernel
+    const char *e = getenv("SF_RS_LN_TILES");
+    return e ? atol(e) : 512L;
+  }();
+  const long tiles = (long)((a.M + 31) / 32) * ((a.n_store + 31) / 32);
+  return a.ln_colsum && !a.ln_ss && !a.res_ln && g_conv_gemm_force.path == 0 && tiles <= max_tiles && a.K >= 256 && conv_gemm_rs_ok(dt, a);
 }
 
 hipError_t launch_conv_gemm_ln(int dt, const ConvGemmArgs &a, hipStream_t s) {
