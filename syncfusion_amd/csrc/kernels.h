@@ -316,6 +316,16 @@ hipError_t launch_conv_tw(int dt, const void *in, int in_ld, int cin_real, const
                           int out_ld, int N, int T, int HW, int relu, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------
+// Frame-walk (1,3,3) convolution, 64 input channels, stride 1, 16-bit types (conv_sp.hip): a workgroup owns one 32-column tile of the output and
+// an 8 x 14 patch of positions and walks the frames with register-stationary weights and one LDS halo tile per frame (VideoOnsetNet layer 1).
+// ---------------------------------------------------------------------------------------
+bool conv_sp_ok(int dt, int cin_real, int cin_ld, int cout, int out_ld);
+size_t conv_sp_weight_elems(int cout);
+hipError_t launch_pack_conv_sp(int dt, const void *w /* [cout][9 * 64], compute type */, int cout, void *out, hipStream_t s);
+hipError_t launch_conv_sp(int dt, const void *in, int in_ld, const void *wfr, const float *shift, int cout, void *out, int out_ld, int N, int T, int H,
+                          int W, int relu, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------
 // Input side (input.hip)
 // ---------------------------------------------------------------------------------------
 // uint8 RGB frames (N, T, H, W, 3) -> (N, 3, T, oh, ow) fp32: /255, antialiased bilinear resize (ATen semantics), (x - mean) / std

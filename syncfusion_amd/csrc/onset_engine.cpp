@@ -19,6 +19,7 @@ namespace {
 
 struct Conv3 {
   ConvW w;
+  void *wsp = nullptr;   // (1,3,3) stride-1 convolutions of 64 channels: weights in the frame-walk kernel's fragment order (conv_sp.hip)
   void *wtw = nullptr;   // (3,1,1) convolutions with 64 outputs: weights in the temporal-walk kernel's fragment order (conv_tw.hip)
   int cin_real = 0, cin_ld = 0, cout = 0, cout_ld = 0;
   int kt = 1, kh = 1, kw = 1, sh = 1, pt = 0, ph = 0;  // sw == sh, pw == ph, st == 1
@@ -68,6 +69,10 @@ Conv3 make_conv(sf_onsetnet &o, Packer &pk, const std::string &conv_name, const 
   SF_HIP(launch_bn_fold(pk.wm.get(bn_name + ".weight", cout), pk.wm.get(bn_name + ".bias", cout), pk.wm.get(bn_name + ".running_mean", cout),
                         pk.wm.get(bn_name + ".running_var", cout), 1e-5f, cout, scale, shift, pk.s));
   c.w = pk.conv(conv_name + ".weight", shift, cout, cin, kt * kh * kw, false, c.cin_ld, scale, 32);
+  if (kt == 1 && kh == 3 && kw == 3 && ph == 1 && sh == 1 && c.w.K == 9 * c.cin_ld && conv_sp_ok(o.dt, cin, c.cin_ld, cout, c.cout_ld)) {
+    c.wsp = o.arena.alloc((int64_t)conv_sp_weight_elems(cout) * dsize(o.dt));
+    SF_HIP(launch_pack_conv_sp(o.dt, c.w.w, cout, c.wsp, pk.s));
+  }
   if (kt == 3 && kh == 1 && kw == 1 && pt == 1 && sh == 1 && c.w.K == 3 * c.cin_ld && conv_tw_ok(o.dt, cin, c.cin_ld, cout, c.cout_ld, c.cout_ld)) {
     c.wtw = o.arena.alloc((int64_t)conv_tw_weight_elems(cin) * dsize(o.dt));
     SF_HIP(launch_pack_conv_tw(o.dt, c.w.w, cin, c.cin_ld, c.wtw, pk.s));
@@ -119,6 +124,11 @@ struct OnsetExec {
 
   void conv(const Conv3 &c, const void *in, int Hi, int Wi, void *out, int &Ho, int &Wo, const void *res, bool relu) {
     out_hw(Hi, Wi, c, Ho, Wo);
+    if (c.wsp && !res) {   // layer-1 spatial convolution: frame walk, register-stationary weights, one halo tile per frame
+      static const int dbg = getenv("SF_SP_NOSTORE") ? 2 : 0;   // timing experiment only (wrong results)
+      SF_HIP(launch_conv_sp(o.dt, in, c.cin_ld, c.wsp, c.w.bias, c.cout, out, c.cout_ld, p.N, p.T, Hi, Wi, (relu ? 1 : 0) | dbg, s));
+      return;
+    }
     if (c.wtw) {   // wide-spatial temporal convolution: frame walk with a three-frame LDS ring (each mid row fetched once, not three times)
       SF_HIP(launch_conv_tw(o.dt, in, c.cin_ld, c.cin_real, c.wtw, c.w.bias, res, c.cout_ld, out, c.cout_ld, p.N, p.T, Ho * Wo, relu ? 1 : 0, s));
       return;
