@@ -389,6 +389,7 @@ template <typename T, int GEOM, bool CAT> hipError_t launch_mt_v(const ConvGemmA
     case 7: return launch_mt<T, 128, 64, 4, 2, GEOM, CAT, 3, 1>(a, s);    // three-slot ring of a 128x64 tile (72 KB): two workgroups per CU
     case 8: return launch_mt<T, 192, 128, 2, 4, GEOM, CAT, 2, 2>(a, s);   // two-slot 192x128 (80 KB): two workgroups per CU, 5/6 of the fill of 128x128
     case 9: return launch_mt<T, 256, 64, 8, 1, GEOM, CAT, 2, 2>(a, s);    // two-slot 256x64 (80 KB): the same for outputs of <= 64 columns
+    case 10: return launch_mt<T, 256, 256, 2, 4, GEOM, CAT, 2, 2>(a, s);  // two-slot 256x256 (128 KB ring), wave tile 128x64: half the fill and 3/4 of the LDS reads per FLOP of 192x128
     default: return launch_mt<T, 256, 128, 4, 2, GEOM, CAT>(a, s);
   }
 }
@@ -421,7 +422,7 @@ int conv_gemm_mt_variant(const ConvGemmArgs &a) {
     const char *e = getenv("SF_MT_VARIANT");
     return e ? atoi(e) : -1;
   }();
-  if (forced >= 0 && forced <= 9) return forced;
+  if (forced >= 0 && forced <= 10) return forced;
   auto cols = [&](int bn) { return (long)((a.n_store + bn - 1) / bn) * bn; };
   static const int rule = [] {   // tuning hook: 0 = three-slot rings only, 1 = two-slot rings for every geometry, default: video geometry only
     const char *e = getenv("SF_MT_RULE");
@@ -483,9 +484,9 @@ int conv_gemm_mt_variant(const ConvGemmArgs &a) {
 }
 
 const char *conv_gemm_mt_name(const ConvGemmArgs &a) {
-  static const char *n[10] = {"conv_gemm_mt<bf16,256x128>", "conv_gemm_mt<bf16,128x128>", "conv_gemm_mt<bf16,128x192>", "conv_gemm_mt<bf16,192x128>",
+  static const char *n[11] = {"conv_gemm_mt<bf16,256x128>", "conv_gemm_mt<bf16,128x128>", "conv_gemm_mt<bf16,128x192>", "conv_gemm_mt<bf16,192x128>",
                              "conv_gemm_mt<bf16,256x64>", "conv_gemm_mt<bf16,128x128,2wg>", "conv_gemm_mt<bf16,128x192,2wg>", "conv_gemm_mt<bf16,128x64,2wg>",
-                             "conv_gemm_mt<bf16,192x128,2wg>", "conv_gemm_mt<bf16,256x64,2wg>"};
+                             "conv_gemm_mt<bf16,192x128,2wg>", "conv_gemm_mt<bf16,256x64,2wg>", "conv_gemm_mt<bf16,256x256>"};
   return n[conv_gemm_mt_variant(a)];
 }
 

@@ -317,6 +317,34 @@ def test_onsetnet_golden(cuda, case, dtype, tol):
         assert torch.equal(y, net(x.to(cuda)))
 
 
+@pytest.mark.parametrize("dtype,tol", [("fp32", FP32_TOL), ("bf16", BF16_TOL), ("fp16", BF16_TOL)])
+@pytest.mark.parametrize("shape", [(1, 1, 32, 32), (2, 2, 24, 40), (1, 3, 36, 60), (3, 7, 48, 32), (2, 5, 20, 116)])
+def test_onsetnet_edge_shapes(cuda, shape, dtype, tol):
+    """Clip counts, frame counts below the depth of the frame-walk kernels' look-ahead (1, 2, 3 frames), and frame sizes whose layer-1
+    grid is not a whole number of the spatial kernel's 8 x 14 patches, against the pinned oracle (oracle/onsetnet_ref.py follows
+    main/resnet.py:36-56,81-114 and main/onset_net.py:12-63) with every stage tapped."""
+    from oracle import onsetnet_ref
+    from syncfusion_amd.onset_net import VideoOnsetNet
+
+    n, t, h, w = shape
+    net = VideoOnsetNet(pretrained=False, dtype=dtype)
+    state = seeded_state(net, 4242 + t)
+    net.load_state_dict(state)
+    net = net.to(cuda).eval()
+    x = torch.randn(n, 3, t, h, w, generator=torch.Generator().manual_seed(17 * h + w))
+    ref_taps = {}
+    y_ref = onsetnet_ref.onsetnet_forward({k_: v.float() for k_, v in state.items()}, x, ref_taps)
+    taps = {}
+    y = net._get_engine().forward(x.to(cuda), taps)
+    for nm in ("stem", "layer1", "layer2", "layer3", "layer4"):
+        r = ref_taps[nm]                                   # (N, C, T, H, W)
+        n_, c_, t_, h_, w_ = r.shape
+        act = taps[nm].cpu().reshape(n_, t_, h_, w_, c_).permute(0, 4, 1, 2, 3)
+        assert rel_l2(act, r) < tol, nm
+    assert y.shape == (n, t)
+    assert rel_l2(y.cpu(), y_ref) < tol
+
+
 def test_onsetnet_train_mode_and_cpu_raise(cuda):
     from syncfusion_amd._lib import SyncFusionAmdError
     from syncfusion_amd.onset_net import VideoOnsetNet
