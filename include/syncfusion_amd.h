@@ -237,6 +237,13 @@ int64_t sf_op_conv1d_bwd_workspace_bytes(int B, int L, int C, int N, int taps, i
 int sf_op_conv1d_bwd_cl(const float *x, const float *w, const float *gamma, const float *beta, int groups, float eps, const float *dy,
                         int B, int L, int C, int N, int taps, int pad, float *dx, float *dw, float *db, float *dgb, void *ws,
                         int64_t ws_bytes, void *stream);
+/* Length reductions of the training composition (fp32, channels-last): out[b][c] = sum_l x[b][l][c] * (y ? y[b][l][c] : 1) -- the
+ * gradient of a per-clip broadcast add (cross-attention over one context token) and of the SkipModulate scale
+ * (a-unet SkipModulate: x + scale[:, None, :] * h).  Two deterministic stages, no atomics.
+ * C: a multiple of 4 with C / 4 dividing 256, or a divisor of 256.  ws >= sf_op_length_sums_workspace_bytes. */
+int64_t sf_op_length_sums_workspace_bytes(int B, int L, int C);
+int sf_op_length_sums(const float *x, const float *y /* or NULL */, int B, int L, int C, float *out /* (B, C) */, void *ws, int64_t ws_bytes,
+                      void *stream);
 /* backward of sf_op_ln_modulate (fp32): dx:(B,L,C); dss:(B,2C) = [dscale | dshift] or NULL; ws >= sf_op_ln_modulate_bwd_workspace_bytes */
 int64_t sf_op_ln_modulate_bwd_workspace_bytes(int B, int L, int C);
 int sf_op_ln_modulate_bwd(const float *x, const float *scale_shift, const float *dy, float eps, int B, int L, int C, float *dx, float *dss,

@@ -144,6 +144,27 @@ def conv1d(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, channels_la
     return _ConvBlockFn.apply(x, weight, bias, None, None, 0, 0.0, bool(channels_last), residual)
 
 
+def length_sums(x: Tensor, y: Optional[Tensor] = None) -> Tensor:
+    """``(x * y).sum(dim=1)`` (``y`` optional) of channels-last fp32 ``(B, L, C)`` tensors -> ``(B, C)``: the length reductions in the
+    backward of a per-clip broadcast add and of the SkipModulate scale, in one HIP pass (no gradient is recorded: backward use only)."""
+    _lib.require_gpu_tensor(x, "syncfusion_amd.autograd")
+    lib = _lib.load()
+    B, L, Cc = x.shape
+    with torch.cuda.device(x.device):
+        xc = _lib.f32c(x)
+        yc = _lib.f32c(y) if y is not None else None
+        if yc is not None and tuple(yc.shape) != (B, L, Cc):
+            raise ValueError(f"length_sums: shapes {tuple(x.shape)} and {tuple(y.shape)} differ")
+        n = lib.sf_op_length_sums_workspace_bytes(B, L, Cc)
+        if n < 0:
+            raise _lib.SyncFusionAmdError(lib.sf_last_error().decode())
+        ws = torch.empty(max(int(n), 256), dtype=torch.uint8, device=x.device)
+        out = torch.empty(B, Cc, dtype=torch.float32, device=x.device)
+        _lib.check(lib.sf_op_length_sums(xc.data_ptr(), yc.data_ptr() if yc is not None else None, B, L, Cc, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                         _lib.stream_ptr(x.device)), "sf_op_length_sums")
+    return out
+
+
 class _LnModulateFn(torch.autograd.Function):
     """y = LayerNorm_C(x; eps, no affine) * (1 + ss[:, :C]) + ss[:, C:] on channels-last ``(B, L, C)`` rows (ss: ``(B, 2C)`` or None)."""
 

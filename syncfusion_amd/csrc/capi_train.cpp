@@ -104,6 +104,23 @@ int sf_op_conv1d_bwd_cl(const float *x, const float *w, const float *gamma, cons
   SF_API_END
 }
 
+int64_t sf_op_length_sums_workspace_bytes(int B, int L, int C) {
+  if (B < 1 || L < 1 || C < 1) return -1;
+  return (int64_t)B * length_sums_slices(B, L) * C * (int64_t)sizeof(float);
+}
+
+int sf_op_length_sums(const float *x, const float *y, int B, int L, int C, float *out, void *ws, int64_t ws_bytes, void *stream) {
+  SF_API_BEGIN
+  if (!x || !out || !ws) fail(SF_ERR_INVALID, "null argument");
+  if (B < 1 || L < 1 || C < 1) fail(SF_ERR_INVALID, "B, L and C must be positive");
+  if (!length_sums_ok(C)) fail(SF_ERR_UNSUPPORTED, "C must be a multiple of 4 with C / 4 dividing 256, or divide 256 (got %d)", C);
+  const int64_t need = sf_op_length_sums_workspace_bytes(B, L, C);
+  if (ws_bytes < need) fail(SF_ERR_WORKSPACE, "workspace too small: need %lld bytes", (long long)need);
+  SF_HIP(launch_length_sums(x, y, B, L, C, static_cast<float *>(ws), out, static_cast<hipStream_t>(stream)));
+  return SF_OK;
+  SF_API_END
+}
+
 int64_t sf_op_ln_modulate_bwd_workspace_bytes(int B, int L, int C) {
   if (B < 1 || L < 1 || C < 1) return -1;
   return (int64_t)B * ln_mod_bwd_chunks(L) * 2 * C * (int64_t)sizeof(float);

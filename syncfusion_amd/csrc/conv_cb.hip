@@ -31,7 +31,6 @@ namespace {
 
 constexpr int KC = 128;         // input channels per workgroup (one K block = 3 taps x 128)
 constexpr int KC_LOG2 = 7;
-constexpr int PITCH = KC + 8;   // LDS row pitch in elements (272 B): conflict-free 16-byte fragment reads
 constexpr int NSLOT = 4;        // clips a (BM + 2 <= 130)-row panel may touch: L >= 44 (host guarantees it)
 constexpr unsigned OOB = 0x80000000u;
 

@@ -142,6 +142,28 @@ def test_ln_modulate_gradients(cuda, B, L, C, with_ss):
         assert rel_l2(sss.grad.cpu(), ss.grad) < TOL, f"dss {rel_l2(sss.grad.cpu(), ss.grad):.3e}"
 
 
+@pytest.mark.parametrize("B,L,C", [(4, 4096, 8), (3, 1000, 32), (2, 77, 64), (1, 1, 128), (4, 300, 1024), (2, 513, 16), (2, 64, 12)])
+@pytest.mark.parametrize("with_y", [False, True])
+def test_length_sums(cuda, B, L, C, with_y):
+    """sum_l x (* y) per clip and channel -- the backward of the per-clip broadcast add and of the SkipModulate scale -- against float64
+    (two deterministic stages: bit-reproducible); unsupported channel counts fail loudly."""
+    from syncfusion_amd import autograd as sfa
+    from syncfusion_amd._lib import SyncFusionAmdError
+
+    g = torch.Generator().manual_seed(B * 1000 + L + C)
+    x = torch.randn(B, L, C, generator=g)
+    y = torch.randn(B, L, C, generator=g) if with_y else None
+    if C == 12:
+        with pytest.raises(SyncFusionAmdError):
+            sfa.length_sums(x.to(cuda), y.to(cuda) if with_y else None)
+        return
+    ref = ((x.double() * y.double()) if with_y else x.double()).sum(dim=1)
+    out = sfa.length_sums(x.to(cuda), y.to(cuda) if with_y else None)
+    assert out.shape == (B, C)
+    assert rel_l2(out.cpu().double(), ref) < 1e-6
+    assert torch.equal(out, sfa.length_sums(x.to(cuda), y.to(cuda) if with_y else None))
+
+
 @pytest.mark.parametrize("B,L,H", [(2, 44, 8), (2, 100, 2), (1, 352, 8), (3, 1, 4), (1, 1000, 1), (2, 17, 3), (1, 2048, 2), (1, 2500, 1)])
 def test_attention_gradients(cuda, B, L, H):
     from syncfusion_amd import autograd as sfa
