@@ -244,11 +244,12 @@ def extra_workloads(model, device, args, noise, channels, emb) -> dict:
     def onset_leg():
         from syncfusion_amd.onset_net import VideoOnsetNet
 
-        N, iters = 32, 5
+        N, iters = 32, 10
         torch.manual_seed(7)
         onset = VideoOnsetNet(False, dtype=args.dtype if args.dtype != "fp32" else "bf16").to(device).eval()
         frames = torch.randn(N, 3, 30, 112, 112, generator=torch.Generator().manual_seed(4000)).to(device)
-        onset(frames)
+        for _ in range(3):   # weight packing on the first call; clocks / caches settle on this workload after the U-Net legs
+            onset(frames)
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
         for _ in range(iters):
