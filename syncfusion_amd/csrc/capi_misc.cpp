@@ -134,8 +134,12 @@ int sf_op_conv1d_cl(int dtype, const void *x, const float *w, const float *bias,
   if (direct && N > 32) fail(SF_ERR_UNSUPPORTED, "thin convolution with N > 32");
   const int wdt = direct ? F32 : dtype;
   const int K = taps * C;
-  void *wp = wk.alloc((int64_t)N * K * dsize(wdt));
-  SF_HIP(launch_pack_conv(wdt, w, N, C, 0, C, taps, C, nullptr, wp, K, 0, s));
+  const void *wp = w;   // fp32 1x1 convolutions: the PyTorch layout (N, C, 1) IS the GEMM's [N][K] (60 % of the training step's convolutions)
+  if (!(taps == 1 && wdt == F32)) {
+    void *packed = wk.alloc((int64_t)N * K * dsize(wdt));
+    SF_HIP(launch_pack_conv(wdt, w, N, C, 0, C, taps, C, nullptr, packed, K, 0, s));
+    wp = packed;
+  }
   ConvGemmArgs a;
   if (!direct && dtype != F32 && (K % 64) == 0 && K <= 2048 && (N % 32) == 0 && (C % 16) == 0) {   // as the engine packs it (conv_gemm_rs.hip)
     void *wfr = wk.alloc((int64_t)N * K * dsize(wdt));
