@@ -16,7 +16,11 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- pyt
 unset SF_NO_PREFETCH
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $O/mfma -- python3 $R/bench.py --no-cpu-baseline --no-extra --steps 3 --warmup 1 --no-graph > /dev/null 2> $O/mfma.log
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $O/mfma_onset -- python3 $R/tools/onset_one.py 32 bf16 3 > /dev/null 2> $O/mfma_onset.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/onset_stats -- python3 $R/tools/onset_one.py 32 bf16 5 > /dev/null 2> $O/onset_stats.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_stats -- python3 $R/tools/train_step_bench.py > $O/train_step_under_profiler.json 2> $O/train_stats.log
 cd $R
+cp $(ls $O/onset_stats/*/*kernel_stats.csv | head -1) $O/onset_kernel_stats.csv
+cp $(ls $O/train_stats/*/*kernel_stats.csv | head -1) $O/train_step_kernel_stats.csv
 cp $(ls $O/stats/*/*kernel_stats.csv | head -1) $O/kernel_stats.csv
 python3 tools/pmc_traffic.py $(ls $O/fetch/*/*counter_collection.csv | head -1) $(ls $O/write/*/*counter_collection.csv | head -1) $O/pmc_traffic.json > $O/pmc_traffic.txt
 python3 tools/mfma_busy.py $O/mfma $O/pmc_mfma_by_kernel.csv > /dev/null
@@ -40,5 +44,5 @@ if [ "${SF_PROFILE_SECONDARY:-1}" = "1" ]; then
   sec cfg3share_b32 32 1.0 6 bf16 45056
   sec refshape_b10_2p18 10 2.0 4 bf16 262144
 fi
-rm -rf $O/stats $O/fetch $O/write $O/mfma $O/mfma_onset
+rm -rf $O/stats $O/fetch $O/write $O/mfma $O/mfma_onset $O/onset_stats $O/train_stats
 ls -la $O
