@@ -252,6 +252,11 @@ int sf_op_ln_modulate_bwd(const float *x, const float *scale_shift, const float 
  * ws >= 2 * B * H * L floats (log-sum-exp and dO.O per query) */
 int sf_op_attention_bwd(const float *q, const float *kv, const float *out, const float *dout, int B, int L, int heads, int head_dim, float *dq,
                         float *dkv, void *ws, int64_t ws_bytes, void *stream);
+/* The same pair with the log-sum-exp of the scaled scores, lse:(B, heads, L), kept by the forward pass and handed to the backward pass
+ * (one score pass less there); fp32, head_dim 64; ws >= B * heads * L * 4 bytes. */
+int sf_op_attention_fwd_lse(const float *q, const float *kv, int B, int L, int heads, int head_dim, float *out, float *lse, void *stream);
+int sf_op_attention_bwd_lse(const float *q, const float *kv, const float *out, const float *dout, const float *lse, int B, int L, int heads, int head_dim,
+                            float *dq, float *dkv, void *ws, int64_t ws_bytes, void *stream);
 /* Kernel tuning aid: average milliseconds of `iters` back-to-back launches of one channels-last conv1d
  * (x:(B,L,C) -> (B,L*upsample,N), `taps` taps, bias + residual epilogue) with a forced kernel family
  * (path 0 auto, 1 classic, 2 wave-split-K, 4 v2), tile variant (-1 auto) and grid split-K factor (-1 auto). */

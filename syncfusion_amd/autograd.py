@@ -207,34 +207,37 @@ def ln_modulate(x: Tensor, scale_shift: Optional[Tensor], eps: float) -> Tensor:
 
 
 class _AttentionFn(torch.autograd.Function):
-    """Multi-head softmax attention (head dim 64) on packed projections: q ``(B, L, H*64)``, kv ``(B, L, 2*H*64)`` -> ``(B, L, H*64)``."""
+    """Multi-head softmax attention (head dim 64) on packed projections: q ``(B, L, H*64)``, kv ``(B, L, 2*H*64)`` -> ``(B, L, H*64)``.
+    The forward pass keeps the log-sum-exp of the scaled scores (B, H, L) for the backward pass (one score pass less there)."""
 
     @staticmethod
     def forward(ctx, q: Tensor, kv: Tensor, heads: int):
         _lib.require_gpu_tensor(q, "syncfusion_amd.autograd")
         lib = _lib.load()
         B, L, HD = q.shape
+        H = int(heads)
         with torch.cuda.device(q.device):
             qc, kc = _lib.f32c(q), _lib.f32c(kv)
             out = torch.empty_like(qc)
-            _lib.check(lib.sf_op_attention(_lib.SF_F32, qc.data_ptr(), kc.data_ptr(), B, L, int(heads), HD // int(heads), out.data_ptr(),
-                                           _lib.stream_ptr(q.device)), "sf_op_attention")
-        ctx.save_for_backward(qc, kc, out)
-        ctx.meta = (B, L, int(heads), HD // int(heads))
+            lse = torch.empty(B, H, L, dtype=torch.float32, device=q.device)
+            _lib.check(lib.sf_op_attention_fwd_lse(qc.data_ptr(), kc.data_ptr(), B, L, H, HD // H, out.data_ptr(), lse.data_ptr(), _lib.stream_ptr(q.device)),
+                       "sf_op_attention_fwd_lse")
+        ctx.save_for_backward(qc, kc, out, lse)
+        ctx.meta = (B, L, H, HD // H)
         return out
 
     @staticmethod
     def backward(ctx, dout: Tensor):
         lib = _lib.load()
-        qc, kc, out = ctx.saved_tensors
+        qc, kc, out, lse = ctx.saved_tensors
         B, L, H, D = ctx.meta
         dev = qc.device
         with torch.cuda.device(dev):
             doc = _lib.f32c(dout)
             dq, dkv = torch.empty_like(qc), torch.empty_like(kc)
-            ws = torch.empty(2 * B * H * L * 4 + 256, dtype=torch.uint8, device=dev)
-            _lib.check(lib.sf_op_attention_bwd(qc.data_ptr(), kc.data_ptr(), out.data_ptr(), doc.data_ptr(), B, L, H, D, dq.data_ptr(), dkv.data_ptr(), ws.data_ptr(),
-                                               ws.numel(), _lib.stream_ptr(dev)), "sf_op_attention_bwd")
+            ws = torch.empty(B * H * L * 4 + 256, dtype=torch.uint8, device=dev)
+            _lib.check(lib.sf_op_attention_bwd_lse(qc.data_ptr(), kc.data_ptr(), out.data_ptr(), doc.data_ptr(), lse.data_ptr(), B, L, H, D, dq.data_ptr(),
+                                                   dkv.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)), "sf_op_attention_bwd_lse")
         return dq, dkv, None
 
 

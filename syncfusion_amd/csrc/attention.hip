@@ -157,7 +157,8 @@ hipError_t go(const void *q, int ldq, const void *kv, int ldkv, int B, int L, in
 hipError_t launch_attention_mfma(int dt, const void *q, int ldq, const void *kv, int ldkv, int B, int L, int H, int Dh, void *out, int ldo,
                                  hipStream_t s);
 bool attention_f32_mfma_ok(int ldq, int ldkv, int ldo, int B, int H);
-hipError_t launch_attention_f32_mfma(const float *q, int ldq, const float *kv, int ldkv, int B, int L, int H, float *out, int ldo, hipStream_t s);
+hipError_t launch_attention_f32_mfma(const float *q, int ldq, const float *kv, int ldkv, int B, int L, int H, float *out, int ldo, hipStream_t s,
+                                     float *lse_out = nullptr);
 
 hipError_t launch_attention(int dt, const void *q, int ldq, const void *kv, int ldkv, int B, int L, int H, int Dh, void *out,
                             int ldo, hipStream_t s) {

@@ -69,7 +69,7 @@ __device__ __forceinline__ int acc_row(int r, int hf) { return 8 * (r >> 2) + 4 
 // half-waves of a query hold different keys; they agree on the tile maximum with one shuffle per tile.  64 MFMAs per 32 x 32 tile.
 constexpr int VPITCH = 72;   // V tile rows are read 4 apart by the two half-waves: 4 * 72 = 32 (mod 64) banks apart
 __global__ __launch_bounds__(256) void attn_fwd_f32_mfma_kernel(const float *__restrict__ q, int ldq, const float *__restrict__ kv, int ldkv, int L, int H,
-                                                                float scale_log2e, float *__restrict__ out, int ldo) {
+                                                                float scale_log2e, float *__restrict__ out, int ldo, float *__restrict__ lse_out) {
   __shared__ __attribute__((aligned(16))) float Ks[TILE * PITCH];
   __shared__ __attribute__((aligned(16))) float Vs[TILE * VPITCH];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, hf = lane >> 5;
@@ -130,6 +130,8 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_mfma_kernel(const float *__r
     }
   }
   lsum += __shfl_xor(lsum, 32);
+  // log sum_j exp(S_ij / 8) in natural units for the backward pass (the running maximum is shared by the half-waves): saves its pass 0
+  if (lse_out && hf == 0 && qv) lse_out[((size_t)b * H + h) * L + qi] = (m + log2f(lsum)) * 0.6931471805599453f;
   if (qv) {
     const float inv = 1.0f / lsum;
     float *op = out + (rb + qi) * ldo + h * HD + 4 * hf;   // O^T: registers 4 g .. 4 g + 3 = head dims 8 g + 4 hf .. + 3 of this lane's query
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_mfma_kernel(const float *__r
 
 __global__ __launch_bounds__(256) void attn_bwd_q_mfma_kernel(const float *__restrict__ q, const float *__restrict__ kv, const float *__restrict__ o,
                                                               const float *__restrict__ dout, int L, int H, float scale, float *__restrict__ dq,
-                                                              float *__restrict__ lse_out, float *__restrict__ dsum_out) {
+                                                              float *__restrict__ lse_out, float *__restrict__ dsum_out, const float *__restrict__ lse_in) {
   __shared__ __attribute__((aligned(16))) float Ks[TILE * PITCH];
   __shared__ __attribute__((aligned(16))) float Vs[TILE * PITCH];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, hf = lane >> 5;
@@ -168,10 +170,10 @@ __global__ __launch_bounds__(256) void attn_bwd_q_mfma_kernel(const float *__res
   dd += __shfl_xor(dd, 32);
   const int nkt = (L + TILE - 1) / TILE;
   TileRegs pk, pv;
-  // ---- pass 0: lse_i = log sum_j exp(S_ij) ---------------------------------------------------------------------------------
+  // ---- pass 0: lse_i = log sum_j exp(S_ij) -- skipped when the forward pass kept it (lse_in) --------------------------------
   float m = -INFINITY, ssum = 0.f;
-  tile_fetch(pk, kv, rb, 0, L, ldkv, h * HD, tid);
-  for (int kt = 0; kt < nkt; ++kt) {
+  if (!lse_in) tile_fetch(pk, kv, rb, 0, L, ldkv, h * HD, tid);
+  for (int kt = 0; kt < (lse_in ? 0 : nkt); ++kt) {
     __syncthreads();
     tile_store(Ks, pk, tid);
     __syncthreads();
@@ -196,14 +198,16 @@ __global__ __launch_bounds__(256) void attn_bwd_q_mfma_kernel(const float *__res
     }
   }
   float lse;
-  {
+  if (lse_in) {
+    lse = qv ? lse_in[((size_t)b * H + h) * L + qi] : 0.f;
+  } else {
     const float m2 = __shfl_xor(m, 32), s2 = __shfl_xor(ssum, 32);
     const float M = fmaxf(m, m2);
     const float tot = (m > -INFINITY ? ssum * expf(m - M) : 0.f) + (m2 > -INFINITY ? s2 * expf(m2 - M) : 0.f);
     lse = M + logf(tot);
   }
   if (hf == 0 && qv) {
-    lse_out[((size_t)b * H + h) * L + qi] = lse;
+    if (!lse_in) lse_out[((size_t)b * H + h) * L + qi] = lse;
     dsum_out[((size_t)b * H + h) * L + qi] = dd;
   }
   // ---- pass 1: dQ ------------------------------------------------------------------------------------------------------------
@@ -340,21 +344,22 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_mfma_kernel(const float *__re
 
 bool attention_f32_mfma_ok(int ldq, int ldkv, int ldo, int B, int H) { return (ldkv % 4) == 0 && (ldo % 4) == 0 && ldq > 0 && B <= 65535 && H <= 65535; }
 
-hipError_t launch_attention_f32_mfma(const float *q, int ldq, const float *kv, int ldkv, int B, int L, int H, float *out, int ldo, hipStream_t s) {
+hipError_t launch_attention_f32_mfma(const float *q, int ldq, const float *kv, int ldkv, int B, int L, int H, float *out, int ldo, hipStream_t s,
+                                     float *lse_out) {
   if (L < 1 || B < 1 || H < 1) return hipErrorInvalidValue;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)HD);
-  hipLaunchKernelGGL(attn_fwd_f32_mfma_kernel, dim3((L + 127) / 128, H, B), dim3(256), 0, s, q, ldq, kv, ldkv, L, H, scale_log2e, out, ldo);
+  hipLaunchKernelGGL(attn_fwd_f32_mfma_kernel, dim3((L + 127) / 128, H, B), dim3(256), 0, s, q, ldq, kv, ldkv, L, H, scale_log2e, out, ldo, lse_out);
   return hipGetLastError();
 }
 
 // q, o, dout, dq: (B, L, H*64);  kv, dkv: (B, L, 2*H*64);  lse, dsum: (B, H, L) scratch
 hipError_t launch_attention_bwd(const float *q, const float *kv, const float *o, const float *dout, int B, int L, int H, int D, float *dq, float *dkv,
-                                float *lse, float *dsum, hipStream_t s) {
+                                float *lse, float *dsum, hipStream_t s, const float *lse_fwd) {
   if (D != HD || L < 1 || B < 1 || H < 1 || H > 65535 || B > 65535) return hipErrorInvalidValue;
   const float scale = 1.0f / sqrtf((float)HD);
   const dim3 grid((L + 127) / 128, H, B);
-  hipLaunchKernelGGL(attn_bwd_q_mfma_kernel, grid, dim3(256), 0, s, q, kv, o, dout, L, H, scale, dq, lse, dsum);
-  hipLaunchKernelGGL(attn_bwd_kv_mfma_kernel, grid, dim3(256), 0, s, q, kv, dout, lse, dsum, L, H, scale, dkv);
+  hipLaunchKernelGGL(attn_bwd_q_mfma_kernel, grid, dim3(256), 0, s, q, kv, o, dout, L, H, scale, dq, lse, dsum, lse_fwd);
+  hipLaunchKernelGGL(attn_bwd_kv_mfma_kernel, grid, dim3(256), 0, s, q, kv, dout, lse_fwd ? lse_fwd : lse, dsum, L, H, scale, dkv);
   return hipGetLastError();
 }
 

@@ -152,4 +152,30 @@ int sf_op_attention_bwd(const float *q, const float *kv, const float *out, const
   SF_API_END
 }
 
+int sf_op_attention_fwd_lse(const float *q, const float *kv, int B, int L, int heads, int head_dim, float *out, float *lse, void *stream) {
+  SF_API_BEGIN
+  if (!q || !kv || !out || !lse) fail(SF_ERR_INVALID, "null argument");
+  if (head_dim != 64) fail(SF_ERR_UNSUPPORTED, "head_dim must be 64");
+  if (B < 1 || L < 1 || heads < 1) fail(SF_ERR_INVALID, "B, L and heads must be positive");
+  const int hd = heads * head_dim;
+  if (!attention_f32_mfma_ok(hd, 2 * hd, hd, B, heads)) fail(SF_ERR_UNSUPPORTED, "shape outside the fp32 matrix-core attention kernel");
+  SF_HIP(launch_attention_f32_mfma(q, hd, kv, 2 * hd, B, L, heads, out, hd, static_cast<hipStream_t>(stream), lse));
+  return SF_OK;
+  SF_API_END
+}
+
+int sf_op_attention_bwd_lse(const float *q, const float *kv, const float *out, const float *dout, const float *lse, int B, int L, int heads, int head_dim,
+                            float *dq, float *dkv, void *ws, int64_t ws_bytes, void *stream) {
+  SF_API_BEGIN
+  if (!q || !kv || !out || !dout || !lse || !dq || !dkv || !ws) fail(SF_ERR_INVALID, "null argument");
+  if (head_dim != 64) fail(SF_ERR_UNSUPPORTED, "head_dim must be 64");
+  if (B < 1 || L < 1 || heads < 1) fail(SF_ERR_INVALID, "B, L and heads must be positive");
+  const int64_t need = (int64_t)B * heads * L * (int64_t)sizeof(float);
+  if (ws_bytes < need) fail(SF_ERR_WORKSPACE, "workspace too small: need %lld bytes", (long long)need);
+  float *dsum = static_cast<float *>(ws);
+  SF_HIP(launch_attention_bwd(q, kv, out, dout, B, L, heads, head_dim, dq, dkv, nullptr, dsum, static_cast<hipStream_t>(stream), lse));
+  return SF_OK;
+  SF_API_END
+}
+
 }  // extern "C"

@@ -363,7 +363,11 @@ hipError_t launch_ln_modulate_bwd(const float *x, const float *ss, const float *
                                   float *dss, hipStream_t s);
 // backward of softmax attention on packed projections (head dim 64): dq (B,L,H*64), dkv (B,L,2*H*64); lse, dsum: (B,H,L) scratch
 hipError_t launch_attention_bwd(const float *q, const float *kv, const float *o, const float *dout, int B, int L, int H, int D, float *dq, float *dkv,
-                                float *lse, float *dsum, hipStream_t s);
+                                float *lse, float *dsum, hipStream_t s, const float *lse_fwd = nullptr);
+// fp32 attention forward on the matrix cores that also keeps log-sum-exp of the scaled scores, (B, H, L), for launch_attention_bwd(lse_fwd)
+bool attention_f32_mfma_ok(int ldq, int ldkv, int ldo, int B, int H);
+hipError_t launch_attention_f32_mfma(const float *q, int ldq, const float *kv, int ldkv, int B, int L, int H, float *out, int ldo, hipStream_t s,
+                                     float *lse_out);
 
 // BatchNorm (eval) -> per-channel scale / shift
 hipError_t launch_bn_fold(const float *gamma, const float *beta, const float *mean, const float *var, float eps, int C,
