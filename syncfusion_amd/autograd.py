@@ -20,6 +20,7 @@ No atomics anywhere: a second backward gives the same bits.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -31,6 +32,9 @@ Tensor = torch.Tensor
 
 def _cl(x: Tensor) -> Tensor:
     return x.transpose(1, 2).contiguous()
+
+
+_FUSED_GN = os.environ.get("SF_TRAIN_FUSED_GN") == "1"   # A/B aid: GroupNorm+SiLU as the convolution kernel's prologue, recomputed in backward
 
 
 class _ConvBlockFn(torch.autograd.Function):
@@ -79,12 +83,23 @@ class _ConvBlockFn(torch.autograd.Function):
                     raise ValueError(f"residual shape {tuple(residual.shape)} does not match the output")
                 if n_real != N:   # zero-padded output width: the kernel's rows are wider than the residual's; add afterwards
                     res_cl, res_late = None, res_cl
-            _lib.check(lib.sf_op_conv1d_cl(_lib.SF_F32, x_cl.data_ptr(), w.data_ptr(), b.data_ptr() if b is not None else None,
-                                           g.data_ptr() if g is not None else None, be.data_ptr() if be is not None else None, int(groups), float(eps),
+            # MFMA-path GroupNorm convolutions: a = silu(groupnorm(x)) is materialised once and KEPT for the backward pass, and the convolution
+            # itself runs as a plain GEMM (macro tiles on the wide levels) -- the fused-prologue kernel was the slowest forward GEMM of the
+            # step and the backward pass recomputed a for the weight gradient (SF_TRAIN_FUSED_GN=1: the former path).
+            act = None
+            if groups > 0 and Cc % 32 == 0 and not _FUSED_GN:
+                act = torch.empty_like(x_cl)
+                ws_gn = torch.empty(B * 32 * groups * 2 + 64, dtype=torch.float32, device=x.device)
+                _lib.check(lib.sf_op_gn_silu(_lib.SF_F32, x_cl.data_ptr(), g.data_ptr(), be.data_ptr(), int(groups), float(eps), B, L, Cc, act.data_ptr(),
+                                             ws_gn.data_ptr(), ws_gn.numel() * 4, _lib.stream_ptr(x.device)), "sf_op_gn_silu")
+            src, gr = (act, 0) if act is not None else (x_cl, int(groups))
+            _lib.check(lib.sf_op_conv1d_cl(_lib.SF_F32, src.data_ptr(), w.data_ptr(), b.data_ptr() if b is not None else None,
+                                           g.data_ptr() if gr > 0 else None, be.data_ptr() if gr > 0 else None, gr, float(eps),
                                            res_cl.data_ptr() if res_cl is not None else None, B, L, Cc, N, taps, 1, pad, 1, out.data_ptr(), ws.data_ptr(),
                                            ws.numel(), _lib.stream_ptr(x.device)),
                        "sf_op_conv1d_cl")
-        ctx.save_for_backward(x_cl, w, g if g is not None else x_cl.new_empty(0), be if be is not None else x_cl.new_empty(0))
+        ctx.save_for_backward(x_cl, w, g if g is not None else x_cl.new_empty(0), be if be is not None else x_cl.new_empty(0),
+                              act if act is not None else x_cl.new_empty(0))
         ctx.meta = (B, L, Cc, N, taps, pad, int(groups), float(eps), bias is not None, c_real, n_real, bool(channels_last))
         if n_real != N:
             out = out[:, :, :n_real]
@@ -95,7 +110,7 @@ class _ConvBlockFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy: Tensor):
         lib = _lib.load()
-        x_cl, w, g, be = ctx.saved_tensors
+        x_cl, w, g, be, act = ctx.saved_tensors
         B, L, Cc, N, taps, pad, groups, eps, has_bias, c_real, n_real, channels_last = ctx.meta
         dev = x_cl.device
         with torch.cuda.device(dev):
@@ -114,11 +129,14 @@ class _ConvBlockFn(torch.autograd.Function):
             if n < 0:
                 raise _lib.SyncFusionAmdError(lib.sf_last_error().decode())
             ws = torch.empty(max(int(n), 256), dtype=torch.uint8, device=dev)
-            _lib.check(lib.sf_op_conv1d_bwd_cl(x_cl.data_ptr(), w.data_ptr(), g.data_ptr() if groups > 0 else None, be.data_ptr() if groups > 0 else None,
-                                               groups, eps, dy_cl.data_ptr(), B, L, Cc, N, taps, pad, dx.data_ptr() if dx is not None else None,
-                                               dw.data_ptr() if dw is not None else None,
-                                               db.data_ptr() if db is not None else None, dgb.data_ptr() if dgb is not None else None,
-                                               ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)), "sf_op_conv1d_bwd_cl")
+            tail = (groups, eps, dy_cl.data_ptr(), B, L, Cc, N, taps, pad, dx.data_ptr() if dx is not None else None,
+                    dw.data_ptr() if dw is not None else None, db.data_ptr() if db is not None else None, dgb.data_ptr() if dgb is not None else None,
+                    ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev))
+            gp, bp = (g.data_ptr() if groups > 0 else None), (be.data_ptr() if groups > 0 else None)
+            if groups > 0 and act.numel() > 0:
+                _lib.check(lib.sf_op_conv1d_bwd_cl_act(x_cl.data_ptr(), act.data_ptr(), w.data_ptr(), gp, bp, *tail), "sf_op_conv1d_bwd_cl_act")
+            else:
+                _lib.check(lib.sf_op_conv1d_bwd_cl(x_cl.data_ptr(), w.data_ptr(), gp, bp, *tail), "sf_op_conv1d_bwd_cl")
         if c_real != Cc:
             dx = dx[:, :, :c_real] if dx is not None else None
             dw = dw[:, :c_real] if dw is not None else None

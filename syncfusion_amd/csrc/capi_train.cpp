@@ -55,7 +55,7 @@ int64_t sf_op_conv1d_bwd_workspace_bytes(int B, int L, int C, int N, int taps, i
   }
 }
 
-int sf_op_conv1d_bwd_cl(const float *x, const float *w, const float *gamma, const float *beta, int groups, float eps, const float *dy, int B, int L,
+static int conv1d_bwd_impl(const float *x, const float *act_saved, const float *w, const float *gamma, const float *beta, int groups, float eps, const float *dy, int B, int L,
                         int C, int N, int taps, int pad, float *dx, float *dw, float *db, float *dgb, void *ws, int64_t ws_bytes, void *stream) {
   SF_API_BEGIN
   if (!x || !w || !dy || !ws) fail(SF_ERR_INVALID, "null argument");
@@ -66,7 +66,10 @@ int sf_op_conv1d_bwd_cl(const float *x, const float *w, const float *gamma, cons
   Workspace wk(ws, ws_bytes);
   BwdPlan p = plan(wk, B, L, C, N, taps, groups);
   const float *act = x;
-  if (groups > 0) {   // recompute a = SiLU(GroupNorm(x)) (cheaper than keeping it from the forward pass)
+  if (groups > 0 && act_saved) {   // a = SiLU(GroupNorm(x)) kept by the forward pass: only the statistics the GroupNorm backward reads
+    SF_HIP(launch_gn_bwd_stats(x, B, L, C, groups, p.gpart, s));
+    act = act_saved;
+  } else if (groups > 0) {         // recompute a
     SF_HIP(launch_gn_silu_recompute(x, gamma, beta, B, L, C, groups, eps, p.act, p.gpart, s));
     act = p.act;
   }
@@ -102,6 +105,21 @@ int sf_op_conv1d_bwd_cl(const float *x, const float *w, const float *gamma, cons
   if (groups > 0) SF_HIP(launch_gn_silu_bwd(x, p.da, gamma, beta, B, L, C, groups, eps, dx, p.gpart, dgb, s));
   return SF_OK;
   SF_API_END
+}
+
+int sf_op_conv1d_bwd_cl(const float *x, const float *w, const float *gamma, const float *beta, int groups, float eps, const float *dy, int B, int L,
+                        int C, int N, int taps, int pad, float *dx, float *dw, float *db, float *dgb, void *ws, int64_t ws_bytes, void *stream) {
+  return conv1d_bwd_impl(x, nullptr, w, gamma, beta, groups, eps, dy, B, L, C, N, taps, pad, dx, dw, db, dgb, ws, ws_bytes, stream);
+}
+
+int sf_op_conv1d_bwd_cl_act(const float *x, const float *act, const float *w, const float *gamma, const float *beta, int groups, float eps,
+                            const float *dy, int B, int L, int C, int N, int taps, int pad, float *dx, float *dw, float *db, float *dgb, void *ws,
+                            int64_t ws_bytes, void *stream) {
+  if (groups > 0 && !act) {
+    set_error("sf_op_conv1d_bwd_cl_act: act is null");
+    return SF_ERR_INVALID;
+  }
+  return conv1d_bwd_impl(x, act, w, gamma, beta, groups, eps, dy, B, L, C, N, taps, pad, dx, dw, db, dgb, ws, ws_bytes, stream);
 }
 
 int64_t sf_op_length_sums_workspace_bytes(int B, int L, int C) {

@@ -462,7 +462,7 @@ bool conv_gemm_prefers_mt(const ConvGemmArgs &a) {
 }
 
 static const char *variant_name_bf16(int dt, const ConvGemmArgs &a) {
-  if (g_conv_gemm_force.path == 6 || (g_conv_gemm_force.path == 0 && conv_gemm_mt_ok(dt, a) && conv_gemm_prefers_mt(a))) return conv_gemm_mt_name(a);
+  if (g_conv_gemm_force.path == 6 || (g_conv_gemm_force.path == 0 && conv_gemm_mt_wanted(dt, a))) return dt == F32 ? "conv_gemm_mt<f32>" : conv_gemm_mt_name(a);
   static const char *names[2][5] = {{"conv_gemm<f32,64x64,scalarA>", "conv_gemm<f32,128x32>", "conv_gemm<f32,128x64>", "conv_gemm<f32,64x64>", "conv_gemm<f32,128x128>"},
                                     {"conv_gemm<bf16,64x64,scalarA>", "conv_gemm<bf16,128x32>", "conv_gemm<bf16,128x64>", "conv_gemm<bf16,64x64>", "conv_gemm<bf16,128x128>"}};
   static const char *sk_names[2][3] = {{"conv_gemm_sk<f32,64x64>", "conv_gemm_sk<f32,64x32>", "conv_gemm_sk<f32,32x32>"},
@@ -492,7 +492,7 @@ bool conv_gemm_emits_rowpart(int dt, const ConvGemmArgs &a) {
   {   // long activations: the macro-tile kernel (no row-statistics epilogue) beats the 32x32 kernels that have one
     ConvGemmArgs plain = a;
     plain.rowpart_out = nullptr;
-    if (conv_gemm_mt_ok(dt, plain) && conv_gemm_prefers_mt(plain)) return false;
+    if (conv_gemm_mt_wanted(dt, plain)) return false;
   }
   if ((a.n_store % 32) || a.n_store != a.N) return false;
   const long t64 = (long)((a.M + 63) / 64) * ((a.n_store + 63) / 64);
@@ -516,7 +516,7 @@ hipError_t launch_conv_gemm(int dt, const ConvGemmArgs &a, hipStream_t s) {
   if (!conv_gemm_supported(dt, a)) return hipErrorInvalidValue;
   const ConvGemmForce &f = g_conv_gemm_force;
   if (f.path == 6) return launch_conv_gemm_mt(dt, a, s);
-  if (f.path == 0 && conv_gemm_mt_ok(dt, a) && conv_gemm_prefers_mt(a)) return launch_conv_gemm_mt(dt, a, s);
+  if (f.path == 0 && conv_gemm_mt_wanted(dt, a)) return launch_conv_gemm_mt(dt, a, s);
   const long t64 = (long)((a.M + 63) / 64) * ((a.n_store + 63) / 64);
   const bool short_act = t64 < short_act_tiles() && a.K >= 256 && (a.K % 32) == 0 && (a.cin % 32) == 0 && (a.cin2 % 32) == 0;
   if (f.path == 4 || (f.path == 0 && !short_act)) {

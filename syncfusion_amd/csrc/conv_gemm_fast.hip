@@ -460,7 +460,7 @@ bool conv_gemm_ln_ok(int dt, const ConvGemmArgs &a) {
     plain.ln_ss = nullptr;
     plain.rowpart_out = nullptr;
     plain.res_ln = 0;
-    if (conv_gemm_mt_ok(dt, plain) && conv_gemm_prefers_mt(plain)) return false;
+    if (conv_gemm_mt_wanted(dt, plain)) return false;
   }
   if (a.taps != 1 || a.stride != 1 || a.up_shift != 0 || a.Lout != a.Lsrc || a.Lout < 32) return false;
   if (!a.ln_part || a.ln_nt * 32 != a.cin || a.ln_nt > 32) return false;

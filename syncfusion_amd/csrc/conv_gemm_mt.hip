@@ -19,14 +19,16 @@
 //     ConvGemmArgs.
 // Geometry: 1-D (taps, stride, nearest upsampling) and video (kt x kh x kw taps), channel counts that are multiples of 64,
 // no concatenated second source, no prologue.
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
 namespace sf {
 namespace {
 
-constexpr int BK = 64;                 // K step: 64 elements = 128 bytes = 8 sixteen-byte chunks per row
-constexpr int ROWB = BK * 2;           // bytes per staged row
+constexpr int BK = 64;                 // K step of the 16-bit types: 64 elements = 128 bytes = 8 sixteen-byte chunks per row
+constexpr int ROWB = 128;              // bytes per staged row (fp32: 32 elements per K step)
 constexpr unsigned OOB = 0x80000000u;
 constexpr int NSTAGE = 3;
 
@@ -45,14 +47,14 @@ __device__ unsigned long long g_mt_stamps[8][8];
 template <typename T, int BM, int BN, int WM, int WN, int GEOM, bool CAT, int NST = NSTAGE, int EP = 1>
 __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a, const int mtiles, const int ntiles, const unsigned bytesA,
                                                            const unsigned bytesA2, const unsigned bytesW) {
-  static_assert(sizeof(T) == 2, "16-bit types only");
+  constexpr int ES = sizeof(T);   // fp32 (training, the parity engine's long activations): same byte geometry, v_mfma_f32_32x32x2_f32
   static_assert(WM * WN == 8 && BM % (32 * WM) == 0 && BN % (32 * WN) == 0 && BM % 64 == 0 && BN % 64 == 0, "tile / wave grid mismatch");
   constexpr int RM = BM / WM, RN = BN / WN;          // rows / columns of a wave's tile
   constexpr int TM = RM / 32, TN = RN / 32;
   constexpr int STAGE = (BM + BN) * ROWB;          // bytes per ring slot: A rows then W rows
   constexpr int PA = BM / 64, PB = BN / 64;         // DMA instructions per thread and K step (8 rows per wave-instruction, 8 waves)
   constexpr int NLD = PA + PB;
-  using frag = typename Frag16<T>::type;
+  using frag = typename std::conditional<sizeof(T) == 4, f32x4, typename Frag16<T>::type>::type;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
     const bool vm = m < a.M;
     const int mm = vm ? m : 0;
     vmask[i] = vm ? 0u : OOB;
-    roff2[i] = CAT ? (((unsigned)(mm * a.src2_ld * 2) + gchunk_b) | vmask[i]) : OOB;
+    roff2[i] = CAT ? (((unsigned)(mm * a.src2_ld * ES) + gchunk_b) | vmask[i]) : OOB;
     if constexpr (GEOM == 0) {
       const int b = mm / a.Lout, l = mm - b * a.Lout;
       rbase[i] = b * a.Lsrc;
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
 #pragma unroll
   for (int j = 0; j < PB; ++j) {
     const int n = n0 + (j * 8 + wave) * 8 + lrow;
-    woff[j] = n < a.N ? ((unsigned)(n * a.K * 2) + gchunk_b) : OOB;
+    woff[j] = n < a.N ? ((unsigned)(n * a.K * ES) + gchunk_b) : OOB;
   }
   const int pmax = (a.Lsrc << a.up_shift) - 1;
   unsigned cur[PA];
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
       for (int i = 0; i < PA; ++i) {
         const int p = rp0[i] + t;
         const unsigned bad = ((unsigned)p > (unsigned)pmax) ? OOB : 0u;
-        cur[i] = ((unsigned)(((rbase[i] + (max(p, 0) >> a.up_shift)) * a.src_ld) * 2) + gchunk_b) | bad | vmask[i];
+        cur[i] = ((unsigned)(((rbase[i] + (max(p, 0) >> a.up_shift)) * a.src_ld) * ES) + gchunk_b) | bad | vmask[i];
       }
     } else {
       const int dw = t % a.kw;
@@ -131,15 +133,15 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
       for (int i = 0; i < PA; ++i) {
         const int ti = rp0[i] + dt, hi = rh[i] + dh, wi = rw_[i] + dw;
         const bool ok = (unsigned)ti < (unsigned)a.Ti && (unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi;
-        cur[i] = ((unsigned)(((((rbase[i] + max(ti, 0)) * a.Hi + max(hi, 0)) * a.Wi + max(wi, 0)) * a.src_ld) * 2) + gchunk_b) |
+        cur[i] = ((unsigned)(((((rbase[i] + max(ti, 0)) * a.Hi + max(hi, 0)) * a.Wi + max(wi, 0)) * a.src_ld) * ES) + gchunk_b) |
                  (ok ? 0u : OOB) | vmask[i];
       }
     }
   };
 
   // ---- load stream state (runs two K steps ahead of the multiply) ------------------------------------------------
-  const int nk = a.K / BK;
-  const unsigned tap_bytes = (unsigned)(a.cin * 2);
+  const int nk = a.K / (ROWB / ES);
+  const unsigned tap_bytes = (unsigned)(a.cin * ES);
   unsigned cb = 0, kb = 0;   // byte offset inside the tap's channels / inside a W row
   int tap = 0;
   bool second = false;   // the stream has reached the concatenated source
@@ -252,10 +254,21 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
       for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const frag *>(slot + offA[i] + ch);
 #pragma unroll
       for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const frag *>(slot + offB[j] + ch);
+      if constexpr (ES == 2) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = mfma32x16(af[i], bf[j], acc[i][j]);
+          for (int j = 0; j < TN; ++j) acc[i][j] = mfma32x16(af[i], bf[j], acc[i][j]);
+      } else {
+        // fp32: the half-wave fh holds floats 4 (2 ks + fh) + e of the K step; element e of both halves forms one k pair of a 32x32x2
+        // product (the k order inside a step is permuted identically for both operands)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+      }
     }
 #ifdef SF_MT_STAMPS
     asm volatile("s_nop 0" ::"v"(acc[0][0][0]));   // the last MFMA of the step has written its accumulator
@@ -305,8 +318,23 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
     const f32x4 v0 = *reinterpret_cast<const f32x4 *>(red + rl * LDR + oct * 8);
     const f32x4 v1 = *reinterpret_cast<const f32x4 *>(red + rl * LDR + oct * 8 + 4);
     float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-    Vec16<T> rv = zero16<T>();
-    if (res && live) rv = ld16<T>(res + (size_t)mc * a.res_ld + n);   // residual rows are n_store wide (pad columns hold zeros)
+    float rres[8];   // residual rows are n_store wide (pad columns hold zeros)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) rres[e] = 0.f;
+    if (res && live) {
+      if constexpr (ES == 2) {
+        const Vec16<T> rv = ld16<T>(res + (size_t)mc * a.res_ld + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rres[e] = rv.get(e);
+      } else {
+        const Vec16<T> r0 = ld16<T>(res + (size_t)mc * a.res_ld + n), r1 = ld16<T>(res + (size_t)mc * a.res_ld + n + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          rres[e] = r0.get(e);
+          rres[4 + e] = r1.get(e);
+        }
+      }
+    }
     float bi[8], sc[8], ad[8];
     if (full) {   // 16-byte vectors of the per-column operands (n is a multiple of 8)
 #pragma unroll
@@ -330,14 +358,30 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
         ad[e] = has_ba ? a.badd[(size_t)b * a.badd_ld + ne] : 0.f;
       }
     }
-    Vec16<T> o;
+    float xo[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float x = (v[e] + bi[e]) * sc[e] + rv.get(e) + ad[e];
+      float x = (v[e] + bi[e]) * sc[e] + rres[e] + ad[e];
       if (a.act == 1) x = fmaxf(x, 0.f);
-      o.set(e, (n + e < a.N) ? x : 0.f);
+      xo[e] = (n + e < a.N) ? x : 0.f;
     }
-    if (live) st16<T>(out + (size_t)m * a.out_ld + n, o);
+    if (live) {
+      if constexpr (ES == 2) {
+        Vec16<T> o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.set(e, xo[e]);
+        st16<T>(out + (size_t)m * a.out_ld + n, o);
+      } else {
+        Vec16<T> o0, o1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o0.set(e, xo[e]);
+          o1.set(e, xo[4 + e]);
+        }
+        st16<T>(out + (size_t)m * a.out_ld + n, o0);
+        st16<T>(out + (size_t)m * a.out_ld + n + 4, o1);
+      }
+    }
   }
   }
 #ifdef SF_MT_STAMPS
@@ -363,10 +407,10 @@ template <typename T, int BM, int BN, int WM, int WN, int GEOM, bool CAT, int NS
   static_assert(lds <= 160 * 1024, "LDS budget");
   const int mtiles = (a.M + BM - 1) / BM, ntiles = (a.n_store + BN - 1) / BN;
   size_t bA;
-  if (GEOM == 0) bA = (size_t)(a.M / a.Lout + (a.M % a.Lout ? 1 : 0)) * a.Lsrc * a.src_ld * 2;
-  else bA = (size_t)((a.M + a.To * a.Ho * a.Wo - 1) / (a.To * a.Ho * a.Wo)) * a.Ti * a.Hi * a.Wi * a.src_ld * 2;
-  const size_t bW = (size_t)a.N * a.K * 2;
-  const size_t bA2 = CAT ? (size_t)a.M * a.src2_ld * 2 : 0;
+  if (GEOM == 0) bA = (size_t)(a.M / a.Lout + (a.M % a.Lout ? 1 : 0)) * a.Lsrc * a.src_ld * sizeof(T);
+  else bA = (size_t)((a.M + a.To * a.Ho * a.Wo - 1) / (a.To * a.Ho * a.Wo)) * a.Ti * a.Hi * a.Wi * a.src_ld * sizeof(T);
+  const size_t bW = (size_t)a.N * a.K * sizeof(T);
+  const size_t bA2 = CAT ? (size_t)a.M * a.src2_ld * sizeof(T) : 0;
   auto kern = conv_gemm_mt_kernel<T, BM, BN, WM, WN, GEOM, CAT, NST, EP>;
   static bool en = false;
   if (!en) {
@@ -398,20 +442,40 @@ template <typename T, int GEOM, bool CAT> hipError_t launch_mt_v(const ConvGemmA
 
 // eligibility (what the kernel implements) -- the CHOICE between this kernel and conv_gemm_v2 is conv_gemm_prefers_mt
 bool conv_gemm_mt_ok(int dt, const ConvGemmArgs &a) {
-  if (dt == F32) return false;
-  if (a.pro != 0 || (a.cin % BK) || (a.cin2 % BK) || a.taps < 1 || a.K != a.taps * a.cin + a.cin2) return false;
-  if (a.cin2 && (a.geom != 0 || !a.src2 || (a.src2_ld % 8) || a.src2_ld < a.cin2 || (size_t)a.M * a.src2_ld * 2 >= 0x7FFFFFF0ull)) return false;
+  const size_t es = dt == F32 ? 4 : 2;
+  const int bke = (int)(ROWB / es), vec = (int)(16 / es);   // elements per K step / per 16-byte access
+  if (dt == F32 && a.geom != 0) return false;                // fp32: the U-Net's 1-D geometry only (training, parity engine)
+  if (a.pro != 0 || (a.cin % bke) || (a.cin2 % bke) || a.taps < 1 || a.K != a.taps * a.cin + a.cin2) return false;
+  if (a.cin2 && (a.geom != 0 || !a.src2 || (a.src2_ld % vec) || a.src2_ld < a.cin2 || (size_t)a.M * a.src2_ld * es >= 0x7FFFFFF0ull)) return false;
   if (a.ln_part || a.ln_colsum || a.rowpart_out || a.out_f32 || a.act > 1) return false;
   if ((a.bscale && (a.bscale_ld % 4)) || (a.badd && (a.badd_ld % 4))) return false;
-  if ((a.n_store % 8) || a.n_store < a.N || (a.out_ld % 8) || a.out_ld < a.n_store || (a.res && ((a.res_ld % 8) || a.res_ld < a.n_store)) || (a.src_ld % 8)) return false;
+  if ((a.n_store % 8) || a.n_store < a.N || (a.out_ld % 8) || a.out_ld < a.n_store || (a.res && ((a.res_ld % 8) || a.res_ld < a.n_store)) || (a.src_ld % vec)) return false;
   if (a.bias && (reinterpret_cast<uintptr_t>(a.bias) & 15)) return false;
   if (a.geom == 1 && (a.bscale || a.badd)) return false;
   const size_t lim = 0x7FFFFFF0ull;
   size_t bA;
-  if (a.geom == 0) bA = (size_t)(a.M / a.Lout + 1) * a.Lsrc * a.src_ld * 2;
-  else bA = (size_t)(a.M / (a.To * a.Ho * a.Wo) + 1) * a.Ti * a.Hi * a.Wi * a.src_ld * 2;
-  if (bA >= lim || (size_t)a.N * a.K * 2 >= lim) return false;
+  if (a.geom == 0) bA = (size_t)(a.M / a.Lout + 1) * a.Lsrc * a.src_ld * es;
+  else bA = (size_t)(a.M / (a.To * a.Ho * a.Wo) + 1) * a.Ti * a.Hi * a.Wi * a.src_ld * es;
+  if (bA >= lim || (size_t)a.N * a.K * es >= lim) return false;
   return true;
+}
+
+// fp32 choice (training step, the fp32 engine's long activations): the fp32 matrix pipe needs 64 cycles per 32x32x2 product, so a K step
+// of ANY tile is MFMA time (2048 cycles per SIMD against ~400 of wait + barrier + DMA issue) and the tile only has to fill the chip:
+// 128x64 (three slots, two workgroups per CU) below 512 tiles of 128x128, 128x128 (two slots, two per CU) above.  Alone on the chip
+// (tools/gemm_f32.py, batch 4 x 2^18 samples): 16384 x 128 x 384 25.3 -> 19.3 us, 8192 x 256 x 768 39.3 -> 32.9, 4096 x 512 x 1536 66.5 -> 60.1,
+// 8192 x 1536 x 256 137.7 -> 62.0, 4096 x 1536 x 512 126.2 -> 58.6 us (110 TFLOP/s of the 157 fp32 peak).
+bool conv_gemm_prefers_mt_f32(const ConvGemmArgs &a) {
+  static const long min_tiles = [] {   // tuning hook: SF_MT_F32_TILES=0 keeps fp32 off the macro tiles
+    const char *e = getenv("SF_MT_F32_TILES");
+    return e ? atol(e) : 256L;   // a full round of 128x64 tiles: at 128 tiles the wave-split-K / 64x64 kernels win (41 vs 57 us, 71 vs 110 us)
+  }();
+  if (min_tiles <= 0 || a.geom != 0 || a.K < 256) return false;
+  return (long)((a.M + 127) / 128) * ((a.n_store + 63) / 64) >= min_tiles;
+}
+bool conv_gemm_mt_wanted(int dt, const ConvGemmArgs &a) {
+  if (!conv_gemm_mt_ok(dt, a)) return false;
+  return dt == F32 ? conv_gemm_prefers_mt_f32(a) : conv_gemm_prefers_mt(a);
 }
 
 // tile variant: 0 = 256x128, 1 = 128x128, 2 = 128x192, 3 = 192x128, 4 = 256x64 (three-slot ring, one workgroup per CU);
@@ -492,6 +556,12 @@ const char *conv_gemm_mt_name(const ConvGemmArgs &a) {
 
 hipError_t launch_conv_gemm_mt(int dt, const ConvGemmArgs &a, hipStream_t s) {
   if (!conv_gemm_mt_ok(dt, a)) return hipErrorInvalidValue;
+  if (dt == F32) {
+    static const int forced = [] { const char *e = getenv("SF_MT_F32_VARIANT"); return e ? atoi(e) : -1; }();   // tuning hook: 1, 5, 7
+    const long t128 = (long)((a.M + 127) / 128) * ((a.n_store + 127) / 128);
+    const int v = forced >= 0 ? forced : ((a.n_store % 64 == 0 && t128 < 512) ? 7 : 5);
+    return a.cin2 ? launch_mt_v<float, 0, true>(a, v, s) : launch_mt_v<float, 0, false>(a, v, s);
+  }
   const int v = conv_gemm_mt_variant(a);
   if (dt == F16) return a.geom == 1 ? launch_mt_v<f16, 1, false>(a, v, s) : (a.cin2 ? launch_mt_v<f16, 0, true>(a, v, s) : launch_mt_v<f16, 0, false>(a, v, s));
   return a.geom == 1 ? launch_mt_v<bf16, 1, false>(a, v, s) : (a.cin2 ? launch_mt_v<bf16, 0, true>(a, v, s) : launch_mt_v<bf16, 0, false>(a, v, s));

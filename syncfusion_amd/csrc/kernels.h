@@ -86,6 +86,7 @@ hipError_t launch_conv_gemm(int dt, const ConvGemmArgs &a, hipStream_t s);
 // macro-tile kernel (conv_gemm_mt.hip): 256x128 tiles, LDS-DMA ring; 16-bit types, long activations
 bool conv_gemm_mt_ok(int dt, const ConvGemmArgs &a);
 bool conv_gemm_prefers_mt(const ConvGemmArgs &a);
+bool conv_gemm_mt_wanted(int dt, const ConvGemmArgs &a);   // eligible AND preferred (the fp32 rule differs: conv_gemm_mt.hip)
 hipError_t launch_conv_gemm_mt(int dt, const ConvGemmArgs &a, hipStream_t s);
 const char *conv_gemm_mt_name(const ConvGemmArgs &a);   // label of the tile variant it picks (bf16 spelling)
 // true when launch_conv_gemm would run `a` on a kernel that honours rowpart_out (fast / wp, 32x32 tiles)
@@ -355,6 +356,7 @@ hipError_t launch_gn_silu_bwd(const float *x, const float *da, const float *gamm
 int64_t gn_silu_bwd_ws_floats(int B, int L, int C, int G);
 hipError_t launch_gn_silu_recompute(const float *x, const float *gamma, const float *beta, int B, int L, int C, int G, float eps, float *act,
                                     float *ws, hipStream_t s);
+hipError_t launch_gn_bwd_stats(const float *x, int B, int L, int C, int G, float *ws, hipStream_t s);
 
 // backward of y = LayerNorm_C(x; eps) * (1 + ss[b][c]) + ss[b][C + c] (ss == nullptr: plain normalisation): dx and, when dss != nullptr,
 // dss (B, 2C) = [dscale | dshift];  dss_part: [B][ln_mod_bwd_chunks(L)][2C] scratch

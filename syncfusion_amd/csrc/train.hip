@@ -877,6 +877,16 @@ hipError_t launch_gn_silu_recompute(const float *x, const float *gamma, const fl
   return hipGetLastError();
 }
 
+// the statistics launch_gn_silu_bwd reads, alone (the forward pass kept SiLU(GroupNorm(x)) itself); nothing to do where its per-group kernel
+// recomputes them
+hipError_t launch_gn_bwd_stats(const float *x, int B, int L, int C, int G, float *ws, hipStream_t s) {
+  if (G < 1 || C % G) return hipErrorInvalidValue;
+  if (!gn_bwd_chunked_ok(C, G)) return hipSuccess;
+  int nch, chunk_rows;
+  gn_bwd_plan(L, C, nch, chunk_rows);
+  return launch_gn_stats(F32, x, C, B, L, C, G, nch, chunk_rows, ws, s);
+}
+
 hipError_t launch_gn_silu_bwd(const float *x, const float *da, const float *gamma, const float *beta, int B, int L, int C, int G, float eps,
                               float *dx, float *ws /* statistics already there (launch_gn_silu_recompute) */, float *dgb /* [2C] = dgamma | dbeta */,
                               hipStream_t s) {

@@ -78,6 +78,9 @@ def _conv_case(cuda, dtype, B, L, C, N, taps, stride, pad, up, groups, residual,
     (8, 5632, 64, 128, 3, 1, 1, 1, 0, True),    # long activation: macro-tile kernel (16-bit types), 176 tiles of 256x128, residual
     (9, 5000, 128, 320, 1, 1, 0, 1, 0, False),  # macro tiles with ragged M (45000 rows) and a partial column tile (320 = 2.5 x 128)
     (8, 2816, 64, 64, 3, 1, 1, 2, 0, True),     # macro tiles reading a nearest-upsampled source, half-empty column tile
+    (4, 4096, 128, 128, 3, 1, 1, 1, 0, True),   # the training step's depth-3 conv: fp32 goes to the macro tiles too (128x64, 256 tiles), residual
+    (3, 3000, 256, 192, 1, 1, 0, 1, 0, False),  # fp32 macro tiles: ragged M (9000 rows), K = 256 (8 fp32 K steps), 192 columns
+    (8, 8192, 128, 128, 3, 1, 1, 1, 0, False),  # fp32 macro tiles, the 128x128 two-slot variant (512 tiles)
 ])
 def test_conv_gemm(cuda, dtype, shape):
     assert _conv_case(cuda, dtype, *shape) < TOL[dtype]
