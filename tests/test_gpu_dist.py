@@ -58,7 +58,8 @@ def _worker(rank: int, world: int, port: int, q):
 
         model = _build(seed_weights=100 + rank)            # ranks start with DIFFERENT weights: the broadcast must fix that
         moved = broadcast_module(model, src=0)
-        out = _shard_sample(model, rank, world)
+        with torch.no_grad():   # as the reference's generation path runs (main/generation.py:11) and as conftest runs the parent's half
+            out = _shard_sample(model, rank, world)
         full = gather_clips(out, B_TOTAL, dst=0)
         q.put((rank, moved, None if full is None else full.cpu()))
     finally:
