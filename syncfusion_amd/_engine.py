@@ -10,8 +10,47 @@ from . import _lib
 from ._lib import SF_MAX_DEPTH, EncoderConfig, UnetConfig, check
 
 
-def _params_version(module: torch.nn.Module) -> Tuple:
-    return tuple((p.data_ptr(), p._version) for p in list(module.parameters()) + list(module.buffers()))
+# Staleness of the packed weights.  Walking a 215 M-parameter U-Net's module tree for its 842 tensors costs 1.6 ms of host time -- 4 % of a
+# 20-step sample() call -- so the walk happens only when the module STRUCTURE may have changed: torch's global registration hooks (a new
+# Parameter / buffer / submodule anywhere) bump an epoch.  In between, a call compares (data_ptr, _version) of the tensors found by the
+# last walk: 0.14 ms.  In-place updates (optimizer steps, load_state_dict) bump `_version`; `.to()` / `.cuda()` go through `_apply`.
+_STRUCT_EPOCH = [0]
+
+
+def _bump_epoch(*_args) -> None:
+    _STRUCT_EPOCH[0] += 1
+
+
+torch.nn.modules.module.register_module_parameter_registration_hook(_bump_epoch)
+torch.nn.modules.module.register_module_buffer_registration_hook(_bump_epoch)
+torch.nn.modules.module.register_module_module_registration_hook(_bump_epoch)
+
+
+class _ParamsVersion:
+    """(data_ptr, _version) of every parameter and buffer of a module, re-walked only after a structural change."""
+
+    def __init__(self, module: torch.nn.Module):
+        self._walk(module)
+        self.value = self._read()
+
+    def _walk(self, module: torch.nn.Module) -> None:
+        self.epoch = _STRUCT_EPOCH[0]
+        self.tensors = list(module.parameters()) + list(module.buffers())
+
+    def _read(self) -> Tuple:
+        return tuple((p.data_ptr(), p._version) for p in self.tensors)
+
+    def changed(self, module: torch.nn.Module) -> bool:
+        if self.epoch != _STRUCT_EPOCH[0]:
+            old = self.tensors
+            self._walk(module)
+            if len(old) != len(self.tensors) or any(a is not b for a, b in zip(old, self.tensors)):
+                return True
+        return self._read() != self.value
+
+
+def _params_version(module: torch.nn.Module) -> "_ParamsVersion":
+    return _ParamsVersion(module)
 
 
 def _fill(arr, values: Sequence[int]) -> None:
@@ -81,7 +120,7 @@ class UNetEngine(_Base):
         check(self.lib.sf_unet_set_branches(self.handle, int(n)), "sf_unet_set_branches")
 
     def stale(self, net: torch.nn.Module, dtype: str) -> bool:
-        return dtype != self.dtype or _params_version(net) != self.version
+        return dtype != self.dtype or self.version.changed(net)
 
     # -- helpers -------------------------------------------------------------------------------
     def _check_inputs(self, x, channels, embedding):
@@ -218,7 +257,7 @@ class EncoderEngine(_Base):
         self.handle = h.value
 
     def stale(self, enc: torch.nn.Module) -> bool:
-        return _params_version(enc) != self.version
+        return self.version.changed(enc)
 
     def forward(self, y: torch.Tensor) -> List[torch.Tensor]:
         _lib.require_gpu_tensor(y, "Encoder1d.forward")
@@ -264,7 +303,7 @@ class OnsetNetEngine(_Base):
         self.handle = h.value
 
     def stale(self, net: torch.nn.Module) -> bool:
-        return _params_version(net) != self.version or getattr(net, "compute_dtype", self.dtype) != self.dtype
+        return self.version.changed(net) or getattr(net, "compute_dtype", self.dtype) != self.dtype
 
     def forward(self, x: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
         N, _, T, H, W = x.shape
