@@ -241,6 +241,14 @@ hipError_t launch_attention(int dt, const void *q, int ldq, const void *kv, int 
 // Element-wise / layout helpers
 // ---------------------------------------------------------------------------------------
 // channels-first fp32 (B, C, L) -> channels-last DT (B*L, ld) with zero padding of columns [C, ld)
+// every cross-attention output projection of a call in one launch (misc.hip): out[b][out_off + n] = sum_k w[n][k] v_all[b][v_off + k] + bias[n]
+struct CrossOutItem {
+  const void *w;       // [N][ldw] in the compute type
+  const float *bias;   // [N] or null
+  int N, ldw, v_off, out_off;
+};
+hipError_t launch_cross_out_grouped(int dt, const CrossOutItem *items, const int2 *blocks /* (item, first column) per workgroup */, int nblocks,
+                                    const void *v_all, int ldv, int Bt, int hd, float *out, int out_ld, hipStream_t s);
 hipError_t launch_cf_to_cl(int dt, const float *x, int B, int C, int L, void *out, int ld, hipStream_t s);
 // channels-last DT (B*L, ld) -> channels-first fp32 (B, C, L)
 hipError_t launch_cl_to_cf(int dt, const void *x, int ld, int B, int C, int L, float *out, hipStream_t s);

@@ -22,6 +22,26 @@ __global__ void cf_to_cl_kernel(const float *__restrict__ x, int B, int C, int L
       out[i * ld + c] = from_f<T>(c < C ? x[(b * C + c) * L + l] : 0.f);
   }
 }
+// the same with one thread per (clip, 8-channel group, position): the loop above is serial over ld channels with 2-byte stores, and the deep
+// context tensors (256 channels x 44 positions) left it 352 threads -- 53 us per launch, 0.43 ms of every sample() call.  Consecutive
+// lanes take consecutive positions (coalesced fp32 reads per channel), each writes one 16-byte vector.
+template <typename T>
+__global__ void cf_to_cl_vec_kernel(const float *__restrict__ x, int B, int C, int L, T *__restrict__ out, int ld) {
+  constexpr int VN = Vec16<T>::N;
+  const int ng = ld / VN;
+  SF_GRID_STRIDE(i, (int64_t)B * ng * L) {
+    const int64_t l = i % L, r = i / L;
+    const int g = (int)(r % ng);
+    const int64_t b = r / ng;
+    Vec16<T> v;
+#pragma unroll
+    for (int j = 0; j < VN; ++j) {
+      const int c = g * VN + j;
+      v.set(j, c < C ? x[(b * C + c) * L + l] : 0.f);
+    }
+    st16<T>(out + (b * L + l) * ld + g * VN, v);
+  }
+}
 template <typename T>
 __global__ void cl_to_cf_kernel(const T *__restrict__ x, int ld, int B, int C, int L, float *__restrict__ out) {
   SF_GRID_STRIDE(i, (int64_t)B * L) {
@@ -176,7 +196,66 @@ __global__ void bn_fold_kernel(const float *g, const float *b, const float *m, c
 }  // namespace
 
 
+// All cross-attention output projections of a call in ONE launch (the collapse of CrossAttentionItem over a single context token:
+// out_i = W_out_i v_i + b_i per item i and clip; 34 launches of an 8-row GEMM each cost 0.3 ms of host + launch time per sample() call).
+// Block = one 64-column group of one item; 64 columns x 4 quarters of the 512-long reduction; v chunk of 8 clips in LDS (broadcast reads).
+template <typename T>
+__global__ __launch_bounds__(256) void cross_out_grouped_kernel(const CrossOutItem *__restrict__ items, const int2 *__restrict__ blocks, const T *__restrict__ v_all,
+                                                                int ldv, int Bt, int hd, float *__restrict__ out, int out_ld) {
+  __shared__ float vs[8 * 1024];
+  __shared__ float red[4][8][64];
+  const int2 blk = blocks[blockIdx.x];
+  const CrossOutItem it = items[blk.x];
+  const int c = threadIdx.x & 63, kq = threadIdx.x >> 6, n = blk.y + c;
+  const bool valid = n < it.N;
+  const int kspan = hd >> 2;
+  const T *wrow = static_cast<const T *>(it.w) + (size_t)(valid ? n : 0) * it.ldw + kq * kspan;
+  for (int b0 = 0; b0 < Bt; b0 += 8) {
+    for (int e = threadIdx.x; e < 8 * hd; e += 256) {
+      const int b = e / hd, k = e - b * hd;
+      vs[b * hd + k] = (b0 + b < Bt) ? to_f(v_all[(size_t)(b0 + b) * ldv + it.v_off + k]) : 0.f;
+    }
+    __syncthreads();
+    float acc[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[b] = 0.f;
+    constexpr int VN = Vec16<T>::N;   // 16-byte weight loads (hd % 32 == 0: a quarter is whole vectors, 16-byte aligned)
+    for (int k = 0; k < kspan; k += VN) {
+      const Vec16<T> wv = ld16<T>(wrow + k);
+#pragma unroll
+      for (int j = 0; j < VN; ++j) {
+        const float w = wv.get(j);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[b] = fmaf(w, vs[b * hd + kq * kspan + k + j], acc[b]);
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < 8; ++b) red[kq][b][c] = acc[b];
+    __syncthreads();
+    if (kq == 0 && valid) {
+      const float bi = it.bias ? it.bias[n] : 0.f;
+#pragma unroll
+      for (int b = 0; b < 8; ++b)
+        if (b0 + b < Bt) out[(size_t)(b0 + b) * out_ld + it.out_off + n] = ((red[0][b][c] + red[1][b][c]) + (red[2][b][c] + red[3][b][c])) + bi;
+    }
+    __syncthreads();
+  }
+}
+
+hipError_t launch_cross_out_grouped(int dt, const CrossOutItem *items, const int2 *blocks, int nblocks, const void *v_all, int ldv, int Bt, int hd, float *out,
+                                    int out_ld, hipStream_t s) {
+  if (nblocks < 1 || hd > 1024 || (hd % 32) || Bt < 1) return hipErrorInvalidValue;
+  SF_DISPATCH_STMT(dt, hipLaunchKernelGGL((cross_out_grouped_kernel<T>), dim3(nblocks), dim3(256), 0, s, items, blocks, (const T *)v_all, ldv, Bt, hd, out, out_ld));
+  return hipGetLastError();
+}
+
 hipError_t launch_cf_to_cl(int dt, const float *x, int B, int C, int L, void *out, int ld, hipStream_t s) {
+  const int vn = dt == F32 ? 4 : 8;
+  if (ld % vn == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+    dim3 g = grid_for((int64_t)B * (ld / vn) * L);
+    SF_DISPATCH_STMT(dt, hipLaunchKernelGGL((cf_to_cl_vec_kernel<T>), g, dim3(TPB), 0, s, x, B, C, L, (T *)out, ld));
+    return hipGetLastError();
+  }
   dim3 g = grid_for((int64_t)B * L);
   SF_DISPATCH_STMT(dt, hipLaunchKernelGGL((cf_to_cl_kernel<T>), g, dim3(TPB), 0, s, x, B, C, L, (T *)out, ld));
   return hipGetLastError();

@@ -92,6 +92,9 @@ struct sf_unet {
   ConvW lin0, mlp0, mlp1, mod, wv_cat;
   int mod_cols = 0, mod_ld = 0, ca_cols = 0, ca_ld = 0, n_ca = 0;
   float *fixed_emb = nullptr;
+  CrossOutItem *ca_items = nullptr;   // every cross-attention output projection, for the one-launch collapse (misc.hip)
+  int2 *ca_blocks = nullptr;
+  int ca_nblocks = 0;
   std::vector<Block> blocks;
   DebugTaps dbg;
   int launches = 0;
@@ -516,6 +519,32 @@ void build(sf_unet &u, const WeightMap *wm, hipStream_t s) {
           SF_HIP(hipMemcpyAsync(u.mod.bias + items[j].mod_off, bi, 2 * b.C * sizeof(float), hipMemcpyDeviceToDevice, s));
         }
       }
+    }
+  }
+  if (!u.listing && u.n_ca > 0 && !getenv("SF_NO_CA_GROUPED")) {   // table of the per-item projections (conditioning() runs them as one launch)
+    std::vector<CrossOutItem> items;
+    std::vector<int2> blks;
+    for (int d = 0; d < c.n_layers; ++d)
+      for (int pass = 0; pass < 2; ++pass)
+        for (const Group &g : (pass == 0 ? u.blocks[d].down_items : u.blocks[d].up_items)) {
+          if (!g.cross || g.cross_out.direct || !g.cross_out.w) continue;
+          CrossOutItem it;
+          it.w = g.cross_out.w;
+          it.bias = g.cross_out.bias;
+          it.N = g.cross_out.N;
+          it.ldw = g.cross_out.K;
+          it.v_off = g.ca_idx * u.hd;
+          it.out_off = g.ca_off;
+          for (int c0 = 0; c0 < it.N; c0 += 64) blks.push_back(make_int2((int)items.size(), c0));
+          items.push_back(it);
+        }
+    if ((int)items.size() == u.n_ca && u.hd <= 1024 && (u.hd % 32) == 0) {
+      u.ca_items = static_cast<CrossOutItem *>(u.arena.alloc((int64_t)items.size() * sizeof(CrossOutItem)));
+      u.ca_blocks = static_cast<int2 *>(u.arena.alloc((int64_t)blks.size() * sizeof(int2)));
+      SF_HIP(hipMemcpyAsync(u.ca_items, items.data(), items.size() * sizeof(CrossOutItem), hipMemcpyHostToDevice, s));
+      SF_HIP(hipMemcpyAsync(u.ca_blocks, blks.data(), blks.size() * sizeof(int2), hipMemcpyHostToDevice, s));
+      SF_HIP(hipStreamSynchronize(s));   // the host vectors die here
+      u.ca_nblocks = (int)blks.size();
     }
   }
   if (!u.listing) SF_HIP(hipStreamSynchronize(s));
@@ -1451,6 +1480,11 @@ struct Exec {
     SF_HIP(launch_pack_rows(u.dt, p.emb2, p.Bt, E, E, nullptr, p.emb_t, E, s));
     SF_HIP(launch_ln_modulate(u.dt, p.emb_t, E, nullptr, 0, 1e-5f, p.Bt, 1, E, p.xhat_e, E, s));
     dense(u.wv_cat, p.xhat_e, E, p.Bt, p.v_all, u.n_ca * u.hd, 0, false);
+    if (u.ca_nblocks > 0) {   // all per-item output projections in one launch
+      SF_HIP(launch_cross_out_grouped(u.dt, u.ca_items, u.ca_blocks, u.ca_nblocks, p.v_all, u.n_ca * u.hd, p.Bt, u.hd, p.ca_all, u.ca_ld, s));
+      ++u.launches;
+      return;
+    }
     for (int d = 0; d < c.n_layers; ++d) {
       const Block &b = u.blocks[d];
       for (int pass = 0; pass < 2; ++pass)
