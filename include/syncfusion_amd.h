@@ -237,10 +237,15 @@ int64_t sf_op_conv1d_bwd_workspace_bytes(int B, int L, int C, int N, int taps, i
 int sf_op_conv1d_bwd_cl(const float *x, const float *w, const float *gamma, const float *beta, int groups, float eps, const float *dy,
                         int B, int L, int C, int N, int taps, int pad, float *dx, float *dw, float *db, float *dgb, void *ws,
                         int64_t ws_bytes, void *stream);
-/* The same with act = silu(groupnorm(x)) (B,L,C) kept by the forward pass (groups > 0): nothing is recomputed but the GroupNorm statistics. */
-int sf_op_conv1d_bwd_cl_act(const float *x, const float *act, const float *w, const float *gamma, const float *beta, int groups, float eps,
-                            const float *dy, int B, int L, int C, int N, int taps, int pad, float *dx, float *dw, float *db, float *dgb, void *ws,
-                            int64_t ws_bytes, void *stream);
+/* The training forward of the GroupNorm convolutions keeps a = silu(groupnorm(x)) and the chunk statistics the GroupNorm backward reads:
+ *   sf_op_gn_silu_train: act:(B,L,C) fp32, stats: sf_op_gn_silu_train_stats_floats() floats (0: none are kept for this shape, stats may be NULL);
+ *   sf_op_conv1d_bwd_cl_act = sf_op_conv1d_bwd_cl with act (and optionally stats) handed in: nothing is recomputed. */
+int64_t sf_op_gn_silu_train_stats_floats(int B, int L, int C, int groups);
+int sf_op_gn_silu_train(const float *x, const float *gamma, const float *beta, int groups, float eps, int B, int L, int C, float *act, float *stats,
+                        void *stream);
+int sf_op_conv1d_bwd_cl_act(const float *x, const float *act, const float *stats /* or NULL */, const float *w, const float *gamma, const float *beta,
+                            int groups, float eps, const float *dy, int B, int L, int C, int N, int taps, int pad, float *dx, float *dw, float *db,
+                            float *dgb, void *ws, int64_t ws_bytes, void *stream);
 /* Length reductions of the training composition (fp32, channels-last): out[b][c] = sum_l x[b][l][c] * (y ? y[b][l][c] : 1) -- the
  * gradient of a per-clip broadcast add (cross-attention over one context token) and of the SkipModulate scale
  * (a-unet SkipModulate: x + scale[:, None, :] * h).  Two deterministic stages, no atomics.

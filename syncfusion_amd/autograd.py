@@ -86,12 +86,15 @@ class _ConvBlockFn(torch.autograd.Function):
             # MFMA-path GroupNorm convolutions: a = silu(groupnorm(x)) is materialised once and KEPT for the backward pass, and the convolution
             # itself runs as a plain GEMM (macro tiles on the wide levels) -- the fused-prologue kernel was the slowest forward GEMM of the
             # step and the backward pass recomputed a for the weight gradient (SF_TRAIN_FUSED_GN=1: the former path).
-            act = None
+            act, stats = None, None
             if groups > 0 and Cc % 32 == 0 and not _FUSED_GN:
                 act = torch.empty_like(x_cl)
-                ws_gn = torch.empty(B * 32 * groups * 2 + 64, dtype=torch.float32, device=x.device)
-                _lib.check(lib.sf_op_gn_silu(_lib.SF_F32, x_cl.data_ptr(), g.data_ptr(), be.data_ptr(), int(groups), float(eps), B, L, Cc, act.data_ptr(),
-                                             ws_gn.data_ptr(), ws_gn.numel() * 4, _lib.stream_ptr(x.device)), "sf_op_gn_silu")
+                nst = int(lib.sf_op_gn_silu_train_stats_floats(B, L, Cc, int(groups)))
+                if nst < 0:
+                    raise _lib.SyncFusionAmdError(lib.sf_last_error().decode())
+                stats = torch.empty(nst, dtype=torch.float32, device=x.device)   # the chunk statistics the GroupNorm backward reads (may be empty)
+                _lib.check(lib.sf_op_gn_silu_train(x_cl.data_ptr(), g.data_ptr(), be.data_ptr(), int(groups), float(eps), B, L, Cc, act.data_ptr(),
+                                                   stats.data_ptr() if nst > 0 else None, _lib.stream_ptr(x.device)), "sf_op_gn_silu_train")
             src, gr = (act, 0) if act is not None else (x_cl, int(groups))
             _lib.check(lib.sf_op_conv1d_cl(_lib.SF_F32, src.data_ptr(), w.data_ptr(), b.data_ptr() if b is not None else None,
                                            g.data_ptr() if gr > 0 else None, be.data_ptr() if gr > 0 else None, gr, float(eps),
@@ -99,7 +102,7 @@ class _ConvBlockFn(torch.autograd.Function):
                                            ws.numel(), _lib.stream_ptr(x.device)),
                        "sf_op_conv1d_cl")
         ctx.save_for_backward(x_cl, w, g if g is not None else x_cl.new_empty(0), be if be is not None else x_cl.new_empty(0),
-                              act if act is not None else x_cl.new_empty(0))
+                              act if act is not None else x_cl.new_empty(0), stats if stats is not None else x_cl.new_empty(0))
         ctx.meta = (B, L, Cc, N, taps, pad, int(groups), float(eps), bias is not None, c_real, n_real, bool(channels_last))
         if n_real != N:
             out = out[:, :, :n_real]
@@ -110,7 +113,7 @@ class _ConvBlockFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy: Tensor):
         lib = _lib.load()
-        x_cl, w, g, be, act = ctx.saved_tensors
+        x_cl, w, g, be, act, stats = ctx.saved_tensors
         B, L, Cc, N, taps, pad, groups, eps, has_bias, c_real, n_real, channels_last = ctx.meta
         dev = x_cl.device
         with torch.cuda.device(dev):
@@ -134,7 +137,8 @@ class _ConvBlockFn(torch.autograd.Function):
                     ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev))
             gp, bp = (g.data_ptr() if groups > 0 else None), (be.data_ptr() if groups > 0 else None)
             if groups > 0 and act.numel() > 0:
-                _lib.check(lib.sf_op_conv1d_bwd_cl_act(x_cl.data_ptr(), act.data_ptr(), w.data_ptr(), gp, bp, *tail), "sf_op_conv1d_bwd_cl_act")
+                _lib.check(lib.sf_op_conv1d_bwd_cl_act(x_cl.data_ptr(), act.data_ptr(), stats.data_ptr() if stats.numel() > 0 else None, w.data_ptr(), gp, bp,
+                                                       *tail), "sf_op_conv1d_bwd_cl_act")
             else:
                 _lib.check(lib.sf_op_conv1d_bwd_cl(x_cl.data_ptr(), w.data_ptr(), gp, bp, *tail), "sf_op_conv1d_bwd_cl")
         if c_real != Cc:

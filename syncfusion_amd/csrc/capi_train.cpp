@@ -55,7 +55,7 @@ int64_t sf_op_conv1d_bwd_workspace_bytes(int B, int L, int C, int N, int taps, i
   }
 }
 
-static int conv1d_bwd_impl(const float *x, const float *act_saved, const float *w, const float *gamma, const float *beta, int groups, float eps, const float *dy, int B, int L,
+static int conv1d_bwd_impl(const float *x, const float *act_saved, const float *stats_saved, const float *w, const float *gamma, const float *beta, int groups, float eps, const float *dy, int B, int L,
                         int C, int N, int taps, int pad, float *dx, float *dw, float *db, float *dgb, void *ws, int64_t ws_bytes, void *stream) {
   SF_API_BEGIN
   if (!x || !w || !dy || !ws) fail(SF_ERR_INVALID, "null argument");
@@ -66,8 +66,8 @@ static int conv1d_bwd_impl(const float *x, const float *act_saved, const float *
   Workspace wk(ws, ws_bytes);
   BwdPlan p = plan(wk, B, L, C, N, taps, groups);
   const float *act = x;
-  if (groups > 0 && act_saved) {   // a = SiLU(GroupNorm(x)) kept by the forward pass: only the statistics the GroupNorm backward reads
-    SF_HIP(launch_gn_bwd_stats(x, B, L, C, groups, p.gpart, s));
+  if (groups > 0 && act_saved) {   // a = SiLU(GroupNorm(x)) kept by the forward pass; its chunk statistics too (else recomputed here)
+    if (!stats_saved) SF_HIP(launch_gn_bwd_stats(x, B, L, C, groups, p.gpart, s));
     act = act_saved;
   } else if (groups > 0) {         // recompute a
     SF_HIP(launch_gn_silu_recompute(x, gamma, beta, B, L, C, groups, eps, p.act, p.gpart, s));
@@ -102,24 +102,40 @@ static int conv1d_bwd_impl(const float *x, const float *act_saved, const float *
   if (dw) SF_HIP(launch_conv_wgrad(dy, act, B, L, C, N, taps, pad, p.wpart, p.S, dw, s));
   if (db) SF_HIP(launch_col_sums(dy, (int64_t)B * L, N, p.bpart, p.Sb, db, s));
   // ---- GroupNorm + SiLU ----------------------------------------------------------------------------------------------
-  if (groups > 0) SF_HIP(launch_gn_silu_bwd(x, p.da, gamma, beta, B, L, C, groups, eps, dx, p.gpart, dgb, s));
+  if (groups > 0) SF_HIP(launch_gn_silu_bwd(x, p.da, gamma, beta, B, L, C, groups, eps, dx, p.gpart, dgb, s, act_saved ? stats_saved : nullptr));
   return SF_OK;
   SF_API_END
 }
 
 int sf_op_conv1d_bwd_cl(const float *x, const float *w, const float *gamma, const float *beta, int groups, float eps, const float *dy, int B, int L,
                         int C, int N, int taps, int pad, float *dx, float *dw, float *db, float *dgb, void *ws, int64_t ws_bytes, void *stream) {
-  return conv1d_bwd_impl(x, nullptr, w, gamma, beta, groups, eps, dy, B, L, C, N, taps, pad, dx, dw, db, dgb, ws, ws_bytes, stream);
+  return conv1d_bwd_impl(x, nullptr, nullptr, w, gamma, beta, groups, eps, dy, B, L, C, N, taps, pad, dx, dw, db, dgb, ws, ws_bytes, stream);
 }
 
-int sf_op_conv1d_bwd_cl_act(const float *x, const float *act, const float *w, const float *gamma, const float *beta, int groups, float eps,
-                            const float *dy, int B, int L, int C, int N, int taps, int pad, float *dx, float *dw, float *db, float *dgb, void *ws,
-                            int64_t ws_bytes, void *stream) {
+int sf_op_conv1d_bwd_cl_act(const float *x, const float *act, const float *stats, const float *w, const float *gamma, const float *beta, int groups,
+                            float eps, const float *dy, int B, int L, int C, int N, int taps, int pad, float *dx, float *dw, float *db, float *dgb,
+                            void *ws, int64_t ws_bytes, void *stream) {
   if (groups > 0 && !act) {
     set_error("sf_op_conv1d_bwd_cl_act: act is null");
     return SF_ERR_INVALID;
   }
-  return conv1d_bwd_impl(x, act, w, gamma, beta, groups, eps, dy, B, L, C, N, taps, pad, dx, dw, db, dgb, ws, ws_bytes, stream);
+  return conv1d_bwd_impl(x, act, stats, w, gamma, beta, groups, eps, dy, B, L, C, N, taps, pad, dx, dw, db, dgb, ws, ws_bytes, stream);
+}
+
+int64_t sf_op_gn_silu_train_stats_floats(int B, int L, int C, int groups) {
+  if (B < 1 || L < 1 || C < 1 || groups < 1 || C % groups) return -1;
+  return gn_bwd_stats_floats(B, L, C, groups);
+}
+
+int sf_op_gn_silu_train(const float *x, const float *gamma, const float *beta, int groups, float eps, int B, int L, int C, float *act, float *stats,
+                        void *stream) {
+  SF_API_BEGIN
+  if (!x || !gamma || !beta || !act) fail(SF_ERR_INVALID, "null argument");
+  if (groups < 1 || C % groups) fail(SF_ERR_INVALID, "channels must be divisible by groups");
+  if (gn_bwd_stats_floats(B, L, C, groups) > 0 && !stats) fail(SF_ERR_INVALID, "stats is null");
+  SF_HIP(launch_gn_silu_recompute(x, gamma, beta, B, L, C, groups, eps, act, stats, static_cast<hipStream_t>(stream)));
+  return SF_OK;
+  SF_API_END
 }
 
 int64_t sf_op_length_sums_workspace_bytes(int B, int L, int C) {

@@ -360,7 +360,8 @@ bool length_sums_ok(int C);
 hipError_t launch_length_sums(const float *x, const float *y, int B, int L, int C, float *part, float *out, hipStream_t s);
 // backward of a = SiLU(GroupNorm_G(x; gamma, beta, eps)): dx, and dgb = [dgamma | dbeta]  (dgb_part: [B][2][C] scratch)
 hipError_t launch_gn_silu_bwd(const float *x, const float *da, const float *gamma, const float *beta, int B, int L, int C, int G, float eps,
-                              float *dx, float *dgb_part, float *dgb, hipStream_t s);
+                              float *dx, float *dgb_part, float *dgb, hipStream_t s, const float *slab_in = nullptr);
+int64_t gn_bwd_stats_floats(int B, int L, int C, int G);
 int64_t gn_silu_bwd_ws_floats(int B, int L, int C, int G);
 hipError_t launch_gn_silu_recompute(const float *x, const float *gamma, const float *beta, int B, int L, int C, int G, float eps, float *act,
                                     float *ws, hipStream_t s);

@@ -887,14 +887,22 @@ hipError_t launch_gn_bwd_stats(const float *x, int B, int L, int C, int G, float
   return launch_gn_stats(F32, x, C, B, L, C, G, nch, chunk_rows, ws, s);
 }
 
+int64_t gn_bwd_stats_floats(int B, int L, int C, int G) {   // size of the chunk statistics alone (0: the per-group kernels keep none)
+  if (G < 1 || C % G || !gn_bwd_chunked_ok(C, G)) return 0;
+  int nch, rows;
+  gn_bwd_plan(L, C, nch, rows);
+  return (int64_t)B * nch * G * 2;
+}
+
 hipError_t launch_gn_silu_bwd(const float *x, const float *da, const float *gamma, const float *beta, int B, int L, int C, int G, float eps,
                               float *dx, float *ws /* statistics already there (launch_gn_silu_recompute) */, float *dgb /* [2C] = dgamma | dbeta */,
-                              hipStream_t s) {
+                              hipStream_t s, const float *slab_in /* the statistics kept by the forward pass instead of those in ws */) {
   if (G < 1 || C % G) return hipErrorInvalidValue;
   if (gn_bwd_chunked_ok(C, G)) {
     int nch, chunk_rows;
     gn_bwd_plan(L, C, nch, chunk_rows);
-    float *slab = ws, *dgb_part = slab + (size_t)B * nch * G * 2, *s12 = dgb_part + (size_t)B * nch * 2 * C;
+    float *dgb_part = ws + (size_t)B * nch * G * 2, *s12 = dgb_part + (size_t)B * nch * 2 * C;
+    const float *slab = slab_in ? slab_in : ws;
     if (gn_bwd_vec(C, G) == 4) {
       hipLaunchKernelGGL(gn_bwd_part_kernel<4>, dim3(nch, B), dim3(256), 0, s, x, da, gamma, beta, slab, L, C, G, nch, chunk_rows, eps, dgb_part, s12);
       hipLaunchKernelGGL(gn_bwd_dx_kernel<4>, dim3(nch, B), dim3(256), 0, s, x, da, gamma, beta, slab, s12, L, C, G, nch, chunk_rows, eps, dx);
