@@ -198,6 +198,8 @@ class _LnModulateFn(torch.autograd.Function):
         with torch.cuda.device(x.device):
             xc = _lib.f32c(x)
             sc = _lib.f32c(ss) if ss is not None else None
+            if sc is not None and sc.data_ptr() % 16:   # a view into a wider buffer (one Linear for every Modulation): the kernel reads 16-byte vectors
+                sc = sc.clone()
             out = torch.empty_like(xc)
             _lib.check(lib.sf_op_ln_modulate(_lib.SF_F32, xc.data_ptr(), sc.data_ptr() if sc is not None else None, float(eps), B, L, Cc, out.data_ptr(),
                                              _lib.stream_ptr(x.device)), "sf_op_ln_modulate")

@@ -736,7 +736,11 @@ int conv_wgrad_splits(int64_t rows, int C, int N, int taps) {
   const int fam = wgrad_family(C, N, taps), Q = taps * C;
   const int T = fam ? 64 * fam : 32;
   const int64_t tiles = (int64_t)((N + T - 1) / T) * ((Q + T - 1) / T);
-  int64_t S = std::max<int64_t>(1, (fam ? 512 : 2048) / std::max<int64_t>(tiles, 1));
+  static const int64_t target = [] {   // tuning hook: workgroups per launch the row splits aim at (LDS-staged families)
+    const char *e = getenv("SF_WGRAD_TARGET");
+    return e ? (int64_t)atol(e) : 512;
+  }();
+  int64_t S = std::max<int64_t>(1, (fam ? target : 2048) / std::max<int64_t>(tiles, 1));
   S = std::min<int64_t>(S, std::max<int64_t>(1, rows / 256));
   return (int)std::min<int64_t>(S, 512);   // >= 2 workgroups per CU; more splits only lengthen the reduction
 }
