@@ -109,7 +109,6 @@ __global__ __launch_bounds__(256, 2) void conv_sp_kernel(const T *__restrict__ i
     orow[j] = (h0 + qy) * W + (w0 + qx);
   }
   auto flush = [&](int f) {
-    if (relu & 2) return;   // (timing experiment without the stores)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int mm = (tid >> 2) + 64 * j;

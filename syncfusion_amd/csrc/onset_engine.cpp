@@ -125,8 +125,7 @@ struct OnsetExec {
   void conv(const Conv3 &c, const void *in, int Hi, int Wi, void *out, int &Ho, int &Wo, const void *res, bool relu) {
     out_hw(Hi, Wi, c, Ho, Wo);
     if (c.wsp && !res) {   // layer-1 spatial convolution: frame walk, register-stationary weights, one halo tile per frame
-      static const int dbg = getenv("SF_SP_NOSTORE") ? 2 : 0;   // timing experiment only (wrong results)
-      SF_HIP(launch_conv_sp(o.dt, in, c.cin_ld, c.wsp, c.w.bias, c.cout, out, c.cout_ld, p.N, p.T, Hi, Wi, (relu ? 1 : 0) | dbg, s));
+      SF_HIP(launch_conv_sp(o.dt, in, c.cin_ld, c.wsp, c.w.bias, c.cout, out, c.cout_ld, p.N, p.T, Hi, Wi, relu ? 1 : 0, s));
       return;
     }
     if (c.wtw) {   // wide-spatial temporal convolution: frame walk with a three-frame LDS ring (each mid row fetched once, not three times)
@@ -163,6 +162,26 @@ struct OnsetExec {
     a.res_ld = c.cout_ld;
     a.act = relu ? 1 : 0;
     a.Lout = a.Lsrc = 1;
+    // Column counts that neither 128- nor 192-wide macro tiles cover well (layer 2's 288 mid channels in 320-channel rows: 384 computed
+    // columns either way, 25 % of the launch on padding): whole 192-wide tiles first, the remaining <= 128 columns as a second launch
+    // (192 + 128 = 320 computed columns).  692 -> ~600 us per convolution at 32 clips.
+    static const bool no_split = getenv("SF_ONSET_NO_NSPLIT") != nullptr;   // A/B aid
+    const int q192 = c.cout / 192, rest = c.cout_ld - 192 * q192;
+    const int cols_now = std::min((c.cout_ld + 127) / 128 * 128, (c.cout_ld + 191) / 192 * 192);
+    if (!no_split && o.dt != F32 && q192 >= 1 && rest > 0 && rest <= 128 && c.cout > 192 * q192 && 192 * q192 + 128 < cols_now) {
+      const size_t es = dsize(o.dt);
+      ConvGemmArgs a1 = a, a2 = a;
+      a1.N = a1.n_store = 192 * q192;
+      a2.N = c.cout - 192 * q192;
+      a2.n_store = rest;
+      a2.w = static_cast<const char *>(a.w) + (size_t)192 * q192 * a.K * es;
+      a2.bias = a.bias ? a.bias + 192 * q192 : nullptr;
+      a2.out = static_cast<char *>(out) + (size_t)192 * q192 * es;
+      a2.res = res ? static_cast<const char *>(res) + (size_t)192 * q192 * es : nullptr;
+      SF_HIP(launch_conv_gemm(o.dt, a1, s));
+      SF_HIP(launch_conv_gemm(o.dt, a2, s));
+      return;
+    }
     SF_HIP(launch_conv_gemm(o.dt, a, s));
   }
 };
