@@ -249,7 +249,7 @@ int sf_op_conv1d_bwd_cl_act(const float *x, const float *act, const float *stats
 /* Length reductions of the training composition (fp32, channels-last): out[b][c] = sum_l x[b][l][c] * (y ? y[b][l][c] : 1) -- the
  * gradient of a per-clip broadcast add (cross-attention over one context token) and of the SkipModulate scale
  * (a-unet SkipModulate: x + scale[:, None, :] * h).  Two deterministic stages, no atomics.
- * C: a multiple of 4 with C / 4 dividing 256, or a divisor of 256.  ws >= sf_op_length_sums_workspace_bytes. */
+ * Any C >= 1 (16-byte vector passes where C / 4 divides 256, one column per lane otherwise).  ws >= sf_op_length_sums_workspace_bytes. */
 int64_t sf_op_length_sums_workspace_bytes(int B, int L, int C);
 int sf_op_length_sums(const float *x, const float *y /* or NULL */, int B, int L, int C, float *out /* (B, C) */, void *ws, int64_t ws_bytes,
                       void *stream);

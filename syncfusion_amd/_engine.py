@@ -25,6 +25,18 @@ torch.nn.modules.module.register_module_parameter_registration_hook(_bump_epoch)
 torch.nn.modules.module.register_module_buffer_registration_hook(_bump_epoch)
 torch.nn.modules.module.register_module_module_registration_hook(_bump_epoch)
 
+# Module._apply (.to / .half / .cuda ...) replaces buffers with `self._buffers[k] = fn(buf)` and fires none of the hooks above
+_module_apply = torch.nn.Module._apply
+
+
+def _apply_and_bump(self, fn, *args, **kwargs):
+    _bump_epoch()
+    return _module_apply(self, fn, *args, **kwargs)
+
+
+torch.nn.Module._apply = _apply_and_bump
+_REWALK_EVERY = 16     # calls between unconditional re-walks: edits no hook sees (`del m.w`, direct _parameters / _buffers writes)
+
 
 class _ParamsVersion:
     """(data_ptr, _version) of every parameter and buffer of a module, re-walked only after a structural change."""
@@ -35,16 +47,19 @@ class _ParamsVersion:
 
     def _walk(self, module: torch.nn.Module) -> None:
         self.epoch = _STRUCT_EPOCH[0]
+        self.calls = 0
         self.tensors = list(module.parameters()) + list(module.buffers())
 
     def _read(self) -> Tuple:
         return tuple((p.data_ptr(), p._version) for p in self.tensors)
 
     def changed(self, module: torch.nn.Module) -> bool:
-        if self.epoch != _STRUCT_EPOCH[0]:
+        self.calls += 1
+        if self.epoch != _STRUCT_EPOCH[0] or self.calls >= _REWALK_EVERY:
             old = self.tensors
             self._walk(module)
             if len(old) != len(self.tensors) or any(a is not b for a, b in zip(old, self.tensors)):
+                self.tensors = []     # stale: the engine is rebuilt with a fresh version object; do not keep dead tensors alive
                 return True
         return self._read() != self.value
 
@@ -305,7 +320,7 @@ class OnsetNetEngine(_Base):
     def stale(self, net: torch.nn.Module) -> bool:
         return self.version.changed(net) or getattr(net, "compute_dtype", self.dtype) != self.dtype
 
-    def forward(self, x: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, taps: Optional[dict] = None, cap_floats: int = 1 << 27) -> torch.Tensor:
         N, _, T, H, W = x.shape
         with torch.cuda.device(self.device):
             xs = _lib.f32c(x)
@@ -316,7 +331,7 @@ class OnsetNetEngine(_Base):
             ws = self._workspace(n, self.device)
             buf = None
             if taps is not None:
-                buf = torch.empty(1 << 27, dtype=torch.float32, device=self.device)
+                buf = torch.empty(cap_floats, dtype=torch.float32, device=self.device)
                 check(self.lib.sf_onsetnet_debug_enable(self.handle, buf.data_ptr(), buf.numel()), "debug_enable")
             try:
                 check(self.lib.sf_onsetnet_forward(self.handle, xs.data_ptr(), N, T, H, W, out.data_ptr(), ws.data_ptr(), ws.numel(),

@@ -135,7 +135,8 @@ int sf_op_conv1d_cl(int dtype, const void *x, const float *w, const float *bias,
   const int wdt = direct ? F32 : dtype;
   const int K = taps * C;
   const void *wp = w;   // fp32 1x1 convolutions: the PyTorch layout (N, C, 1) IS the GEMM's [N][K] (60 % of the training step's convolutions)
-  if (!(taps == 1 && wdt == F32)) {
+  // (the kernels read weights as 16-byte vectors: a view at a storage offset that is not a multiple of 4 floats is packed like the rest)
+  if (!(taps == 1 && wdt == F32 && (reinterpret_cast<uintptr_t>(w) % 16) == 0)) {
     void *packed = wk.alloc((int64_t)N * K * dsize(wdt));
     SF_HIP(launch_pack_conv(wdt, w, N, C, 0, C, taps, C, nullptr, packed, K, 0, s));
     wp = packed;

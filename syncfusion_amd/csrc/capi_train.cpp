@@ -147,7 +147,6 @@ int sf_op_length_sums(const float *x, const float *y, int B, int L, int C, float
   SF_API_BEGIN
   if (!x || !out || !ws) fail(SF_ERR_INVALID, "null argument");
   if (B < 1 || L < 1 || C < 1) fail(SF_ERR_INVALID, "B, L and C must be positive");
-  if (!length_sums_ok(C)) fail(SF_ERR_UNSUPPORTED, "C must be a multiple of 4 with C / 4 dividing 256, or divide 256 (got %d)", C);
   const int64_t need = sf_op_length_sums_workspace_bytes(B, L, C);
   if (ws_bytes < need) fail(SF_ERR_WORKSPACE, "workspace too small: need %lld bytes", (long long)need);
   SF_HIP(launch_length_sums(x, y, B, L, C, static_cast<float *>(ws), out, static_cast<hipStream_t>(stream)));

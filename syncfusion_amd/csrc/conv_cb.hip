@@ -399,6 +399,7 @@ bool conv_cb_shape_ok(int dt, int B, int L, int C, int N, int G) {
   if (dt == F32) return false;
   if (C < KC || (C % KC) || (N % 128) || C / KC > 8 || ((C / KC) & (C / KC - 1))) return false;
   if (L < 44 || (int64_t)B * L * (int64_t)(C > N ? C : N) * 4 >= 0x7FFFFFF0ll) return false;   // a 130-row panel touches <= NSLOT clips
+  if ((uint64_t)B * L * (uint64_t)L >= (1ull << 32)) return false;   // row / L by multiply-high (magicL) is exact only while row * L < 2^32
   if (G > 0) {
     if (C % G) return false;
     const int cpg = C / G;

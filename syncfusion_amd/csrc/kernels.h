@@ -356,7 +356,6 @@ hipError_t launch_conv_wgrad(const float *dy, const float *act, int B, int L, in
 hipError_t launch_col_sums(const float *x, int64_t rows, int cols, float *part, int S, float *out, hipStream_t s);
 // out[b][c] = sum_l x[b][l][c] * (y ? y[b][l][c] : 1); part: B * length_sums_slices(B, L) * C floats
 int length_sums_slices(int B, int L);
-bool length_sums_ok(int C);
 hipError_t launch_length_sums(const float *x, const float *y, int B, int L, int C, float *part, float *out, hipStream_t s);
 // backward of a = SiLU(GroupNorm_G(x; gamma, beta, eps)): dx, and dgb = [dgamma | dbeta]  (dgb_part: [B][2][C] scratch)
 hipError_t launch_gn_silu_bwd(const float *x, const float *da, const float *gamma, const float *beta, int B, int L, int C, int G, float eps,

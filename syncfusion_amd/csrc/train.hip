@@ -806,6 +806,21 @@ __global__ __launch_bounds__(256) void length_sums_kernel(const float *__restric
     dst[c] = t;
   }
 }
+// any channel count (96, 192, 320, 3, 6 ...): one column per lane, the rows of a slice in order
+template <bool MUL>
+__global__ __launch_bounds__(64) void length_sums_generic_kernel(const float *__restrict__ x, const float *__restrict__ y, int L, int cols,
+                                                                 int rows_per_slice, float *__restrict__ part) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= cols) return;
+  const size_t base = (size_t)blockIdx.z * L * cols + c;
+  const int r0 = blockIdx.y * rows_per_slice, r1 = min(L, r0 + rows_per_slice);
+  float acc = 0.f;
+  for (int r = r0; r < r1; ++r) {
+    const size_t o = base + (size_t)r * cols;
+    acc = MUL ? fmaf(x[o], y[o], acc) : acc + x[o];
+  }
+  part[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * cols + c] = acc;
+}
 __global__ __launch_bounds__(256) void length_sums_reduce_kernel(const float *__restrict__ part, int S, int cols, float *__restrict__ out) {
   __shared__ float sh[256];   // 32 outputs per workgroup, 8 threads per output over the slices, combined in a fixed order
   const int col = blockIdx.x * 32 + (threadIdx.x & 31);
@@ -818,13 +833,19 @@ int length_sums_slices(int B, int L) {   // ~512 workgroups per launch, at least
   const int want = (512 + B - 1) / B;
   return max(1, min(want, (L + 63) / 64));
 }
-bool length_sums_ok(int C) { return (C % 4 == 0 && C <= 1024 && (256 % (C / 4)) == 0) || (C <= 256 && (256 % C) == 0); }
+// the vectorised forms; every other channel count runs the one-column-per-lane kernel
+static bool length_sums_vec4(int C) { return C % 4 == 0 && C <= 1024 && (256 % (C / 4)) == 0; }
+static bool length_sums_vec1(int C) { return C <= 256 && (256 % C) == 0; }
 
 hipError_t launch_length_sums(const float *x, const float *y, int B, int L, int C, float *part, float *out, hipStream_t s) {
-  if (!length_sums_ok(C)) return hipErrorInvalidValue;
+  if (B < 1 || L < 1 || C < 1) return hipErrorInvalidValue;
   const int S = length_sums_slices(B, L), rps = (L + S - 1) / S;
   const dim3 grid(S, B);
-  if (C % 4 == 0 && (256 % (C / 4)) == 0) {
+  if (!length_sums_vec4(C) && !length_sums_vec1(C)) {
+    const dim3 gg((C + 63) / 64, S, B);
+    if (y) hipLaunchKernelGGL(length_sums_generic_kernel<true>, gg, dim3(64), 0, s, x, y, L, C, rps, part);
+    else hipLaunchKernelGGL(length_sums_generic_kernel<false>, gg, dim3(64), 0, s, x, y, L, C, rps, part);
+  } else if (length_sums_vec4(C)) {
     if (y) hipLaunchKernelGGL((length_sums_kernel<4, true>), grid, dim3(256), 0, s, x, y, L, C, rps, part);
     else hipLaunchKernelGGL((length_sums_kernel<4, false>), grid, dim3(256), 0, s, x, y, L, C, rps, part);
   } else {

@@ -954,6 +954,7 @@ struct Exec {
       pi.res_ln = 1;
       fuse_mod = conv_gemm_emits_rowpart(u.dt, filled(g.conv2, pc)) && conv_gemm_ln_ok(u.dt, filled(g.inject, pi));
     }
+    const bool use_cb = l.cb && !fuse_act && g.conv1.wcb && g.conv2.wcb && g.conv1.bias && g.conv2.bias && p.cbslab;
     bool fuse_attn = false;
     if (g.attn && C % 32 == 0 && !u.no_ln_fusion) {
       ConvGemmArgs pq = qkv_args(tB);
@@ -962,10 +963,11 @@ struct Exec {
       pq.ln_eps = 1e-5f;
       pq.ln_colsum = g.qkv_colsum;
       ConvGemmArgs pi = inject_args(tA, tB);
-      const bool inj_emits = fuse_mod ? true : conv_gemm_emits_rowpart(u.dt, filled(g.inject, pi));
+      // the LN-folded InjectChannels kernel always writes row partials; the channel-block chain launches the PLAIN InjectChannels GEMM
+      // whatever fuse_mod says, so ask about the launch that will actually run
+      const bool inj_emits = (fuse_mod && !use_cb) ? true : conv_gemm_emits_rowpart(u.dt, filled(g.inject, pi));
       fuse_attn = inj_emits && conv_gemm_ln_ok(u.dt, filled(g.qkv, pq));
     }
-    const bool use_cb = l.cb && !fuse_act && g.conv1.wcb && g.conv2.wcb && g.conv1.bias && g.conv2.bias && p.cbslab;
     if (use_cb) {
       // Channel-block split-K chain (conv_cb.hip): the two launches that followed the convolutions anyway (GroupNorm+SiLU, LayerNorm +
       // Modulation) sum the fp32 partial slabs; the second convolution applies GroupNorm+SiLU while staging its activation panel.

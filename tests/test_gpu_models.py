@@ -17,6 +17,13 @@ pytestmark = pytest.mark.gpu
 
 FP32_TOL = 1e-4
 BF16_TOL = 5e-2
+# VideoOnsetNet on the 16-bit engines, gated at about 5x the error measured on MI355X (pinned oracle / golden vectors of the imported
+# reference): rel-L2 of the logits and of the worst stage activation, separately (`pytest -rA` prints them).  Measured over the 9 golden
+# cases, the 15 edge shapes and the 32-clip case: logits <= 1.0e-2 (bf16) / 1.6e-3 (fp16) -- random-init logits sit near 0.1 with a
+# spread of a few 1e-3, so their RELATIVE error is larger than that of the activations feeding them (absolute: 1.9e-3 / 1.1e-4) --
+# stages <= 6.5e-3 / 9.0e-4; fp32 <= 1.4e-6.
+ONSET_LOGIT_TOL = {"fp32": FP32_TOL, "bf16": 5e-2, "fp16": 8e-3}
+ONSET_TAP_TOL = {"fp32": FP32_TOL, "bf16": 3e-2, "fp16": 4.5e-3}
 
 
 def _oracle_unet(net, x, sigma, emb, chans, scale, taps=None):
@@ -295,8 +302,8 @@ def test_encoder1d_parity(cuda, B, L0):
 # VideoOnsetNet: golden vectors produced by the reference itself (oracle/gen_golden_onsetnet.py)
 # ----------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("case", ["small", "rect", "full"])
-@pytest.mark.parametrize("dtype,tol", [("fp32", FP32_TOL), ("bf16", BF16_TOL), ("fp16", BF16_TOL)])
-def test_onsetnet_golden(cuda, case, dtype, tol):
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
+def test_onsetnet_golden(cuda, case, dtype):
     from syncfusion_amd.onset_net import VideoOnsetNet
 
     gold = np.load(os.path.join(GOLDEN, f"onsetnet_{case}.npz"))
@@ -306,20 +313,25 @@ def test_onsetnet_golden(cuda, case, dtype, tol):
     x = golden_onsetnet_input(gold)     # "full" = the BASELINE shape (1,3,30,112,112), regenerated from its seed
     taps = {}
     y = net._get_engine().forward(x.to(cuda), taps)
+    worst = 0.0
     for nm in ("stem", "layer1", "layer2", "layer3", "layer4"):
         n_, c_, t_, h_, w_ = [int(v) for v in gold[f"{nm}_shape"]]
         act = taps[nm].cpu().reshape(n_, t_, h_, w_, c_).permute(0, 4, 1, 2, 3).reshape(-1)
         got = act[torch.from_numpy(gold[f"{nm}_idx"])]
-        assert rel_l2(got, torch.from_numpy(gold[f"{nm}_val"])) < tol, nm
+        e = rel_l2(got, torch.from_numpy(gold[f"{nm}_val"]))
+        worst = max(worst, e)
+        assert e < ONSET_TAP_TOL[dtype], f"{nm}: {e:.3e}"
     assert y.shape == (x.shape[0], x.shape[2])
-    assert rel_l2(y.cpu(), torch.from_numpy(gold["y"])) < tol
+    e_y = rel_l2(y.cpu(), torch.from_numpy(gold["y"]))
+    print(f"onset golden {case} {dtype}: logits rel-L2 {e_y:.3e}, worst stage {worst:.3e}")
+    assert e_y < ONSET_LOGIT_TOL[dtype]
     if dtype == "fp32":
         assert torch.equal(y, net(x.to(cuda)))
 
 
-@pytest.mark.parametrize("dtype,tol", [("fp32", FP32_TOL), ("bf16", BF16_TOL), ("fp16", BF16_TOL)])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("shape", [(1, 1, 32, 32), (2, 2, 24, 40), (1, 3, 36, 60), (3, 7, 48, 32), (2, 5, 20, 116)])
-def test_onsetnet_edge_shapes(cuda, shape, dtype, tol):
+def test_onsetnet_edge_shapes(cuda, shape, dtype):
     """Clip counts, frame counts below the depth of the frame-walk kernels' look-ahead (1, 2, 3 frames), and frame sizes whose layer-1
     grid is not a whole number of the spatial kernel's 8 x 14 patches, against the pinned oracle (oracle/onsetnet_ref.py follows
     main/resnet.py:36-56,81-114 and main/onset_net.py:12-63) with every stage tapped."""
@@ -336,13 +348,74 @@ def test_onsetnet_edge_shapes(cuda, shape, dtype, tol):
     y_ref = onsetnet_ref.onsetnet_forward({k_: v.float() for k_, v in state.items()}, x, ref_taps)
     taps = {}
     y = net._get_engine().forward(x.to(cuda), taps)
+    worst = 0.0
     for nm in ("stem", "layer1", "layer2", "layer3", "layer4"):
         r = ref_taps[nm]                                   # (N, C, T, H, W)
         n_, c_, t_, h_, w_ = r.shape
         act = taps[nm].cpu().reshape(n_, t_, h_, w_, c_).permute(0, 4, 1, 2, 3)
-        assert rel_l2(act, r) < tol, nm
+        e = rel_l2(act, r)
+        worst = max(worst, e)
+        assert e < ONSET_TAP_TOL[dtype], f"{nm}: {e:.3e}"
     assert y.shape == (n, t)
-    assert rel_l2(y.cpu(), y_ref) < tol
+    e_y = rel_l2(y.cpu(), y_ref)
+    print(f"onset edge {shape} {dtype}: logits rel-L2 {e_y:.3e}, worst stage {worst:.3e}")
+    assert e_y < ONSET_LOGIT_TOL[dtype]
+
+
+# BASELINE configs[4]'s per-GPU onset-net batch, the shape bench.py's extra.onset_net_n32 times: 32 clips of (3, 30, 112, 112).
+# At this clip count layers 2-4 dispatch the 192 x 128 two-slot and 256 x 64 macro tiles (conv_gemm_mt.hip, from 1024 tiles) and the
+# 32-clip grids of the frame-walk kernels (conv_sp / conv_tw) -- kernel variants the <= 4-clip tests above never reach.
+_ONSET_N32 = {}
+
+
+def _onset_n32_case():
+    if not _ONSET_N32:
+        from oracle import onsetnet_ref
+        from syncfusion_amd.onset_net import VideoOnsetNet
+
+        probe = VideoOnsetNet(pretrained=False)
+        state = seeded_state(probe, 4000)
+        x = torch.randn(32, 3, 30, 112, 112, generator=torch.Generator().manual_seed(4000))
+        pick = [0, 31]
+        ref_taps = {}
+        y_ref = onsetnet_ref.onsetnet_forward({k_: v.float() for k_, v in state.items()}, x[pick], ref_taps)   # two clips on the CPU
+        _ONSET_N32.update(state=state, x=x, pick=pick, y_ref=y_ref, ref_taps=ref_taps)
+    return _ONSET_N32
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
+def test_onsetnet_benchmarked_shape_n32(cuda, dtype):
+    """main/onset_net.py:57-63 at N = 32 x (3, 30, 112, 112): clips 0 and 31 of the 32-clip forward, every stage tapped, against the
+    pinned oracle; then clip independence -- the same two clips run as a 2-clip batch (different tile variants, different grids)
+    give the same logits up to the arithmetic type's rounding."""
+    from syncfusion_amd.onset_net import VideoOnsetNet
+
+    c = _onset_n32_case()
+    net = VideoOnsetNet(pretrained=False, dtype=dtype)
+    net.load_state_dict(c["state"])
+    net = net.to(cuda).eval()
+    gx = c["x"].to(cuda)
+    taps = {}
+    y = net._get_engine().forward(gx, taps, cap_floats=560_000_000)
+    assert y.shape == (32, 30) and torch.isfinite(y).all()
+    worst = ("", 0.0)
+    for nm in ("stem", "layer1", "layer2", "layer3", "layer4"):
+        r = c["ref_taps"][nm]                                   # (2, C, T, H, W)
+        _, c_, t_, h_, w_ = r.shape
+        act = taps[nm].reshape(32, t_, h_, w_, c_)[c["pick"]].permute(0, 4, 1, 2, 3).cpu()
+        e = rel_l2(act, r)
+        worst = max(worst, (nm, e), key=lambda p: p[1])
+        assert e < ONSET_TAP_TOL[dtype], f"{nm}: {e:.3e}"
+    del taps
+    e_y = rel_l2(y[c["pick"]].cpu(), c["y_ref"])
+    y_prod = net(gx)                                            # the untapped call bench.py times
+    assert torch.equal(y_prod, y)
+    y2 = net(gx[c["pick"]].contiguous())
+    e_ind = rel_l2(y2.cpu(), y[c["pick"]].cpu())
+    print(f"onset N=32 {dtype}: logits rel-L2 {e_y:.3e}, worst stage {worst[0]} {worst[1]:.3e}; N=32 vs N=2 logits {e_ind:.3e}")
+    assert e_y < ONSET_LOGIT_TOL[dtype]
+    assert e_ind < (1e-5 if dtype == "fp32" else ONSET_LOGIT_TOL[dtype] / 10)    # measured 1.1e-6 (fp32), bit-equal (bf16, fp16)
 
 
 def test_onsetnet_train_mode_and_cpu_raise(cuda):
@@ -532,6 +605,27 @@ def test_config0_exact_one_clip_ten_guided_steps_fp32(cuda, full_model):
     e = rel_l2(out.cpu(), ref)
     print(f"configs[0] (1 clip, 10 steps, scale 2.0, full model, fp32 engine): rel-L2 {e:.3e}")
     assert out.shape == (B, 1, L0) and e < FP32_TOL
+
+
+LOWP_SAMPLE50_TOL = {"bf16": 4e-3, "fp16": 3.5e-4}   # 50 guided steps, one clip (measured 7.7e-4 / 6.8e-5; fp32 engine 4.6e-7)
+
+
+@pytest.mark.timeout(2400)
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
+def test_full_size_50_step_guided_sample_parity(cuda, full_model, dtype):
+    """The 50-step schedule BASELINE configs[1]-[3] name, in the reference's call shape (main/generation.py:77-83: sample(noise,
+    num_steps, channels=xs[2:-1], embedding, embedding_scale)): one clip, the full 215 M-parameter model, guidance scale 2.0,
+    L0 = 45056, against sampler_ref on identical noise.  fp32 engine at the north-star 1e-4; 16-bit engines at ~5x measured."""
+    B, L0, steps, scale = 1, 45056, 50, 2.0
+    _, _, emb, chans = _full_inputs(full_model, B, L0, 84)
+    noise = torch.randn(B, 1, L0, generator=torch.Generator().manual_seed(1000))
+    ref = _memo("cfg_b1_sample50", lambda: _oracle_sample(full_model.model, noise, steps, emb, chans, scale))
+    with _compute_dtype(full_model, dtype):
+        out = full_model.model.sample(x_noisy=noise.to(cuda), num_steps=steps, channels=[c.to(cuda) for c in chans], embedding=emb.to(cuda),
+                                      embedding_scale=scale)
+    e = rel_l2(out.cpu(), ref)
+    print(f"{dtype} full-size 50-step guided sample (1 clip, scale 2.0): rel-L2 {e:.3e}")
+    assert out.shape == (B, 1, L0) and e < (FP32_TOL if dtype == "fp32" else LOWP_SAMPLE50_TOL[dtype])
 
 
 # ----------------------------------------------------------------------------------------------------------

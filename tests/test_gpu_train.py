@@ -5,7 +5,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from helpers import SMALL_UNET, oracle_params, rel_l2, small_unet_module, synth_inputs
+from helpers import SMALL_UNET, oracle_params, rel_l2, seeded_state, small_unet_module, synth_inputs
 
 pytestmark = [pytest.mark.gpu, pytest.mark.autograd]
 TOL = 2e-5
@@ -142,21 +142,18 @@ def test_ln_modulate_gradients(cuda, B, L, C, with_ss):
         assert rel_l2(sss.grad.cpu(), ss.grad) < TOL, f"dss {rel_l2(sss.grad.cpu(), ss.grad):.3e}"
 
 
-@pytest.mark.parametrize("B,L,C", [(4, 4096, 8), (3, 1000, 32), (2, 77, 64), (1, 1, 128), (4, 300, 1024), (2, 513, 16), (2, 64, 12)])
+@pytest.mark.parametrize("B,L,C", [(4, 4096, 8), (3, 1000, 32), (2, 77, 64), (1, 1, 128), (4, 300, 1024), (2, 513, 16), (2, 64, 12), (3, 501, 96), (2, 130, 320),
+                                   (2, 999, 3), (1, 70, 6), (2, 200, 1280)])
 @pytest.mark.parametrize("with_y", [False, True])
 def test_length_sums(cuda, B, L, C, with_y):
     """sum_l x (* y) per clip and channel -- the backward of the per-clip broadcast add and of the SkipModulate scale -- against float64
-    (two deterministic stages: bit-reproducible); unsupported channel counts fail loudly."""
+    (two deterministic stages: bit-reproducible); channel counts outside the vectorised forms (12, 96, 320, 3, 6, 1280: in_channels and
+    the widths GroupNorm and the convolutions accept) run the one-column-per-lane kernel."""
     from syncfusion_amd import autograd as sfa
-    from syncfusion_amd._lib import SyncFusionAmdError
 
     g = torch.Generator().manual_seed(B * 1000 + L + C)
     x = torch.randn(B, L, C, generator=g)
     y = torch.randn(B, L, C, generator=g) if with_y else None
-    if C == 12:
-        with pytest.raises(SyncFusionAmdError):
-            sfa.length_sums(x.to(cuda), y.to(cuda) if with_y else None)
-        return
     ref = ((x.double() * y.double()) if with_y else x.double()).sum(dim=1)
     out = sfa.length_sums(x.to(cuda), y.to(cuda) if with_y else None)
     assert out.shape == (B, C)
@@ -253,6 +250,41 @@ def test_unet_training_forward_and_every_gradient_against_oracle_autograd(cuda, 
     with torch.no_grad():
         v_eng = net(xs.detach(), sigma.to(cuda), embedding=emb.to(cuda), channels=[c.detach() for c in cs], embedding_scale=scale)
     assert not v_eng.requires_grad and rel_l2(v_eng.cpu(), v.detach().cpu()) < 1e-5
+
+
+def test_unet_training_gradients_at_channel_counts_outside_the_vectorised_reductions(cuda):
+    """in_channels = 3 and widths 24 / 96 / 320: GroupNorm and the convolutions accept them, and the length reductions in the
+    backward of the per-clip add and of SkipModulate (sf_op_length_sums) take their one-column-per-lane form; every gradient against
+    autograd through the oracle."""
+    from oracle import unet_ref
+    from syncfusion_amd.diffusion import UNetV0
+
+    hp = dict(SMALL_UNET, in_channels=3, channels=[24, 96, 320], factors=[1, 4, 2], items=[1, 1, 1], attentions=[0, 0, 1],
+              cross_attentions=[1, 1, 1], context_channels=[2, 8, 16])
+    net = UNetV0(dim=1, use_embedding_cfg=True, dtype="fp32", seed=5, **hp)
+    net.load_state_dict(seeded_state(net, 5))
+    cfg = dict(net.hparams)
+    P = {k: v.clone().requires_grad_() for k, v in oracle_params(net, "net.").items()}
+    B, L0 = 2, 8 * 9
+    x, sigma, emb, chans = synth_inputs(hp, B, L0, seed=31)
+    target = torch.randn(B, 3, L0, generator=torch.Generator().manual_seed(32))
+    v_ref = unet_ref.unet_forward(P, cfg, x, sigma, embedding=emb, channels=chans, embedding_scale=1.0)
+    F.mse_loss(v_ref, target).backward()
+    net = net.to(cuda)
+    v = net(x.to(cuda).requires_grad_(), sigma.to(cuda), embedding=emb.to(cuda), channels=[c.to(cuda) for c in chans])
+    assert v.requires_grad and rel_l2(v.detach().cpu(), v_ref.detach()) < 1e-5
+    F.mse_loss(v, target.to(cuda)).backward()
+    typical = float(torch.cat([p.grad.reshape(-1) for p in P.values() if p.grad is not None]).abs().mean())
+    bad = []
+    for name, p in net.named_parameters():
+        ref = P["net." + name].grad
+        if ref is None:
+            continue
+        assert p.grad is not None, f"{name}: no gradient"
+        zero = _zero_by_construction(name, lambda parts: hp["channels"][int(parts[1])], hp["resnet_groups"])
+        if not _grad_close(p.grad.cpu(), ref, 1e-4, typical, zero):
+            bad.append((name, rel_l2(p.grad.cpu(), ref)))
+    assert not bad, bad[:8]
 
 
 def test_encoder1d_training_gradients_against_oracle_autograd(cuda):

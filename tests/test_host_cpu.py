@@ -262,3 +262,30 @@ def test_save_wav_writes_ieee_float_like_torchaudio_save(tmp_path):
     assert r == 22050 and got.dtype == torch.float32 and torch.equal(got, a)
     with pytest.raises(ValueError):
         save_wav(p, a[0], 22050)
+
+
+def test_params_version_sees_in_place_updates_replaced_buffers_and_unhooked_edits():
+    """The engines' staleness check (syncfusion_amd/_engine.py): in-place updates, Module._apply replacing buffers out of place (fires no
+    registration hook), and edits no hook sees at all (direct _buffers writes: caught by the periodic re-walk)."""
+    import torch
+
+    from syncfusion_amd import _engine
+
+    def fresh():
+        m = torch.nn.Sequential(torch.nn.Conv1d(2, 2, 1), torch.nn.BatchNorm1d(2))
+        return m, _engine._params_version(m)
+
+    m, v = fresh()
+    assert not v.changed(m)
+    with torch.no_grad():
+        m[0].weight.mul_(2.0)
+    assert v.changed(m)
+    m, v = fresh()
+    m._apply(lambda t: t.clone())                       # what .to() / .half() do: new buffer objects, no hook
+    assert v.changed(m)
+    m, v = fresh()
+    m[1]._buffers["running_mean"] = torch.ones(2)       # no hook, no _apply
+    seen = [v.changed(m) for _ in range(_engine._REWALK_EVERY)]
+    assert seen[-1] and not v.tensors
+    m, v = fresh()
+    assert not any(v.changed(m) for _ in range(3 * _engine._REWALK_EVERY))
