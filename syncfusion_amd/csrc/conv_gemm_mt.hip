@@ -513,6 +513,14 @@ int conv_gemm_mt_variant(const ConvGemmArgs &a) {
     if (wide) return 6;
     return (long)((a.M + 191) / 192) * ((a.n_store + 127) / 128) >= tall_min ? v_sq : 5;
   }
+  {
+    static const int wide_small = [] {   // tuning hook: 192-wide candidates with at most this many 128x128 tiles take the 128x64 tile instead
+      const char *e = getenv("SF_MT_WIDE_SMALL");
+      return e ? atoi(e) : 176;   // the qkv projections of depths 6-7 at 16-32 evaluations per branch (1408 x 1536 x 1024: 88 tiles of 128x192)
+    }();
+    const long t128w = (long)((a.M + 127) / 128) * ((a.n_store + 127) / 128);
+    if (wide && a.geom == 0 && t128w <= wide_small && a.n_store % 64 == 0 && a.K >= 512) return 7;
+  }
   if (wide) return rule == 0 ? 2 : 6;   // in the U-Net step too the two-slot 128x192 tile wins on the qkv projections (28.6 vs 34.2 us)
   if (a.geom == 0) {
     // one workgroup per CU (the LDS ring fills it), each bound by its L2 -> LDS fill ~ (BM + BN) per K step: a launch costs
@@ -533,7 +541,7 @@ int conv_gemm_mt_variant(const ConvGemmArgs &a) {
       const long t128 = (long)((a.M + 127) / 128) * nt;
       static const int kmin = [] {   // tuning hook: shortest reduction that takes the rule
         const char *e = getenv("SF_MT_SMALL_KMIN");
-        return e ? atoi(e) : 512;
+        return e ? atoi(e) : 256;   // 256 (was 512): + the InjectChannels GEMMs of depth 4; with SF_MT_WIDE_SMALL: configs[2] +1.4 %, batch 32 +3.8 % (profiles/r5_b_ab_tiles.txt)
       }();
       if (t128 <= thr && a.K >= kmin && a.n_store % 64 == 0 && rule != 0) return 7;
     }
