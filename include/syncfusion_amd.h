@@ -283,6 +283,19 @@ int sf_op_resnet_mod_cb(int dtype, const void *x, const float *w1, const float *
                         const float *gn1_b, const float *gn2_g, const float *gn2_b, int groups, float eps_gn, const float *scale_shift,
                         float eps_ln, int B, int L, int C, int kb /* 128-channel blocks per workgroup: 1 or 2 */, void *h_out, void *m_out,
                         void *ws, int64_t ws_bytes, void *stream);
+/* InjectChannels followed by the attention pre-norm projection, as the engine chains the two GEMMs of an item (a-unet InjectChannelsItem
+ * + the LayerNorm / to_q | to_kv Linear of AttentionItem), 16-bit dtypes:
+ *   z = m + Conv1x1(cat[m, ctx]) + b_inj            m:(B,L,C), ctx:(B,L,C2) channels-last in `dtype`; w_inj:(C, C + C2) fp32
+ *   q = Linear(LayerNorm_C(z; gamma, beta, eps))    w_q:(N, C) fp32, bias-free
+ * The first GEMM's epilogue leaves per-row LayerNorm partials per 32-column tile, the second multiplies the RAW rows of z and
+ * normalises its accumulator, rstd * (acc - mean * colsum) -- no LayerNorm launch in between.  Which kernel family runs (macro tiles at
+ * long activations, the 32x32 families at short ones) follows the engine's dispatch, except that the macro-tile form is always offered
+ * here (the engine takes it only with SF_MT_LN=1: in the two-branch step it measured no gain); SF_ERR_UNSUPPORTED where no kernel fits.
+ * fused_out (optional): set to 1 when the fused pair ran, 0 when the op fell back to z -> ln_modulate -> plain projection. */
+int64_t sf_op_inject_prenorm_proj_workspace_bytes(int B, int L, int C, int C2, int N);
+int sf_op_inject_prenorm_proj(int dtype, const void *m, const void *ctx, const float *w_inj, const float *b_inj, const float *gamma,
+                              const float *beta, float eps, const float *w_q, int B, int L, int C, int C2, int N, void *z_out, void *q_out,
+                              int *fused_out, void *ws, int64_t ws_bytes, void *stream);
 /* Kernel tuning aid: average milliseconds of the four launches of that chain on random data (ms[0] convolution, ms[1] reduction +
  * GroupNorm sums, ms[2] convolution with prologue, ms[3] reduction + LayerNorm); cold != 0 streams the weights from HBM. */
 int sf_bench_conv_cb(int dtype, int B, int L, int C, int groups, int kb, int cold, int iters, float *ms /* [4] */);

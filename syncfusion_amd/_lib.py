@@ -104,6 +104,8 @@ SYMBOLS = {
     "sf_op_length_sums": (_I, [_P, _P, _I, _I, _I, _P, _P, _L, _P]),
     "sf_bench_conv1d": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_float)]),
     "sf_op_gn_silu": (_I, [_I, _P, _P, _P, _I, _F, _I, _I, _I, _P, _P, _L, _P]),
+    "sf_op_inject_prenorm_proj_workspace_bytes": (_L, [_I, _I, _I, _I, _I]),
+    "sf_op_inject_prenorm_proj": (_I, [_I, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _L, _P]),
     "sf_op_resnet_mod_cb_workspace_bytes": (_L, [_I, _I, _I]),
     "sf_op_resnet_mod_cb": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P, _F, _I, _I, _I, _I, _P, _P, _P, _L, _P]),
     "sf_bench_conv_cb": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_float)]),

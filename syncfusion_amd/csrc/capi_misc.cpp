@@ -345,6 +345,90 @@ int sf_op_resnet_mod_cb(int dtype, const void *x, const float *w1, const float *
   SF_API_END
 }
 
+int64_t sf_op_inject_prenorm_proj_workspace_bytes(int B, int L, int C, int C2, int N) {
+  if (B < 1 || L < 1 || C < 32 || C2 < 0 || N < 8) return -1;
+  const int64_t M = (int64_t)B * L, K1 = C + (C2 + 31) / 32 * 32;
+  return (int64_t)C * K1 * 2 + (int64_t)N * C * 2 + M * C * 2 + M * (C / 32) * 8 + (int64_t)(2 * N + C) * 4 + 4096;
+}
+
+int sf_op_inject_prenorm_proj(int dtype, const void *m, const void *ctx, const float *w_inj, const float *b_inj, const float *gamma,
+                              const float *beta, float eps, const float *w_q, int B, int L, int C, int C2, int N, void *z_out, void *q_out,
+                              int *fused_out, void *ws, int64_t ws_bytes, void *stream) {
+  SF_API_BEGIN
+  if (!m || !w_inj || !b_inj || !gamma || !beta || !w_q || !z_out || !q_out || !ws) fail(SF_ERR_INVALID, "null argument");
+  if (dtype != BF16 && dtype != F16) fail(SF_ERR_UNSUPPORTED, "16-bit dtypes only");
+  if (C % 32 || C2 % 32 || N % 32 || (C2 > 0 && !ctx)) fail(SF_ERR_UNSUPPORTED, "C, C2 and N must be multiples of 32");
+  const int64_t need = sf_op_inject_prenorm_proj_workspace_bytes(B, L, C, C2, N);
+  if (need < 0 || ws_bytes < need) fail(SF_ERR_WORKSPACE, "workspace too small: need %lld bytes", (long long)need);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  Workspace wk(ws, ws_bytes);
+  const int64_t M = (int64_t)B * L;
+  const int K1 = C + C2;
+  void *w1 = wk.alloc((int64_t)C * K1 * 2), *w2 = wk.alloc((int64_t)N * C * 2), *tmp = wk.alloc(M * C * 2);
+  float *rowpart = static_cast<float *>(wk.alloc(M * (C / 32) * 8));
+  float *bias2 = static_cast<float *>(wk.alloc((int64_t)N * 4)), *colsum = static_cast<float *>(wk.alloc((int64_t)N * 4));
+  SF_HIP(launch_pack_rows(dtype, w_inj, C, K1, K1, nullptr, w1, K1, s));
+  SF_HIP(launch_pack_rows(dtype, w_q, N, C, C, gamma, w2, C, s));          // W (g * xhat + b) = (W diag g) xhat + W b
+  SF_HIP(launch_fold_bias(w_q, N, C, beta, nullptr, bias2, s));
+  SF_HIP(launch_row_sums(dtype, w2, N, C, colsum, s));
+  ConvGemmArgs a;   // InjectChannels
+  a.src = m;
+  a.src_ld = C;
+  a.src2 = ctx;
+  a.src2_ld = C2;
+  a.w = w1;
+  a.bias = b_inj;
+  a.M = (int)M;
+  a.N = a.n_store = C;
+  a.K = K1;
+  a.cin = C;
+  a.cin2 = C2;
+  a.taps = 1;
+  a.Lout = a.Lsrc = L;
+  a.out = z_out;
+  a.out_ld = C;
+  a.res = m;
+  a.res_ld = C;
+  ConvGemmArgs q;   // pre-normed projection
+  q.src = z_out;
+  q.src_ld = C;
+  q.w = w2;
+  q.bias = bias2;
+  q.M = (int)M;
+  q.N = q.n_store = N;
+  q.K = q.cin = C;
+  q.taps = 1;
+  q.Lout = q.Lsrc = L;
+  q.out = q_out;
+  q.out_ld = N;
+  ConvGemmArgs ar = a, ql = q;
+  ar.rowpart_out = rowpart;
+  ar.rowpart_nt = C / 32;
+  ql.ln_part = rowpart;
+  ql.ln_nt = C / 32;
+  ql.ln_eps = eps;
+  ql.ln_colsum = colsum;
+  struct MtLnOn {   // the op always offers the macro-tile form (the engine only with SF_MT_LN=1, see conv_gemm.hip)
+    int prev;
+    MtLnOn() : prev(conv_gemm_mt_ln_enabled() ? 1 : 0) { g_conv_gemm_mt_ln = 1; }
+    ~MtLnOn() { g_conv_gemm_mt_ln = prev; }
+  } mt_ln_on;
+  const bool fused = conv_gemm_emits_rowpart(dtype, ar) && conv_gemm_ln_ok(dtype, ql);
+  if (fused_out) *fused_out = fused ? 1 : 0;
+  if (fused) {
+    SF_HIP(launch_conv_gemm(dtype, ar, s));
+    SF_HIP(launch_conv_gemm_ln(dtype, ql, s));
+  } else {
+    if (!conv_gemm_supported(dtype, a) || !conv_gemm_supported(dtype, q)) fail(SF_ERR_UNSUPPORTED, "shape outside the GEMM kernels' coverage");
+    SF_HIP(launch_conv_gemm(dtype, a, s));
+    SF_HIP(launch_ln_modulate(dtype, z_out, C, nullptr, 0, eps, B, L, C, tmp, C, s));
+    q.src = tmp;
+    SF_HIP(launch_conv_gemm(dtype, q, s));
+  }
+  return SF_OK;
+  SF_API_END
+}
+
 // Timing aid: the four launches of the channel-block chain, each averaged over `iters` back-to-back launches on random data
 // (ms[0] conv_cb without prologue, ms[1] cb_reduce_gn, ms[2] conv_cb with the GroupNorm+SiLU prologue, ms[3] cb_reduce_ln).
 // cold != 0: rotate through enough weight copies that every launch streams its weights from HBM.

@@ -487,12 +487,32 @@ static const char *variant_name_bf16(int dt, const ConvGemmArgs &a) {
 
 ConvGemmForce g_conv_gemm_force;
 
+// Row-LayerNorm fusion on the macro tiles (row partials in the epilogue, LayerNorm on the accumulator): parity-tested at op level, but in
+// the two-branch step the launches it removes were hidden under the other branch's kernels and its epilogue work is not -- same-box A/B
+// (profiles/r5_c_ab_mt_ln.txt): configs[2] 202 -> 203.5 steps/s, batch 32 without guidance 301 -> 291.  Off unless SF_MT_LN=1.
+int g_conv_gemm_mt_ln = -1;
+bool conv_gemm_mt_ln_enabled() {
+  if (g_conv_gemm_mt_ln < 0) {
+    const char *e = getenv("SF_MT_LN");
+    g_conv_gemm_mt_ln = (e && atoi(e) > 0) ? 1 : 0;
+  }
+  return g_conv_gemm_mt_ln > 0;
+}
+
 bool conv_gemm_emits_rowpart(int dt, const ConvGemmArgs &a) {
   if (g_conv_gemm_force.path != 0 || !conv_gemm_supported(dt, a)) return false;
-  {   // long activations: the macro-tile kernel (no row-statistics epilogue) beats the 32x32 kernels that have one
+  {   // long activations: the macro-tile kernel; its epilogue writes the row partials for column counts that are multiples of 32
     ConvGemmArgs plain = a;
     plain.rowpart_out = nullptr;
-    if (conv_gemm_mt_wanted(dt, plain)) return false;
+    if (conv_gemm_mt_wanted(dt, plain)) {
+      const bool off = !conv_gemm_mt_ln_enabled();
+      ConvGemmArgs probe = a;   // (callers ask before they arm the launch)
+      if (!probe.rowpart_out) {
+        probe.rowpart_out = reinterpret_cast<float *>(16);
+        probe.rowpart_nt = a.n_store / 32;
+      }
+      return !off && conv_gemm_mt_wanted(dt, probe);
+    }
   }
   if ((a.n_store % 32) || a.n_store != a.N) return false;
   const long t64 = (long)((a.M + 63) / 64) * ((a.n_store + 63) / 64);

@@ -451,17 +451,27 @@ bool conv_gemm_fast_ok(int dt, const ConvGemmArgs &a) {
   return true;
 }
 
+// long activations: the macro-tile GEMM beats the LayerNorm-fused 32x32 kernel; it carries the accumulator-side LayerNorm (ln_colsum)
+// but no operand transform (Modulation + InjectChannels keep their ln_modulate launch there)
+static bool ln_goes_mt(int dt, const ConvGemmArgs &a, bool *supported = nullptr) {
+  ConvGemmArgs plain = a;
+  plain.ln_part = nullptr;
+  plain.ln_colsum = nullptr;
+  plain.ln_ss = nullptr;
+  plain.rowpart_out = nullptr;
+  plain.res_ln = 0;
+  if (!conv_gemm_mt_wanted(dt, plain)) return false;
+  const bool off = !conv_gemm_mt_ln_enabled();
+  if (supported) *supported = !off && a.ln_part && a.ln_colsum && !a.ln_ss && !a.res_ln && conv_gemm_mt_ok(dt, a);
+  return true;
+}
+
 bool conv_gemm_ln_ok(int dt, const ConvGemmArgs &a) {
-  if (!conv_gemm_fast_ok(dt, a)) return false;
-  {   // long activations: a separate ln_modulate launch + the macro-tile GEMM beats the LayerNorm-fused 32x32 kernel
-    ConvGemmArgs plain = a;
-    plain.ln_part = nullptr;
-    plain.ln_colsum = nullptr;
-    plain.ln_ss = nullptr;
-    plain.rowpart_out = nullptr;
-    plain.res_ln = 0;
-    if (conv_gemm_mt_wanted(dt, plain)) return false;
+  {
+    bool sup = false;
+    if (ln_goes_mt(dt, a, &sup)) return sup;
   }
+  if (!conv_gemm_fast_ok(dt, a)) return false;
   if (a.taps != 1 || a.stride != 1 || a.up_shift != 0 || a.Lout != a.Lsrc || a.Lout < 32) return false;
   if (!a.ln_part || a.ln_nt * 32 != a.cin || a.ln_nt > 32) return false;
   if (a.res_ln && (a.N != a.cin || !a.res)) return false;
@@ -482,6 +492,7 @@ static bool ln_goes_wp(int dt, const ConvGemmArgs &a) {
 
 static bool ln_goes_rs(int dt, const ConvGemmArgs &a);
 const char *conv_gemm_ln_variant_name(int dt, const ConvGemmArgs &a) {
+  if (ln_goes_mt(dt, a)) return label_for_dtype(dt, conv_gemm_mt_name(a));
   if (ln_goes_rs(dt, a)) return label_for_dtype(dt, "conv_gemm_rs<bf16,32x32>");
   if (dt == F32) return ln_goes_wp(dt, a) ? "conv_gemm_wp<f32,32x32>" : "conv_gemm_fast<f32,32x32>";
   return label_for_dtype(dt, ln_goes_wp(dt, a) ? "conv_gemm_wp<bf16,32x32>" : "conv_gemm_fast<bf16,32x32>");
@@ -501,6 +512,7 @@ static bool ln_goes_rs(int dt, const ConvGemmArgs &a) {
 
 hipError_t launch_conv_gemm_ln(int dt, const ConvGemmArgs &a, hipStream_t s) {
   if (!conv_gemm_ln_ok(dt, a)) return hipErrorInvalidValue;
+  if (ln_goes_mt(dt, a)) return launch_conv_gemm_mt(dt, a, s);
   if (ln_goes_rs(dt, a)) return launch_conv_gemm_rs(dt, a, s);
   if (ln_goes_wp(dt, a)) return launch_conv_gemm_wp(dt, a, 2, s);
   return SF_DISPATCH_T(dt, (a.cin2 ? launch_fast3<T, 32, 32, true, 32, 2, true>(a, s) : launch_fast3<T, 32, 32, false, 32, 2, true>(a, s)));

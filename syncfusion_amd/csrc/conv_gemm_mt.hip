@@ -17,8 +17,13 @@
 //   * no ordinary global load inside the K loop (hipcc would drain the DMA queue for it): epilogue operands are read after it;
 //   * epilogue through LDS: row-major 16-byte stores; bias / per-clip scale / residual / per-clip add / activation as in
 //     ConvGemmArgs.
+//   * row-LayerNorm fusion at long activations (the guidance batch: 20 ln_modulate launches per branch and step disappear):
+//     rowpart_out -- the epilogue also writes (mean, M2) of the STORED values per row and 32-column tile (four lanes hold a row's 32
+//     columns of a pass: two quad permutes); ln_colsum + ln_part -- the operand rows go through the matrix cores RAW and the
+//     LayerNorm lands on the accumulator, rstd_m * (acc - mean_m * colsum[n]); the row statistics are pooled from the producer's
+//     partials, whose loads are issued before the K loop and reduced after it into the tail of the retired ring.
 // Geometry: 1-D (taps, stride, nearest upsampling) and video (kt x kh x kw taps), channel counts that are multiples of 64,
-// no concatenated second source, no prologue.
+// no prologue.
 #include <type_traits>
 
 #include "common.h"
@@ -44,7 +49,9 @@ __device__ unsigned long long g_mt_stamps[8][8];
 
 // CAT: K = taps * cin + cin2, the last cin2 columns read row m of a second source (InjectChannels: Conv1x1 over cat[x, ctx])
 // WM x WN = 8 waves; a wave owns (BM / WM) x (BN / WN) = (32 TM) x (32 TN) of the block tile
-template <typename T, int BM, int BN, int WM, int WN, int GEOM, bool CAT, int NST = NSTAGE, int EP = 1>
+// LNE: the accumulator-side LayerNorm is compiled in (its pooled partials stay in registers across the K loop: only the tiles the
+// LayerNorm-folded projections take carry it)
+template <typename T, int BM, int BN, int WM, int WN, int GEOM, bool CAT, int NST = NSTAGE, int EP = 1, bool LNE = false>
 __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a, const int mtiles, const int ntiles, const unsigned bytesA,
                                                            const unsigned bytesA2, const unsigned bytesW) {
   constexpr int ES = sizeof(T);   // fp32 (training, the parity engine's long activations): same byte geometry, v_mfma_f32_32x32x2_f32
@@ -191,6 +198,22 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
   }
   const unsigned sw = (unsigned)((fr >> 1) & 7);   // rows of a fragment: every row base is a multiple of 32, so (row >> 1) & 7 == (fr >> 1) & 7
 
+  // ---- LayerNorm on the accumulator: this thread's share of its row's producer partials, requested ahead of the DMA stream (they
+  // are older than every DMA piece, so the counted waits of the K loop cover them; first use is after the loop) ----------------------
+  static_assert(!LNE || (ES == 2 && GEOM == 0 && !CAT && (BM == 128 || BM == 256)), "accumulator-side LayerNorm: 16-bit 1-D projections");
+  constexpr int TPR = LNE ? 512 / BM : 4;             // threads per row of the block tile (2 or 4: one DPP quad)
+  constexpr int LNP = LNE ? 32 / TPR : 1;             // partials per thread (ln_nt <= 32)
+  const bool ln_epi = LNE && a.ln_colsum != nullptr;
+  float2 lnp[LNP];
+  if (ln_epi) {
+    const int m = min(m0 + tid / TPR, a.M - 1), t0_ = tid % TPR;
+#pragma unroll
+    for (int j = 0; j < LNP; ++j) {
+      const int pidx = t0_ + TPR * j;
+      lnp[j] = pidx < a.ln_nt ? *reinterpret_cast<const float2 *>(a.ln_part + ((size_t)m * a.ln_nt + pidx) * 2) : make_float2(0.f, 0.f);
+    }
+  }
+
   // ---- prologue: two K steps in flight ---------------------------------------------------------------------------
 #ifdef SF_MT_STAMPS
   SF_STAMP(t_begin);
@@ -287,6 +310,30 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
   constexpr int RPT = 32 / EP;     // rows of a 32-row MFMA tile handled per pass
   constexpr int RMP = RM / EP;     // rows a wave parks per pass
   float *red = reinterpret_cast<float *>(smem) + (size_t)wave * RMP * LDR;
+  float *rowstat = reinterpret_cast<float *>(smem) + (size_t)8 * RMP * LDR;   // (mean, rstd) per row of the block tile, behind the parking area
+  if (ln_epi) {
+    float sm = 0.f;
+#pragma unroll
+    for (int j = 0; j < LNP; ++j) sm += lnp[j].x;          // absent partials are zeros
+    sm += dpp_mov_f<0xb1, 0xf>(sm);
+    if constexpr (TPR == 4) sm += dpp_mov_f<0x4e, 0xf>(sm);
+    const float mean = sm / (float)a.ln_nt;                // every partial covers 32 channels
+    float dq = 0.f;
+#pragma unroll
+    for (int j = 0; j < LNP; ++j) {
+      if ((tid % TPR) + TPR * j < a.ln_nt) {
+        const float d = lnp[j].x - mean;
+        dq += fmaf(32.f * d, d, lnp[j].y);
+      }
+    }
+    dq += dpp_mov_f<0xb1, 0xf>(dq);
+    if constexpr (TPR == 4) dq += dpp_mov_f<0x4e, 0xf>(dq);
+    if (tid % TPR == 0) {
+      rowstat[2 * (tid / TPR)] = mean;
+      rowstat[2 * (tid / TPR) + 1] = rsqrtf(dq / (float)a.cin + a.ln_eps);
+    }
+    __syncthreads();
+  }
   T *out = static_cast<T *>(a.out);
   const T *res = static_cast<const T *>(a.res);
   const bool has_bs = a.bscale != nullptr, has_ba = a.badd != nullptr;
@@ -318,6 +365,17 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
     const f32x4 v0 = *reinterpret_cast<const f32x4 *>(red + rl * LDR + oct * 8);
     const f32x4 v1 = *reinterpret_cast<const f32x4 *>(red + rl * LDR + oct * 8 + 4);
     float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    if (ln_epi) {   // LayerNorm of the raw operand rows, folded into the accumulator (colsum[n] = sum_k w[n][k])
+      const int rb = wm * RM + (rl / RPT) * 32 + pass * RPT + (rl % RPT);   // row inside the block tile
+      const float mu = rowstat[2 * rb], rstd = rowstat[2 * rb + 1];
+      const int ncs = min(n, a.N - 8);   // (ln_epi implies N % 8 == 0: see conv_gemm_mt_ok)
+      const f32x4 c0 = *reinterpret_cast<const f32x4 *>(a.ln_colsum + ncs), c1 = *reinterpret_cast<const f32x4 *>(a.ln_colsum + ncs + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = rstd * (v[e] - mu * c0[e]);
+        v[4 + e] = rstd * (v[4 + e] - mu * c1[e]);
+      }
+    }
     float rres[8];   // residual rows are n_store wide (pad columns hold zeros)
 #pragma unroll
     for (int e = 0; e < 8; ++e) rres[e] = 0.f;
@@ -371,6 +429,10 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
 #pragma unroll
         for (int e = 0; e < 8; ++e) o.set(e, xo[e]);
         st16<T>(out + (size_t)m * a.out_ld + n, o);
+        if (a.rowpart_out) {   // (mean, M2) of the row's 32 stored values of this column tile: the four lanes of a quad hold them
+#pragma unroll
+          for (int e = 0; e < 8; ++e) xo[e] = o.get(e);
+        }
       } else {
         Vec16<T> o0, o1;
 #pragma unroll
@@ -380,6 +442,25 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
         }
         st16<T>(out + (size_t)m * a.out_ld + n, o0);
         st16<T>(out + (size_t)m * a.out_ld + n + 4, o1);
+      }
+    }
+    if constexpr (ES == 2 && GEOM == 0) {
+      if (a.rowpart_out) {   // every lane of the wave takes part (rows / columns outside the tensor contribute zeros and store nothing)
+        float sm = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sm += live ? xo[e] : 0.f;
+        sm += dpp_mov_f<0xb1, 0xf>(sm);
+        sm += dpp_mov_f<0x4e, 0xf>(sm);
+        const float mean = sm * (1.0f / 32.0f);
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = (live ? xo[e] : 0.f) - mean;
+          q = fmaf(d, d, q);
+        }
+        q += dpp_mov_f<0xb1, 0xf>(q);
+        q += dpp_mov_f<0x4e, 0xf>(q);
+        if (live && (oct & 3) == 0) *reinterpret_cast<float2 *>(a.rowpart_out + ((size_t)m * a.rowpart_nt + (n >> 5)) * 2) = make_float2(mean, q);
       }
     }
   }
@@ -400,9 +481,10 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
 #endif
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int GEOM, bool CAT, int NST = NSTAGE, int EP = 1> hipError_t launch_mt(const ConvGemmArgs &a, hipStream_t s) {
+template <typename T, int BM, int BN, int WM, int WN, int GEOM, bool CAT, int NST = NSTAGE, int EP = 1, bool LNE = false>
+hipError_t launch_mt(const ConvGemmArgs &a, hipStream_t s) {
   constexpr size_t ring = (size_t)NST * (BM + BN) * ROWB;
-  constexpr size_t redb = (size_t)8 * (BM / WM / EP) * (BN / WN + 4) * sizeof(float);
+  constexpr size_t redb = (size_t)8 * (BM / WM / EP) * (BN / WN + 4) * sizeof(float) + (size_t)BM * 2 * sizeof(float);   // parking area + rowstat
   constexpr size_t lds = ring > redb ? ring : redb;
   static_assert(lds <= 160 * 1024, "LDS budget");
   const int mtiles = (a.M + BM - 1) / BM, ntiles = (a.n_store + BN - 1) / BN;
@@ -411,7 +493,7 @@ template <typename T, int BM, int BN, int WM, int WN, int GEOM, bool CAT, int NS
   else bA = (size_t)((a.M + a.To * a.Ho * a.Wo - 1) / (a.To * a.Ho * a.Wo)) * a.Ti * a.Hi * a.Wi * a.src_ld * sizeof(T);
   const size_t bW = (size_t)a.N * a.K * sizeof(T);
   const size_t bA2 = CAT ? (size_t)a.M * a.src2_ld * sizeof(T) : 0;
-  auto kern = conv_gemm_mt_kernel<T, BM, BN, WM, WN, GEOM, CAT, NST, EP>;
+  auto kern = conv_gemm_mt_kernel<T, BM, BN, WM, WN, GEOM, CAT, NST, EP, LNE>;
   static bool en = false;
   if (!en) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -422,7 +504,19 @@ template <typename T, int BM, int BN, int WM, int WN, int GEOM, bool CAT, int NS
   return hipGetLastError();
 }
 
+// the tile variants the accumulator-side LayerNorm is instantiated for (the LayerNorm-folded qkv projections: 128x192 two-slot, 128x64)
+static bool mt_lne_variant(int v) { return v == 6 || v == 7; }
+
 template <typename T, int GEOM, bool CAT> hipError_t launch_mt_v(const ConvGemmArgs &a, int variant, hipStream_t s) {
+  if constexpr (GEOM == 0 && !CAT && sizeof(T) == 2) {
+    if (a.ln_colsum) {
+      if (variant == 6) return launch_mt<T, 128, 192, 4, 2, GEOM, CAT, 2, 2, true>(a, s);
+      if (variant == 7) return launch_mt<T, 128, 64, 4, 2, GEOM, CAT, 3, 1, true>(a, s);
+      return hipErrorInvalidValue;
+    }
+  } else {
+    if (a.ln_colsum) return hipErrorInvalidValue;
+  }
   switch (variant) {
     case 1: return launch_mt<T, 128, 128, 2, 4, GEOM, CAT>(a, s);   // short M: twice the tiles of 256x128
     case 2: return launch_mt<T, 128, 192, 4, 2, GEOM, CAT>(a, s);   // column counts that are multiples of 192 but not of 128
@@ -440,6 +534,7 @@ template <typename T, int GEOM, bool CAT> hipError_t launch_mt_v(const ConvGemmA
 
 }  // namespace
 
+int conv_gemm_mt_variant(const ConvGemmArgs &a);
 // eligibility (what the kernel implements) -- the CHOICE between this kernel and conv_gemm_v2 is conv_gemm_prefers_mt
 bool conv_gemm_mt_ok(int dt, const ConvGemmArgs &a) {
   const size_t es = dt == F32 ? 4 : 2;
@@ -447,7 +542,12 @@ bool conv_gemm_mt_ok(int dt, const ConvGemmArgs &a) {
   if (dt == F32 && a.geom != 0) return false;                // fp32: the U-Net's 1-D geometry only (training, parity engine)
   if (a.pro != 0 || (a.cin % bke) || (a.cin2 % bke) || a.taps < 1 || a.K != a.taps * a.cin + a.cin2) return false;
   if (a.cin2 && (a.geom != 0 || !a.src2 || (a.src2_ld % vec) || a.src2_ld < a.cin2 || (size_t)a.M * a.src2_ld * es >= 0x7FFFFFF0ull)) return false;
-  if (a.ln_part || a.ln_colsum || a.rowpart_out || a.out_f32 || a.act > 1) return false;
+  if (a.out_f32 || a.act > 1 || a.ln_ss || a.res_ln) return false;
+  if (a.rowpart_out && (dt == F32 || a.geom != 0 || (a.n_store % 32) || a.rowpart_nt * 32 != a.n_store || a.N != a.n_store)) return false;
+  if ((a.ln_part != nullptr) != (a.ln_colsum != nullptr)) return false;   // accumulator-side LayerNorm only (no operand transform on a DMA ring)
+  if (a.ln_colsum && (dt == F32 || a.geom != 0 || a.taps != 1 || a.cin2 || a.stride != 1 || a.up_shift || a.Lout != a.Lsrc || a.ln_nt * 32 != a.cin ||
+                      a.ln_nt > 32 || (a.N % 8) || (reinterpret_cast<uintptr_t>(a.ln_colsum) & 15) || !mt_lne_variant(conv_gemm_mt_variant(a))))
+    return false;
   if ((a.bscale && (a.bscale_ld % 4)) || (a.badd && (a.badd_ld % 4))) return false;
   if ((a.n_store % 8) || a.n_store < a.N || (a.out_ld % 8) || a.out_ld < a.n_store || (a.res && ((a.res_ld % 8) || a.res_ld < a.n_store)) || (a.src_ld % vec)) return false;
   if (a.bias && (reinterpret_cast<uintptr_t>(a.bias) & 15)) return false;

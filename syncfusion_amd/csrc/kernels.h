@@ -89,7 +89,10 @@ bool conv_gemm_prefers_mt(const ConvGemmArgs &a);
 bool conv_gemm_mt_wanted(int dt, const ConvGemmArgs &a);   // eligible AND preferred (the fp32 rule differs: conv_gemm_mt.hip)
 hipError_t launch_conv_gemm_mt(int dt, const ConvGemmArgs &a, hipStream_t s);
 const char *conv_gemm_mt_name(const ConvGemmArgs &a);   // label of the tile variant it picks (bf16 spelling)
-// true when launch_conv_gemm would run `a` on a kernel that honours rowpart_out (fast / wp, 32x32 tiles)
+// process-wide switch of the macro-tile row-LayerNorm fusion (SF_MT_LN=1; -1 = not read yet); sf_op_inject_prenorm_proj turns it on for its call
+extern int g_conv_gemm_mt_ln;
+bool conv_gemm_mt_ln_enabled();
+// true when launch_conv_gemm would run `a` on a kernel that honours rowpart_out (fast / wp, 32x32 tiles; macro tiles with SF_MT_LN=1)
 bool conv_gemm_emits_rowpart(int dt, const ConvGemmArgs &a);
 // register-staged kernel (conv_gemm_rs.hip): 32x32 tiles, all operand fragments of a wave in flight, fragment-ordered weights
 bool conv_gemm_rs_ok(int dt, const ConvGemmArgs &a);

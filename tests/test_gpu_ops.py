@@ -343,3 +343,58 @@ def test_conv_cb_rejects_shapes_outside_its_coverage(cuda):
         rc = lib.sf_op_resnet_mod_cb(_l.DTYPES[dtype], t.data_ptr(), *[f.data_ptr()] * 8, 8, 1e-5, None, 1e-6, B, L, C, 1, None, t.data_ptr(),
                                      ws.data_ptr(), ws.numel(), _l.stream_ptr(cuda))
         assert rc != 0
+
+
+# ----------------------------------------------------------------------------------------------------------
+# InjectChannels -> attention pre-norm projection as one fused pair (row partials in the first GEMM's epilogue, LayerNorm on the
+# second GEMM's accumulator): the macro-tile kernel at the guidance batch's long activations, the 32x32 families at short ones.
+# ----------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", [
+    # B, L, C, C2, N, expect the fused pair
+    (32, 44, 1024, 256, 1536, True),    # depth 7 at 32 evaluations per branch: 128x64 macro tiles on both GEMMs
+    (16, 44, 1024, 256, 1536, True),    # ... at 16 (batch 32 without guidance)
+    (32, 88, 1024, 256, 1536, True),    # depth 6: 128x192 two-slot tiles on the projection
+    (32, 176, 512, 128, 1536, True),    # depth 5
+    (32, 352, 256, 64, 1536, True),     # depth 4: K = 256, four 64-deep steps
+    (7, 301, 256, 64, 384, True),       # ragged rows (2107 = 16 x 128 + 59), 192-wide tiles with an empty half, three heads
+    (5, 1000, 128, 32, 256, False),     # C2 = 32 is outside the macro tile's 64-channel steps: falls back to the unfused launches
+    (4, 44, 1024, 256, 1536, True),     # small batch: the register-staged / staged 32x32 kernels carry the same fusion
+])
+def test_inject_prenorm_projection_pair(cuda, dtype, shape):
+    """z = m + Conv1x1(cat[m, ctx]) + b and q = Linear(LayerNorm(z)) (a-unet InjectChannelsItem, AttentionItem's pre-norm + to_q | to_kv;
+    SURVEY appendix A.3 items 3-4) through sf_op_inject_prenorm_proj against fp32 torch from the same 16-bit-rounded inputs."""
+    _l, lib = _lib()
+    B, L, C, C2, N, want_fused = shape
+    td = TD[dtype]
+    g = torch.Generator().manual_seed(B * 1000 + L + C)
+    m = torch.randn(B, L, C, generator=g) * 1.3 + 0.4      # a mean well away from zero: the accumulator-side LayerNorm subtracts mean * colsum
+    ctx = torch.randn(B, L, C2, generator=g)
+    w_inj = torch.randn(C, C + C2, generator=g) / (C + C2) ** 0.5
+    b_inj = torch.randn(C, generator=g) * 0.1
+    gamma = 1 + 0.2 * torch.randn(C, generator=g)
+    beta = 0.1 * torch.randn(C, generator=g)
+    w_q = torch.randn(N, C, generator=g) / C ** 0.5
+    mr, cr = m.to(td).float(), ctx.to(td).float()
+    z_ref = mr + F.linear(torch.cat([mr, cr], dim=-1), w_inj.to(td).float(), b_inj)
+    q_ref = F.linear(F.layer_norm(z_ref.to(td).float(), (C,), gamma, beta, eps=1e-5), w_q)
+    dev = lambda t: t.contiguous().to(cuda)
+    md, cd = dev(m.to(td)), dev(ctx.to(td))
+    z = torch.empty(B, L, C, dtype=td, device=cuda)
+    q = torch.empty(B, L, N, dtype=td, device=cuda)
+    n = lib.sf_op_inject_prenorm_proj_workspace_bytes(B, L, C, C2, N)
+    assert n > 0
+    ws = torch.empty(n, dtype=torch.uint8, device=cuda)
+    import ctypes
+
+    fused = ctypes.c_int(-1)
+    args = [dev(t) for t in (w_inj, b_inj, gamma, beta, w_q)]
+    rc = lib.sf_op_inject_prenorm_proj(_l.DTYPES[dtype], md.data_ptr(), cd.data_ptr(), args[0].data_ptr(), args[1].data_ptr(), args[2].data_ptr(),
+                                       args[3].data_ptr(), 1e-5, args[4].data_ptr(), B, L, C, C2, N, z.data_ptr(), q.data_ptr(), ctypes.byref(fused),
+                                       ws.data_ptr(), ws.numel(), _l.stream_ptr(cuda))
+    _l.check(rc, "sf_op_inject_prenorm_proj")
+    torch.cuda.synchronize()
+    ez, eq = rel_l2(z.float().cpu(), z_ref), rel_l2(q.float().cpu(), q_ref)
+    print(f"inject + pre-norm projection {dtype} {shape}: fused {fused.value}, z {ez:.3e}, q {eq:.3e}")
+    assert fused.value == (1 if want_fused else 0)
+    assert ez < TOL[dtype] and eq < TOL[dtype], f"{dtype} {shape}: z {ez:.3e} q {eq:.3e}"
