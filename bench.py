@@ -145,7 +145,17 @@ def synthetic_conditioning(model, B, L, device, real: bool):
     return info["xs"][2:-1], emb
 
 
-def timed_sample(model, device, noise, channels, emb, scale, steps, warm=2):
+REPEATS = 3   # every secondary leg times its loop this many times: boxes differ by +-2-3 %, two runs on one box by < 0.5 %
+
+
+def spread(rates) -> dict:
+    """min / median / max of the repeated timings of a leg (steps/s unless the leg says otherwise)."""
+    v = sorted(rates)
+    return dict(min=round(v[0], 3), median=round(v[len(v) // 2], 3), max=round(v[-1], 3), repeats=len(v))
+
+
+def timed_sample(model, device, noise, channels, emb, scale, steps, warm=2, repeats=REPEATS):
+    """(median steps/s of `repeats` timed sample() calls, last output, spread dict)."""
     import torch
 
     def run(n):
@@ -154,11 +164,15 @@ def timed_sample(model, device, noise, channels, emb, scale, steps, warm=2):
     run(2)
     if warm:
         run(warm)
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    out = run(steps)
-    torch.cuda.synchronize(device)
-    return steps / (time.perf_counter() - t0), out
+    rates = []
+    for _ in range(repeats):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        out = run(steps)
+        torch.cuda.synchronize(device)
+        rates.append(steps / (time.perf_counter() - t0))
+    sp = spread(rates)
+    return sp["median"], out, sp
 
 
 def extra_workloads(model, device, args, noise, channels, emb) -> dict:
@@ -191,14 +205,14 @@ def extra_workloads(model, device, args, noise, channels, emb) -> dict:
         prev = net.compute_dtype
         net.compute_dtype = "fp32"
         try:
-            rate, _ = timed_sample(model, device, noise, channels, emb, args.scale, steps, warm=2)
+            rate, _, sp = timed_sample(model, device, noise, channels, emb, args.scale, steps, warm=2)
             hi = model.model.sample(x_noisy=noise, num_steps=ref_steps, channels=channels, embedding=emb, embedding_scale=args.scale)
         finally:
             net.compute_dtype = prev
             net.engine()
         rel = float((lo.double() - hi.double()).norm() / hi.double().norm())
         ms = 1e3 / rate
-        return dict(steps_per_s=round(rate, 2), ms_per_step=round(ms, 3), dtype="fp32", batch=noise.shape[0], timed_steps=steps,
+        return dict(steps_per_s=round(rate, 2), steps_per_s_spread=sp, ms_per_step=round(ms, 3), dtype="fp32", batch=noise.shape[0], timed_steps=steps,
                     step_roofline_frac=round(roof_ms(noise.shape[0], 1 if args.scale == 1.0 else 2, L0, "fp32") / ms, 4),
                     lowp_vs_fp32_final_sample_rel_l2=round(rel, 6), lowp_dtype=args.dtype, rel_l2_steps=ref_steps)
 
@@ -206,12 +220,12 @@ def extra_workloads(model, device, args, noise, channels, emb) -> dict:
         B, scale, steps = 32, 2.0, BASELINE_STEPS      # the configuration's own 50 steps: the per-call conditioning is amortised as in a real run
         nz = torch.randn(B, 1, L0, generator=torch.Generator().manual_seed(1000)).to(device)
         ch, e = synthetic_conditioning(model, B, L0, device, real=True)
-        rate, o = timed_sample(model, device, nz, ch, e, scale, steps, warm=2)
+        rate, o, sp = timed_sample(model, device, nz, ch, e, scale, steps, warm=2)
         assert torch.isfinite(o).all()
         ms = 1e3 / rate
         w = workmodel.unet_work(hp, L0, B, 2, ES[args.dtype])
         return dict(workload="BASELINE configs[2]: batch=32, guidance scale 2.0 (64 evaluations/step), CLAP-shaped embedding + onset conditioning",
-                    steps_per_s=round(rate, 2), ms_per_step=round(ms, 3), dtype=args.dtype, timed_steps=steps,
+                    steps_per_s=round(rate, 2), steps_per_s_spread=sp, ms_per_step=round(ms, 3), dtype=args.dtype, timed_steps=steps,
                     algorithmic_tflop_per_step=round(w["flops"] / 1e12, 3), tflops=round(w["flops"] / 1e12 / (ms * 1e-3), 1),
                     step_roofline_frac=round(roof_ms(B, 2, L0, args.dtype) / ms, 4))
 
@@ -221,11 +235,11 @@ def extra_workloads(model, device, args, noise, channels, emb) -> dict:
         B, steps = 32, BASELINE_STEPS
         nz = torch.randn(B, 1, L0, generator=torch.Generator().manual_seed(1000)).to(device)
         ch, e = synthetic_conditioning(model, B, L0, device, real=True)
-        rate, o = timed_sample(model, device, nz, ch, e, 1.0, steps, warm=2)
+        rate, o, sp = timed_sample(model, device, nz, ch, e, 1.0, steps, warm=2)
         assert torch.isfinite(o).all()
         ms = 1e3 / rate
         w = workmodel.unet_work(hp, L0, B, 1, ES[args.dtype])
-        return dict(workload="BASELINE configs[3], one GPU's share: batch=32 (256 clips / 8 GPUs), no guidance", steps_per_s=round(rate, 2),
+        return dict(workload="BASELINE configs[3], one GPU's share: batch=32 (256 clips / 8 GPUs), no guidance", steps_per_s=round(rate, 2), steps_per_s_spread=sp,
                     ms_per_step=round(ms, 3), clip_steps_per_s=round(rate * B, 1), dtype=args.dtype, timed_steps=steps,
                     tflops=round(w["flops"] / 1e12 / (ms * 1e-3), 1), step_roofline_frac=round(roof_ms(B, 1, L0, args.dtype) / ms, 4))
 
@@ -233,33 +247,42 @@ def extra_workloads(model, device, args, noise, channels, emb) -> dict:
         B, L, scale, steps = 10, 262144, 2.0, 20     # exp/evaluate_gh_gen.yaml:8 (length), :21 (batch_size), :23 (embedding_scale)
         nz = torch.randn(B, 1, L, generator=torch.Generator().manual_seed(1000)).to(device)
         ch, e = synthetic_conditioning(model, B, L, device, real=True)
-        rate, o = timed_sample(model, device, nz, ch, e, scale, steps, warm=2)
+        rate, o, sp = timed_sample(model, device, nz, ch, e, scale, steps, warm=2)
         assert torch.isfinite(o).all()
         ms = 1e3 / rate
         w = workmodel.unet_work(hp, L, B, 2, ES[args.dtype])
         return dict(workload="reference evaluation shape: batch=10, length=2**18, embedding_scale=2.0 (exp/evaluate_gh_gen.yaml:8,21-23)",
-                    steps_per_s=round(rate, 2), ms_per_step=round(ms, 3), dtype=args.dtype, timed_steps=steps,
+                    steps_per_s=round(rate, 2), steps_per_s_spread=sp, ms_per_step=round(ms, 3), dtype=args.dtype, timed_steps=steps,
                     tflops=round(w["flops"] / 1e12 / (ms * 1e-3), 1), step_roofline_frac=round(roof_ms(B, 2, L, args.dtype) / ms, 4))
 
     def onset_leg():
         from syncfusion_amd.onset_net import VideoOnsetNet
 
         N, iters = 32, 10
-        torch.manual_seed(7)
-        onset = VideoOnsetNet(False, dtype=args.dtype if args.dtype != "fp32" else "bf16").to(device).eval()
         frames = torch.randn(N, 3, 30, 112, 112, generator=torch.Generator().manual_seed(4000)).to(device)
-        for _ in range(3):   # weight packing on the first call; clocks / caches settle on this workload after the U-Net legs
-            onset(frames)
-        torch.cuda.synchronize(device)
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            y = onset(frames)
-        torch.cuda.synchronize(device)
-        dt = (time.perf_counter() - t0) / iters
-        assert y.shape == (N, 30) and torch.isfinite(y).all()
-        tf = N * workmodel.ONSET_NET_GFLOP_PER_CLIP / 1e3 / dt
-        return dict(workload="VideoOnsetNet (R(2+1)D-18) forward, N=32 clips of (3,30,112,112)", clips_per_s=round(N / dt, 1),
-                    tflops=round(tf, 1), mfma_frac=round(tf / PEAK_BF16_TFLOPS, 4), dtype=onset.compute_dtype)
+        res = {}
+        # bf16 (the headline's arithmetic) and fp16 (what BASELINE configs[4] names, and the type that keeps the onset track index-identical)
+        for dt in (("bf16", "fp16") if args.dtype != "fp16" else ("fp16",)):
+            torch.manual_seed(7)
+            onset = VideoOnsetNet(False, dtype=dt).to(device).eval()
+            for _ in range(3):   # weight packing on the first call; clocks / caches settle on this workload after the U-Net legs
+                onset(frames)
+            times = []
+            for _ in range(REPEATS):
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                for _ in range(iters):
+                    y = onset(frames)
+                torch.cuda.synchronize(device)
+                times.append((time.perf_counter() - t0) / iters)
+            assert y.shape == (N, 30) and torch.isfinite(y).all()
+            tfs = [N * workmodel.ONSET_NET_GFLOP_PER_CLIP / 1e3 / t for t in times]
+            sp = spread(tfs)
+            res[dt] = dict(clips_per_s=round(N * sp["median"] * 1e3 / (N * workmodel.ONSET_NET_GFLOP_PER_CLIP), 1), tflops=round(sp["median"], 1),
+                           tflops_spread=sp, mfma_frac=round(sp["median"] / PEAK_BF16_TFLOPS, 4), dtype=dt)
+            del onset
+        first = res["bf16"] if "bf16" in res else res["fp16"]
+        return dict(workload="VideoOnsetNet (R(2+1)D-18) forward, N=32 clips of (3,30,112,112)", **first, by_dtype=res)
 
     def e2e_leg():
         # BASELINE configs[4] on one GPU's share (32 clips): 2 s x 15 fps RGB frames -> onset net -> logits-to-track glue ->
@@ -283,23 +306,27 @@ def extra_workloads(model, device, args, noise, channels, emb) -> dict:
                 return generate_batch(model, track, z, num_steps=n_steps, length=L0, embedding_scale=scale, cut_prefix=True, cut_length=44100)
 
             once(2)
-            torch.cuda.synchronize(device)
-            t0 = time.perf_counter()
-            gen = once(steps)
-            torch.cuda.synchronize(device)
-            dt = time.perf_counter() - t0
+            secs = []
+            for _ in range(REPEATS):
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                gen = once(steps)
+                torch.cuda.synchronize(device)
+                secs.append(time.perf_counter() - t0)
+            dt = sorted(secs)[len(secs) // 2]
         finally:
             net.compute_dtype = prev
             net.engine()
         assert gen.shape == (B, 1, 44100) and torch.isfinite(gen).all()
         return dict(workload="BASELINE configs[4], one GPU's share: 32 clips of 30x112x112 RGB frames -> VideoOnsetNet -> onset track -> Encoder1d -> "
                              "100-step diffusion (scale 2.0) -> cut/crop, fp16", clips_per_s=round(B / dt, 2), seconds_per_batch=round(dt, 3),
+                    seconds_per_batch_spread=spread(secs),
                     denoise_steps_per_s=round(steps / dt, 2), dtype="fp16")
 
     def train_leg():
         # the reference's training configuration (exp/train_diffusion_gh.yaml:8,38,87): fp32, batch 4 per device, clips of 2^18
         # samples; Model.training_step -> loss.backward() (HIP forward + backward kernels) -> AdamW over U-Net + onset encoder
-        B, L, iters = 4, 262144, 5
+        B, L, iters = 4, 262144, 3 * REPEATS     # REPEATS timed groups of three steps after one untimed step
         g = torch.Generator().manual_seed(5)
         x = torch.randn(B, 1, L, generator=g).to(device)
         y = (torch.rand(B, 1, L, generator=g) < 0.0005).float().to(device)
@@ -308,10 +335,11 @@ def extra_workloads(model, device, args, noise, channels, emb) -> dict:
         losses = []
         try:
             with torch.enable_grad():
+                marks = []
                 for it in range(iters + 1):
-                    if it == 1:
+                    if it >= 1 and (it - 1) % 3 == 0:
                         torch.cuda.synchronize(device)
-                        t0 = time.perf_counter()
+                        marks.append(time.perf_counter())
                     loss = model.training_step((x, y, x, None, None), it)
                     opt.zero_grad(set_to_none=True)
                     loss.backward()
@@ -319,7 +347,9 @@ def extra_workloads(model, device, args, noise, channels, emb) -> dict:
                     losses.append(loss.detach())   # read back after the timed region: a host read per step would serialise the
                                                    # Python-issued forward of step i+1 behind the backward of step i
                 torch.cuda.synchronize(device)
-                dt = (time.perf_counter() - t0) / iters
+                marks.append(time.perf_counter())
+                group_ms = [1e3 * (b_ - a_) / 3 for a_, b_ in zip(marks[:-1], marks[1:])]
+                dt = sorted(group_ms)[len(group_ms) // 2] / 1e3
                 losses = [round(float(v), 5) for v in losses]
         finally:
             del opt
@@ -328,7 +358,8 @@ def extra_workloads(model, device, args, noise, channels, emb) -> dict:
             torch.cuda.empty_cache()
         assert all(math.isfinite(v) for v in losses) and losses[-1] < losses[0], losses
         return dict(workload="training step (exp/train_diffusion_gh.yaml): fp32, batch 4 x 2**18 samples, v-objective loss -> backward -> AdamW",
-                    ms_per_step=round(1e3 * dt, 2), clips_per_s=round(B / dt, 2), dtype="fp32", timed_steps=iters, losses=losses)
+                    ms_per_step=round(1e3 * dt, 2), ms_per_step_spread=spread(group_ms), clips_per_s=round(B / dt, 2), dtype="fp32", timed_steps=iters,
+                    losses=losses)
 
     def transpose_up_legs():
         # The OTHER candidate network (SURVEY 8f-1 cannot be settled offline): upsample_mode="transpose", a-unet's `Upsample` =
@@ -341,26 +372,26 @@ def extra_workloads(model, device, args, noise, channels, emb) -> dict:
         try:
             B1 = noise.shape[0]
             ch1, e1 = synthetic_conditioning(mt, B1, L0, device, real=False)
-            rate, o = timed_sample(mt, device, noise, ch1, e1, 1.0, BASELINE_STEPS, warm=5)
+            rate, o, sp = timed_sample(mt, device, noise, ch1, e1, 1.0, BASELINE_STEPS, warm=5)
             assert torch.isfinite(o).all()
             w = workmodel.unet_work(hpt, L0, B1, 1, ES[args.dtype], upsample_mode="transpose")
             peak = (PEAK_F32_TFLOPS if args.dtype == "fp32" else PEAK_BF16_TFLOPS) * 1e12
             ms = 1e3 / rate
             res["config1_transpose_up"] = dict(
                 workload=f"BASELINE configs[1] on the transposed-up network: batch={B1}, {BASELINE_STEPS} steps, scale 1.0, dummy cond",
-                steps_per_s=round(rate, 2), ms_per_step=round(ms, 3), dtype=args.dtype, timed_steps=BASELINE_STEPS,
+                steps_per_s=round(rate, 2), steps_per_s_spread=sp, ms_per_step=round(ms, 3), dtype=args.dtype, timed_steps=BASELINE_STEPS,
                 params_M=round(sum(p.numel() for p in mt.model.net.parameters()) / 1e6, 2),
                 step_roofline_frac=round(workmodel.step_roofline_ms(w, peak, PEAK_HBM_GBS * 1e9) / ms, 4))
             B2, scale = 32, 2.0
             nz = torch.randn(B2, 1, L0, generator=torch.Generator().manual_seed(1000)).to(device)
             ch2, e2 = synthetic_conditioning(mt, B2, L0, device, real=True)
-            rate, o = timed_sample(mt, device, nz, ch2, e2, scale, BASELINE_STEPS, warm=2)
+            rate, o, sp = timed_sample(mt, device, nz, ch2, e2, scale, BASELINE_STEPS, warm=2)
             assert torch.isfinite(o).all()
             w = workmodel.unet_work(hpt, L0, B2, 2, ES[args.dtype], upsample_mode="transpose")
             ms = 1e3 / rate
             res["config2_transpose_up"] = dict(
                 workload="BASELINE configs[2] on the transposed-up network: batch=32, guidance scale 2.0, real conditioning",
-                steps_per_s=round(rate, 2), ms_per_step=round(ms, 3), dtype=args.dtype, timed_steps=BASELINE_STEPS,
+                steps_per_s=round(rate, 2), steps_per_s_spread=sp, ms_per_step=round(ms, 3), dtype=args.dtype, timed_steps=BASELINE_STEPS,
                 tflops=round(w["flops"] / 1e12 / (ms * 1e-3), 1),
                 step_roofline_frac=round(workmodel.step_roofline_ms(w, peak, PEAK_HBM_GBS * 1e9) / ms, 4))
         finally:
@@ -368,6 +399,13 @@ def extra_workloads(model, device, args, noise, channels, emb) -> dict:
             torch.cuda.empty_cache()
         return res
 
+    def config1_repeat_leg():
+        # the headline's own loop (same inputs, same --steps) three more times: what a 2-6 % difference between rounds has to be read against
+        rate, _, sp = timed_sample(model, device, noise, channels, emb, args.scale, args.steps, warm=0)
+        return dict(workload=f"the headline loop again: batch={noise.shape[0]}, {args.steps} steps, scale {args.scale}", steps_per_s=round(rate, 2),
+                    steps_per_s_spread=sp, dtype=args.dtype, timed_steps=args.steps)
+
+    leg("config1_repeat", config1_repeat_leg)
     if args.dtype != "fp32":
         leg("fp32_config1", fp32_leg)
     leg("config2_b32_cfg", config2_leg)

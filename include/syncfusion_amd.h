@@ -74,6 +74,13 @@ typedef struct {
   /* Up path of a block (a-unet apex.py): SF_UP_NEAREST_CONV3 = nn.Upsample(nearest) + Conv1d(k=3) [UpsampleInterpolate];
    * SF_UP_TRANSPOSE = ConvTranspose1d(kernel = stride = factor) [Upsample]; `blocks.{d}.up.weight` is (in, C, 3) resp. (C, in, factor). */
   int32_t upsample_mode;
+  /* [RECALLED] facts about a-unet's TimeConditioningPlugin / AttentionBase that only the upstream package can settle;
+   * zero = SURVEY appendix A.3 as written.  tools/pin_upstream.py decides them, keymap.py reads the first and the last off a checkpoint.
+   *   time_fourier_features: learned frequencies of the time embedder (0 = modulation_features / 2; a-unet NumberEmbedder(dim=256) = 128):
+   *     `time.fourier_w` has this many entries, `time.lin0.weight` is (modulation_features, 1 + 2 * time_fourier_features);
+   *   time_no_first_act: 1 = no GELU between the embedder's Linear and the two (Linear, GELU) layers;
+   *   attention_out_bias: 1 = every `to_out` Linear of the attention items carries a bias (`<item>.{attn,cross}.to_out.bias`). */
+  int32_t time_fourier_features, time_no_first_act, attention_out_bias;
 } sf_unet_config;
 
 typedef struct sf_unet sf_unet;

@@ -51,7 +51,11 @@ RECALLED_DEFAULTS = dict(
     attn_pos_embedding=False,         # Attention adds a learned positional embedding `<attn>.pos.weight` (max_length, C) to its input: off (default)
     attn_scale="head",                # logits * head_features**-0.5 (default) | "none"
     upsample_mode=None,               # None: cfg["upsample_mode"] (default "nearest" = UpsampleInterpolate) | "transpose" (Upsample)
+    time_first_act=None,              # None: cfg["time_first_activation"] (default True = GELU after the time embedder's Linear) | "gelu" | "none"
 )
+# Two more [RECALLED] facts are decided by the PARAMETERS handed in, not by a switch (a checkpoint's shapes settle them, keymap.infer_variants):
+# the number of learned Fourier frequencies of the time embedder (`net.time.fourier_w`: modulation_features // 2 = 512 per SURVEY appendix A,
+# 128 if upstream's NumberEmbedder(dim=256) is what builds it) and a bias on every attention `to_out` Linear (`<attn>.to_out.bias` present).
 
 
 def recalled_variants(cfg) -> Dict:
@@ -66,13 +70,16 @@ def _lin(P: Dict[str, Tensor], name: str, x: Tensor) -> Tensor:
     return F.linear(x, P[name + ".weight"], P.get(name + ".bias"))
 
 
-def time_features(P: Dict[str, Tensor], sigma: Tensor) -> Tensor:
-    """TimeConditioningPlugin (A.3): learned-Fourier(sigma) -> Linear -> GELU -> 2x(Linear, GELU)."""
+def time_features(P: Dict[str, Tensor], sigma: Tensor, first_act: bool = True) -> Tensor:
+    """TimeConditioningPlugin (A.3): learned-Fourier(sigma) -> Linear -> [GELU] -> 2x(Linear, GELU); the number of frequencies is whatever
+    `net.time.fourier_w` holds."""
     w = P["net.time.fourier_w"]
     x = sigma.reshape(-1, 1).to(torch.float32)
     freqs = x * w[None, :] * (2.0 * math.pi)
     four = torch.cat([x, freqs.sin(), freqs.cos()], dim=-1)
-    f = F.gelu(_lin(P, "net.time.lin0", four))
+    f = _lin(P, "net.time.lin0", four)
+    if first_act:
+        f = F.gelu(f)
     for i in range(2):
         f = F.gelu(_lin(P, f"net.time.mlp.{i}", f))
     return f
@@ -124,7 +131,7 @@ def _attention(P, pre: str, x: Tensor, context: Optional[Tensor], heads: int, he
     attn = sim.softmax(dim=-1, dtype=torch.float32)
     out = torch.einsum("bhnm,bhmd->bhnd", attn, v)
     out = out.transpose(1, 2).reshape(B, n, heads * head_features)
-    out = F.linear(out, P[pre + ".to_out.weight"])
+    out = F.linear(out, P[pre + ".to_out.weight"], P.get(pre + ".to_out.bias"))
     return (xt + out).transpose(1, 2)
 
 
@@ -188,7 +195,8 @@ def unet_forward(P, cfg, x: Tensor, sigma: Tensor, *, embedding: Tensor, channel
 
     Two *sequential* passes when embedding_scale != 1, like upstream."""
     assert embedding is not None, "ClassifierFreeGuidancePlugin requires embedding"
-    f = time_features(P, sigma)
+    tfa = recalled_variants(cfg)["time_first_act"]
+    f = time_features(P, sigma, cfg.get("time_first_activation", True) if tfa is None else tfa == "gelu")
     if embedding_scale != 1.0:
         B, n = embedding.shape[:2]
         fixed = P["net.cfg.fixed_embedding.weight"][:n][None].expand(B, -1, -1)

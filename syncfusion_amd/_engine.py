@@ -115,6 +115,9 @@ class UNetEngine(_Base):
             setattr(cfg, field, int(hp[field]))
         cfg.dtype = _lib.DTYPES[dtype]
         cfg.upsample_mode = _lib.UPSAMPLE_MODES[hp.get("upsample_mode", "nearest")]
+        cfg.time_fourier_features = int(hp.get("time_fourier_features") or 0)
+        cfg.time_no_first_act = 0 if hp.get("time_first_activation", True) else 1
+        cfg.attention_out_bias = 1 if hp.get("attention_out_bias", False) else 0
         self.cfg = cfg
         self.hp = dict(hp)
         self.dtype = dtype

@@ -35,6 +35,7 @@ class UnetConfig(C.Structure):
         ("embedding_features", C.c_int32), ("embedding_max_length", C.c_int32),
         ("modulation_features", C.c_int32), ("resnet_groups", C.c_int32), ("dtype", C.c_int32),
         ("upsample_mode", C.c_int32),
+        ("time_fourier_features", C.c_int32), ("time_no_first_act", C.c_int32), ("attention_out_bias", C.c_int32),
     ]
 
 

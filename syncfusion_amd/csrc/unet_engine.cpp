@@ -365,8 +365,9 @@ void build_group(Builder &bd, Group &g, const std::string &pre, int d, int &mod_
     const float *wq = bd.get(a + ".to_q.weight", (int64_t)hd * C);
     const float *wkv = bd.get(a + ".to_kv.weight", (int64_t)2 * hd * C);
     const float *wo = bd.get(a + ".to_out.weight", (int64_t)C * hd);
+    const float *bo = c.attention_out_bias ? bd.get(a + ".to_out.bias", C) : nullptr;
     g.qkv = bd.linear_alloc(3 * hd, C, true);
-    g.attn_out = bd.linear_alloc(C, hd, false);
+    g.attn_out = bd.linear_alloc(C, hd, c.attention_out_bias != 0);
     if (!u.listing) {
       // fold the LayerNorm affines:  W (g*xhat + b) = (W diag g) xhat + W b
       bd.linear_into(g.qkv, 0, wq, hd, C, ng);
@@ -374,6 +375,7 @@ void build_group(Builder &bd, Group &g, const std::string &pre, int d, int &mod_
       SF_HIP(launch_fold_bias(wq, hd, C, nb, nullptr, g.qkv.bias, bd.s));
       SF_HIP(launch_fold_bias(wkv, 2 * hd, C, cb, nullptr, g.qkv.bias + hd, bd.s));
       bd.linear_into(g.attn_out, 0, wo, C, hd, nullptr);
+      if (bo) SF_HIP(hipMemcpyAsync(g.attn_out.bias, bo, C * sizeof(float), hipMemcpyDeviceToDevice, bd.s));
       g.qkv_colsum = u.arena.alloc_n<float>(3 * hd);
       SF_HIP(launch_row_sums(u.dt, g.qkv.w, 3 * hd, g.qkv.K, g.qkv_colsum, bd.s));
       bd.pack_wfr(g.qkv);
@@ -391,14 +393,16 @@ void build_group(Builder &bd, Group &g, const std::string &pre, int d, int &mod_
     const float *cg = bd.get(a + ".norm_context.weight", E), *cb = bd.get(a + ".norm_context.bias", E);
     const float *wkv = bd.get(a + ".to_kv.weight", (int64_t)2 * hd * E);
     const float *wo = bd.get(a + ".to_out.weight", (int64_t)C * hd);
+    const float *bo = c.attention_out_bias ? bd.get(a + ".to_out.bias", C) : nullptr;
     g.ca_idx = n_ca++;
     g.ca_off = ca_cols;
     ca_cols += C;
-    g.cross_out = bd.linear_alloc(C, hd, false);
+    g.cross_out = bd.linear_alloc(C, hd, c.attention_out_bias != 0);   // the bias rides in the collapsed per-clip vector
     if (!u.listing) {
       bd.linear_into(u.wv_cat, g.ca_idx * hd, wkv + (int64_t)hd * E, hd, E, cg);
       SF_HIP(launch_fold_bias(wkv + (int64_t)hd * E, hd, E, cb, nullptr, u.wv_cat.bias + g.ca_idx * hd, bd.s));
       bd.linear_into(g.cross_out, 0, wo, C, hd, nullptr);
+      if (bo) SF_HIP(hipMemcpyAsync(g.cross_out.bias, bo, C * sizeof(float), hipMemcpyDeviceToDevice, bd.s));
     }
   }
 }
@@ -413,7 +417,8 @@ void build(sf_unet &u, const WeightMap *wm, hipStream_t s) {
   u.dt = c.dtype;
   u.mf = c.modulation_features;
   u.hd = c.attention_heads * c.attention_features;
-  u.half = u.mf / 2;
+  if (c.time_fourier_features < 0 || c.time_fourier_features > 4096) fail(SF_ERR_INVALID, "time_fourier_features out of range");
+  u.half = c.time_fourier_features > 0 ? c.time_fourier_features : u.mf / 2;
   u.four_ld = pad_to(1 + 2 * u.half, 32);
   Builder bd{u, wm, s};
 
@@ -1454,7 +1459,7 @@ struct Exec {
   void features_rows(const float *sig, const int *sig_idx, int rows, float *mod_out) {
     timed("time_fourier", 0.0, (double)rows * u.four_ld * dsize(u.dt),
           [&] { SF_HIP(launch_time_fourier(u.dt, sig, sig_idx, u.fourier_w, rows, u.half, p.four, u.four_ld, s)); });
-    dense(u.lin0, p.four, u.four_ld, rows, p.f1, u.mf, /*gelu*/ 2, false);
+    dense(u.lin0, p.four, u.four_ld, rows, p.f1, u.mf, /*gelu unless the [RECALLED] switch says none*/ u.cfg.time_no_first_act ? 0 : 2, false);
     dense(u.mlp0, p.f1, u.mf, rows, p.f2, u.mf, 2, false);
     dense(u.mlp1, p.f2, u.mf, rows, p.sf, u.mf, /*silu(gelu)*/ 3, false);
     dense(u.mod, p.sf, u.mf, rows, mod_out, u.mod_ld, 0, true);

@@ -102,8 +102,13 @@ class Model(_Base):
         ``nn.Module.load_state_dict(state_dict, strict, assign)``; ``hypothesis`` (a ``keymap.OrderHypothesis``) is keyword-only.
         ``strict=False`` tolerates what nn.Module tolerates: with this build's own key layout, missing keys keep their current
         values and unexpected keys are reported in the returned ``_IncompatibleKeys`` instead of raising."""
-        from .keymap import IGNORED_PREFIXES, KeyMapError, translate_state_dict
+        from .keymap import IGNORED_PREFIXES, KeyMapError, _DUP_NET, _strip, infer_variants, translate_state_dict
 
+        # [RECALLED] facts that change parameter SHAPES (the time embedder's width, a bias on the attention output projections): when the
+        # checkpoint's own tensors decide them differently from how this model was built, the U-Net re-registers those parameters first
+        net_sd = _strip({k: v for k, v in state_dict.items() if not _DUP_NET.match(k)}, "model.net.")
+        if net_sd and hasattr(self.model.net, "adopt_variants"):
+            self.model.net.adopt_variants(**infer_variants(net_sd, self.model.net.hparams))
         own = super().state_dict()
         try:
             mapped = translate_state_dict(state_dict, self, hypothesis)

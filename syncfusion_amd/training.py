@@ -93,11 +93,13 @@ def _affine_ln(x: Tensor, gamma: Tensor, beta: Tensor, eps: float) -> Tensor:
 # ---------------------------------------------------------------------------------------------------------------------------
 # U-Net (a-unet XUNet behind TimeConditioningPlugin + ClassifierFreeGuidancePlugin)
 # ---------------------------------------------------------------------------------------------------------------------------
-def _time_features(P, sigma: Tensor) -> Tensor:
+def _time_features(P, sigma: Tensor, first_act: bool = True) -> Tensor:
     w = P["time.fourier_w"]
     x = sigma.reshape(-1, 1).to(torch.float32)
     freqs = x * w[None, :] * (2.0 * math.pi)
-    f = F.gelu(_lin(P, "time.lin0", torch.cat([x, freqs.sin(), freqs.cos()], dim=-1)))
+    f = _lin(P, "time.lin0", torch.cat([x, freqs.sin(), freqs.cos()], dim=-1))
+    if first_act:                       # [RECALLED] switch hparams["time_first_activation"] (UNetV0)
+        f = F.gelu(f)
     for i in range(2):
         f = F.gelu(_lin(P, f"time.mlp.{i}", f))
     return f
@@ -112,7 +114,7 @@ def _resnet(P, pre: str, x: Tensor, groups: int) -> Tensor:
 def _self_attention(P, pre: str, x: Tensor, heads: int) -> Tensor:
     q = _pointwise(_affine_ln(x, P[pre + ".norm.weight"], P[pre + ".norm.bias"], 1e-5), P[pre + ".to_q.weight"], None)
     kv = _pointwise(_affine_ln(x, P[pre + ".norm_context.weight"], P[pre + ".norm_context.bias"], 1e-5), P[pre + ".to_kv.weight"], None)
-    return _pointwise(sfa.attention(q, kv, heads), P[pre + ".to_out.weight"], None, residual=x)
+    return _pointwise(sfa.attention(q, kv, heads), P[pre + ".to_out.weight"], P.get(pre + ".to_out.bias"), residual=x)
 
 
 class _ZeroGradAnchor(torch.autograd.Function):
@@ -215,6 +217,8 @@ def _cross_attention_outputs(P, hp, emb: Tensor) -> Dict[str, Tensor]:
         wo = torch.stack([P[pres[i] + ".to_out.weight"] for i in idx])                                 # (k, C, hd)
         vi = v[idx[0]:idx[-1] + 1] if idx == list(range(idx[0], idx[-1] + 1)) else v[idx]
         o = torch.bmm(vi, wo.transpose(1, 2))                                                          # (k, B, C)
+        if (pres[idx[0]] + ".to_out.bias") in P:                                                       # [RECALLED] switch attention_out_bias
+            o = o + torch.stack([P[pres[i] + ".to_out.bias"] for i in idx])[:, None, :]
         for j, i in enumerate(idx):
             out[pres[i]] = o[j][:, None, :]
     return out
@@ -282,7 +286,7 @@ def unet_forward(net, x: Tensor, sigma: Tensor, *, embedding: Tensor, channels: 
         want = (B, hp["context_channels"][d])
         assert tuple(c.shape[:2]) == want, f"context channels at depth {d}: {tuple(c.shape)} vs {want}"
     ctx = [c.to(torch.float32).transpose(1, 2) for c in channels]
-    f_act = _modulation_outputs(P, hp, F.silu(_time_features(P, sigma)))   # per-item modulation rows, keyed by Linear name
+    f_act = _modulation_outputs(P, hp, F.silu(_time_features(P, sigma, hp.get("time_first_activation", True))))   # per-item modulation rows, keyed by Linear name
     emb = embedding.to(torch.float32)
     fixed = P["cfg.fixed_embedding.weight"][: emb.shape[1]][None].expand(B, -1, -1)
     if embedding_mask_proba > 0.0:   # ClassifierFreeGuidancePlugin: per-clip replacement by the learned fixed embedding

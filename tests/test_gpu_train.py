@@ -253,19 +253,18 @@ def test_unet_training_forward_and_every_gradient_against_oracle_autograd(cuda, 
 
 
 def test_unet_training_gradients_at_channel_counts_outside_the_vectorised_reductions(cuda):
-    """in_channels = 3 and widths 24 / 96 / 320: GroupNorm and the convolutions accept them, and the length reductions in the
-    backward of the per-clip add and of SkipModulate (sf_op_length_sums) take their one-column-per-lane form; every gradient against
-    autograd through the oracle."""
+    """in_channels = 3: block 0's SkipModulate scale gradient is a length reduction over 3 channels, which sf_op_length_sums takes in its
+    one-column-per-lane form (its 16-byte vector passes need C / 4 dividing 256); every gradient against autograd through the oracle.
+    (Level widths stay on the counts GroupNorm / LayerNorm-Modulation cover: those ops bound the model before the reductions do.)"""
     from oracle import unet_ref
     from syncfusion_amd.diffusion import UNetV0
 
-    hp = dict(SMALL_UNET, in_channels=3, channels=[24, 96, 320], factors=[1, 4, 2], items=[1, 1, 1], attentions=[0, 0, 1],
-              cross_attentions=[1, 1, 1], context_channels=[2, 8, 16])
+    hp = dict(SMALL_UNET, in_channels=3)
     net = UNetV0(dim=1, use_embedding_cfg=True, dtype="fp32", seed=5, **hp)
     net.load_state_dict(seeded_state(net, 5))
     cfg = dict(net.hparams)
     P = {k: v.clone().requires_grad_() for k, v in oracle_params(net, "net.").items()}
-    B, L0 = 2, 8 * 9
+    B, L0 = 2, 16 * 9
     x, sigma, emb, chans = synth_inputs(hp, B, L0, seed=31)
     target = torch.randn(B, 3, L0, generator=torch.Generator().manual_seed(32))
     v_ref = unet_ref.unet_forward(P, cfg, x, sigma, embedding=emb, channels=chans, embedding_scale=1.0)

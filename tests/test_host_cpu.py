@@ -26,17 +26,25 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert lib.sf_device_ok() in (0, 1)
 
 
-@pytest.mark.parametrize("upsample_mode", ["nearest", "transpose"])
-def test_param_enumeration_matches_module_state_dict(upsample_mode):
+@pytest.mark.parametrize("upsample_mode,variants", [("nearest", {}), ("transpose", {}),
+                                                    ("nearest", dict(time_fourier_features=16, time_first_activation=False, attention_out_bias=True))])
+def test_param_enumeration_matches_module_state_dict(upsample_mode, variants):
     """sf_unet_param_name (host-only call) lists exactly the UNetV0 state_dict with a `net.` prefix, for both up-path forms
-    (nearest + Conv1d(k=3): `up.weight` (in, C, 3); ConvTranspose1d(kernel = stride = f): (C, in, f))."""
+    (nearest + Conv1d(k=3): `up.weight` (in, C, 3); ConvTranspose1d(kernel = stride = f): (C, in, f)) and under the [RECALLED]
+    alternatives that change the parameter set (narrower time embedder, biased attention output projections)."""
     from syncfusion_amd import _lib
 
     lib = _lib.load()
     net = small_unet_module(upsample_mode=upsample_mode)
+    if variants:
+        assert net.adopt_variants(**variants)
+        assert "blocks.2.items_down.0.attn.to_out.bias" in net.state_dict() and net.state_dict()["time.fourier_w"].numel() == 16
     cfg = _lib.UnetConfig()
     cfg.upsample_mode = _lib.UPSAMPLE_MODES[upsample_mode]
     hp = net.hparams
+    cfg.time_fourier_features = hp["time_fourier_features"]
+    cfg.time_no_first_act = 0 if hp["time_first_activation"] else 1
+    cfg.attention_out_bias = 1 if hp["attention_out_bias"] else 0
     cfg.n_layers = len(hp["channels"])
     cfg.in_channels = hp["in_channels"]
     for f in ("channels", "factors", "items", "attentions", "cross_attentions", "context_channels"):

@@ -258,7 +258,7 @@ def test_every_recalled_switch_changes_the_oracle_output():
     base = run(None, P)
     assert torch.equal(base, run(dict(unet_ref.RECALLED_DEFAULTS)))       # the defaults ARE the unparametrised oracle; extra params unused
     alternatives = dict(skip_form="h_plus_scaled_skip", mod_ln_eps=1e-5, mod_ln_affine=True, mod_act="none", attn_pos_embedding=True,
-                        attn_scale="none")
+                        attn_scale="none", time_first_act="none")
     assert set(alternatives) | {"upsample_mode"} == set(unet_ref.RECALLED_DEFAULTS)
     for key, alt in alternatives.items():
         if key == "mod_ln_eps":
@@ -273,6 +273,22 @@ def test_every_recalled_switch_changes_the_oracle_output():
     m6 = unet_ref._modulation(P, pre, xs_, f_, unet_ref.recalled_variants({}))
     m5 = unet_ref._modulation(P, pre, xs_, f_, unet_ref.recalled_variants(dict(variants=dict(mod_ln_eps=1e-5))))
     assert rel_l2(m5, m6) > 1e-2
+    # the two facts decided by the PARAMETERS handed in (VERDICT r4 missing #1): the width of the time embedder and a bias on the
+    # attention output projections -- the oracle follows the tensors, and both move the output
+    assert torch.equal(run({"time_first_act": "gelu"}, P), base) and torch.equal(run(None, P), base)
+    P3 = dict(P)
+    for k in P:
+        if k.endswith(".to_out.weight"):
+            P3[k.replace("to_out.weight", "to_out.bias")] = 0.3 * torch.randn(P[k].shape[0], generator=g)
+    assert rel_l2(run(None, P3), base) > 1e-3, "attention output bias"
+    net_n = small_unet_module()
+    assert net_n.adopt_variants(time_fourier_features=16) and not net_n.adopt_variants(time_fourier_features=16)
+    Pn = oracle_params(net_n, "net.")
+    assert Pn["net.time.fourier_w"].shape == (16,) and Pn["net.time.lin0.weight"].shape == (SMALL_UNET["modulation_features"], 33)
+    assert all(torch.equal(Pn[k], P[k]) for k in P if not k.startswith("net.time.fourier_w") and not k.startswith("net.time.lin0"))
+    with torch.no_grad():
+        out_n = unet_ref.unet_forward(Pn, dict(net_n.hparams), x, sigma, embedding=emb, channels=chans)
+    assert out_n.shape == base.shape and rel_l2(out_n, base) > 1e-3, "time embedder width"
     # the up-path switch needs the other weight layout (ConvTranspose1d): its own module
     net_t = small_unet_module(upsample_mode="transpose")
     Pt, cfgt = oracle_params(net_t, "net."), dict(net_t.hparams)
@@ -309,12 +325,13 @@ def test_pin_tool_search_identifies_a_hidden_combination():
     net = small_unet_module()
     P, hp = oracle_params(net, "net."), dict(net.hparams)
     x, sigma, emb, chans = synth_inputs(SMALL_UNET, 2, 16 * 4, seed=12)
-    secret = dict(unet_ref.RECALLED_DEFAULTS, skip_form="h_plus_scaled_skip", attn_scale="none", mod_ln_eps=1e-5, upsample_mode="nearest")
+    secret = dict(unet_ref.RECALLED_DEFAULTS, skip_form="h_plus_scaled_skip", attn_scale="none", mod_ln_eps=1e-5, upsample_mode="nearest",
+                  time_first_act="none")
     cfg = dict(hp, variants=secret)
     with torch.no_grad():
         fwd = lambda xx, ss, sc: unet_ref.unet_forward(P, cfg, xx, ss, embedding=emb, channels=chans, embedding_scale=sc)
         targets = (fwd(x, sigma, 1.0), fwd(x, sigma, 2.0), sampler_ref.vsample(lambda xx, ss: fwd(xx, ss, 2.0), x, 5))
     space = list(pin.search_space(unet_ref, False, dict(eps=1e-5, affine=False), False))
-    assert len(space) == 8 and dict(unet_ref.RECALLED_DEFAULTS, mod_ln_eps=1e-5, upsample_mode="nearest") in space
+    assert len(space) == 16 and dict(unet_ref.RECALLED_DEFAULTS, mod_ln_eps=1e-5, upsample_mode="nearest", time_first_act="gelu") in space
     winners = pin.find_combinations(P, hp, (x, sigma, emb, chans), targets, space, log=lambda *_: None)
     assert winners == [secret]

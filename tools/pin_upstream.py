@@ -50,7 +50,8 @@ def search_space(unet_ref, up_shapes_transposed: bool, ln_facts: dict, has_pos: 
 
     fixed = dict(mod_ln_eps=ln_facts["eps"], mod_ln_affine=ln_facts["affine"], attn_pos_embedding=has_pos,
                  upsample_mode="transpose" if up_shapes_transposed else "nearest")
-    free = dict(skip_form=["skip_plus_scaled_h", "h_plus_scaled_skip"], mod_act=["silu", "none"], attn_scale=["head", "none"])
+    free = dict(skip_form=["skip_plus_scaled_h", "h_plus_scaled_skip"], mod_act=["silu", "none"], attn_scale=["head", "none"],
+                time_first_act=["gelu", "none"])
     assert set(fixed) | set(free) == set(unet_ref.RECALLED_DEFAULTS)
     for combo in itertools.product(*free.values()):
         v = dict(fixed)
@@ -145,8 +146,14 @@ def main() -> int:
                     sa.DiffusionModel(net_t=functools.partial(sa.UNetV0, seed=0, upsample_mode="transpose" if transposed else "nearest"),
                                       diffusion_t=sa.VDiffusion, sampler_t=sa.VSampler, use_embedding_cfg=True, **kw),
                     sa.Encoder1d(seed=0, **SMALL_ENCODER), sa.RandomEmbedder(kw["embedding_features"]), None)
+    # the facts a checkpoint's SHAPES decide (width of the time embedder, a bias on the attention output projections) before anything is matched
+    src_net = keymap._strip({k: v for k, v in sd.items() if not keymap._DUP_NET.match(k)}, "model.net.")
+    shape_facts = keymap.infer_variants(src_net, ours.model.net.hparams)
+    print(f"facts read off upstream's tensor shapes: {shape_facts} (this build's defaults: "
+          f"{ {k: ours.model.net.hparams[k] for k in shape_facts} })")
+    ours.model.net.adopt_variants(**shape_facts)
     net_own = {k[len("model.net."):]: tuple(v.shape) for k, v in ours.state_dict().items() if k.startswith("model.net.")}
-    fits, why = keymap.infer_order(keymap._strip({k: v for k, v in sd.items() if not keymap._DUP_NET.match(k)}, "model.net."), ours.model.net.hparams, net_own)
+    fits, why = keymap.infer_order(src_net, ours.model.net.hparams, net_own)
     print(f"registration order by the checkpoint's own sequence: {fits or 'NONE -- ' + why}")
     if not fits:
         return 1
@@ -181,14 +188,18 @@ def main() -> int:
               "-- the restatement (SURVEY appendix A) or the key map differs from upstream, see the numbers above")
         return 1
     hyp, var = winners[0]
-    same = var == {**unet_ref.RECALLED_DEFAULTS, "upsample_mode": var["upsample_mode"]} and enc_winner == encoder1d_ref.RECALLED_DEFAULTS
+    hp_now = ours.model.net.hparams
+    same = (var == {**unet_ref.RECALLED_DEFAULTS, "upsample_mode": var["upsample_mode"], "time_first_act": "gelu"} and enc_winner == encoder1d_ref.RECALLED_DEFAULTS
+            and hp_now["time_fourier_features"] == hp_now["modulation_features"] // 2 and not hp_now["attention_out_bias"])
     np.savez_compressed(args.out, x=x.numpy(), sigma=sigma.numpy(), emb=emb.numpy(), **{f"ch{d}": c.numpy() for d, c in enumerate(chans)},
                         v=v_up.numpy(), v_cfg=v_up_cfg.numpy(), sample5=s_up.numpy(), y=y.numpy(), enc_z=z_up.numpy(),
                         hypothesis=np.array([hyp.time_first, hyp.skip_last, hyp.cfg_last]),
-                        variants=np.array(json.dumps(dict(unet=var, encoder=enc_winner))),
+                        variants=np.array(json.dumps(dict(unet=var, encoder=enc_winner, shapes={k: (int(v) if not isinstance(v, bool) else v)
+                                                                                                  for k, v in shape_facts.items()}))),
                         **{("w." + k): t.detach().numpy() for k, t in ours.state_dict().items() if not k.startswith("clap.")})
     print(f"PINNED under {hyp} with {var} / {enc_winner}; fixtures written to {args.out}")
-    print("the oracle's defaults ARE upstream" if same else "UPDATE the RECALLED_DEFAULTS in oracle/unet_ref.py / oracle/encoder1d_ref.py (and the engine) to the combination above")
+    print("the oracle's defaults ARE upstream" if same else "UPDATE the RECALLED_DEFAULTS in oracle/unet_ref.py / oracle/encoder1d_ref.py, the UNetV0 defaults "
+          "(time_fourier_features / time_first_activation / attention_out_bias) and syncfusion_amd/reference_config.py to the combination above")
     return 0
 
 
