@@ -718,6 +718,27 @@ struct Exec {
   int cur_depth = -1;               // depth tag of the launches being issued (profile records, roofline.depth_groups)
 
   template <class F> void timed(const char *label, double flops, double bytes, F &&f) {
+    {
+      // measurement aid (phase removal): SF_SKIP_LABELS=gn_silu,ln_modulate,... drops every launch whose label starts with one of the
+      // listed prefixes -- results are garbage, the step's wall time shows what that kernel family costs inside the two-branch step
+      static const std::vector<std::string> skip = [] {
+        std::vector<std::string> v;
+        if (const char *e = getenv("SF_SKIP_LABELS")) {
+          std::string all(e);
+          size_t a = 0;
+          while (a <= all.size()) {
+            const size_t b = all.find(',', a);
+            const std::string t = all.substr(a, b == std::string::npos ? std::string::npos : b - a);
+            if (!t.empty()) v.push_back(t);
+            if (b == std::string::npos) break;
+            a = b + 1;
+          }
+        }
+        return v;
+      }();
+      for (const std::string &t : skip)
+        if (strncmp(label, t.c_str(), t.size()) == 0) return;
+    }
     ++u.launches;
     if (!u.prof_on) {
       f();
