@@ -512,7 +512,13 @@ static hipError_t attention_mfma_go(const void *q, int ldq, const void *kv, int 
     return v > 0 ? v : 128L;
   }();
   const bool long_kernel = L >= 256 && wgs4 >= wgs4_min;
-  if (!long_kernel && waves_plain < 2048 && L <= 4096) {
+  static const long ksplit_waves = [] {   // tuning hook: the key-split kernel runs while the 2-wave kernel would launch fewer waves than this
+    const char *e = getenv("SF_ATTN_KSPLIT_WAVES");
+    const long v = e ? atol(e) : 0;
+    return v > 0 ? v : 1024L;   // (2048 until round 5: at 32 evaluations per branch the 176-position level keeps 6 key-split workgroups per head
+                                // re-reading K and V; configs[2] +1.0 %, batch 32 without guidance +-0, profiles/r5_f_ab_attn_ksplit.txt)
+  }();
+  if (!long_kernel && waves_plain < ksplit_waves && L <= 4096) {
     dim3 g2((L + 31) / 32, H, B);
     hipLaunchKernelGGL((attention_ksplit_kernel<T>), g2, dim3(256), 0, s, static_cast<const T *>(q), ldq, static_cast<const T *>(kv), ldkv,
                        L, H, static_cast<T *>(out), ldo, 1.0f / sqrtf((float)D));
