@@ -458,7 +458,11 @@ bool conv_gemm_prefers_mt(const ConvGemmArgs &a) {
   // temporal convolution); the 128x64 tile with two workgroups per CU (video geometry) wins (542 vs 770 us on that shape)
   if (a.n_store <= 64 && a.geom != 1) return false;
   const long tiles = (long)((a.M + 127) / 128) * ((a.n_store + 127) / 128);   // the 128x128 variant takes over below 160 tiles of 256x128
-  return tiles >= 2 * min_tiles && a.K >= (a.geom == 1 ? 128 : 256);   // two workgroups per CU cover the short pipelines of the video geometry
+  static const int kmin = [] {   // tuning hook: shortest 1-D reduction on the macro tiles
+    const char *e = getenv("SF_MT_KMIN");
+    return e && atoi(e) > 0 ? atoi(e) : 256;
+  }();
+  return tiles >= 2 * min_tiles && a.K >= (a.geom == 1 ? 128 : kmin);   // two workgroups per CU cover the short pipelines of the video geometry
 }
 
 static const char *variant_name_bf16(int dt, const ConvGemmArgs &a) {

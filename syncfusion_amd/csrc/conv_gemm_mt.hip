@@ -51,7 +51,10 @@ __device__ unsigned long long g_mt_stamps[8][8];
 // WM x WN = 8 waves; a wave owns (BM / WM) x (BN / WN) = (32 TM) x (32 TN) of the block tile
 // LNE: the accumulator-side LayerNorm is compiled in (its pooled partials stay in registers across the K loop: only the tiles the
 // LayerNorm-folded projections take carry it)
-template <typename T, int BM, int BN, int WM, int WN, int GEOM, bool CAT, int NST = NSTAGE, int EP = 1, bool LNE = false>
+// PRE: the epilogue's residual rows and per-column / per-clip vectors are requested BEFORE the K loop and wait in registers (they are
+// older than every DMA piece: the loop's counted waits cover them) -- otherwise every workgroup of a launch ends on one exposed
+// global-load round trip, which is 20-50 % of a short-reduction launch.  Single-pass epilogues with a lane's column octet fixed (64 % OCT == 0).
+template <typename T, int BM, int BN, int WM, int WN, int GEOM, bool CAT, int NST = NSTAGE, int EP = 1, bool LNE = false, bool PRE = false>
 __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a, const int mtiles, const int ntiles, const unsigned bytesA,
                                                            const unsigned bytesA2, const unsigned bytesW) {
   constexpr int ES = sizeof(T);   // fp32 (training, the parity engine's long activations): same byte geometry, v_mfma_f32_32x32x2_f32
@@ -197,6 +200,35 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
     offB[j] = (unsigned)(BM * ROWB + row * ROWB);
   }
   const unsigned sw = (unsigned)((fr >> 1) & 7);   // rows of a fragment: every row base is a multiple of 32, so (row >> 1) & 7 == (fr >> 1) & 7
+
+  // ---- PRE: epilogue operands of this lane's (row, column octet) pairs ---------------------------------------------------------------
+  constexpr int EIT = (RM / EP) * (RN / 8) / 64;      // epilogue iterations per lane and pass
+  static_assert(!PRE || (EP == 1 && sizeof(T) == 2 && GEOM == 0 && 64 % (RN / 8) == 0), "PRE: single-pass 16-bit 1-D epilogues");
+  Vec16<T> pre_res[PRE ? EIT : 1];
+  f32x4 pre_bias[2], pre_bs[PRE ? EIT : 1][2], pre_ba[PRE ? EIT : 1][2];
+  if constexpr (PRE) {
+    constexpr int OCTP = RN / 8;
+    const int octp = lane % OCTP;
+    const int n = n0 + wn * RN + octp * 8;
+    const bool full = n + 8 <= a.N;
+    const int nc = full ? n : 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) pre_bias[h] = (a.bias && full) ? *reinterpret_cast<const f32x4 *>(a.bias + nc + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < EIT; ++it) {
+      const int rl = (it * 64 + lane) / OCTP;
+      const int m = m0 + wm * RM + rl;
+      const bool live = m < a.M && n < a.n_store;
+      const int mc = min(m, a.M - 1);
+      const int b = mc / a.Lout;
+      pre_res[it] = (a.res && live) ? ld16<T>(static_cast<const T *>(a.res) + (size_t)mc * a.res_ld + n) : zero16<T>();
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        pre_bs[it][h] = (a.bscale && full) ? *reinterpret_cast<const f32x4 *>(a.bscale + (size_t)b * a.bscale_ld + nc + 4 * h) : f32x4{1.f, 1.f, 1.f, 1.f};
+        pre_ba[it][h] = (a.badd && full) ? *reinterpret_cast<const f32x4 *>(a.badd + (size_t)b * a.badd_ld + nc + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  }
 
   // ---- LayerNorm on the accumulator: this thread's share of its row's producer partials, requested ahead of the DMA stream (they
   // are older than every DMA piece, so the counted waits of the K loop cover them; first use is after the loop) ----------------------
@@ -379,7 +411,10 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
     float rres[8];   // residual rows are n_store wide (pad columns hold zeros)
 #pragma unroll
     for (int e = 0; e < 8; ++e) rres[e] = 0.f;
-    if (res && live) {
+    if constexpr (PRE) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) rres[e] = pre_res[it].get(e);
+    } else if (res && live) {
       if constexpr (ES == 2) {
         const Vec16<T> rv = ld16<T>(res + (size_t)mc * a.res_ld + n);
 #pragma unroll
@@ -394,7 +429,16 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
       }
     }
     float bi[8], sc[8], ad[8];
-    if (full) {   // 16-byte vectors of the per-column operands (n is a multiple of 8)
+    if (PRE && full) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          bi[4 * h + e] = pre_bias[h][e];
+          sc[4 * h + e] = pre_bs[it][h][e];
+          ad[4 * h + e] = pre_ba[it][h][e];
+        }
+    } else if (full) {   // 16-byte vectors of the per-column operands (n is a multiple of 8)
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const f32x4 bv = a.bias ? *reinterpret_cast<const f32x4 *>(a.bias + nc + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -481,7 +525,7 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
 #endif
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int GEOM, bool CAT, int NST = NSTAGE, int EP = 1, bool LNE = false>
+template <typename T, int BM, int BN, int WM, int WN, int GEOM, bool CAT, int NST = NSTAGE, int EP = 1, bool LNE = false, bool PRE = false>
 hipError_t launch_mt(const ConvGemmArgs &a, hipStream_t s) {
   constexpr size_t ring = (size_t)NST * (BM + BN) * ROWB;
   constexpr size_t redb = (size_t)8 * (BM / WM / EP) * (BN / WN + 4) * sizeof(float) + (size_t)BM * 2 * sizeof(float);   // parking area + rowstat
@@ -493,7 +537,7 @@ hipError_t launch_mt(const ConvGemmArgs &a, hipStream_t s) {
   else bA = (size_t)((a.M + a.To * a.Ho * a.Wo - 1) / (a.To * a.Ho * a.Wo)) * a.Ti * a.Hi * a.Wi * a.src_ld * sizeof(T);
   const size_t bW = (size_t)a.N * a.K * sizeof(T);
   const size_t bA2 = CAT ? (size_t)a.M * a.src2_ld * sizeof(T) : 0;
-  auto kern = conv_gemm_mt_kernel<T, BM, BN, WM, WN, GEOM, CAT, NST, EP, LNE>;
+  auto kern = conv_gemm_mt_kernel<T, BM, BN, WM, WN, GEOM, CAT, NST, EP, LNE, PRE>;
   static bool en = false;
   if (!en) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -524,7 +568,12 @@ template <typename T, int GEOM, bool CAT> hipError_t launch_mt_v(const ConvGemmA
     case 4: return launch_mt<T, 256, 64, 8, 1, GEOM, CAT>(a, s);    // outputs of <= 64 columns
     case 5: return launch_mt<T, 128, 128, 2, 4, GEOM, CAT, 2, 2>(a, s);   // two-slot ring, 64 KB of LDS: two workgroups per CU
     case 6: return launch_mt<T, 128, 192, 4, 2, GEOM, CAT, 2, 2>(a, s);   // the same for 192-wide column tiles (80 KB)
-    case 7: return launch_mt<T, 128, 64, 4, 2, GEOM, CAT, 3, 1>(a, s);    // three-slot ring of a 128x64 tile (72 KB): two workgroups per CU
+    case 7:                                                               // three-slot ring of a 128x64 tile (72 KB): two workgroups per CU
+      if constexpr (GEOM == 0 && sizeof(T) == 2) {
+        static const bool no_pre = getenv("SF_MT_NO_PRE") != nullptr;      // A/B aid: epilogue operands loaded in the epilogue as before
+        if (!no_pre) return launch_mt<T, 128, 64, 4, 2, GEOM, CAT, 3, 1, false, true>(a, s);
+      }
+      return launch_mt<T, 128, 64, 4, 2, GEOM, CAT, 3, 1>(a, s);
     case 8: return launch_mt<T, 192, 128, 2, 4, GEOM, CAT, 2, 2>(a, s);   // two-slot 192x128 (80 KB): two workgroups per CU, 5/6 of the fill of 128x128
     case 9: return launch_mt<T, 256, 64, 8, 1, GEOM, CAT, 2, 2>(a, s);    // two-slot 256x64 (80 KB): the same for outputs of <= 64 columns
     case 10: return launch_mt<T, 256, 256, 2, 4, GEOM, CAT, 2, 2>(a, s);  // two-slot 256x256 (128 KB ring), wave tile 128x64: half the fill and 3/4 of the LDS reads per FLOP of 192x128

@@ -353,7 +353,8 @@ void build_group(Builder &bd, Group &g, const std::string &pre, int d, int &mod_
   g.mod_off = mod_cols;
   mod_cols = pad_to(mod_cols + 2 * C, 4);
   const int ctx = c.context_channels[d];
-  g.inject = bd.conv(pre + ".inject.conv", C, C, 1, ctx, true, thin, C, pad_to(ctx, 32));
+  static const bool ctx_pad64 = getenv("SF_CTX_PAD64") != nullptr;
+  g.inject = bd.conv(pre + ".inject.conv", C, C, 1, ctx, true, thin, C, pad_to(ctx, (ctx_pad64 && !thin && C >= 128 && C % 64 == 0) ? 64 : 32));
   g.attn = c.attentions[d] != 0;
   g.cross = c.cross_attentions[d] != 0;
   const int hd = u.hd;
@@ -450,7 +451,10 @@ void build(sf_unet &u, const WeightMap *wm, hipStream_t s) {
     b.ctx = c.context_channels[d];
     while ((1 << b.up_shift) < b.factor) ++b.up_shift;
     const bool thin = (b.C % 32) != 0;
-    b.ctx_ld = thin ? pad_to(b.ctx, 8) : pad_to(b.ctx, 32);   // pad columns are zero-filled by the layout conversion
+    // (pad columns are zero-filled by the layout conversion.)  Tuning hook SF_CTX_PAD64=1: from 128 channels up the context is padded to 64
+    // columns, so that the K = C + ctx reduction of InjectChannels is whole 64-element steps of the macro-tile kernel at depth 3 too
+    static const bool ctx_pad64 = getenv("SF_CTX_PAD64") != nullptr;
+    b.ctx_ld = thin ? pad_to(b.ctx, 8) : pad_to(b.ctx, (ctx_pad64 && b.C >= 128 && b.C % 64 == 0) ? 64 : 32);
     const std::string pre = "net.blocks." + std::to_string(d);
     // Downsample: Conv1d(cin, C, kernel=f, stride=f).  As a GEMM it is a plain matrix product over the
     // (rows/f, f*cin) view of the input when that width is MFMA-friendly; else the direct kernel.
