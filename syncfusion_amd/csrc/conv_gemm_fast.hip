@@ -472,6 +472,9 @@ bool conv_gemm_ln_ok(int dt, const ConvGemmArgs &a) {
     if (ln_goes_mt(dt, a, &sup)) return sup;
   }
   if (!conv_gemm_fast_ok(dt, a)) return false;
+  // the operand-transform form runs on the 32x32 staged kernel: short activations only (with the macro-tile row partials a long
+  // producer can offer them too -- depth 3 at batch 32: 8 launches of 13 us more than ln_modulate + the 64x64 kernel)
+  if ((a.ln_ss || a.res_ln || !a.ln_colsum) && (long)((a.M + 63) / 64) * ((a.n_store + 63) / 64) >= 500) return false;
   if (a.taps != 1 || a.stride != 1 || a.up_shift != 0 || a.Lout != a.Lsrc || a.Lout < 32) return false;
   if (!a.ln_part || a.ln_nt * 32 != a.cin || a.ln_nt > 32) return false;
   if (a.res_ln && (a.N != a.cin || !a.res)) return false;
