@@ -11,7 +11,7 @@ import time
 
 root = os.path.abspath(sys.argv[1])
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-legs = (sys.argv[3] if len(sys.argv) > 3 else "cfg2,cfg3,ref,e2e").split(",")
+legs = (sys.argv[3] if len(sys.argv) > 3 else "cfg1,cfg2,cfg3,ref,e2e").split(",")
 sys.path.insert(0, root)
 import torch  # noqa: E402
 
@@ -49,6 +49,8 @@ with torch.no_grad():
         ts = timed(lambda: run(steps), reps)
         report(name, [steps / t for t in ts], "steps/s")
 
+    if "cfg1" in legs:
+        sample_leg("cfg1", 8, L0, 1.0, 50)
     if "cfg2" in legs:
         sample_leg("cfg2", 32, L0, 2.0, 50)
     if "cfg3" in legs:

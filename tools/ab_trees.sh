@@ -6,6 +6,6 @@ for rep in $(seq 1 ${AB_REPS:-2}); do
   for spec in "$@"; do
     v=${spec%%=*}; T=$R/${spec#*=}
     echo "== round $rep  $v ($T)"
-    python3 $R/tools/ab_tree_legs.py $T ${AB_INNER:-3} ${AB_LEGS:-cfg2,cfg3,ref,e2e} 2>/dev/null | sed "s/^/$v  /"
+    python3 $R/tools/ab_tree_legs.py $T ${AB_INNER:-3} ${AB_LEGS:-cfg1,cfg2,cfg3,ref,e2e} 2>/dev/null | sed "s/^/$v  /"
   done
 done
