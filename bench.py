@@ -50,7 +50,8 @@ BASELINE_STEPS = 50         # BASELINE.json configs[1]: 50-step DDIM
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 / fp16 MFMA, MI355X_MICROARCH.md chip table
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
-ES = {"bf16": 2, "fp16": 2, "fp32": 4}
+ES = {"bf16": 2, "fp16": 2, "fp32": 4, "fp32x": 4}
+PEAK_X3_TFLOPS = PEAK_BF16_TFLOPS / 3.0   # fp32x: three fp16 MFMAs per product
 
 
 def parse_args(argv=None):
@@ -59,7 +60,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=BASELINE_STEPS)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32", "fp32x"])
     ap.add_argument("--scale", type=float, default=1.0, help="embedding_scale (!= 1 -> classifier-free guidance, 2 evals/step)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -154,8 +155,33 @@ def spread(rates) -> dict:
     return dict(min=round(v[0], 3), median=round(v[len(v) // 2], 3), max=round(v[-1], 3), repeats=len(v))
 
 
-def timed_sample(model, device, noise, channels, emb, scale, steps, warm=2, repeats=REPEATS):
-    """(median steps/s of `repeats` timed sample() calls, last output, spread dict)."""
+_SIDE = {}
+
+
+def clock_probe_start(device, microseconds: float) -> None:
+    """One wave on a side stream compares the shader-cycle counter with the 100 MHz counter while the timed loop runs (sf_clock_probe_*)."""
+    import torch
+
+    from syncfusion_amd import _lib
+
+    if "stream" not in _SIDE:
+        _SIDE["stream"] = torch.cuda.Stream(device)
+    _lib.check(_lib.load().sf_clock_probe_start(float(microseconds), int(_SIDE["stream"].cuda_stream)), "sf_clock_probe_start")
+
+
+def clock_probe_read() -> float:
+    import ctypes
+
+    from syncfusion_amd import _lib
+
+    mhz = ctypes.c_double()
+    _lib.check(_lib.load().sf_clock_probe_read(ctypes.byref(mhz)), "sf_clock_probe_read")
+    return round(mhz.value, 1)
+
+
+def timed_sample(model, device, noise, channels, emb, scale, steps, warm=2, repeats=REPEATS, clock=False):
+    """(median steps/s of `repeats` timed sample() calls, last output, spread dict).  clock: the LAST repetition runs with the in-kernel
+    clock probe beside it (spread["shader_mhz_during_last"]); its rate is reported separately and not part of the spread."""
     import torch
 
     def run(n):
@@ -172,6 +198,14 @@ def timed_sample(model, device, noise, channels, emb, scale, steps, warm=2, repe
         torch.cuda.synchronize(device)
         rates.append(steps / (time.perf_counter() - t0))
     sp = spread(rates)
+    if clock:
+        torch.cuda.synchronize(device)
+        clock_probe_start(device, 0.8 * 1e6 * steps / sp["median"])     # watches the first 80 % of the loop
+        t0 = time.perf_counter()
+        run(steps)
+        torch.cuda.synchronize(device)
+        sp["probed_run_steps_per_s"] = round(steps / (time.perf_counter() - t0), 3)
+        sp["shader_mhz_during_probed_run"] = clock_probe_read()
     return sp["median"], out, sp
 
 
@@ -185,6 +219,8 @@ def extra_workloads(model, device, args, noise, channels, emb) -> dict:
     hp = dict(net.hparams)
     out: dict = {}
 
+    stash: dict = {}    # (noise, channels, embedding, scale, steps, final sample) of the 16-bit legs, for their parity-grade twins
+
     def leg(name, fn):
         try:
             out[name] = fn()
@@ -194,27 +230,69 @@ def extra_workloads(model, device, args, noise, channels, emb) -> dict:
 
     def roof_ms(clips, evals, L, dtype):
         w = workmodel.unet_work(hp, L, clips, evals, ES[dtype])
-        peak = (PEAK_F32_TFLOPS if dtype == "fp32" else PEAK_BF16_TFLOPS) * 1e12
+        peak = {"fp32": PEAK_F32_TFLOPS, "fp32x": PEAK_X3_TFLOPS}.get(dtype, PEAK_BF16_TFLOPS) * 1e12
         return workmodel.step_roofline_ms(w, peak, PEAK_HBM_GBS * 1e9)
 
-    def fp32_leg():
-        # the same torch module, engine repacked in fp32 (identical weights): the path gated at 1e-4 against the oracle
-        steps = 40   # (10 timed steps gave 179-209 steps/s from run to run on boxes where 30 give 216 three times in a row)
-        ref_steps = min(args.steps, 20)
-        lo = model.model.sample(x_noisy=noise, num_steps=ref_steps, channels=channels, embedding=emb, embedding_scale=args.scale)
+    import contextlib
+
+    @contextlib.contextmanager
+    def engine_dtype(dt):
+        """the same torch module with its engine repacked in another arithmetic (identical fp32 master weights)"""
         prev = net.compute_dtype
-        net.compute_dtype = "fp32"
+        net.compute_dtype = dt
         try:
-            rate, _, sp = timed_sample(model, device, noise, channels, emb, args.scale, steps, warm=2)
-            hi = model.model.sample(x_noisy=noise, num_steps=ref_steps, channels=channels, embedding=emb, embedding_scale=args.scale)
+            yield
         finally:
             net.compute_dtype = prev
             net.engine()
-        rel = float((lo.double() - hi.double()).norm() / hi.double().norm())
+
+    def rel_l2(a, b):
+        return float((a.double() - b.double()).norm() / b.double().norm())
+
+    def parity_twin(dt, nz, ch, e, scale, steps, lowp_out, L):
+        """The workload of a 16-bit leg again on a parity-grade engine (`dt` = fp32 or fp32x): its rate, its roofline fraction against the fp32
+        MFMA peak, and the distance of the 16-bit engine's final sample from it after the configuration's own step count."""
+        with engine_dtype(dt):
+            rate, o, sp = timed_sample(model, device, nz, ch, e, scale, steps, warm=2, repeats=REPEATS)
         ms = 1e3 / rate
-        return dict(steps_per_s=round(rate, 2), steps_per_s_spread=sp, ms_per_step=round(ms, 3), dtype="fp32", batch=noise.shape[0], timed_steps=steps,
-                    step_roofline_frac=round(roof_ms(noise.shape[0], 1 if args.scale == 1.0 else 2, L0, "fp32") / ms, 4),
-                    lowp_vs_fp32_final_sample_rel_l2=round(rel, 6), lowp_dtype=args.dtype, rel_l2_steps=ref_steps)
+        B_ = nz.shape[0]
+        return dict(steps_per_s=round(rate, 2), steps_per_s_spread=sp, ms_per_step=round(ms, 3), dtype=dt, timed_steps=steps,
+                    step_roofline_frac_vs_fp32_peak=round(roof_ms(B_, 1 if scale == 1.0 else 2, L, "fp32") / ms, 4),
+                    lowp_dtype=args.dtype, lowp_final_sample_rel_l2=float(f"{rel_l2(lowp_out, o):.3e}"), rel_l2_steps=steps,
+                    gate_1e4_met_by_lowp=bool(rel_l2(lowp_out, o) < 1e-4)), o
+
+    PARITY_DTYPES = [d for d in ("fp32", "fp32x") if d in __import__("syncfusion_amd")._lib.DTYPES]
+
+    def with_twins(res, nz, ch, e, scale, steps, lowp_out, L):
+        outs = {}
+        for dt in PARITY_DTYPES:
+            try:
+                res[dt], outs[dt] = parity_twin(dt, nz, ch, e, scale, steps, lowp_out, L)
+            except Exception as ex:  # noqa: BLE001
+                res[dt] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+        if "fp32" in outs and "fp32x" in outs:
+            res["fp32x"]["final_sample_rel_l2_vs_fp32"] = float(f"{rel_l2(outs['fp32x'], outs['fp32']):.3e}")
+            res["fp32x"]["speedup_vs_fp32"] = round(res["fp32x"]["steps_per_s"] / res["fp32"]["steps_per_s"], 3)
+        return res
+
+    def fp32_leg(pdt="fp32"):
+        # the same torch module, engine repacked in fp32 / fp32x (identical weights): the paths gated at 1e-4 against the oracle
+        steps = 40   # (10 timed steps gave 179-209 steps/s from run to run on boxes where 30 give 216 three times in a row)
+        ref_steps = min(args.steps, 20)
+        lo = model.model.sample(x_noisy=noise, num_steps=ref_steps, channels=channels, embedding=emb, embedding_scale=args.scale)
+        with engine_dtype(pdt):
+            rate, _, sp = timed_sample(model, device, noise, channels, emb, args.scale, steps, warm=2)
+            hi = model.model.sample(x_noisy=noise, num_steps=ref_steps, channels=channels, embedding=emb, embedding_scale=args.scale)
+        rel = rel_l2(lo, hi)
+        ms = 1e3 / rate
+        res = dict(steps_per_s=round(rate, 2), steps_per_s_spread=sp, ms_per_step=round(ms, 3), dtype=pdt, batch=noise.shape[0], timed_steps=steps,
+                   step_roofline_frac=round(roof_ms(noise.shape[0], 1 if args.scale == 1.0 else 2, L0, "fp32") / ms, 4),
+                   lowp_vs_fp32_final_sample_rel_l2=round(rel, 6), lowp_dtype=args.dtype, rel_l2_steps=ref_steps)
+        if pdt == "fp32":
+            stash["fp32_config1"] = hi
+        elif "fp32_config1" in stash:
+            res["final_sample_rel_l2_vs_fp32"] = float(f"{rel_l2(hi, stash.pop('fp32_config1')):.3e}")
+        return res
 
     def config2_leg():
         B, scale, steps = 32, 2.0, BASELINE_STEPS      # the configuration's own 50 steps: the per-call conditioning is amortised as in a real run
@@ -222,6 +300,7 @@ def extra_workloads(model, device, args, noise, channels, emb) -> dict:
         ch, e = synthetic_conditioning(model, B, L0, device, real=True)
         rate, o, sp = timed_sample(model, device, nz, ch, e, scale, steps, warm=2)
         assert torch.isfinite(o).all()
+        stash["config2"] = (nz, ch, e, scale, steps, o)
         ms = 1e3 / rate
         w = workmodel.unet_work(hp, L0, B, 2, ES[args.dtype])
         return dict(workload="BASELINE configs[2]: batch=32, guidance scale 2.0 (64 evaluations/step), CLAP-shaped embedding + onset conditioning",
@@ -237,6 +316,7 @@ def extra_workloads(model, device, args, noise, channels, emb) -> dict:
         ch, e = synthetic_conditioning(model, B, L0, device, real=True)
         rate, o, sp = timed_sample(model, device, nz, ch, e, 1.0, steps, warm=2)
         assert torch.isfinite(o).all()
+        stash["config3"] = (nz, ch, e, 1.0, steps, o)
         ms = 1e3 / rate
         w = workmodel.unet_work(hp, L0, B, 1, ES[args.dtype])
         return dict(workload="BASELINE configs[3], one GPU's share: batch=32 (256 clips / 8 GPUs), no guidance", steps_per_s=round(rate, 2), steps_per_s_spread=sp,
@@ -284,7 +364,7 @@ def extra_workloads(model, device, args, noise, channels, emb) -> dict:
         first = res["bf16"] if "bf16" in res else res["fp16"]
         return dict(workload="VideoOnsetNet (R(2+1)D-18) forward, N=32 clips of (3,30,112,112)", **first, by_dtype=res)
 
-    def e2e_leg():
+    def e2e_leg(udt="fp16"):
         # BASELINE configs[4] on one GPU's share (32 clips): 2 s x 15 fps RGB frames -> onset net -> logits-to-track glue ->
         # Encoder1d -> 100-step guided diffusion -> cut_prefix / crop, everything in fp16, no host round trip in between
         from syncfusion_amd.generation import generate_batch
@@ -297,7 +377,7 @@ def extra_workloads(model, device, args, noise, channels, emb) -> dict:
         frames = torch.randn(B, 3, 30, 112, 112, generator=torch.Generator().manual_seed(4000)).to(device)
         z = (torch.randn(B, 1, L0, generator=torch.Generator().manual_seed(1)) * 0.1).to(device)
         prev = net.compute_dtype
-        net.compute_dtype = "fp16"
+        net.compute_dtype = udt
         try:
             def once(n_steps):
                 logits = onset(frames)
@@ -318,10 +398,38 @@ def extra_workloads(model, device, args, noise, channels, emb) -> dict:
             net.compute_dtype = prev
             net.engine()
         assert gen.shape == (B, 1, 44100) and torch.isfinite(gen).all()
-        return dict(workload="BASELINE configs[4], one GPU's share: 32 clips of 30x112x112 RGB frames -> VideoOnsetNet -> onset track -> Encoder1d -> "
-                             "100-step diffusion (scale 2.0) -> cut/crop, fp16", clips_per_s=round(B / dt, 2), seconds_per_batch=round(dt, 3),
-                    seconds_per_batch_spread=spread(secs),
-                    denoise_steps_per_s=round(steps / dt, 2), dtype="fp16")
+        res = dict(workload="BASELINE configs[4], one GPU's share: 32 clips of 30x112x112 RGB frames -> VideoOnsetNet (fp16) -> onset track -> Encoder1d -> "
+                            f"100-step diffusion (scale 2.0, {udt}) -> cut/crop", clips_per_s=round(B / dt, 2), seconds_per_batch=round(dt, 3),
+                   seconds_per_batch_spread=spread(secs),
+                   denoise_steps_per_s=round(steps / dt, 2), dtype=udt)
+        if udt == "fp16":
+            stash["e2e"] = gen
+        elif "e2e" in stash:
+            r = rel_l2(stash["e2e"], gen)
+            res.update(fp16_final_audio_rel_l2=float(f"{r:.3e}"), gate_1e4_met_by_fp16=bool(r < 1e-4))
+            stash["e2e_" + udt] = gen
+            if udt == "fp32x" and "e2e_fp32" in stash:
+                res["final_audio_rel_l2_vs_fp32"] = float(f"{rel_l2(gen, stash['e2e_fp32']):.3e}")
+        return res
+
+    def parity_legs():
+        """The parity-grade engines (fp32: v_mfma_f32_32x32x2_f32; fp32x: fp32-accurate products from split 16-bit operands) at EVERY BASELINE
+        configuration the 16-bit legs above ran: steps/s, roofline fraction against the fp32 MFMA peak, and the 16-bit engine's final-sample
+        rel-L2 against them after the configuration's own step count (north_star's gate is 1e-4)."""
+        res = {}
+        for name, key, L in (("config2_b32_cfg", "config2", L0), ("config3_share_b32", "config3", L0)):
+            if key in stash:
+                nz, ch, e, scale, steps, o = stash.pop(key)
+                res[name] = with_twins({}, nz, ch, e, scale, steps, o, L)
+                del nz, ch, e, o
+        for dt in PARITY_DTYPES:
+            try:
+                res.setdefault("e2e_config4", {})[dt] = e2e_leg(dt)
+            except Exception as ex:  # noqa: BLE001
+                res.setdefault("e2e_config4", {})[dt] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+        stash.clear()
+        torch.cuda.empty_cache()
+        return res
 
     def train_leg():
         # the reference's training configuration (exp/train_diffusion_gh.yaml:8,38,87): fp32, batch 4 per device, clips of 2^18
@@ -375,7 +483,7 @@ def extra_workloads(model, device, args, noise, channels, emb) -> dict:
             rate, o, sp = timed_sample(mt, device, noise, ch1, e1, 1.0, BASELINE_STEPS, warm=5)
             assert torch.isfinite(o).all()
             w = workmodel.unet_work(hpt, L0, B1, 1, ES[args.dtype], upsample_mode="transpose")
-            peak = (PEAK_F32_TFLOPS if args.dtype == "fp32" else PEAK_BF16_TFLOPS) * 1e12
+            peak = {"fp32": PEAK_F32_TFLOPS, "fp32x": PEAK_X3_TFLOPS}.get(args.dtype, PEAK_BF16_TFLOPS) * 1e12
             ms = 1e3 / rate
             res["config1_transpose_up"] = dict(
                 workload=f"BASELINE configs[1] on the transposed-up network: batch={B1}, {BASELINE_STEPS} steps, scale 1.0, dummy cond",
@@ -401,13 +509,16 @@ def extra_workloads(model, device, args, noise, channels, emb) -> dict:
 
     def config1_repeat_leg():
         # the headline's own loop (same inputs, same --steps) three more times: what a 2-6 % difference between rounds has to be read against
-        rate, _, sp = timed_sample(model, device, noise, channels, emb, args.scale, args.steps, warm=0)
-        return dict(workload=f"the headline loop again: batch={noise.shape[0]}, {args.steps} steps, scale {args.scale}", steps_per_s=round(rate, 2),
+        rate, _, sp = timed_sample(model, device, noise, channels, emb, args.scale, args.steps, warm=0, clock=True)
+        return dict(workload=f"the headline loop again AFTER the roofline / cpu_baseline legs (the engine was rebuilt once in between): batch={noise.shape[0]}, "
+                             f"{args.steps} steps, scale {args.scale}", steps_per_s=round(rate, 2),
                     steps_per_s_spread=sp, dtype=args.dtype, timed_steps=args.steps)
 
     leg("config1_repeat", config1_repeat_leg)
     if args.dtype != "fp32":
         leg("fp32_config1", fp32_leg)
+        if "fp32x" in PARITY_DTYPES:
+            leg("fp32x_config1", lambda: fp32_leg("fp32x"))
     leg("config2_b32_cfg", config2_leg)
     try:
         out.update(transpose_up_legs())
@@ -418,6 +529,8 @@ def extra_workloads(model, device, args, noise, channels, emb) -> dict:
     leg("reference_eval_shape", reference_leg)
     leg("onset_net_n32", onset_leg)
     leg("e2e_config4_fp16", e2e_leg)
+    if args.dtype != "fp32":
+        leg("parity_engines", parity_legs)
     leg("train_step_fp32", train_leg)      # last: it updates (and then restores) the weights
     return out
 
@@ -491,6 +604,15 @@ def main() -> int:
         elapsed = float(t)
     assert torch.isfinite(out).all()
     gathered = sfd.gather_clips(out, B * world, dst=0)         # RCCL gather of the finished clips, once, after the loop
+    # The same loop three more times RIGHT AWAY (same engine object, same graphs, nothing else has run): what the headline has to be read
+    # against.  `config1_repeat` in `extra` does the same after the roofline / cpu_baseline legs.
+    repeat_early = None
+    if rank == 0 and world == 1 and not args.no_extra and not args.force_dist:
+        try:
+            r_, _, sp_ = timed_sample(model, device, noise, channels, emb, args.scale, args.steps, warm=0, clock=True)
+            repeat_early = dict(steps_per_s=round(r_, 2), steps_per_s_spread=sp_, timed_steps=args.steps)
+        except Exception as e:  # noqa: BLE001
+            repeat_early = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     if rank != 0:
         if dist_on:
@@ -530,7 +652,7 @@ def main() -> int:
     total_ms = sum(a[0] for a in agg.values())
     dom = max(agg, key=lambda k: agg[k][0])
     d_ms, d_fl, d_by, d_n = agg[dom]
-    peak = PEAK_F32_TFLOPS if args.dtype == "fp32" else PEAK_BF16_TFLOPS
+    peak = {"fp32": PEAK_F32_TFLOPS, "fp32x": PEAK_X3_TFLOPS}.get(args.dtype, PEAK_BF16_TFLOPS)
     # the roofline that bounds the dominant kernel: whichever of its algorithmic FLOPs / MFMA peak and algorithmic bytes / HBM
     # peak takes longer (the small-batch GEMMs sit BELOW the machine balance of ~310 FLOP/B: they are HBM-side kernels)
     mfma_kernel = d_fl / (peak * 1e12) >= d_by / (PEAK_HBM_GBS * 1e9)
@@ -665,6 +787,7 @@ def main() -> int:
     extra = None
     if not args.no_extra and world == 1 and not args.force_dist:
         extra = extra_workloads(model, device, args, noise, channels, emb)
+        extra["config1_repeat_early"] = repeat_early
 
     line = {
         "metric": "U-Net denoise steps/sec (batch x 2 s@22.05 kHz)",

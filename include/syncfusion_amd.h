@@ -35,7 +35,11 @@ enum {
 };
 
 enum { SF_UP_NEAREST_CONV3 = 0, SF_UP_TRANSPOSE = 1 };
-enum { SF_F32 = 0, SF_BF16 = 1, SF_F16 = 2 }; /* arithmetic/storage type of the activations and packed weights (accumulation, statistics, softmax and the sampler state are fp32 in every mode) */
+/* arithmetic / storage type of the activations and packed weights (accumulation, statistics, softmax and the sampler state are fp32 in every
+ * mode).  SF_F32X ("fp32x", the parity-grade fast path): activations stay fp32 in HBM, every matrix product is built from split fp16
+ * operands -- a = hi + lo'/2048, three v_mfma_f32_32x32x16_f16 per product, fp32 accumulation -- which measures 7.5e-8 rel-L2 against fp64
+ * on a K = 3072 GEMM (plain fp32 MFMA: 3.5e-7) at several times the fp32 matrix rate; operands must stay inside the fp16 range (< 65504). */
+enum { SF_F32 = 0, SF_BF16 = 1, SF_F16 = 2, SF_F32X = 3 };
 
 /* One named parameter of a torch state_dict: fp32, contiguous, PyTorch layout, device memory. */
 typedef struct {
@@ -48,6 +52,11 @@ const char *sf_version(void);
 const char *sf_last_error(void);
 /* 1 when a gfx950 device is visible to the HIP runtime, else 0 (never fails). */
 int sf_device_ok(void);
+/* Measurement aid (bench.py; no reference counterpart): the shader clock the chip holds WHILE a workload runs.  _start puts a one-wave
+ * kernel on `stream` (a side stream) that compares the shader-cycle counter with the constant 100 MHz counter for `microseconds`;
+ * _read waits for it and returns MHz (host pointer).  One probe at a time per process. */
+int sf_clock_probe_start(double microseconds, void *stream);
+int sf_clock_probe_read(double *mhz_out);
 
 /* ------------------------------------------------------------------------------------------
  * U-Net denoiser + v-sampler

@@ -13,9 +13,10 @@ from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 import torch
 
 SF_MAX_DEPTH = 12
-SF_F32, SF_BF16, SF_F16 = 0, 1, 2
+SF_F32, SF_BF16, SF_F16, SF_F32X = 0, 1, 2, 3
 UPSAMPLE_MODES = {"nearest": 0, "transpose": 1}
-DTYPES = {"fp32": SF_F32, "float32": SF_F32, "f32": SF_F32, "bf16": SF_BF16, "bfloat16": SF_BF16, "fp16": SF_F16, "float16": SF_F16, "f16": SF_F16, "half": SF_F16}
+DTYPES = {"fp32": SF_F32, "float32": SF_F32, "f32": SF_F32, "bf16": SF_BF16, "bfloat16": SF_BF16, "fp16": SF_F16, "float16": SF_F16, "f16": SF_F16, "half": SF_F16,
+          "fp32x": SF_F32X}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SF_LIB_PATH") or os.path.join(_HERE, "lib", "libsyncfusion_amd.so")   # SF_LIB_PATH: A/B builds of the HIP library (tuning aid)
@@ -53,6 +54,8 @@ SYMBOLS = {
     "sf_version": (C.c_char_p, []),
     "sf_last_error": (C.c_char_p, []),
     "sf_device_ok": (_I, []),
+    "sf_clock_probe_start": (_I, [C.c_double, _P]),
+    "sf_clock_probe_read": (_I, [C.POINTER(C.c_double)]),
     "sf_unet_create": (_I, [C.POINTER(UnetConfig), C.POINTER(SfTensor), _I, _P, C.POINTER(_P)]),
     "sf_unet_destroy": (None, [_P]),
     "sf_unet_param_count": (_I, [C.POINTER(UnetConfig)]),

@@ -35,6 +35,32 @@ int sf_device_ok(void) {
   return std::string(prop.gcnArchName).rfind("gfx950", 0) == 0 ? 1 : 0;
 }
 
+// Measurement aid (bench.py): the shader clock the chip holds WHILE a workload runs.  sf_clock_probe_start puts a one-wave kernel on `stream`
+// (use a side stream) that watches the shader-cycle counter against the constant 100 MHz counter for `microseconds`; sf_clock_probe_read
+// waits for it and returns MHz.  One probe at a time per process.
+static unsigned long long *g_clock_buf = nullptr;
+static hipEvent_t g_clock_ev = nullptr;
+int sf_clock_probe_start(double microseconds, void *stream) {
+  SF_API_BEGIN
+  if (microseconds <= 0.0 || microseconds > 5.0e6) fail(SF_ERR_INVALID, "clock probe: 0 < microseconds <= 5e6");
+  if (!g_clock_buf) SF_HIP(hipHostMalloc(reinterpret_cast<void **>(&g_clock_buf), 2 * sizeof(unsigned long long), hipHostMallocDefault));
+  if (!g_clock_ev) SF_HIP(hipEventCreateWithFlags(&g_clock_ev, hipEventDisableTiming));
+  g_clock_buf[0] = g_clock_buf[1] = 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  SF_HIP(launch_clock_probe(microseconds, g_clock_buf, s));
+  SF_HIP(hipEventRecord(g_clock_ev, s));
+  return SF_OK;
+  SF_API_END
+}
+int sf_clock_probe_read(double *mhz_out) {
+  SF_API_BEGIN
+  if (!mhz_out || !g_clock_ev || !g_clock_buf) fail(SF_ERR_INVALID, "clock probe: nothing started");
+  SF_HIP(hipEventSynchronize(g_clock_ev));
+  *mhz_out = g_clock_buf[1] ? 100.0 * (double)g_clock_buf[0] / (double)g_clock_buf[1] : 0.0;
+  return SF_OK;
+  SF_API_END
+}
+
 int sf_onsets_to_track(const float *logits, int N, int T, const int32_t *start_frame, float frame_rate, float sample_rate,
                        float threshold, float *track, int L, void *stream) {
   SF_API_BEGIN
@@ -130,6 +156,8 @@ int sf_op_conv1d_cl(int dtype, const void *x, const float *w, const float *bias,
   if (upsample < 1 || (upsample & (upsample - 1))) fail(SF_ERR_UNSUPPORTED, "upsample must be a power of two");
   hipStream_t s = static_cast<hipStream_t>(stream);
   Workspace wk(ws, ws_bytes);
+  const bool x3 = dtype == SF_F32X;   // fp32 tensors, products from split fp16 operands (needs N * K * 4 more bytes of workspace)
+  if (x3) dtype = F32;
   const bool direct = (C % 32) != 0;
   if (direct && N > 32) fail(SF_ERR_UNSUPPORTED, "thin convolution with N > 32");
   const int wdt = direct ? F32 : dtype;
@@ -146,6 +174,11 @@ int sf_op_conv1d_cl(int dtype, const void *x, const float *w, const float *bias,
     void *wfr = wk.alloc((int64_t)N * K * dsize(wdt));
     SF_HIP(launch_pack_wfr(dtype, wp, N, K, wfr, s));
     a.wfr = wfr;
+  }
+  if (x3 && !direct && (K % 32) == 0) {
+    void *wx = wk.alloc((int64_t)N * K * 4);
+    SF_HIP(launch_pack_wx(static_cast<const float *>(wp), N, K, wx, s));
+    a.wx = wx;
   }
   a.src = x;
   a.src_ld = C;
@@ -199,6 +232,8 @@ int sf_op_gn_silu(int dtype, const void *x, const float *gamma, const float *bet
 int sf_bench_conv1d(int dtype, int B, int L, int C, int N, int taps, int upsample, int path, int tile, int sk, int iters, float *ms_out) {
   SF_API_BEGIN
   if (!ms_out || iters < 1) fail(SF_ERR_INVALID, "bad argument");
+  const bool x3 = dtype == SF_F32X;
+  if (x3) dtype = F32;
   const size_t es = dsize(dtype);
   const int K = taps * C, Lout = L * upsample, M = B * Lout;
   void *x = nullptr, *w = nullptr, *out = nullptr, *res = nullptr;
@@ -253,6 +288,14 @@ int sf_bench_conv1d(int dtype, int B, int L, int C, int N, int taps, int upsampl
     SF_HIP(hipMemcpy(wfr, w, wbytes * ncopy, hipMemcpyDeviceToDevice));
     a.wfr = wfr;
   }
+  void *wx = nullptr;
+  if (x3) {   // split-fp16 images of the same rotation of weight copies
+    if (K % 32) fail(SF_ERR_UNSUPPORTED, "fp32x needs K %% 32 == 0");
+    SF_HIP(hipMalloc(&wx, wbytes * ncopy));
+    for (int c = 0; c < ncopy; ++c)
+      SF_HIP(launch_pack_wx(reinterpret_cast<const float *>(static_cast<char *>(w) + (size_t)c * wbytes), N, K, static_cast<char *>(wx) + (size_t)c * wbytes, nullptr));
+    a.wx = wx;
+  }
   for (int i = 0; i < 3 && err == hipSuccess; ++i) err = launch_conv_gemm(dtype, a, nullptr);
   if (err == hipSuccess) {
     SF_HIP(hipDeviceSynchronize());
@@ -266,6 +309,7 @@ int sf_bench_conv1d(int dtype, int B, int L, int C, int N, int taps, int upsampl
     for (int i = 0; i < iters && err == hipSuccess; ++i) {
       a.w = static_cast<char *>(w) + (size_t)(i % ncopy) * wbytes;
       if (wfr) a.wfr = static_cast<char *>(wfr) + (size_t)(i % ncopy) * wbytes;
+      if (wx) a.wx = static_cast<char *>(wx) + (size_t)(i % ncopy) * wbytes;
       if (pre > 0) err = launch_touch(a.w, wbytes, pre % 1000, sink, nullptr);
       if (pre < 1000 && err == hipSuccess) err = launch_conv_gemm(dtype, a, nullptr);
     }
@@ -280,6 +324,7 @@ int sf_bench_conv1d(int dtype, int B, int L, int C, int N, int taps, int upsampl
   for (void *p : {x, w, out, res, (void *)bias}) (void)hipFree(p);
   if (sink) (void)hipFree(sink);
   if (wfr) (void)hipFree(wfr);
+  if (wx) (void)hipFree(wx);
   if (err != hipSuccess) fail(SF_ERR_UNSUPPORTED, "variant not applicable: %s", hipGetErrorString(err));
   return SF_OK;
   SF_API_END

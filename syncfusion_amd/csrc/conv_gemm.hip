@@ -426,7 +426,18 @@ const char *label_for_dtype(int dt, const char *bf16_label) {
 }
 
 static const char *variant_name_bf16(int dt, const ConvGemmArgs &a);
-const char *conv_gemm_variant_name(int dt, const ConvGemmArgs &a) { return label_for_dtype(dt, variant_name_bf16(dt, a)); }
+// fp32 launches that carry split-fp16 weights: the families that honour them are labelled <x3,...> (the others multiply in fp32)
+static const char *label_x3(const ConvGemmArgs &a, const char *f32_label) {
+  if (!a.wx) return f32_label;
+  std::string s(f32_label);
+  if (s.rfind("conv_gemm_wp<f32", 0) != 0 && s.rfind("conv_gemm_fast<f32", 0) != 0) return f32_label;
+  static std::set<std::string> pool;
+  s.replace(s.find("f32"), 3, "x3");
+  return pool.insert(s).first->c_str();
+}
+const char *conv_gemm_variant_name(int dt, const ConvGemmArgs &a) {
+  return dt == F32 ? label_x3(a, variant_name_bf16(dt, a)) : label_for_dtype(dt, variant_name_bf16(dt, a));
+}
 
 // Macro tiles pay from ~80 tiles of 256x128 per launch: a launch then occupies ~1/3 of the CUs at 4+ TFLOP/s each, and the
 // engine's second clip-parallel branch fills most of the rest (measured on BASELINE configs[2]: threshold 160 -> 138, 80 -> 145.5
@@ -466,7 +477,7 @@ bool conv_gemm_prefers_mt(const ConvGemmArgs &a) {
 }
 
 static const char *variant_name_bf16(int dt, const ConvGemmArgs &a) {
-  if (g_conv_gemm_force.path == 6 || (g_conv_gemm_force.path == 0 && conv_gemm_mt_wanted(dt, a))) return dt == F32 ? "conv_gemm_mt<f32>" : conv_gemm_mt_name(a);
+  if (g_conv_gemm_force.path == 6 || (g_conv_gemm_force.path == 0 && conv_gemm_mt_wanted(dt, a))) return dt == F32 ? (a.wx ? "conv_gemm_mt<x3>" : "conv_gemm_mt<f32>") : conv_gemm_mt_name(a);
   static const char *names[2][5] = {{"conv_gemm<f32,64x64,scalarA>", "conv_gemm<f32,128x32>", "conv_gemm<f32,128x64>", "conv_gemm<f32,64x64>", "conv_gemm<f32,128x128>"},
                                     {"conv_gemm<bf16,64x64,scalarA>", "conv_gemm<bf16,128x32>", "conv_gemm<bf16,128x64>", "conv_gemm<bf16,64x64>", "conv_gemm<bf16,128x128>"}};
   static const char *sk_names[2][3] = {{"conv_gemm_sk<f32,64x64>", "conv_gemm_sk<f32,64x32>", "conv_gemm_sk<f32,32x32>"},

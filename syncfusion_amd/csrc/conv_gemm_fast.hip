@@ -29,7 +29,9 @@ template <typename T> __device__ __forceinline__ Vec16<T> buf_ld16(__amdgpu_buff
 // NSET = K chunks in flight per workgroup.  The weights of a denoising step stream from HBM (they do not fit the
 // Infinity Cache), so a workgroup needs latency x bandwidth bytes outstanding: 2 chunks (32 KB) cap a CU at ~45 GB/s.
 // LN: the first source is LayerNorm-modulated on the fly (ConvGemmArgs::ln_*; 32x32 tiles, one tap, Lout >= 32).
-template <typename T, int BM, int BN, bool CAT, int KW, int NSET, bool LN>
+// X3 (T = float, KW = 32): split-fp16 weights (ConvGemmArgs::wx; wave w multiplies the w-th (32 hi | 32 lo') group of the staged 128-deep
+// chunk), fp32 activation fragments split in registers after the (optional) LayerNorm transform, three fp16 MFMAs per product (common.h)
+template <typename T, int BM, int BN, bool CAT, int KW, int NSET, bool LN, bool X3 = false>
 __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(const ConvGemmArgs a, const int mtiles, const int ntiles, const int swz,
                                                              const unsigned bytesA, const unsigned bytesA2, const unsigned bytesW) {
   constexpr int BKT = 4 * KW;
@@ -71,7 +73,8 @@ __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(const ConvGemmArgs 
 
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.src), 0, bytesA, 0x00020000);
   const __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(CAT ? a.src2 : a.src), 0, CAT ? bytesA2 : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.w), 0, bytesW, 0x00020000);
+  static_assert(!X3 || (sizeof(T) == 4 && KW == 32), "split mode: fp32 activations, one 32-deep group per wave");
+  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(X3 ? a.wx : a.w), 0, bytesW, 0x00020000);
 
   // ---- per-row byte offsets, once ---------------------------------------------------------------
   unsigned offA[PA][3], offA2[PA], offW[PB];
@@ -97,12 +100,16 @@ __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(const ConvGemmArgs 
   }
 
   f32x16 acc[TM][TN];
+  f32x16 accL[X3 ? TM : 1][X3 ? TN : 1];   // split mode: cross terms (scaled by 2048)
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) {
+        acc[i][j][r] = 0.f;
+        if constexpr (X3) accL[i][j][r] = 0.f;
+      }
 
   // LN: per staged row (mean, rstd, clip selector) -- filled after the first chunks are in flight
   float ln_mu[PA], ln_rs[PA];
@@ -196,7 +203,27 @@ __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(const ConvGemmArgs 
   const int fr = lane & 31, fh = lane >> 5;
   const int kw0 = KW * wave;
   auto compute = [&]() {
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (X3) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const float *ap = reinterpret_cast<const float *>(As) + (i * 32 + fr) * LD + kw0 + 16 * s + 8 * fh;
+          x3_split(*reinterpret_cast<const f32x4 *>(ap), *reinterpret_cast<const f32x4 *>(ap + 4), ah[i], al[i]);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const unsigned char *bp = reinterpret_cast<const unsigned char *>(Bs + (j * 32 + fr) * LD + kw0) + 32 * s + 16 * fh;
+          bh[j] = *reinterpret_cast<const f16x8 *>(bp);
+          bl[j] = *reinterpret_cast<const f16x8 *>(bp + 64);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) x3_mfma(ah[i], al[i], bh[j], bl[j], acc[i][j], accL[i][j]);
+      }
+    } else if constexpr (sizeof(T) == 2) {
 #pragma unroll
       for (int s = 0; s < KW / 16; ++s) {
         using frag = typename Frag16<T>::type;
@@ -333,7 +360,10 @@ __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(const ConvGemmArgs 
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) myred[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LDR + j * 32 + fr] = acc[i][j][r];
+      for (int r = 0; r < 16; ++r) {
+        if constexpr (X3) myred[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LDR + j * 32 + fr] = fmaf(accL[i][j][r], X3_INV, acc[i][j][r]);
+        else myred[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LDR + j * 32 + fr] = acc[i][j][r];
+      }
   __syncthreads();
 
   T *out = static_cast<T *>(a.out);
@@ -406,7 +436,7 @@ __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(const ConvGemmArgs 
   }
 }
 
-template <typename T, int BM, int BN, bool CAT, int KW, int NSET, bool LN = false> hipError_t launch_fast3(const ConvGemmArgs &a, hipStream_t s) {
+template <typename T, int BM, int BN, bool CAT, int KW, int NSET, bool LN = false, bool X3 = false> hipError_t launch_fast3(const ConvGemmArgs &a, hipStream_t s) {
   constexpr int BKT = 4 * KW;
   constexpr int LD = BKT + 16 / (int)sizeof(T);
   constexpr size_t stage_bytes = (size_t)(BM + BN) * LD * sizeof(T);
@@ -419,7 +449,7 @@ template <typename T, int BM, int BN, bool CAT, int KW, int NSET, bool LN = fals
   const size_t bA = (size_t)(a.M / a.Lout + (a.M % a.Lout ? 1 : 0)) * a.Lsrc * a.src_ld * es;
   const size_t bA2 = CAT ? (size_t)a.M * a.src2_ld * es : 0;
   const size_t bW = (size_t)a.N * a.K * es;
-  auto kern = conv_gemm_fast_kernel<T, BM, BN, CAT, KW, NSET, LN>;
+  auto kern = conv_gemm_fast_kernel<T, BM, BN, CAT, KW, NSET, LN, X3>;
   static bool en = false;
   if (!en) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
@@ -497,6 +527,7 @@ static bool ln_goes_rs(int dt, const ConvGemmArgs &a);
 const char *conv_gemm_ln_variant_name(int dt, const ConvGemmArgs &a) {
   if (ln_goes_mt(dt, a)) return label_for_dtype(dt, conv_gemm_mt_name(a));
   if (ln_goes_rs(dt, a)) return label_for_dtype(dt, "conv_gemm_rs<bf16,32x32>");
+  if (dt == F32 && a.wx) return ln_goes_wp(dt, a) ? "conv_gemm_wp<x3,32x32>" : "conv_gemm_fast<x3,32x32>";
   if (dt == F32) return ln_goes_wp(dt, a) ? "conv_gemm_wp<f32,32x32>" : "conv_gemm_fast<f32,32x32>";
   return label_for_dtype(dt, ln_goes_wp(dt, a) ? "conv_gemm_wp<bf16,32x32>" : "conv_gemm_fast<bf16,32x32>");
 }
@@ -518,6 +549,7 @@ hipError_t launch_conv_gemm_ln(int dt, const ConvGemmArgs &a, hipStream_t s) {
   if (ln_goes_mt(dt, a)) return launch_conv_gemm_mt(dt, a, s);
   if (ln_goes_rs(dt, a)) return launch_conv_gemm_rs(dt, a, s);
   if (ln_goes_wp(dt, a)) return launch_conv_gemm_wp(dt, a, 2, s);
+  if (dt == F32 && a.wx) return a.cin2 ? launch_fast3<float, 32, 32, true, 32, 2, true, true>(a, s) : launch_fast3<float, 32, 32, false, 32, 2, true, true>(a, s);
   return SF_DISPATCH_T(dt, (a.cin2 ? launch_fast3<T, 32, 32, true, 32, 2, true>(a, s) : launch_fast3<T, 32, 32, false, 32, 2, true>(a, s)));
 }
 
@@ -527,6 +559,15 @@ hipError_t launch_conv_gemm_fast(int dt, const ConvGemmArgs &a, int variant, hip
 #define SF_FAST(T, BM, BN)                                                                                              \
   (wide ? (a.cin2 ? launch_fast2<T, BM, BN, true, 64>(a, s) : launch_fast2<T, BM, BN, false, 64>(a, s))                 \
         : (a.cin2 ? launch_fast2<T, BM, BN, true, 32>(a, s) : launch_fast2<T, BM, BN, false, 32>(a, s)))
+  if (dt == F32 && a.wx) {   // split mode
+#define SF_FASTX(BM, BN) (a.cin2 ? launch_fast3<float, BM, BN, true, 32, 2, false, true>(a, s) : launch_fast3<float, BM, BN, false, 32, 2, false, true>(a, s))
+    switch (variant) {
+      case 0: return SF_FASTX(64, 64);
+      case 1: return SF_FASTX(64, 32);
+      default: return SF_FASTX(32, 32);
+    }
+#undef SF_FASTX
+  }
   if (dt == F32) {
     switch (variant) {
       case 0: return SF_FAST(float, 64, 64);

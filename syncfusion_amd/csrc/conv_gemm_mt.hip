@@ -54,10 +54,14 @@ __device__ unsigned long long g_mt_stamps[8][8];
 // PRE: the epilogue's residual rows and per-column / per-clip vectors are requested BEFORE the K loop and wait in registers (they are
 // older than every DMA piece: the loop's counted waits cover them) -- otherwise every workgroup of a launch ends on one exposed
 // global-load round trip, which is 20-50 % of a short-reduction launch.  Single-pass epilogues with a lane's column octet fixed (64 % OCT == 0).
-template <typename T, int BM, int BN, int WM, int WN, int GEOM, bool CAT, int NST = NSTAGE, int EP = 1, bool LNE = false, bool PRE = false>
+// X3 (T = float): the weights are the split-fp16 image (ConvGemmArgs::wx, the same 128 bytes per row and K step: 32 hi | 32 lo'), the fp32
+// activation fragments are split in registers after the LDS read, three v_mfma_f32_32x32x16_f16 per product into two accumulators
+// (common.h, x3_split): fp32-grade results at 16-bit matrix rates.  DMA ring, swizzle and epilogue are those of the fp32 instantiation.
+template <typename T, int BM, int BN, int WM, int WN, int GEOM, bool CAT, int NST = NSTAGE, int EP = 1, bool LNE = false, bool PRE = false, bool X3 = false>
 __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a, const int mtiles, const int ntiles, const unsigned bytesA,
                                                            const unsigned bytesA2, const unsigned bytesW) {
   constexpr int ES = sizeof(T);   // fp32 (training, the parity engine's long activations): same byte geometry, v_mfma_f32_32x32x2_f32
+  static_assert(!X3 || (sizeof(T) == 4 && !LNE && !PRE), "split mode: fp32 activations");
   static_assert(WM * WN == 8 && BM % (32 * WM) == 0 && BN % (32 * WN) == 0 && BM % 64 == 0 && BN % 64 == 0, "tile / wave grid mismatch");
   constexpr int RM = BM / WM, RN = BN / WN;          // rows / columns of a wave's tile
   constexpr int TM = RM / 32, TN = RN / 32;
@@ -83,7 +87,7 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
   const int m0 = mt * BM, n0 = nt * BN;
 
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.src), 0, bytesA, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.w), 0, bytesW, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(X3 ? a.wx : a.w), 0, bytesW, 0x00020000);
   const __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(CAT ? a.src2 : a.src), 0, CAT ? bytesA2 : 0, 0x00020000);
 
   // ---- DMA lane geometry: a wave-instruction fills 8 rows x 128 B; lane -> (row lane>>3, LDS chunk lane&7), source chunk swizzled
@@ -180,12 +184,16 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
   };
 
   f32x16 acc[TM][TN];
+  f32x16 accL[X3 ? TM : 1][X3 ? TN : 1];   // split mode: the cross terms hi lo' + lo' hi (scaled by 2048)
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) {
+        acc[i][j][r] = 0.f;
+        if constexpr (X3) accL[i][j][r] = 0.f;
+      }
 
   // fragment read offsets inside a slot: row-dependent part once, the k sub-step enters through the XOR
   unsigned offA[TM], offB[TN];
@@ -301,6 +309,29 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
     SF_STAMP(t4);
 #endif
     const unsigned char *slot = smem + (k % NST) * STAGE;
+    if constexpr (X3) {
+      // a K step = 32 k = two 16-deep products.  Activation row: 8 chunks of 4 floats, the half-wave fh takes chunks 4 s + 2 fh, + 1
+      // (k = 16 s + 8 fh + 0..7); weight row: chunks 0-3 = hi, 4-7 = lo', chunk 2 s + fh holds the same eight k.
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const f32x4 p = *reinterpret_cast<const f32x4 *>(slot + offA[i] + (unsigned)(((4 * s2 + 2 * fh) ^ sw) * 16));
+          const f32x4 q = *reinterpret_cast<const f32x4 *>(slot + offA[i] + (unsigned)(((4 * s2 + 2 * fh + 1) ^ sw) * 16));
+          x3_split(p, q, ah[i], al[i]);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          bh[j] = *reinterpret_cast<const f16x8 *>(slot + offB[j] + (unsigned)(((2 * s2 + fh) ^ sw) * 16));
+          bl[j] = *reinterpret_cast<const f16x8 *>(slot + offB[j] + (unsigned)(((4 + 2 * s2 + fh) ^ sw) * 16));
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) x3_mfma(ah[i], al[i], bh[j], bl[j], acc[i][j], accL[i][j]);
+      }
+    } else {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const unsigned ch = (unsigned)(((2 * ks + fh) ^ sw) * 16);
@@ -325,6 +356,7 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
             for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
       }
     }
+    }   // !X3
 #ifdef SF_MT_STAMPS
     asm volatile("s_nop 0" ::"v"(acc[0][0][0]));   // the last MFMA of the step has written its accumulator
     SF_STAMP(t5);
@@ -381,7 +413,8 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
       for (int r = 0; r < 16; ++r) {
         if (EP == 2 && (r >> 3) != pass) continue;   // registers 0-7 = rows 0-15 of the tile, 8-15 = rows 16-31
         const int lr = EP == 1 ? (r & 3) + 8 * (r >> 2) + 4 * fh : (r & 3) + 8 * ((r >> 2) & 1) + 4 * fh;
-        red[(i * RPT + lr) * LDR + j * 32 + fr] = acc[i][j][r];
+        if constexpr (X3) red[(i * RPT + lr) * LDR + j * 32 + fr] = fmaf(accL[i][j][r], X3_INV, acc[i][j][r]);
+        else red[(i * RPT + lr) * LDR + j * 32 + fr] = acc[i][j][r];
       }
   __builtin_amdgcn_wave_barrier();   // same-wave LDS operations execute in order; this only pins the compiler
 #pragma unroll
@@ -525,7 +558,7 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
 #endif
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int GEOM, bool CAT, int NST = NSTAGE, int EP = 1, bool LNE = false, bool PRE = false>
+template <typename T, int BM, int BN, int WM, int WN, int GEOM, bool CAT, int NST = NSTAGE, int EP = 1, bool LNE = false, bool PRE = false, bool X3 = false>
 hipError_t launch_mt(const ConvGemmArgs &a, hipStream_t s) {
   constexpr size_t ring = (size_t)NST * (BM + BN) * ROWB;
   constexpr size_t redb = (size_t)8 * (BM / WM / EP) * (BN / WN + 4) * sizeof(float) + (size_t)BM * 2 * sizeof(float);   // parking area + rowstat
@@ -537,7 +570,7 @@ hipError_t launch_mt(const ConvGemmArgs &a, hipStream_t s) {
   else bA = (size_t)((a.M + a.To * a.Ho * a.Wo - 1) / (a.To * a.Ho * a.Wo)) * a.Ti * a.Hi * a.Wi * a.src_ld * sizeof(T);
   const size_t bW = (size_t)a.N * a.K * sizeof(T);
   const size_t bA2 = CAT ? (size_t)a.M * a.src2_ld * sizeof(T) : 0;
-  auto kern = conv_gemm_mt_kernel<T, BM, BN, WM, WN, GEOM, CAT, NST, EP, LNE, PRE>;
+  auto kern = conv_gemm_mt_kernel<T, BM, BN, WM, WN, GEOM, CAT, NST, EP, LNE, PRE, X3>;
   static bool en = false;
   if (!en) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -578,6 +611,18 @@ template <typename T, int GEOM, bool CAT> hipError_t launch_mt_v(const ConvGemmA
     case 9: return launch_mt<T, 256, 64, 8, 1, GEOM, CAT, 2, 2>(a, s);    // two-slot 256x64 (80 KB): the same for outputs of <= 64 columns
     case 10: return launch_mt<T, 256, 256, 2, 4, GEOM, CAT, 2, 2>(a, s);  // two-slot 256x256 (128 KB ring), wave tile 128x64: half the fill and 3/4 of the LDS reads per FLOP of 192x128
     default: return launch_mt<T, 256, 128, 4, 2, GEOM, CAT>(a, s);
+  }
+}
+
+// split mode (fp32 activations x split-fp16 weights): wave tiles of at least 32 x 64, so that a split activation fragment feeds six MFMAs
+template <bool CAT> hipError_t launch_mt_x3(const ConvGemmArgs &a, int v, hipStream_t s) {
+  switch (v) {
+    case 0: return launch_mt<float, 256, 128, 4, 2, 0, CAT, 3, 1, false, false, true>(a, s);   // wave tile 64 x 64, one workgroup per CU
+    case 1: return launch_mt<float, 128, 128, 4, 2, 0, CAT, 3, 1, false, false, true>(a, s);   // wave tile 32 x 64, three slots (96 KB)
+    case 5: return launch_mt<float, 128, 128, 4, 2, 0, CAT, 2, 2, false, false, true>(a, s);   // the same with two slots (64 KB): two workgroups per CU
+    case 7: return launch_mt<float, 128, 64, 4, 2, 0, CAT, 3, 1, false, false, true>(a, s);    // wave tile 32 x 32 (72 KB): two workgroups per CU
+    case 8: return launch_mt<float, 192, 128, 2, 4, 0, CAT, 2, 2, false, false, true>(a, s);   // wave tile 96 x 32, two slots (80 KB)
+    default: return hipErrorInvalidValue;
   }
 }
 
@@ -622,8 +667,27 @@ bool conv_gemm_prefers_mt_f32(const ConvGemmArgs &a) {
   if (min_tiles <= 0 || a.geom != 0 || a.K < 256) return false;
   return (long)((a.M + 127) / 128) * ((a.n_store + 63) / 64) >= min_tiles;
 }
+// split mode: the matrix pipe is fast again, so the choice follows the 16-bit rule (launches that give most CUs a tile)
+static bool conv_gemm_prefers_mt_x3(const ConvGemmArgs &a) {
+  static const long min_tiles = [] {   // tuning hook: fewest 128x64 tiles that take the macro tiles (0 = never)
+    const char *e = tune_env("SF_MT_X3_TILES");
+    return e ? atol(e) : 128L;
+  }();
+  if (min_tiles <= 0 || a.geom != 0 || a.K < 256) return false;
+  return (long)((a.M + 127) / 128) * ((a.n_store + 63) / 64) >= min_tiles;
+}
+static int conv_gemm_mt_x3_variant(const ConvGemmArgs &a) {
+  static const int forced = [] { const char *e = tune_env("SF_MT_X3_VARIANT"); return e ? atoi(e) : -1; }();   // tuning hook: 0, 1, 5, 7, 8
+  if (forced >= 0) return forced;
+  const long t128 = (long)((a.M + 127) / 128) * ((a.n_store + 127) / 128), t256 = (long)((a.M + 255) / 256) * ((a.n_store + 127) / 128);
+  if (a.n_store % 128 && a.n_store % 64 == 0 && a.n_store <= 192) return 7;
+  if (t256 >= 512) return 0;        // two full rounds of 256x128 tiles
+  if (t128 >= 256) return 5;        // 128x128, two workgroups per CU
+  return a.n_store % 64 == 0 ? 7 : 5;
+}
 bool conv_gemm_mt_wanted(int dt, const ConvGemmArgs &a) {
   if (!conv_gemm_mt_ok(dt, a)) return false;
+  if (dt == F32 && a.wx) return conv_gemm_prefers_mt_x3(a);
   return dt == F32 ? conv_gemm_prefers_mt_f32(a) : conv_gemm_prefers_mt(a);
 }
 
@@ -713,6 +777,10 @@ const char *conv_gemm_mt_name(const ConvGemmArgs &a) {
 
 hipError_t launch_conv_gemm_mt(int dt, const ConvGemmArgs &a, hipStream_t s) {
   if (!conv_gemm_mt_ok(dt, a)) return hipErrorInvalidValue;
+  if (dt == F32 && a.wx) {
+    const int v = conv_gemm_mt_x3_variant(a);
+    return a.cin2 ? launch_mt_x3<true>(a, v, s) : launch_mt_x3<false>(a, v, s);
+  }
   if (dt == F32) {
     static const int forced = [] { const char *e = getenv("SF_MT_F32_VARIANT"); return e ? atoi(e) : -1; }();   // tuning hook: 1, 5, 7
     const long t128 = (long)((a.M + 127) / 128) * ((a.n_store + 127) / 128);

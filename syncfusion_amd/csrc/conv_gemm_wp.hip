@@ -31,7 +31,9 @@ template <typename T> __device__ __forceinline__ Vec16<T> buf_ld16(__amdgpu_buff
 
 // NSET = K chunks a wave keeps in flight (register sets); ONE private LDS staging buffer per wave suffices because a
 // wave's LDS operations execute in program order (the next chunk's writes queue behind this chunk's fragment reads).
-template <typename T, int BM, int BN, bool CAT, int NSET>
+// X3 (T = float): split-fp16 weights (ConvGemmArgs::wx: per 32 k, 32 hi | 32 lo' -- the same 256 bytes per row and chunk), fp32 activation
+// fragments split in registers, three v_mfma_f32_32x32x16_f16 per product (common.h, x3_split)
+template <typename T, int BM, int BN, bool CAT, int NSET, bool X3 = false>
 __global__ __launch_bounds__(256) void conv_gemm_wp_kernel(const ConvGemmArgs a, const int mtiles, const int ntiles, const int swz,
                                                            const unsigned bytesA, const unsigned bytesA2, const unsigned bytesW) {
   constexpr int VEC = Vec16<T>::N;
@@ -67,7 +69,8 @@ __global__ __launch_bounds__(256) void conv_gemm_wp_kernel(const ConvGemmArgs a,
 
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.src), 0, bytesA, 0x00020000);
   const __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(CAT ? a.src2 : a.src), 0, CAT ? bytesA2 : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.w), 0, bytesW, 0x00020000);
+  static_assert(!X3 || sizeof(T) == 4, "split mode: fp32 activations");
+  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(X3 ? a.wx : a.w), 0, bytesW, 0x00020000);
 
   // ---- per staged row (once): clip base, first tap position, validity ------------------------------------------
   int rbase[PA], rp0[PA];
@@ -92,12 +95,16 @@ __global__ __launch_bounds__(256) void conv_gemm_wp_kernel(const ConvGemmArgs a,
   }
 
   f32x16 acc[TM][TN];
+  f32x16 accL[X3 ? TM : 1][X3 ? TN : 1];   // split mode: cross terms (scaled by 2048)
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) {
+        acc[i][j][r] = 0.f;
+        if constexpr (X3) accL[i][j][r] = 0.f;
+      }
 
   // ---- this wave's K range: a contiguous quarter of the 64-wide chunks ----------------------------------------
   const int k_taps = a.taps * a.cin;
@@ -169,7 +176,29 @@ __global__ __launch_bounds__(256) void conv_gemm_wp_kernel(const ConvGemmArgs a,
   const int fr = lane & 31, fh = lane >> 5;
   auto compute = [&]() {
     const T *As = wlds, *Bs = As + BM * LD;
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (X3) {
+      // the 64-deep chunk = four 16-deep products; weight row: two groups of (32 hi | 32 lo'), product s reads eight hi at byte
+      // 128 (s / 2) + 32 (s % 2) + 16 fh and the matching lo' 64 bytes behind
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const float *ap = reinterpret_cast<const float *>(As) + (i * 32 + fr) * LD + 16 * s + 8 * fh;
+          x3_split(*reinterpret_cast<const f32x4 *>(ap), *reinterpret_cast<const f32x4 *>(ap + 4), ah[i], al[i]);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const unsigned char *bp = reinterpret_cast<const unsigned char *>(Bs + (j * 32 + fr) * LD) + 128 * (s >> 1) + 32 * (s & 1) + 16 * fh;
+          bh[j] = *reinterpret_cast<const f16x8 *>(bp);
+          bl[j] = *reinterpret_cast<const f16x8 *>(bp + 64);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) x3_mfma(ah[i], al[i], bh[j], bl[j], acc[i][j], accL[i][j]);
+      }
+    } else if constexpr (sizeof(T) == 2) {
 #pragma unroll
       for (int s = 0; s < BK / 16; ++s) {
         using frag = typename Frag16<T>::type;
@@ -294,7 +323,10 @@ __global__ __launch_bounds__(256) void conv_gemm_wp_kernel(const ConvGemmArgs a,
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) myred[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LDR + j * 32 + fr] = acc[i][j][r];
+      for (int r = 0; r < 16; ++r) {
+        if constexpr (X3) myred[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LDR + j * 32 + fr] = fmaf(accL[i][j][r], X3_INV, acc[i][j][r]);
+        else myred[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LDR + j * 32 + fr] = acc[i][j][r];
+      }
   __syncthreads();
 
   T *out = static_cast<T *>(a.out);
@@ -370,7 +402,7 @@ __global__ __launch_bounds__(256) void conv_gemm_wp_kernel(const ConvGemmArgs a,
   }
 }
 
-template <typename T, int BM, int BN, bool CAT, int NSET> hipError_t launch_wp3(const ConvGemmArgs &a, hipStream_t s) {
+template <typename T, int BM, int BN, bool CAT, int NSET, bool X3 = false> hipError_t launch_wp3(const ConvGemmArgs &a, hipStream_t s) {
   constexpr int LD = BK + 16 / (int)sizeof(T);
   constexpr size_t stage_bytes = (size_t)4 * (BM + BN) * LD * sizeof(T);
   constexpr size_t red_bytes = (size_t)4 * BM * (BN + 4) * sizeof(float) + (size_t)4 * BM * sizeof(float);   // + (mean, rstd) and (sum, sumsq) per row
@@ -382,7 +414,7 @@ template <typename T, int BM, int BN, bool CAT, int NSET> hipError_t launch_wp3(
   const size_t bA = (size_t)(a.M / a.Lout + (a.M % a.Lout ? 1 : 0)) * a.Lsrc * a.src_ld * es;
   const size_t bA2 = CAT ? (size_t)a.M * a.src2_ld * es : 0;
   const size_t bW = (size_t)a.N * a.K * es;
-  auto kern = conv_gemm_wp_kernel<T, BM, BN, CAT, NSET>;
+  auto kern = conv_gemm_wp_kernel<T, BM, BN, CAT, NSET, X3>;
   static bool en = false;
   if (!en) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
@@ -413,6 +445,9 @@ bool conv_gemm_wp_ok(int dt, const ConvGemmArgs &a) {
 // variant: 0 = 64x64, 1 = 64x32, 2 = 32x32
 hipError_t launch_conv_gemm_wp(int dt, const ConvGemmArgs &a, int variant, hipStream_t s) {
 #define SF_WP(T, BM, BN) (a.cin2 ? launch_wp2<T, BM, BN, true>(a, s) : launch_wp2<T, BM, BN, false>(a, s))
+  if (dt == F32 && a.wx) {   // split mode: 32x32 tiles (the variants the fp32 engine uses on short activations)
+    return a.cin2 ? launch_wp3<float, 32, 32, true, 2, true>(a, s) : launch_wp3<float, 32, 32, false, 2, true>(a, s);
+  }
   if (dt == F32) {
     switch (variant) {
       case 0: return SF_WP(float, 64, 64);

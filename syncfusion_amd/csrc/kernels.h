@@ -5,7 +5,18 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
+
 namespace sf {
+
+// Tuning / measurement hooks (tools/, profiles/HISTORY*.md): environment variables that force tile variants, thresholds or drop launches.
+// They exist ONLY in builds made with -DSF_TUNING_HOOKS (make tuning -> lib/libsyncfusion_amd_tuning.so, loaded through SF_LIB_PATH by
+// the A/B scripts); the product library compiles every one of them to "not set" and contains none of the names.
+#ifdef SF_TUNING_HOOKS
+inline const char *tune_env(const char *name) { return getenv(name); }
+#else
+inline const char *tune_env(const char *) { return nullptr; }
+#endif
 
 enum DType { F32 = 0, BF16 = 1, F16 = 2 };
 inline size_t dsize(int dt) { return dt == F32 ? 4 : 2; }
@@ -41,6 +52,10 @@ struct ConvGemmArgs {
   const void *src = nullptr, *src2 = nullptr, *w = nullptr, *res = nullptr;
   const void *wfr = nullptr;    // optional: the same [N][K] matrix in MFMA fragment order [N / 32][K / 16][64][8] (conv_gemm_rs.hip)
   const float *w32 = nullptr;   // the same weights in fp32, [N][taps*C] (8-channel level: conv_d0.hip reads these as scalar operands)
+  // fp32 launches only ("x3", the fp32x engine): the same [N][K] matrix as split fp16 operands, [N][K / 32][hi 32 | lo' 32] (launch_pack_wx;
+  // the same bytes per row as fp32).  When set, the kernels that carry the split mode multiply fp32 activations against it with three
+  // v_mfma_f32_32x32x16_f16 per product (common.h, x3_split); every other kernel ignores it and multiplies `w` in fp32.
+  const void *wx = nullptr;
   void *out = nullptr;
   const float *bias = nullptr, *gamma = nullptr, *beta = nullptr, *stats = nullptr;
   const float *badd = nullptr, *bscale = nullptr;
@@ -99,6 +114,8 @@ bool conv_gemm_rs_ok(int dt, const ConvGemmArgs &a);
 bool conv_gemm_rs_rows_ok(int64_t rows, int N);   // few enough 32x32 tiles for the small-batch kernels (the rule launch_conv_gemm applies)
 hipError_t launch_conv_gemm_rs(int dt, const ConvGemmArgs &a, hipStream_t s);
 hipError_t launch_pack_wfr(int dt, const void *w /* [N][K], compute type */, int N, int K, void *out, hipStream_t s);
+// split-fp16 image of a packed fp32 [N][K] matrix (K % 32 == 0): out[n][k / 32][0][k % 32] = hi, [1][k % 32] = lo' (common.h, x3_split)
+hipError_t launch_pack_wx(const float *w, int N, int K, void *out, hipStream_t s);
 // true when launch_conv_gemm would run `a` on the kernel that honours gnpart_out (wp, 32x32 tiles)
 bool conv_gemm_emits_gnpart(int dt, const ConvGemmArgs &a);
 // GEMM whose first source is LayerNorm-modulated on the fly from producer-side row partials (see ConvGemmArgs)
@@ -273,6 +290,8 @@ hipError_t launch_vsampler_update(float *x, const float *v, const float *v_uncon
 hipError_t launch_step_select(const float *table, int ld, int *step_idx, float *cur, hipStream_t s);
 // one wave busy-waits for `microseconds` (tuning aid)
 hipError_t launch_spin(double microseconds, hipStream_t s);
+// one wave measures the shader clock over `microseconds` of wall time: out2 = (shader cycles, 100 MHz ticks)
+hipError_t launch_clock_probe(double microseconds, unsigned long long *out2, hipStream_t s);
 hipError_t launch_touch(const void *p, size_t bytes, int wgs, unsigned *sink, hipStream_t s);
 // (*step_idx)++ -- its own 1-thread launch so that no kernel of a step races with the increment
 hipError_t launch_step_advance(int *step_idx, hipStream_t s);

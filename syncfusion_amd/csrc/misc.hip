@@ -121,6 +121,21 @@ __global__ void spin_kernel(unsigned long long ticks) {
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
+// one wave spins for `ticks` of the constant 100 MHz counter and reports how many shader-clock cycles went by: the in-kernel clock of
+// the chip WHILE whatever else is running runs (MI355X_MICROARCH.md, "in-kernel clock"): out = (d s_memtime, d s_memrealtime)
+__global__ void clock_probe_kernel(unsigned long long ticks, unsigned long long *out) {
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+  unsigned long long r1 = r0;
+  while (r1 - r0 < ticks) {
+    __builtin_amdgcn_s_sleep(32);
+    r1 = __builtin_amdgcn_s_memrealtime();
+  }
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0) {
+    out[0] = c1 - c0;
+    out[1] = r1 - r0;
+  }
+}
 __global__ void step_advance_kernel(int *step_idx) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *step_idx = *step_idx + 1;
 }
@@ -175,6 +190,17 @@ __global__ void pack_rows_kernel(const float *__restrict__ in, int64_t rows, int
     int64_t r = i / cols;
     int c = (int)(i - r * cols);
     out[r * ldo + c] = from_f<T>(in[r * ldi + c] * (cscale ? cscale[c] : 1.0f));
+  }
+}
+// split-fp16 image of a packed fp32 [N][K] matrix: out[(n * K + 64 * (k / 32)) + {0, 32} + k % 32] = (hi, lo') of w[n][k]  (common.h, x3_split)
+__global__ void pack_wx_kernel(const float *__restrict__ w, int64_t total, f16 *__restrict__ out) {
+  SF_GRID_STRIDE(i, total) {
+    const float v = w[i];
+    const f16 h = (f16)v;
+    const int64_t g = i >> 5;
+    const int e = (int)(i & 31);
+    out[g * 64 + e] = h;
+    out[g * 64 + 32 + e] = (f16)((v - (float)h) * X3_SCALE);
   }
 }
 __global__ void fold_bias_kernel(const float *__restrict__ w, int N, int K, const float *__restrict__ v, const float *__restrict__ add,
@@ -350,6 +376,10 @@ hipError_t launch_spin(double microseconds, hipStream_t s) {
   hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s, (unsigned long long)(microseconds * 100.0));
   return hipGetLastError();
 }
+hipError_t launch_clock_probe(double microseconds, unsigned long long *out2, hipStream_t s) {
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, s, (unsigned long long)(microseconds * 100.0), out2);
+  return hipGetLastError();
+}
 hipError_t launch_step_advance(int *step_idx, hipStream_t s) {
   hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, s, step_idx);
   return hipGetLastError();
@@ -395,6 +425,12 @@ hipError_t launch_pack_rows(int dt, const float *in, int64_t rows, int cols, int
                             int64_t ldo, hipStream_t s) {
   dim3 g = grid_for(rows * cols);
   SF_DISPATCH_STMT(dt, hipLaunchKernelGGL((pack_rows_kernel<T>), g, dim3(TPB), 0, s, in, rows, cols, ldi, cscale, (T *)out, ldo));
+  return hipGetLastError();
+}
+hipError_t launch_pack_wx(const float *w, int N, int K, void *out, hipStream_t s) {
+  if (K % 32) return hipErrorInvalidValue;
+  const int64_t total = (int64_t)N * K;
+  hipLaunchKernelGGL(pack_wx_kernel, grid_for(total), dim3(TPB), 0, s, w, total, static_cast<f16 *>(out));
   return hipGetLastError();
 }
 hipError_t launch_fold_bias(const float *w, int N, int K, const float *v, const float *add, float *out, hipStream_t s) {

@@ -86,6 +86,7 @@ struct Plan {  // everything carved out of the caller's workspace for one (B, L0
 struct sf_unet {
   sf_unet_config cfg{};
   int dt = SF_F32;
+  bool x3 = false;   // SF_F32X: fp32 activations and kernels, every GEMM on split fp16 operands (ConvW::wx)
   DeviceArena arena;
   float *fourier_w = nullptr;
   int half = 0, four_ld = 0, mf = 0, hd = 0;
@@ -414,8 +415,9 @@ void build(sf_unet &u, const WeightMap *wm, hipStream_t s) {
   if (c.attention_features != 64) fail(SF_ERR_UNSUPPORTED, "attention_features must be 64 (got %d)", c.attention_features);
   if (c.embedding_max_length != 1) fail(SF_ERR_UNSUPPORTED, "embedding_max_length must be 1 (CLAP embedding), got %d", c.embedding_max_length);
   if (c.modulation_features % 32 || c.embedding_features % 32) fail(SF_ERR_UNSUPPORTED, "modulation/embedding features must be multiples of 32");
-  if (c.dtype != SF_F32 && c.dtype != SF_BF16 && c.dtype != SF_F16) fail(SF_ERR_INVALID, "bad dtype");
-  u.dt = c.dtype;
+  if (c.dtype != SF_F32 && c.dtype != SF_BF16 && c.dtype != SF_F16 && c.dtype != SF_F32X) fail(SF_ERR_INVALID, "bad dtype");
+  u.x3 = c.dtype == SF_F32X;
+  u.dt = u.x3 ? (int)SF_F32 : c.dtype;
   u.mf = c.modulation_features;
   u.hd = c.attention_heads * c.attention_features;
   if (c.time_fourier_features < 0 || c.time_fourier_features > 4096) fail(SF_ERR_INVALID, "time_fourier_features out of range");
@@ -554,6 +556,22 @@ void build(sf_unet &u, const WeightMap *wm, hipStream_t s) {
       SF_HIP(hipMemcpyAsync(u.ca_blocks, blks.data(), blks.size() * sizeof(int2), hipMemcpyHostToDevice, s));
       SF_HIP(hipStreamSynchronize(s));   // the host vectors die here
       u.ca_nblocks = (int)blks.size();
+    }
+  }
+  if (!u.listing && u.x3) {
+    // fp32x: every MFMA-path matrix a second time as split fp16 operands (after all linear_into() fills and affine folds)
+    auto split = [&](ConvW &w) {
+      if (w.direct || !w.w || (w.K % 32)) return;   // (the kernels check the channel counts of the launch they are given)
+      w.wx = u.arena.alloc((int64_t)w.N * w.K * 4);
+      SF_HIP(launch_pack_wx(static_cast<const float *>(w.w), w.N, w.K, w.wx, s));
+    };
+    for (ConvW *w : {&u.lin0, &u.mlp0, &u.mlp1, &u.mod, &u.wv_cat}) split(*w);
+    for (Block &b : u.blocks) {
+      split(b.down);
+      split(b.up);
+      for (int pass = 0; pass < 2; ++pass)
+        for (Group &g : (pass == 0 ? b.down_items : b.up_items))
+          for (ConvW *w : {&g.conv1, &g.conv2, &g.inject, &g.qkv, &g.attn_out, &g.cross_out}) split(*w);
     }
   }
   if (!u.listing) SF_HIP(hipStreamSynchronize(s));
@@ -763,7 +781,7 @@ struct Exec {
   // the fragment-ordered copy (conv_gemm_rs.hip)
   Prefetch pf_for(const ConvW &w, int host_wgs, int64_t rows = -1) const {
     const bool rs = w.wfr && rows >= 0 && conv_gemm_rs_rows_ok(rows, w.N);
-    return pf_bytes(w.direct ? nullptr : (rs ? w.wfr : w.w), (size_t)w.N * w.K * dsize(u.dt), host_wgs);
+    return pf_bytes(w.direct ? nullptr : (rs ? w.wfr : (w.wx ? w.wx : w.w)), (size_t)w.N * w.K * dsize(u.dt), host_wgs);
   }
   Prefetch pf_cb(const ConvW &w, int host_wgs) const { return pf_bytes(w.wcb, conv_cb_weight_elems(w.N, w.cin) * dsize(u.dt), host_wgs); }
   Prefetch pf_bytes(const void *ptr, size_t bytes, int host_wgs) const {
@@ -808,6 +826,7 @@ struct Exec {
   ConvGemmArgs filled(const ConvW &w, ConvGemmArgs a) const {
     a.w = w.w;
     a.wfr = w.wfr;
+    a.wx = w.wx;
     a.bias = w.bias;
     a.N = w.N;
     a.K = w.K;
