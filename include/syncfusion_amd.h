@@ -262,6 +262,12 @@ int sf_op_gn_silu_train(const float *x, const float *gamma, const float *beta, i
 int sf_op_conv1d_bwd_cl_act(const float *x, const float *act, const float *stats /* or NULL */, const float *w, const float *gamma, const float *beta,
                             int groups, float eps, const float *dy, int B, int L, int C, int N, int taps, int pad, float *dx, float *dw, float *db,
                             float *dgb, void *ws, int64_t ws_bytes, void *stream);
+/* The same with the arithmetic of the two GEMMs chosen by `dtype`: SF_F32 (v_mfma_f32_32x32x2_f32) or SF_F32X (fp32 tensors, products from
+ * split fp16 operands: data gradient through the forward kernels' split mode, weight gradient with both operands split while staged).
+ * act / stats may be NULL (recomputed). */
+int sf_op_conv1d_bwd_cl_x(int dtype, const float *x, const float *act, const float *stats, const float *w, const float *gamma, const float *beta,
+                          int groups, float eps, const float *dy, int B, int L, int C, int N, int taps, int pad, float *dx, float *dw, float *db,
+                          float *dgb, void *ws, int64_t ws_bytes, void *stream);
 /* Length reductions of the training composition (fp32, channels-last): out[b][c] = sum_l x[b][l][c] * (y ? y[b][l][c] : 1) -- the
  * gradient of a per-clip broadcast add (cross-attention over one context token) and of the SkipModulate scale
  * (a-unet SkipModulate: x + scale[:, None, :] * h).  Two deterministic stages, no atomics.

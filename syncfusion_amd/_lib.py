@@ -97,6 +97,7 @@ SYMBOLS = {
     "sf_op_conv1d_bwd_workspace_bytes": (_L, [_I, _I, _I, _I, _I, _I]),
     "sf_op_conv1d_bwd_cl": (_I, [_P, _P, _P, _P, _I, _F, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _L, _P]),
     "sf_op_conv1d_bwd_cl_act": (_I, [_P, _P, _P, _P, _P, _P, _I, _F, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _L, _P]),
+    "sf_op_conv1d_bwd_cl_x": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _F, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _L, _P]),
     "sf_op_gn_silu_train_stats_floats": (_L, [_I, _I, _I, _I]),
     "sf_op_gn_silu_train": (_I, [_P, _P, _P, _I, _F, _I, _I, _I, _P, _P, _P]),
     "sf_op_ln_modulate_bwd_workspace_bytes": (_L, [_I, _I, _I]),

@@ -22,6 +22,7 @@ namespace {
 
 struct BwdPlan {
   float *act = nullptr, *da = nullptr, *wd = nullptr, *wpart = nullptr, *bpart = nullptr, *gpart = nullptr;
+  void *wdx = nullptr;   // the dgrad matrix as split fp16 operands (SF_F32X)
   int S = 1, Sb = 1, ldn = 0;
 };
 
@@ -32,6 +33,7 @@ BwdPlan plan(Workspace &ws, int B, int L, int C, int N, int taps, int groups) {
   if (groups > 0) p.act = ws.alloc_n<float>(rows * C);
   p.da = ws.alloc_n<float>(rows * C);
   p.wd = ws.alloc_n<float>((int64_t)C * taps * p.ldn);
+  p.wdx = ws.alloc((int64_t)C * taps * p.ldn * 4);
   p.S = conv_wgrad_splits(rows, C, N, taps);
   p.wpart = ws.alloc_n<float>((int64_t)p.S * N * taps * C);
   p.Sb = (int)std::min<int64_t>(256, std::max<int64_t>(1, rows * N / 16384));   // >= 16 K elements per slice
@@ -55,10 +57,12 @@ int64_t sf_op_conv1d_bwd_workspace_bytes(int B, int L, int C, int N, int taps, i
   }
 }
 
-static int conv1d_bwd_impl(const float *x, const float *act_saved, const float *stats_saved, const float *w, const float *gamma, const float *beta, int groups, float eps, const float *dy, int B, int L,
+static int conv1d_bwd_impl(int dtype, const float *x, const float *act_saved, const float *stats_saved, const float *w, const float *gamma, const float *beta, int groups, float eps, const float *dy, int B, int L,
                         int C, int N, int taps, int pad, float *dx, float *dw, float *db, float *dgb, void *ws, int64_t ws_bytes, void *stream) {
   SF_API_BEGIN
   if (!x || !w || !dy || !ws) fail(SF_ERR_INVALID, "null argument");
+  if (dtype != SF_F32 && dtype != SF_F32X) fail(SF_ERR_INVALID, "dtype must be SF_F32 or SF_F32X");
+  const bool x3 = dtype == SF_F32X;
   if (!dx && !dw && !db && !dgb) fail(SF_ERR_INVALID, "nothing to compute: dx, dw, db and dgb are all null");
   if (groups > 0 && (!gamma || !beta || !dgb || !dx)) fail(SF_ERR_INVALID, "GroupNorm backward needs gamma, beta, dgb and dx");
   if (taps < 1 || pad < 0 || pad >= taps || 2 * pad != taps - 1) fail(SF_ERR_UNSUPPORTED, "stride-1 'same' convolutions only (2 * pad == taps - 1)");
@@ -95,11 +99,16 @@ static int conv1d_bwd_impl(const float *x, const float *act_saved, const float *
     a.n_store = C;
     const bool direct = (N % 32) != 0;
     if (direct && C > 32) fail(SF_ERR_UNSUPPORTED, "dgrad of a thin convolution (N %% 32 != 0) needs C <= 32");
+    if (x3 && !direct && (a.K % 32) == 0) {   // fp32-accurate products from split fp16 operands (kernels.h, ConvGemmArgs::wx)
+      SF_HIP(launch_pack_wx(p.wd, C, a.K, p.wdx, s, X3_BF16));   // gradients span the whole fp32 exponent range: the bf16 split
+      a.wx = p.wdx;
+      a.wx_mode = X3_BF16;
+    }
     if (direct) SF_HIP(launch_conv_direct(F32, F32, a, s));
     else SF_HIP(launch_conv_gemm(F32, a, s));
   }
   // ---- wgrad / bias grad ------------------------------------------------------------------------------------------
-  if (dw) SF_HIP(launch_conv_wgrad(dy, act, B, L, C, N, taps, pad, p.wpart, p.S, dw, s));
+  if (dw) SF_HIP(launch_conv_wgrad(dy, act, B, L, C, N, taps, pad, p.wpart, p.S, dw, s, x3 ? X3_BF16 : 0));
   if (db) SF_HIP(launch_col_sums(dy, (int64_t)B * L, N, p.bpart, p.Sb, db, s));
   // ---- GroupNorm + SiLU ----------------------------------------------------------------------------------------------
   if (groups > 0) SF_HIP(launch_gn_silu_bwd(x, p.da, gamma, beta, B, L, C, groups, eps, dx, p.gpart, dgb, s, act_saved ? stats_saved : nullptr));
@@ -109,7 +118,7 @@ static int conv1d_bwd_impl(const float *x, const float *act_saved, const float *
 
 int sf_op_conv1d_bwd_cl(const float *x, const float *w, const float *gamma, const float *beta, int groups, float eps, const float *dy, int B, int L,
                         int C, int N, int taps, int pad, float *dx, float *dw, float *db, float *dgb, void *ws, int64_t ws_bytes, void *stream) {
-  return conv1d_bwd_impl(x, nullptr, nullptr, w, gamma, beta, groups, eps, dy, B, L, C, N, taps, pad, dx, dw, db, dgb, ws, ws_bytes, stream);
+  return conv1d_bwd_impl(SF_F32, x, nullptr, nullptr, w, gamma, beta, groups, eps, dy, B, L, C, N, taps, pad, dx, dw, db, dgb, ws, ws_bytes, stream);
 }
 
 int sf_op_conv1d_bwd_cl_act(const float *x, const float *act, const float *stats, const float *w, const float *gamma, const float *beta, int groups,
@@ -119,7 +128,13 @@ int sf_op_conv1d_bwd_cl_act(const float *x, const float *act, const float *stats
     set_error("sf_op_conv1d_bwd_cl_act: act is null");
     return SF_ERR_INVALID;
   }
-  return conv1d_bwd_impl(x, act, stats, w, gamma, beta, groups, eps, dy, B, L, C, N, taps, pad, dx, dw, db, dgb, ws, ws_bytes, stream);
+  return conv1d_bwd_impl(SF_F32, x, act, stats, w, gamma, beta, groups, eps, dy, B, L, C, N, taps, pad, dx, dw, db, dgb, ws, ws_bytes, stream);
+}
+
+int sf_op_conv1d_bwd_cl_x(int dtype, const float *x, const float *act, const float *stats, const float *w, const float *gamma, const float *beta,
+                          int groups, float eps, const float *dy, int B, int L, int C, int N, int taps, int pad, float *dx, float *dw, float *db,
+                          float *dgb, void *ws, int64_t ws_bytes, void *stream) {
+  return conv1d_bwd_impl(dtype, x, act, stats, w, gamma, beta, groups, eps, dy, B, L, C, N, taps, pad, dx, dw, db, dgb, ws, ws_bytes, stream);
 }
 
 int64_t sf_op_gn_silu_train_stats_floats(int B, int L, int C, int groups) {

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "kernels.h"   // X3_F16 / X3_BF16
+
 namespace sf {
 
 typedef __bf16 bf16;
@@ -47,27 +49,52 @@ template <> struct Frag16<f16> {
 __device__ __forceinline__ f32x16 mfma32x16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x16 mfma32x16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
-// ---- fp32-accurate products from split fp16 operands ("x3", the parity-grade fast path) --------------------------------------------------
-// a = hi + lo' / 2048 with hi = fp16(a), lo' = fp16((a - hi) * 2048): 22 significant bits per operand, the scale keeps lo' out of the fp16
-// subnormal range.  A product is three v_mfma_f32_32x32x16_f16:  accM += hi_a hi_b;  accL += hi_a lo'_b + lo'_a hi_b;  result = accM +
-// accL / 2048 (the lo' lo' term is 2^-22 of the product and dropped).  Measured against fp64 on a 256 x 256 x 3072 GEMM: rel-L2 7.5e-8 (plain
-// fp32 MFMA 3.5e-7, three bf16 products 4.4e-6, one fp16 product 2.9e-4).  Range: |a| < 65504 (fp16 maximum), as for the fp16 engine.
-constexpr float X3_SCALE = 2048.0f, X3_INV = 1.0f / 2048.0f;
-__device__ __forceinline__ void x3_split(const f32x4 p, const f32x4 q, f16x8 &hi, f16x8 &lo) {
+// ---- fp32-accurate products from split 16-bit operands ("x3", the parity-grade fast path) ------------------------------------------------
+// An fp32 operand is split in registers into two 16-bit parts, a = hi + lo / SCALE, and a product is three 16-bit MFMAs into two fp32
+// accumulators:  accM += hi_a hi_b;  accL += hi_a lo_b + lo_a hi_b;  result = accM + accL / SCALE  (the lo lo term is dropped).
+//   mode 1 (forward passes): hi = fp16(a), lo = fp16((a - hi) * 2048) -- 22 significant bits per operand, the scale keeps lo out of the
+//     fp16 subnormal range.  Measured against fp64 on a 256 x 256 x 3072 GEMM: rel-L2 7.5e-8 (plain fp32 MFMA 3.5e-7, one fp16 product
+//     2.9e-4).  Range: |a| < 65504 (fp16 maximum), as for the fp16 engine; values below ~1e-7 of the tensor's typical magnitude lose bits.
+//   mode 2 (backward passes, whose gradients span the whole fp32 exponent range): hi = bf16(a), lo = bf16(a - hi), SCALE = 1 -- 16 significant
+//     bits per operand, 4.4e-6 on the same GEMM, no range restriction.
+template <int MODE> struct X3P;
+template <> struct X3P<X3_F16> {
+  using v8 = f16x8;
+  using elem = f16;
+  static constexpr float SCALE = 2048.0f, INV = 1.0f / 2048.0f;
+  static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct X3P<X3_BF16> {
+  using v8 = bf16x8;
+  using elem = bf16;
+  static constexpr float SCALE = 1.0f, INV = 1.0f;
+  static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <int MODE> __device__ __forceinline__ void x3_split1(float v, typename X3P<MODE>::elem &hi, typename X3P<MODE>::elem &lo) {
+  using E = typename X3P<MODE>::elem;
+  const E h = (E)v;
+  hi = h;
+  lo = (E)((v - (float)h) * X3P<MODE>::SCALE);
+}
+template <int MODE> __device__ __forceinline__ void x3_split(const f32x4 p, const f32x4 q, typename X3P<MODE>::v8 &hi, typename X3P<MODE>::v8 &lo) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const f16 h = (f16)p[e], g = (f16)q[e];
+    typename X3P<MODE>::elem h, l;
+    x3_split1<MODE>(p[e], h, l);
     hi[e] = h;
-    hi[4 + e] = g;
-    lo[e] = (f16)((p[e] - (float)h) * X3_SCALE);
-    lo[4 + e] = (f16)((q[e] - (float)g) * X3_SCALE);
+    lo[e] = l;
+    x3_split1<MODE>(q[e], h, l);
+    hi[4 + e] = h;
+    lo[4 + e] = l;
   }
 }
 // the three products of one 32x32x16 step
-__device__ __forceinline__ void x3_mfma(const f16x8 ah, const f16x8 al, const f16x8 bh, const f16x8 bl, f32x16 &accM, f32x16 &accL) {
-  accM = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, accM, 0, 0, 0);
-  accL = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accL, 0, 0, 0);
-  accL = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accL, 0, 0, 0);
+template <int MODE>
+__device__ __forceinline__ void x3_mfma(const typename X3P<MODE>::v8 ah, const typename X3P<MODE>::v8 al, const typename X3P<MODE>::v8 bh,
+                                        const typename X3P<MODE>::v8 bl, f32x16 &accM, f32x16 &accL) {
+  accM = X3P<MODE>::mfma(ah, bh, accM);
+  accL = X3P<MODE>::mfma(ah, bl, accL);
+  accL = X3P<MODE>::mfma(al, bh, accL);
 }
 
 template <typename T> __device__ __forceinline__ Vec16<T> ld16(const T *p) {

@@ -31,7 +31,7 @@ template <typename T> __device__ __forceinline__ Vec16<T> buf_ld16(__amdgpu_buff
 // LN: the first source is LayerNorm-modulated on the fly (ConvGemmArgs::ln_*; 32x32 tiles, one tap, Lout >= 32).
 // X3 (T = float, KW = 32): split-fp16 weights (ConvGemmArgs::wx; wave w multiplies the w-th (32 hi | 32 lo') group of the staged 128-deep
 // chunk), fp32 activation fragments split in registers after the (optional) LayerNorm transform, three fp16 MFMAs per product (common.h)
-template <typename T, int BM, int BN, bool CAT, int KW, int NSET, bool LN, bool X3 = false>
+template <typename T, int BM, int BN, bool CAT, int KW, int NSET, bool LN, int X3 = 0>
 __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(const ConvGemmArgs a, const int mtiles, const int ntiles, const int swz,
                                                              const unsigned bytesA, const unsigned bytesA2, const unsigned bytesW) {
   constexpr int BKT = 4 * KW;
@@ -206,22 +206,23 @@ __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(const ConvGemmArgs 
     if constexpr (X3) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+        using xv = typename X3P<X3 ? X3 : 1>::v8;
+        xv ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           const float *ap = reinterpret_cast<const float *>(As) + (i * 32 + fr) * LD + kw0 + 16 * s + 8 * fh;
-          x3_split(*reinterpret_cast<const f32x4 *>(ap), *reinterpret_cast<const f32x4 *>(ap + 4), ah[i], al[i]);
+          x3_split<X3 ? X3 : 1>(*reinterpret_cast<const f32x4 *>(ap), *reinterpret_cast<const f32x4 *>(ap + 4), ah[i], al[i]);
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const unsigned char *bp = reinterpret_cast<const unsigned char *>(Bs + (j * 32 + fr) * LD + kw0) + 32 * s + 16 * fh;
-          bh[j] = *reinterpret_cast<const f16x8 *>(bp);
-          bl[j] = *reinterpret_cast<const f16x8 *>(bp + 64);
+          bh[j] = *reinterpret_cast<const xv *>(bp);
+          bl[j] = *reinterpret_cast<const xv *>(bp + 64);
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) x3_mfma(ah[i], al[i], bh[j], bl[j], acc[i][j], accL[i][j]);
+          for (int j = 0; j < TN; ++j) x3_mfma<X3 ? X3 : 1>(ah[i], al[i], bh[j], bl[j], acc[i][j], accL[i][j]);
       }
     } else if constexpr (sizeof(T) == 2) {
 #pragma unroll
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(const ConvGemmArgs 
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        if constexpr (X3) myred[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LDR + j * 32 + fr] = fmaf(accL[i][j][r], X3_INV, acc[i][j][r]);
+        if constexpr (X3) myred[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LDR + j * 32 + fr] = fmaf(accL[i][j][r], X3P<X3 ? X3 : 1>::INV, acc[i][j][r]);
         else myred[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LDR + j * 32 + fr] = acc[i][j][r];
       }
   __syncthreads();
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(256) void conv_gemm_fast_kernel(const ConvGemmArgs 
   }
 }
 
-template <typename T, int BM, int BN, bool CAT, int KW, int NSET, bool LN = false, bool X3 = false> hipError_t launch_fast3(const ConvGemmArgs &a, hipStream_t s) {
+template <typename T, int BM, int BN, bool CAT, int KW, int NSET, bool LN = false, int X3 = 0> hipError_t launch_fast3(const ConvGemmArgs &a, hipStream_t s) {
   constexpr int BKT = 4 * KW;
   constexpr int LD = BKT + 16 / (int)sizeof(T);
   constexpr size_t stage_bytes = (size_t)(BM + BN) * LD * sizeof(T);
@@ -527,7 +528,7 @@ static bool ln_goes_rs(int dt, const ConvGemmArgs &a);
 const char *conv_gemm_ln_variant_name(int dt, const ConvGemmArgs &a) {
   if (ln_goes_mt(dt, a)) return label_for_dtype(dt, conv_gemm_mt_name(a));
   if (ln_goes_rs(dt, a)) return label_for_dtype(dt, "conv_gemm_rs<bf16,32x32>");
-  if (dt == F32 && a.wx) return ln_goes_wp(dt, a) ? "conv_gemm_wp<x3,32x32>" : "conv_gemm_fast<x3,32x32>";
+  if (dt == F32 && a.wx && a.wx_mode == X3_F16) return ln_goes_wp(dt, a) ? "conv_gemm_wp<x3,32x32>" : "conv_gemm_fast<x3,32x32>";
   if (dt == F32) return ln_goes_wp(dt, a) ? "conv_gemm_wp<f32,32x32>" : "conv_gemm_fast<f32,32x32>";
   return label_for_dtype(dt, ln_goes_wp(dt, a) ? "conv_gemm_wp<bf16,32x32>" : "conv_gemm_fast<bf16,32x32>");
 }
@@ -549,7 +550,7 @@ hipError_t launch_conv_gemm_ln(int dt, const ConvGemmArgs &a, hipStream_t s) {
   if (ln_goes_mt(dt, a)) return launch_conv_gemm_mt(dt, a, s);
   if (ln_goes_rs(dt, a)) return launch_conv_gemm_rs(dt, a, s);
   if (ln_goes_wp(dt, a)) return launch_conv_gemm_wp(dt, a, 2, s);
-  if (dt == F32 && a.wx) return a.cin2 ? launch_fast3<float, 32, 32, true, 32, 2, true, true>(a, s) : launch_fast3<float, 32, 32, false, 32, 2, true, true>(a, s);
+  if (dt == F32 && a.wx && a.wx_mode == X3_F16) return a.cin2 ? launch_fast3<float, 32, 32, true, 32, 2, true, X3_F16>(a, s) : launch_fast3<float, 32, 32, false, 32, 2, true, X3_F16>(a, s);
   return SF_DISPATCH_T(dt, (a.cin2 ? launch_fast3<T, 32, 32, true, 32, 2, true>(a, s) : launch_fast3<T, 32, 32, false, 32, 2, true>(a, s)));
 }
 
@@ -559,8 +560,15 @@ hipError_t launch_conv_gemm_fast(int dt, const ConvGemmArgs &a, int variant, hip
 #define SF_FAST(T, BM, BN)                                                                                              \
   (wide ? (a.cin2 ? launch_fast2<T, BM, BN, true, 64>(a, s) : launch_fast2<T, BM, BN, false, 64>(a, s))                 \
         : (a.cin2 ? launch_fast2<T, BM, BN, true, 32>(a, s) : launch_fast2<T, BM, BN, false, 32>(a, s)))
-  if (dt == F32 && a.wx) {   // split mode
-#define SF_FASTX(BM, BN) (a.cin2 ? launch_fast3<float, BM, BN, true, 32, 2, false, true>(a, s) : launch_fast3<float, BM, BN, false, 32, 2, false, true>(a, s))
+  if (dt == F32 && a.wx && a.wx_mode == X3_BF16 && !a.cin2) {   // split mode, gradients
+    switch (variant) {
+      case 0: return launch_fast3<float, 64, 64, false, 32, 2, false, X3_BF16>(a, s);
+      case 1: return launch_fast3<float, 64, 32, false, 32, 2, false, X3_BF16>(a, s);
+      default: return launch_fast3<float, 32, 32, false, 32, 2, false, X3_BF16>(a, s);
+    }
+  }
+  if (dt == F32 && a.wx && a.wx_mode == X3_F16) {   // split mode
+#define SF_FASTX(BM, BN) (a.cin2 ? launch_fast3<float, BM, BN, true, 32, 2, false, X3_F16>(a, s) : launch_fast3<float, BM, BN, false, 32, 2, false, X3_F16>(a, s))
     switch (variant) {
       case 0: return SF_FASTX(64, 64);
       case 1: return SF_FASTX(64, 32);

@@ -57,7 +57,7 @@ __device__ unsigned long long g_mt_stamps[8][8];
 // X3 (T = float): the weights are the split-fp16 image (ConvGemmArgs::wx, the same 128 bytes per row and K step: 32 hi | 32 lo'), the fp32
 // activation fragments are split in registers after the LDS read, three v_mfma_f32_32x32x16_f16 per product into two accumulators
 // (common.h, x3_split): fp32-grade results at 16-bit matrix rates.  DMA ring, swizzle and epilogue are those of the fp32 instantiation.
-template <typename T, int BM, int BN, int WM, int WN, int GEOM, bool CAT, int NST = NSTAGE, int EP = 1, bool LNE = false, bool PRE = false, bool X3 = false>
+template <typename T, int BM, int BN, int WM, int WN, int GEOM, bool CAT, int NST = NSTAGE, int EP = 1, bool LNE = false, bool PRE = false, int X3 = 0>
 __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a, const int mtiles, const int ntiles, const unsigned bytesA,
                                                            const unsigned bytesA2, const unsigned bytesW) {
   constexpr int ES = sizeof(T);   // fp32 (training, the parity engine's long activations): same byte geometry, v_mfma_f32_32x32x2_f32
@@ -314,22 +314,23 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
       // (k = 16 s + 8 fh + 0..7); weight row: chunks 0-3 = hi, 4-7 = lo', chunk 2 s + fh holds the same eight k.
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+        using xv = typename X3P<X3 ? X3 : 1>::v8;
+        xv ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           const f32x4 p = *reinterpret_cast<const f32x4 *>(slot + offA[i] + (unsigned)(((4 * s2 + 2 * fh) ^ sw) * 16));
           const f32x4 q = *reinterpret_cast<const f32x4 *>(slot + offA[i] + (unsigned)(((4 * s2 + 2 * fh + 1) ^ sw) * 16));
-          x3_split(p, q, ah[i], al[i]);
+          x3_split<X3 ? X3 : 1>(p, q, ah[i], al[i]);
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          bh[j] = *reinterpret_cast<const f16x8 *>(slot + offB[j] + (unsigned)(((2 * s2 + fh) ^ sw) * 16));
-          bl[j] = *reinterpret_cast<const f16x8 *>(slot + offB[j] + (unsigned)(((4 + 2 * s2 + fh) ^ sw) * 16));
+          bh[j] = *reinterpret_cast<const xv *>(slot + offB[j] + (unsigned)(((2 * s2 + fh) ^ sw) * 16));
+          bl[j] = *reinterpret_cast<const xv *>(slot + offB[j] + (unsigned)(((4 + 2 * s2 + fh) ^ sw) * 16));
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) x3_mfma(ah[i], al[i], bh[j], bl[j], acc[i][j], accL[i][j]);
+          for (int j = 0; j < TN; ++j) x3_mfma<X3 ? X3 : 1>(ah[i], al[i], bh[j], bl[j], acc[i][j], accL[i][j]);
       }
     } else {
 #pragma unroll
@@ -413,7 +414,7 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
       for (int r = 0; r < 16; ++r) {
         if (EP == 2 && (r >> 3) != pass) continue;   // registers 0-7 = rows 0-15 of the tile, 8-15 = rows 16-31
         const int lr = EP == 1 ? (r & 3) + 8 * (r >> 2) + 4 * fh : (r & 3) + 8 * ((r >> 2) & 1) + 4 * fh;
-        if constexpr (X3) red[(i * RPT + lr) * LDR + j * 32 + fr] = fmaf(accL[i][j][r], X3_INV, acc[i][j][r]);
+        if constexpr (X3) red[(i * RPT + lr) * LDR + j * 32 + fr] = fmaf(accL[i][j][r], X3P<X3 ? X3 : 1>::INV, acc[i][j][r]);
         else red[(i * RPT + lr) * LDR + j * 32 + fr] = acc[i][j][r];
       }
   __builtin_amdgcn_wave_barrier();   // same-wave LDS operations execute in order; this only pins the compiler
@@ -558,7 +559,7 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
 #endif
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int GEOM, bool CAT, int NST = NSTAGE, int EP = 1, bool LNE = false, bool PRE = false, bool X3 = false>
+template <typename T, int BM, int BN, int WM, int WN, int GEOM, bool CAT, int NST = NSTAGE, int EP = 1, bool LNE = false, bool PRE = false, int X3 = 0>
 hipError_t launch_mt(const ConvGemmArgs &a, hipStream_t s) {
   constexpr size_t ring = (size_t)NST * (BM + BN) * ROWB;
   constexpr size_t redb = (size_t)8 * (BM / WM / EP) * (BN / WN + 4) * sizeof(float) + (size_t)BM * 2 * sizeof(float);   // parking area + rowstat
@@ -615,13 +616,12 @@ template <typename T, int GEOM, bool CAT> hipError_t launch_mt_v(const ConvGemmA
 }
 
 // split mode (fp32 activations x split-fp16 weights): wave tiles of at least 32 x 64, so that a split activation fragment feeds six MFMAs
-template <bool CAT> hipError_t launch_mt_x3(const ConvGemmArgs &a, int v, hipStream_t s) {
+template <bool CAT, int MODE> hipError_t launch_mt_x3(const ConvGemmArgs &a, int v, hipStream_t s) {
   switch (v) {
-    case 0: return launch_mt<float, 256, 128, 4, 2, 0, CAT, 3, 1, false, false, true>(a, s);   // wave tile 64 x 64, one workgroup per CU
-    case 1: return launch_mt<float, 128, 128, 4, 2, 0, CAT, 3, 1, false, false, true>(a, s);   // wave tile 32 x 64, three slots (96 KB)
-    case 5: return launch_mt<float, 128, 128, 4, 2, 0, CAT, 2, 2, false, false, true>(a, s);   // the same with two slots (64 KB): two workgroups per CU
-    case 7: return launch_mt<float, 128, 64, 4, 2, 0, CAT, 3, 1, false, false, true>(a, s);    // wave tile 32 x 32 (72 KB): two workgroups per CU
-    case 8: return launch_mt<float, 192, 128, 2, 4, 0, CAT, 2, 2, false, false, true>(a, s);   // wave tile 96 x 32, two slots (80 KB)
+    case 0: return launch_mt<float, 256, 128, 4, 2, 0, CAT, 3, 1, false, false, MODE>(a, s);   // wave tile 64 x 64, one workgroup per CU
+    case 1: return launch_mt<float, 128, 128, 4, 2, 0, CAT, 3, 1, false, false, MODE>(a, s);   // wave tile 32 x 64, three slots (96 KB)
+    case 5: return launch_mt<float, 128, 128, 4, 2, 0, CAT, 2, 2, false, false, MODE>(a, s);   // the same with two slots (64 KB): two workgroups per CU
+    case 7: return launch_mt<float, 128, 64, 4, 2, 0, CAT, 3, 1, false, false, MODE>(a, s);    // wave tile 32 x 32 (72 KB): two workgroups per CU
     default: return hipErrorInvalidValue;
   }
 }
@@ -635,6 +635,7 @@ bool conv_gemm_mt_ok(int dt, const ConvGemmArgs &a) {
   const int bke = (int)(ROWB / es), vec = (int)(16 / es);   // elements per K step / per 16-byte access
   if (dt == F32 && a.geom != 0) return false;                // fp32: the U-Net's 1-D geometry only (training, parity engine)
   if (a.pro != 0 || (a.cin % bke) || (a.cin2 % bke) || a.taps < 1 || a.K != a.taps * a.cin + a.cin2) return false;
+  if (a.wx && a.wx_mode == X3_BF16 && a.cin2) return false;
   if (a.cin2 && (a.geom != 0 || !a.src2 || (a.src2_ld % vec) || a.src2_ld < a.cin2 || (size_t)a.M * a.src2_ld * es >= 0x7FFFFFF0ull)) return false;
   if (a.out_f32 || a.act > 1 || a.ln_ss || a.res_ln) return false;
   if (a.rowpart_out && (dt == F32 || a.geom != 0 || (a.n_store % 32) || a.rowpart_nt * 32 != a.n_store || a.N != a.n_store)) return false;
@@ -677,7 +678,7 @@ static bool conv_gemm_prefers_mt_x3(const ConvGemmArgs &a) {
   return (long)((a.M + 127) / 128) * ((a.n_store + 63) / 64) >= min_tiles;
 }
 static int conv_gemm_mt_x3_variant(const ConvGemmArgs &a) {
-  static const int forced = [] { const char *e = tune_env("SF_MT_X3_VARIANT"); return e ? atoi(e) : -1; }();   // tuning hook: 0, 1, 5, 7, 8
+  static const int forced = [] { const char *e = tune_env("SF_MT_X3_VARIANT"); return e ? atoi(e) : -1; }();   // tuning hook: 0, 1, 5, 7
   if (forced >= 0) return forced;
   const long t128 = (long)((a.M + 127) / 128) * ((a.n_store + 127) / 128), t256 = (long)((a.M + 255) / 256) * ((a.n_store + 127) / 128);
   if (a.n_store % 128 && a.n_store % 64 == 0 && a.n_store <= 192) return 7;
@@ -779,7 +780,8 @@ hipError_t launch_conv_gemm_mt(int dt, const ConvGemmArgs &a, hipStream_t s) {
   if (!conv_gemm_mt_ok(dt, a)) return hipErrorInvalidValue;
   if (dt == F32 && a.wx) {
     const int v = conv_gemm_mt_x3_variant(a);
-    return a.cin2 ? launch_mt_x3<true>(a, v, s) : launch_mt_x3<false>(a, v, s);
+    if (a.wx_mode == X3_BF16) return a.cin2 ? hipErrorInvalidValue : launch_mt_x3<false, X3_BF16>(a, v, s);   // (gradient GEMMs have one source)
+    return a.cin2 ? launch_mt_x3<true, X3_F16>(a, v, s) : launch_mt_x3<false, X3_F16>(a, v, s);
   }
   if (dt == F32) {
     static const int forced = [] { const char *e = getenv("SF_MT_F32_VARIANT"); return e ? atoi(e) : -1; }();   // tuning hook: 1, 5, 7

@@ -33,7 +33,7 @@ template <typename T> __device__ __forceinline__ Vec16<T> buf_ld16(__amdgpu_buff
 // wave's LDS operations execute in program order (the next chunk's writes queue behind this chunk's fragment reads).
 // X3 (T = float): split-fp16 weights (ConvGemmArgs::wx: per 32 k, 32 hi | 32 lo' -- the same 256 bytes per row and chunk), fp32 activation
 // fragments split in registers, three v_mfma_f32_32x32x16_f16 per product (common.h, x3_split)
-template <typename T, int BM, int BN, bool CAT, int NSET, bool X3 = false>
+template <typename T, int BM, int BN, bool CAT, int NSET, int X3 = 0>
 __global__ __launch_bounds__(256) void conv_gemm_wp_kernel(const ConvGemmArgs a, const int mtiles, const int ntiles, const int swz,
                                                            const unsigned bytesA, const unsigned bytesA2, const unsigned bytesW) {
   constexpr int VEC = Vec16<T>::N;
@@ -181,22 +181,23 @@ __global__ __launch_bounds__(256) void conv_gemm_wp_kernel(const ConvGemmArgs a,
       // 128 (s / 2) + 32 (s % 2) + 16 fh and the matching lo' 64 bytes behind
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+        using xv = typename X3P<X3 ? X3 : 1>::v8;
+        xv ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           const float *ap = reinterpret_cast<const float *>(As) + (i * 32 + fr) * LD + 16 * s + 8 * fh;
-          x3_split(*reinterpret_cast<const f32x4 *>(ap), *reinterpret_cast<const f32x4 *>(ap + 4), ah[i], al[i]);
+          x3_split<X3 ? X3 : 1>(*reinterpret_cast<const f32x4 *>(ap), *reinterpret_cast<const f32x4 *>(ap + 4), ah[i], al[i]);
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const unsigned char *bp = reinterpret_cast<const unsigned char *>(Bs + (j * 32 + fr) * LD) + 128 * (s >> 1) + 32 * (s & 1) + 16 * fh;
-          bh[j] = *reinterpret_cast<const f16x8 *>(bp);
-          bl[j] = *reinterpret_cast<const f16x8 *>(bp + 64);
+          bh[j] = *reinterpret_cast<const xv *>(bp);
+          bl[j] = *reinterpret_cast<const xv *>(bp + 64);
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) x3_mfma(ah[i], al[i], bh[j], bl[j], acc[i][j], accL[i][j]);
+          for (int j = 0; j < TN; ++j) x3_mfma<X3 ? X3 : 1>(ah[i], al[i], bh[j], bl[j], acc[i][j], accL[i][j]);
       }
     } else if constexpr (sizeof(T) == 2) {
 #pragma unroll
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(256) void conv_gemm_wp_kernel(const ConvGemmArgs a,
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        if constexpr (X3) myred[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LDR + j * 32 + fr] = fmaf(accL[i][j][r], X3_INV, acc[i][j][r]);
+        if constexpr (X3) myred[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LDR + j * 32 + fr] = fmaf(accL[i][j][r], X3P<X3 ? X3 : 1>::INV, acc[i][j][r]);
         else myred[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LDR + j * 32 + fr] = acc[i][j][r];
       }
   __syncthreads();
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(256) void conv_gemm_wp_kernel(const ConvGemmArgs a,
   }
 }
 
-template <typename T, int BM, int BN, bool CAT, int NSET, bool X3 = false> hipError_t launch_wp3(const ConvGemmArgs &a, hipStream_t s) {
+template <typename T, int BM, int BN, bool CAT, int NSET, int X3 = 0> hipError_t launch_wp3(const ConvGemmArgs &a, hipStream_t s) {
   constexpr int LD = BK + 16 / (int)sizeof(T);
   constexpr size_t stage_bytes = (size_t)4 * (BM + BN) * LD * sizeof(T);
   constexpr size_t red_bytes = (size_t)4 * BM * (BN + 4) * sizeof(float) + (size_t)4 * BM * sizeof(float);   // + (mean, rstd) and (sum, sumsq) per row
@@ -446,7 +447,8 @@ bool conv_gemm_wp_ok(int dt, const ConvGemmArgs &a) {
 hipError_t launch_conv_gemm_wp(int dt, const ConvGemmArgs &a, int variant, hipStream_t s) {
 #define SF_WP(T, BM, BN) (a.cin2 ? launch_wp2<T, BM, BN, true>(a, s) : launch_wp2<T, BM, BN, false>(a, s))
   if (dt == F32 && a.wx) {   // split mode: 32x32 tiles (the variants the fp32 engine uses on short activations)
-    return a.cin2 ? launch_wp3<float, 32, 32, true, 2, true>(a, s) : launch_wp3<float, 32, 32, false, 2, true>(a, s);
+    if (a.wx_mode == X3_BF16) return a.cin2 ? hipErrorInvalidValue : launch_wp3<float, 32, 32, false, 2, X3_BF16>(a, s);
+    return a.cin2 ? launch_wp3<float, 32, 32, true, 2, X3_F16>(a, s) : launch_wp3<float, 32, 32, false, 2, X3_F16>(a, s);
   }
   if (dt == F32) {
     switch (variant) {

@@ -19,6 +19,8 @@ inline const char *tune_env(const char *) { return nullptr; }
 #endif
 
 enum DType { F32 = 0, BF16 = 1, F16 = 2 };
+// split modes of the fp32x GEMMs (common.h, X3<MODE>): fp16 hi + 2048-scaled fp16 lo (forward), bf16 hi + bf16 lo (gradients)
+constexpr int X3_F16 = 1, X3_BF16 = 2;
 inline size_t dsize(int dt) { return dt == F32 ? 4 : 2; }
 // three-way dispatch on the arithmetic type: SF_DISPATCH_T(dt, f<T>(args)) evaluates f with T = float / bf16 / f16;
 // SF_DISPATCH_STMT(dt, statement using T) is the statement form (kernel launches)
@@ -56,6 +58,7 @@ struct ConvGemmArgs {
   // the same bytes per row as fp32).  When set, the kernels that carry the split mode multiply fp32 activations against it with three
   // v_mfma_f32_32x32x16_f16 per product (common.h, x3_split); every other kernel ignores it and multiplies `w` in fp32.
   const void *wx = nullptr;
+  int wx_mode = 1;              // 1: fp16 hi + 2048-scaled fp16 lo (forward passes); 2: bf16 hi + bf16 lo (gradients: no range restriction)
   void *out = nullptr;
   const float *bias = nullptr, *gamma = nullptr, *beta = nullptr, *stats = nullptr;
   const float *badd = nullptr, *bscale = nullptr;
@@ -115,7 +118,7 @@ bool conv_gemm_rs_rows_ok(int64_t rows, int N);   // few enough 32x32 tiles for 
 hipError_t launch_conv_gemm_rs(int dt, const ConvGemmArgs &a, hipStream_t s);
 hipError_t launch_pack_wfr(int dt, const void *w /* [N][K], compute type */, int N, int K, void *out, hipStream_t s);
 // split-fp16 image of a packed fp32 [N][K] matrix (K % 32 == 0): out[n][k / 32][0][k % 32] = hi, [1][k % 32] = lo' (common.h, x3_split)
-hipError_t launch_pack_wx(const float *w, int N, int K, void *out, hipStream_t s);
+hipError_t launch_pack_wx(const float *w, int N, int K, void *out, hipStream_t s, int mode = 1);
 // true when launch_conv_gemm would run `a` on the kernel that honours gnpart_out (wp, 32x32 tiles)
 bool conv_gemm_emits_gnpart(int dt, const ConvGemmArgs &a);
 // GEMM whose first source is LayerNorm-modulated on the fly from producer-side row partials (see ConvGemmArgs)
@@ -372,8 +375,9 @@ hipError_t launch_times_to_track(const double *times, const int *clip_of, int n_
 hipError_t launch_pack_dgrad(const float *w, int N, int C, int taps, int ldn, float *out, hipStream_t s);
 // dw (N, C, taps) = sum_rows dy[row][n] * act[row + t - pad][c];  partial: [S][N][taps*C] scratch, S = conv_wgrad_splits(...)
 int conv_wgrad_splits(int64_t rows, int C, int N, int taps);
+// x3: the products from split fp16 operands (both operands are activations: split while they are staged)
 hipError_t launch_conv_wgrad(const float *dy, const float *act, int B, int L, int C, int N, int taps, int pad, float *partial, int S, float *dw,
-                             hipStream_t s);
+                             hipStream_t s, int x3_mode = 0);
 // out[col] = sum_rows x[row][col]   (part: [S][cols] scratch)
 hipError_t launch_col_sums(const float *x, int64_t rows, int cols, float *part, int S, float *out, hipStream_t s);
 // out[b][c] = sum_l x[b][l][c] * (y ? y[b][l][c] : 1); part: B * length_sums_slices(B, L) * C floats

@@ -193,14 +193,11 @@ __global__ void pack_rows_kernel(const float *__restrict__ in, int64_t rows, int
   }
 }
 // split-fp16 image of a packed fp32 [N][K] matrix: out[(n * K + 64 * (k / 32)) + {0, 32} + k % 32] = (hi, lo') of w[n][k]  (common.h, x3_split)
-__global__ void pack_wx_kernel(const float *__restrict__ w, int64_t total, f16 *__restrict__ out) {
+template <int MODE> __global__ void pack_wx_kernel(const float *__restrict__ w, int64_t total, typename X3P<MODE>::elem *__restrict__ out) {
   SF_GRID_STRIDE(i, total) {
-    const float v = w[i];
-    const f16 h = (f16)v;
     const int64_t g = i >> 5;
     const int e = (int)(i & 31);
-    out[g * 64 + e] = h;
-    out[g * 64 + 32 + e] = (f16)((v - (float)h) * X3_SCALE);
+    x3_split1<MODE>(w[i], out[g * 64 + e], out[g * 64 + 32 + e]);
   }
 }
 __global__ void fold_bias_kernel(const float *__restrict__ w, int N, int K, const float *__restrict__ v, const float *__restrict__ add,
@@ -427,10 +424,11 @@ hipError_t launch_pack_rows(int dt, const float *in, int64_t rows, int cols, int
   SF_DISPATCH_STMT(dt, hipLaunchKernelGGL((pack_rows_kernel<T>), g, dim3(TPB), 0, s, in, rows, cols, ldi, cscale, (T *)out, ldo));
   return hipGetLastError();
 }
-hipError_t launch_pack_wx(const float *w, int N, int K, void *out, hipStream_t s) {
+hipError_t launch_pack_wx(const float *w, int N, int K, void *out, hipStream_t s, int mode) {
   if (K % 32) return hipErrorInvalidValue;
   const int64_t total = (int64_t)N * K;
-  hipLaunchKernelGGL(pack_wx_kernel, grid_for(total), dim3(TPB), 0, s, w, total, static_cast<f16 *>(out));
+  if (mode == X3_BF16) hipLaunchKernelGGL(pack_wx_kernel<X3_BF16>, grid_for(total), dim3(TPB), 0, s, w, total, static_cast<bf16 *>(out));
+  else hipLaunchKernelGGL(pack_wx_kernel<X3_F16>, grid_for(total), dim3(TPB), 0, s, w, total, static_cast<f16 *>(out));
   return hipGetLastError();
 }
 hipError_t launch_fold_bias(const float *w, int N, int K, const float *v, const float *add, float *out, hipStream_t s) {

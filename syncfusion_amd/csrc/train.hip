@@ -229,6 +229,179 @@ __global__ __launch_bounds__(256) void conv_wgrad_lds_kernel(const float *__rest
     }
 }
 
+// The LDS-staged weight gradient on split fp16 operands (SF_F32X; common.h, x3_split): both operands are activations, so they are split
+// ONCE per element while the chunk is staged -- dy and the activation window land in LDS as (hi, lo') fp16 images, row-major
+// [row][column] -- and the k-strided fragments (8 consecutive ROWS of one column per lane) are gathered by the hardware transpose
+// read `ds_read_b64_tr_b16` (cdna_hip_programming.md T10): per 16-lane group a 4-row x 16-column block, column i to lane i.
+// A chunk of 32 rows = two 16-deep products per accumulator tile, three MFMAs each.  Rows whose shifted position leaves the clip are
+// cleared in the fragment through per-tap validity masks of the chunk (all ones except at clip boundaries: wave-uniform fast path).
+typedef short v4i16_w __attribute__((ext_vector_type(4)));
+typedef short v8i16_w __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) v4i16_w lds_v4i16_w;
+
+template <int TW, int MODE>
+__global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const float *__restrict__ dy, const float *__restrict__ act, int rows, int L, int C, int N,
+                                                            int taps, int pad, int rows_per_split, float *__restrict__ partial,
+                                                            float *__restrict__ dw_direct) {
+  // pitch in fp16 elements: consecutive rows 64 B apart modulo 256 B, so the 4 rows x 2 column groups a 32-lane half gathers with one
+  // transposed read fall into eight disjoint 8-bank ranges
+  constexpr int KR = 32, TILE = 64 * TW, PITCH = TILE + 32, NRMAX = KR + 8;
+  using XE = typename X3P<MODE>::elem;
+  using XV = typename X3P<MODE>::v8;
+  __shared__ __attribute__((aligned(16))) XE dyH[KR * PITCH], dyL[KR * PITCH];
+  __shared__ __attribute__((aligned(16))) XE acH[NRMAX * PITCH], acL[NRMAX * PITCH];
+  __shared__ unsigned vmask[9];   // bit k of vmask[t]: row k of the chunk may read tap t (its shifted position stays inside the clip)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 31, fh = lane >> 5;
+  const int wn = wave >> 1, wq = wave & 1;
+  const int Q = taps * C;
+  const int n0 = blockIdx.x * TILE, q0 = blockIdx.y * TILE;
+  const bool single = taps == 1 || (C % TILE) == 0;
+  const int t0 = single ? q0 / C : 0;
+  const int cw0 = single ? q0 - t0 * C : 0;
+  const int cwid = single ? min(TILE, C - cw0) : C;
+  const int nr = single ? KR : KR + taps - 1;
+  const int rshift = single ? t0 - pad : -pad;
+  int tj[TW], koff[TW], coff[TW];
+  bool qok[TW];
+#pragma unroll
+  for (int j = 0; j < TW; ++j) {
+    const int qs = q0 + (wq * TW + j) * 32;
+    qok[j] = qs < Q;
+    const int t = qok[j] ? qs / C : 0;
+    tj[j] = t;
+    koff[j] = single ? 0 : t;
+    coff[j] = single ? (wq * TW + j) * 32 : (qok[j] ? qs - t * C : 0);
+  }
+  const int r_begin = blockIdx.z * rows_per_split, r_end = min(rows, r_begin + rows_per_split);
+  f32x16 acc[TW][TW], accL[TW][TW];
+#pragma unroll
+  for (int i = 0; i < TW; ++i)
+#pragma unroll
+    for (int j = 0; j < TW; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = accL[i][j][e] = 0.f;
+  constexpr int DYV = KR * TILE / 4 / 256;
+  constexpr int ACV = (NRMAX * TILE / 4 + 255) / 256;
+  f32x4 pdy[DYV], pac[ACV];
+  const int vpr = cwid / 4;
+  auto fetch = [&](int r0) {
+#pragma unroll
+    for (int u = 0; u < DYV; ++u) {
+      const int idx = tid + 256 * u, k = idx / (TILE / 4), c4 = idx - k * (TILE / 4);
+      const int r = r0 + k, n = n0 + 4 * c4;
+      pdy[u] = (r < r_end && n < N) ? *reinterpret_cast<const f32x4 *>(dy + (size_t)r * N + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < ACV; ++u) {
+      const int idx = tid + 256 * u, k = idx / vpr, c4 = idx - k * vpr;
+      const int g = r0 + k + rshift;
+      pac[u] = (k < nr && g >= 0 && g < rows) ? *reinterpret_cast<const f32x4 *>(act + (size_t)g * C + cw0 + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  typedef XE f16x4 __attribute__((ext_vector_type(4)));
+  auto split4 = [](const f32x4 v, f16x4 &hi, f16x4 &lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      XE h, l;
+      x3_split1<MODE>(v[e], h, l);
+      hi[e] = h;
+      lo[e] = l;
+    }
+  };
+  auto stash = [&](int r0) {
+#pragma unroll
+    for (int u = 0; u < DYV; ++u) {
+      const int idx = tid + 256 * u, k = idx / (TILE / 4), c4 = idx - k * (TILE / 4);
+      f16x4 hi, lo;
+      split4(pdy[u], hi, lo);
+      *reinterpret_cast<f16x4 *>(dyH + k * PITCH + 4 * c4) = hi;
+      *reinterpret_cast<f16x4 *>(dyL + k * PITCH + 4 * c4) = lo;
+    }
+#pragma unroll
+    for (int u = 0; u < ACV; ++u) {
+      const int idx = tid + 256 * u, k = idx / vpr, c4 = idx - k * vpr;
+      if (k < nr) {
+        f16x4 hi, lo;
+        split4(pac[u], hi, lo);
+        *reinterpret_cast<f16x4 *>(acH + k * PITCH + 4 * c4) = hi;
+        *reinterpret_cast<f16x4 *>(acL + k * PITCH + 4 * c4) = lo;
+      }
+    }
+    if (wave == 0) {   // validity masks of the chunk: one ballot per tap over the 32 rows (lanes 32-63 repeat them)
+      const int l = (r0 + (lane & 31)) % L;
+      for (int t = 0; t < taps; ++t) {
+        const unsigned long long b = __ballot((unsigned)(l + t - pad) < (unsigned)L);
+        if (lane == 0) vmask[t] = (unsigned)b;
+      }
+    }
+  };
+  // transposed-read lane geometry: lane 4 q + p of a 16-lane group addresses row q, columns 4 p .. 4 p + 3 of the group's 16 columns
+  const int tr_off = (8 * fh + ((lane & 15) >> 2)) * PITCH + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  auto trfrag = [&](const XE *base) {
+    const v4i16_w a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_w *)(base));
+    const v4i16_w b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_w *)(base + 4 * PITCH));
+    const v8i16_w both = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return both;
+  };
+  if (r_begin < r_end) fetch(r_begin);
+  for (int r0 = r_begin; r0 < r_end; r0 += KR) {
+    __syncthreads();
+    stash(r0);
+    __syncthreads();
+    if (r0 + KR < r_end) fetch(r0 + KR);
+    unsigned vm[TW];
+#pragma unroll
+    for (int j = 0; j < TW; ++j) vm[j] = vmask[tj[j]];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      XV ah[TW], al[TW], bh[TW], bl[TW];
+#pragma unroll
+      for (int i = 0; i < TW; ++i) {
+        const int o = (16 * st) * PITCH + (wn * TW + i) * 32 + tr_off;
+        ah[i] = __builtin_bit_cast(XV, trfrag(dyH + o));
+        al[i] = __builtin_bit_cast(XV, trfrag(dyL + o));
+      }
+#pragma unroll
+      for (int j = 0; j < TW; ++j) {
+        const int o = (16 * st + koff[j]) * PITCH + coff[j] + tr_off;
+        v8i16_w h = trfrag(acH + o), l = trfrag(acL + o);
+        if (vm[j] != 0xffffffffu) {   // wave-uniform: a clip boundary inside the chunk -- clear the rows that may not read this tap
+          const unsigned bits = vm[j] >> (16 * st + 8 * fh);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const short keep = (bits >> e) & 1u ? (short)-1 : (short)0;
+            h[e] &= keep;
+            l[e] &= keep;
+          }
+        }
+        bh[j] = __builtin_bit_cast(XV, h);
+        bl[j] = __builtin_bit_cast(XV, l);
+      }
+#pragma unroll
+      for (int i = 0; i < TW; ++i)
+#pragma unroll
+        for (int j = 0; j < TW; ++j) x3_mfma<MODE>(ah[i], al[i], bh[j], bl[j], acc[i][j], accL[i][j]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TW; ++i)
+#pragma unroll
+    for (int j = 0; j < TW; ++j) {
+      const int qq = q0 + (wq * TW + j) * 32 + fr;
+      if (qq >= Q) continue;
+      const int t = qq / C, cc = qq - t * C;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int nn = n0 + (wn * TW + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        if (nn < N) {
+          const float v = fmaf(accL[i][j][e], X3P<MODE>::INV, acc[i][j][e]);
+          if (dw_direct) dw_direct[((size_t)nn * C + cc) * taps + t] = v;
+          else partial[((size_t)blockIdx.z * N + nn) * Q + qq] = v;
+        }
+      }
+    }
+}
+
 // Sum over the leading (slice) dimension: 32 outputs per workgroup, 8 threads per output take the slices k = kq, kq + 8, ... and
 // are combined through LDS in a fixed order (deterministic; the loads of a 32-lane group are 128 contiguous bytes).
 __device__ __forceinline__ float slice_sum_8(const float *__restrict__ part, int S, size_t stride, size_t col, bool valid, float *sh /* [256] */) {
@@ -746,13 +919,18 @@ int conv_wgrad_splits(int64_t rows, int C, int N, int taps) {
 }
 
 hipError_t launch_conv_wgrad(const float *dy, const float *act, int B, int L, int C, int N, int taps, int pad, float *partial, int S, float *dw,
-                             hipStream_t s) {
+                             hipStream_t s, int x3) {
   const int rows = B * L, Q = taps * C;
   int rps = (rows + S - 1) / S;
   rps = (rps + 31) / 32 * 32;
   float *direct = S == 1 ? dw : nullptr;
   const int fam = wgrad_family(C, N, taps);
-  if (fam == 2)
+  // (the gradients dy span the whole fp32 exponent range: the bf16 split, whatever the forward pass uses)
+  if (x3 && fam == 2)
+    hipLaunchKernelGGL((conv_wgrad_x3_kernel<2, X3_BF16>), dim3((N + 127) / 128, (Q + 127) / 128, S), dim3(256), 0, s, dy, act, rows, L, C, N, taps, pad, rps, partial, direct);
+  else if (x3 && fam == 1)
+    hipLaunchKernelGGL((conv_wgrad_x3_kernel<1, X3_BF16>), dim3((N + 63) / 64, (Q + 63) / 64, S), dim3(256), 0, s, dy, act, rows, L, C, N, taps, pad, rps, partial, direct);
+  else if (fam == 2)
     hipLaunchKernelGGL(conv_wgrad_lds_kernel<2>, dim3((N + 127) / 128, (Q + 127) / 128, S), dim3(256), 0, s, dy, act, rows, L, C, N, taps, pad, rps, partial, direct);
   else if (fam == 1)
     hipLaunchKernelGGL(conv_wgrad_lds_kernel<1>, dim3((N + 63) / 64, (Q + 63) / 64, S), dim3(256), 0, s, dy, act, rows, L, C, N, taps, pad, rps, partial, direct);

@@ -86,6 +86,60 @@ def test_conv_gemm(cuda, dtype, shape):
     assert _conv_case(cuda, dtype, *shape) < TOL[dtype]
 
 
+def _conv_x3_case(cuda, dtype, B, L, C, N, taps, up, residual, seed=0):
+    """plain convolution (no prologue) through sf_op_conv1d_cl against fp64 torch on the UNROUNDED fp32 inputs"""
+    _l, lib = _lib()
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, C, L, generator=g) * 1.5 + 0.3
+    w = torch.randn(N, C, taps, generator=g) / (C * taps) ** 0.5
+    bias = torch.randn(N, generator=g) * 0.1
+    h = x.double()
+    if up > 1:
+        h = F.interpolate(h, scale_factor=up, mode="nearest")
+    ref = F.conv1d(h, w.double(), bias.double(), padding=taps // 2)
+    Lout = ref.shape[-1]
+    res = torch.randn(B, N, Lout, generator=g) if residual else None
+    if residual:
+        ref = ref + res.double()
+    x_cl = x.transpose(1, 2).contiguous().to(cuda)
+    res_cl = res.transpose(1, 2).contiguous().to(cuda) if residual else None
+    out = torch.empty(B, Lout, N, device=cuda)
+    ws = torch.empty(256 << 20, dtype=torch.uint8, device=cuda)
+    wd, bd = w.to(cuda), bias.to(cuda)
+    _l.check(lib.sf_op_conv1d_cl(_l.DTYPES[dtype], x_cl.data_ptr(), wd.data_ptr(), bd.data_ptr(), None, None, 0, 1e-5,
+                                 res_cl.data_ptr() if residual else None, B, L, C, N, taps, 1, taps // 2, up, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                 _l.stream_ptr(cuda)), "sf_op_conv1d_cl")
+    torch.cuda.synchronize()
+    got = out.double().cpu().transpose(1, 2)
+    return float((got - ref).norm() / ref.norm())
+
+
+@pytest.mark.parametrize("shape", [
+    # B, L, C, N, taps, up, residual                   the kernel family the engine's dispatch picks for it
+    (8, 5632, 64, 128, 3, 1, True),       # K = 192: below the split kernels' reach -> plain fp32 (the mode must fall back, not fail)
+    (9, 5000, 128, 320, 1, 1, False),     # macro tiles, ragged M and a partial column tile
+    (4, 4096, 128, 128, 3, 1, True),      # macro tiles 128x64
+    (3, 3000, 256, 192, 1, 1, False),     # macro tiles, 192 columns, K = 256 (8 K steps)
+    (8, 8192, 128, 128, 3, 1, False),     # macro tiles 128x128 (two workgroups per CU)
+    (8, 1408, 512, 512, 3, 1, True),      # macro tiles, K = 1536
+    (32, 176, 1024, 1024, 3, 1, True),    # the deepest level at the guidance batch: K = 3072
+    (32, 176, 1024, 1536, 1, 1, False),   # qkv projection
+    (64, 512, 256, 256, 3, 1, True),      # 256x128 macro tiles (two full rounds)
+    (4, 88, 1024, 1024, 3, 1, True),      # few rows: wave-private 32x32 split-K
+    (8, 44, 512, 256, 3, 1, True),        # clips shorter than a tile
+    (2, 100, 256, 320, 1, 1, False),      # ragged M and N on the 32x32 kernels
+    (4, 352, 256, 256, 3, 1, True),       # staged 32x32 kernel
+    (2, 352, 128, 128, 3, 2, True),       # nearest x2 upsample
+])
+def test_conv_gemm_fp32x_against_fp64(cuda, shape):
+    """The split-operand mode (SF_F32X: fp32 tensors, three fp16 MFMAs per product) per GEMM against fp64: the gate is 1e-6 rel-L2
+    (<= 2e-6); measured 9e-8 ... 3e-7, inside what the plain fp32 MFMA path gives on the same shape (1.3e-7 ... 8e-7)."""
+    ex = _conv_x3_case(cuda, "fp32x", *shape)
+    e32 = _conv_x3_case(cuda, "fp32", *shape)
+    print(f"conv {shape}: rel-L2 vs fp64  fp32 {e32:.2e}  fp32x {ex:.2e}")
+    assert ex < 1e-6 and e32 < 2e-6
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("shape", [
     (2, 2816, 8, 8, 3, 1, 1, 1, 8, True),       # U-Net depth 0 ResnetItem

@@ -49,6 +49,43 @@ def test_conv_block_gradients(cuda, B, L, C, N, taps, groups):
     assert torch.equal(leaves2[1].grad, ws.grad) and torch.equal(leaves2[0].grad, xs.grad)
 
 
+@pytest.mark.parametrize("mode", ["fp32", "fp32x"])
+@pytest.mark.parametrize("dy_scale", [1.0, 1e-9, 1e6])
+@pytest.mark.parametrize("B,L,C,N,taps,groups", [
+    (4, 4096, 128, 128, 3, 8),   # macro-tile dgrad, 128x128 LDS-staged wgrad tiles (whole-rows staging: C <= tile)
+    (2, 2048, 256, 512, 1, 0),   # 1x1: single-tap staging
+    (3, 700, 256, 256, 3, 8),    # ragged length: clip boundaries inside the 32-row chunks (per-tap validity masks)
+    (2, 1024, 64, 64, 3, 8),     # 64x64 wgrad tiles
+])
+def test_conv_block_gradients_gemm_modes_and_gradient_scales(cuda, monkeypatch, mode, dy_scale, B, L, C, N, taps, groups):
+    """The training GEMMs in both arithmetics (autograd.GEMM_DTYPE): "fp32" = fp32 MFMA, "fp32x" = products from split 16-bit operands --
+    fp16 hi / lo for the forward pass, bf16 hi / lo for the data and weight gradients, whose operand dy spans the whole fp32 exponent range
+    (a v-objective loss averaged over 10^6 samples sends 1e-7 ... 1e-9 down the network): gradients scaled by 1e-9 and by 1e6 must come out
+    as accurately as at scale 1.  Unchanged tolerance (2e-5 rel-L2 against fp32 torch autograd on the CPU)."""
+    from syncfusion_amd import autograd as sfa
+
+    monkeypatch.setattr(sfa, "GEMM_DTYPE", mode)
+    g = torch.Generator().manual_seed(B * 1000 + L + C)
+    x = (torch.randn(B, C, L, generator=g) * 1.3 + 0.2).requires_grad_()
+    w = (torch.randn(N, C, taps, generator=g) / (C * taps) ** 0.5).requires_grad_()
+    b = (torch.randn(N, generator=g) * 0.1).requires_grad_()
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).requires_grad_()
+    beta = (0.1 * torch.randn(C, generator=g)).requires_grad_()
+    dy = torch.randn(B, N, L, generator=g) * dy_scale
+    h = F.silu(F.group_norm(x, groups, gamma, beta, eps=1e-5)) if groups else x
+    y_ref = F.conv1d(h, w, b, padding=taps // 2)
+    y_ref.backward(dy)
+    leaves = [t.detach().clone().to(cuda).requires_grad_() for t in (x, w, b, gamma, beta)]
+    xs, ws, bs, gs, bes = leaves
+    y = sfa.gn_silu_conv1d(xs, ws, bs, gs, bes, groups) if groups else sfa.conv1d(xs, ws, bs)
+    assert rel_l2(y.detach().cpu(), y_ref.detach()) < TOL
+    y.backward(dy.to(cuda))
+    names = ["dx", "dw", "db"] + (["dgamma", "dbeta"] if groups else [])
+    for nm, got, ref in zip(names, (xs, ws, bs, gs, bes), (x, w, b, gamma, beta)):
+        e = rel_l2(got.grad.cpu(), ref.grad)
+        assert e < TOL, f"{mode} dy x {dy_scale:g} {nm}: {e:.3e}"
+
+
 @pytest.mark.parametrize("groups", [0, 8])
 def test_conv_block_skips_gradients_nobody_asked_for(cuda, groups):
     """backward honours ctx.needs_input_grad -- an input that needs no gradient (the raw waveform in front of the first
