@@ -286,6 +286,8 @@ int sf_op_attention_bwd(const float *q, const float *kv, const float *out, const
 /* The same pair with the log-sum-exp of the scaled scores, lse:(B, heads, L), kept by the forward pass and handed to the backward pass
  * (one score pass less there); fp32, head_dim 64; ws >= B * heads * L * 4 bytes. */
 int sf_op_attention_fwd_lse(const float *q, const float *kv, int B, int L, int heads, int head_dim, float *out, float *lse, void *stream);
+/* the same with the arithmetic chosen by `dtype` (SF_F32, or SF_F32X: products from split fp16 operands) */
+int sf_op_attention_fwd_lse_x(int dtype, const float *q, const float *kv, int B, int L, int heads, int head_dim, float *out, float *lse, void *stream);
 int sf_op_attention_bwd_lse(const float *q, const float *kv, const float *out, const float *dout, const float *lse, int B, int L, int heads, int head_dim,
                             float *dq, float *dkv, void *ws, int64_t ws_bytes, void *stream);
 /* Kernel tuning aid: average milliseconds of `iters` back-to-back launches of one channels-last conv1d

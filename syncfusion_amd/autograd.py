@@ -249,8 +249,8 @@ class _AttentionFn(torch.autograd.Function):
             qc, kc = _lib.f32c(q), _lib.f32c(kv)
             out = torch.empty_like(qc)
             lse = torch.empty(B, H, L, dtype=torch.float32, device=q.device)
-            _lib.check(lib.sf_op_attention_fwd_lse(qc.data_ptr(), kc.data_ptr(), B, L, H, HD // H, out.data_ptr(), lse.data_ptr(), _lib.stream_ptr(q.device)),
-                       "sf_op_attention_fwd_lse")
+            _lib.check(lib.sf_op_attention_fwd_lse_x(_lib.DTYPES[GEMM_DTYPE], qc.data_ptr(), kc.data_ptr(), B, L, H, HD // H, out.data_ptr(), lse.data_ptr(),
+                                                     _lib.stream_ptr(q.device)), "sf_op_attention_fwd_lse_x")
         ctx.save_for_backward(qc, kc, out, lse)
         ctx.meta = (B, L, H, HD // H)
         return out

@@ -156,17 +156,16 @@ hipError_t go(const void *q, int ldq, const void *kv, int ldkv, int B, int L, in
 
 hipError_t launch_attention_mfma(int dt, const void *q, int ldq, const void *kv, int ldkv, int B, int L, int H, int Dh, void *out, int ldo,
                                  hipStream_t s);
-bool attention_f32_mfma_ok(int ldq, int ldkv, int ldo, int B, int H);
-hipError_t launch_attention_f32_mfma(const float *q, int ldq, const float *kv, int ldkv, int B, int L, int H, float *out, int ldo, hipStream_t s,
-                                     float *lse_out = nullptr);
 
 hipError_t launch_attention(int dt, const void *q, int ldq, const void *kv, int ldkv, int B, int L, int H, int Dh, void *out,
-                            int ldo, hipStream_t s) {
+                            int ldo, hipStream_t s, bool x3, bool xfmt) {
   if (Dh != D || L <= 0) return hipErrorInvalidValue;
+  if (xfmt && (dt != F32 || !x3 || !attention_f32_mfma_ok(ldq, ldkv, ldo, B, H))) return hipErrorInvalidValue;
   if (dt != F32 && (ldq % 8) == 0 && (ldkv % 8) == 0 && (ldo % 8) == 0)   // matrix-core path (attention_mfma.hip)
     return launch_attention_mfma(dt, q, ldq, kv, ldkv, B, L, H, Dh, out, ldo, s);
   if (dt == F32 && attention_f32_mfma_ok(ldq, ldkv, ldo, B, H) && !getenv("SF_ATTN_F32_VALU"))   // fp32 matrix cores (attention_bwd.hip)
-    return launch_attention_f32_mfma(static_cast<const float *>(q), ldq, static_cast<const float *>(kv), ldkv, B, L, H, static_cast<float *>(out), ldo, s);
+    return launch_attention_f32_mfma(static_cast<const float *>(q), ldq, static_cast<const float *>(kv), ldkv, B, L, H, static_cast<float *>(out), ldo, s,
+                                     nullptr, x3, xfmt);
   return SF_DISPATCH_T(dt, go<T>(q, ldq, kv, ldkv, B, L, H, out, ldo, s));
 }
 

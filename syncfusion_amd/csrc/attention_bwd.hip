@@ -143,6 +143,156 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_mfma_kernel(const float *__r
   }
 }
 
+// The same forward on split fp16 operands (SF_F32X; common.h X3P<X3_F16>): q (pre-scaled, so that the scores come out in log2 units) is split
+// once into registers; the K and V tiles are split while they are staged and sit in LDS as (hi, lo') fp16 images, K read row-wise (a key
+// per lane, 8 consecutive head dims), V gathered column-wise by the hardware transpose read; the probabilities (in [0, 1]) are split in
+// registers and fed back as the B operand in the accumulator's own key order (element j of half h = key 16 s + 8 (j / 4) + 4 h + j % 4:
+// two blocks of four consecutive keys = two transposed reads of V per fragment).  24 MFMAs of 32 cycles per 32 x 32 tile instead of 64 of 64.
+constexpr int KP16 = 72, VP16 = 96;   // fp16 row pitches: K rows 144 B (row reads conflict-free), V rows 192 B (rows 64 B apart modulo 256)
+typedef short v4i16_a __attribute__((ext_vector_type(4)));
+typedef short v8i16_a __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) v4i16_a lds_v4i16_a;
+typedef f16 f16x4_a __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void tile_store_x3(f16 *hi, f16 *lo, const TileRegs &t, int tid, int pitch) {
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int idx = tid + 256 * e, r = idx >> 4, c4 = idx & 15;
+    f16x4_a h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f16 a, b;
+      x3_split1<X3_F16>(t.v[e][j], a, b);
+      h[j] = a;
+      l[j] = b;
+    }
+    *reinterpret_cast<f16x4_a *>(hi + r * pitch + 4 * c4) = h;
+    *reinterpret_cast<f16x4_a *>(lo + r * pitch + 4 * c4) = l;
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_x3_kernel(const float *__restrict__ q, int ldq, const float *__restrict__ kv, int ldkv, int L, int H,
+                                                          float scale_log2e, float *__restrict__ out, int ldo, float *__restrict__ lse_out, const int xfmt) {
+  __shared__ __attribute__((aligned(16))) f16 KsH[TILE * KP16], KsL[TILE * KP16];
+  __shared__ __attribute__((aligned(16))) f16 VsH[TILE * VP16], VsL[TILE * VP16];
+  using XP = X3P<X3_F16>;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, hf = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const size_t rb = (size_t)b * L;
+  const int qi = blockIdx.x * 128 + wave * 32 + li;
+  const bool qv = qi < L;
+  // B operand of S^T = K q^T: this lane's query, head dims 16 s + 8 hf .. + 7 of step s
+  f16x8 qh[4], ql[4];
+  {
+    const float *qp = q + (rb + (qv ? qi : 0)) * ldq + h * HD + 8 * hf;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      f32x4 a = qv ? *reinterpret_cast<const f32x4 *>(qp + 16 * s) : f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 c = qv ? *reinterpret_cast<const f32x4 *>(qp + 16 * s + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a[e] *= scale_log2e;
+        c[e] *= scale_log2e;
+      }
+      x3_split<X3_F16>(a, c, qh[s], ql[s]);
+    }
+  }
+  const int nkt = (L + TILE - 1) / TILE;
+  float m = -INFINITY, lsum = 0.f;
+  f32x16 o0 = zero16(), o1 = zero16(), o0l = zero16(), o1l = zero16();
+  TileRegs pk, pv;
+  tile_fetch(pk, kv, rb, 0, L, ldkv, h * HD, tid);
+  tile_fetch(pv, kv, rb, 0, L, ldkv, (H + h) * HD, tid);
+  // transposed-read geometry (cdna_hip_programming.md T10): lane 4 q + p of a 16-lane group addresses key row q, head dims 4 p .. 4 p + 3
+  const int tr_off = (4 * hf + ((lane & 15) >> 2)) * VP16 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  auto vfrag = [&](const f16 *base) {
+    const v4i16_a a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_a *)(base));
+    const v4i16_a c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_a *)(base + 8 * VP16));
+    const v8i16_a both = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+    return __builtin_bit_cast(f16x8, both);
+  };
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();
+    tile_store_x3(KsH, KsL, pk, tid, KP16);
+    tile_store_x3(VsH, VsL, pv, tid, VP16);
+    __syncthreads();
+    if (kt + 1 < nkt) {
+      tile_fetch(pk, kv, rb, (kt + 1) * TILE, L, ldkv, h * HD, tid);
+      tile_fetch(pv, kv, rb, (kt + 1) * TILE, L, ldkv, (H + h) * HD, tid);
+    }
+    f32x16 sm = zero16(), sl = zero16();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const f16x8 kh = *reinterpret_cast<const f16x8 *>(KsH + li * KP16 + 16 * s + 8 * hf);
+      const f16x8 kl = *reinterpret_cast<const f16x8 *>(KsL + li * KP16 + 16 * s + 8 * hf);
+      x3_mfma<X3_F16>(kh, kl, qh[s], ql[s], sm, sl);
+    }
+    float sv[16];
+    float tm = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float x = fmaf(sl[r], XP::INV, sm[r]);
+      sv[r] = (kt * TILE + acc_row(r, hf) < L) ? x : -INFINITY;
+      tm = fmaxf(tm, sv[r]);
+    }
+    tm = fmaxf(tm, __shfl_xor(tm, 32));
+    const float mn = fmaxf(m, tm), alpha = exp2f(m - mn);
+    float add = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      sv[r] = exp2f(sv[r] - mn);
+      add += sv[r];
+    }
+    lsum = lsum * alpha + add;
+    m = mn;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      o0[r] *= alpha;
+      o1[r] *= alpha;
+      o0l[r] *= alpha;
+      o1l[r] *= alpha;
+    }
+    // O^T += V^T P^T: step s covers the keys of accumulator registers 8 s .. 8 s + 7 (this lane's B operand), A = V columns from the
+    // row-major images by two transposed reads (keys 16 s + 4 hf + 0..3 and + 8)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      f16x8 ph, pl;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        f16 a, c;
+        x3_split1<X3_F16>(sv[8 * s + j], a, c);
+        ph[j] = a;
+        pl[j] = c;
+      }
+      const int o = (16 * s) * VP16 + tr_off;
+      x3_mfma<X3_F16>(vfrag(VsH + o), vfrag(VsL + o), ph, pl, o0, o0l);
+      x3_mfma<X3_F16>(vfrag(VsH + o + 32), vfrag(VsL + o + 32), ph, pl, o1, o1l);
+    }
+  }
+  lsum += __shfl_xor(lsum, 32);
+  if (lse_out && hf == 0 && qv) lse_out[((size_t)b * H + h) * L + qi] = (m + log2f(lsum)) * 0.6931471805599453f;
+  if (qv) {
+    const float inv = 1.0f / lsum;
+    float *op = out + (rb + qi) * ldo + h * HD + 4 * hf;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 a, c;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a[e] = fmaf(o0l[4 * g + e], XP::INV, o0[4 * g + e]) * inv;
+        c[e] = fmaf(o1l[4 * g + e], XP::INV, o1[4 * g + e]) * inv;
+      }
+      if (xfmt) {   // rows pre-split for the output projection (common.h, st4_x3)
+        st4_x3(out + (rb + qi) * ldo, h * HD + 4 * hf + 8 * g, a);
+        st4_x3(out + (rb + qi) * ldo, h * HD + 4 * hf + 8 * g + 32, c);
+      } else {
+        *reinterpret_cast<f32x4 *>(op + 8 * g) = a;
+        *reinterpret_cast<f32x4 *>(op + 32 + 8 * g) = c;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void attn_bwd_q_mfma_kernel(const float *__restrict__ q, const float *__restrict__ kv, const float *__restrict__ o,
                                                               const float *__restrict__ dout, int L, int H, float scale, float *__restrict__ dq,
                                                               float *__restrict__ lse_out, float *__restrict__ dsum_out, const float *__restrict__ lse_in) {
@@ -345,9 +495,14 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_mfma_kernel(const float *__re
 bool attention_f32_mfma_ok(int ldq, int ldkv, int ldo, int B, int H) { return (ldkv % 4) == 0 && (ldo % 4) == 0 && ldq > 0 && B <= 65535 && H <= 65535; }
 
 hipError_t launch_attention_f32_mfma(const float *q, int ldq, const float *kv, int ldkv, int B, int L, int H, float *out, int ldo, hipStream_t s,
-                                     float *lse_out) {
+                                     float *lse_out, bool x3, bool xfmt) {
   if (L < 1 || B < 1 || H < 1) return hipErrorInvalidValue;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)HD);
+  if (xfmt && !(x3 && (ldq % 4) == 0 && ldo == H * HD && (ldo % 32) == 0)) return hipErrorInvalidValue;
+  if (x3 && (ldq % 4) == 0) {   // the split-operand forward (16-byte query loads)
+    hipLaunchKernelGGL(attn_fwd_x3_kernel, dim3((L + 127) / 128, H, B), dim3(256), 0, s, q, ldq, kv, ldkv, L, H, scale_log2e, out, ldo, lse_out, xfmt ? 1 : 0);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(attn_fwd_f32_mfma_kernel, dim3((L + 127) / 128, H, B), dim3(256), 0, s, q, ldq, kv, ldkv, L, H, scale_log2e, out, ldo, lse_out);
   return hipGetLastError();
 }

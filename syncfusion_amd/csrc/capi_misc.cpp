@@ -556,8 +556,9 @@ int sf_op_ln_modulate(int dtype, const void *x, const float *scale_shift, float 
 int sf_op_attention(int dtype, const void *q, const void *kv, int B, int L, int heads, int head_dim, void *out, void *stream) {
   SF_API_BEGIN
   if (!q || !kv || !out) fail(SF_ERR_INVALID, "null argument");
-  SF_HIP(launch_attention(dtype, q, heads * head_dim, kv, 2 * heads * head_dim, B, L, heads, head_dim, out, heads * head_dim,
-                          static_cast<hipStream_t>(stream)));
+  const bool x3 = dtype == SF_F32X;   // fp32 tensors, products from split fp16 operands
+  SF_HIP(launch_attention(x3 ? (int)F32 : dtype, q, heads * head_dim, kv, 2 * heads * head_dim, B, L, heads, head_dim, out, heads * head_dim,
+                          static_cast<hipStream_t>(stream), x3));
   return SF_OK;
   SF_API_END
 }

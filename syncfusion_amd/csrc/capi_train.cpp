@@ -200,14 +200,22 @@ int sf_op_attention_bwd(const float *q, const float *kv, const float *out, const
   SF_API_END
 }
 
+static int attention_fwd_lse_impl(int dtype, const float *q, const float *kv, int B, int L, int heads, int head_dim, float *out, float *lse, void *stream);
 int sf_op_attention_fwd_lse(const float *q, const float *kv, int B, int L, int heads, int head_dim, float *out, float *lse, void *stream) {
+  return attention_fwd_lse_impl(SF_F32, q, kv, B, L, heads, head_dim, out, lse, stream);
+}
+int sf_op_attention_fwd_lse_x(int dtype, const float *q, const float *kv, int B, int L, int heads, int head_dim, float *out, float *lse, void *stream) {
+  return attention_fwd_lse_impl(dtype, q, kv, B, L, heads, head_dim, out, lse, stream);
+}
+static int attention_fwd_lse_impl(int dtype, const float *q, const float *kv, int B, int L, int heads, int head_dim, float *out, float *lse, void *stream) {
   SF_API_BEGIN
+  if (dtype != SF_F32 && dtype != SF_F32X) fail(SF_ERR_INVALID, "dtype must be SF_F32 or SF_F32X");
   if (!q || !kv || !out || !lse) fail(SF_ERR_INVALID, "null argument");
   if (head_dim != 64) fail(SF_ERR_UNSUPPORTED, "head_dim must be 64");
   if (B < 1 || L < 1 || heads < 1) fail(SF_ERR_INVALID, "B, L and heads must be positive");
   const int hd = heads * head_dim;
   if (!attention_f32_mfma_ok(hd, 2 * hd, hd, B, heads)) fail(SF_ERR_UNSUPPORTED, "shape outside the fp32 matrix-core attention kernel");
-  SF_HIP(launch_attention_f32_mfma(q, hd, kv, 2 * hd, B, L, heads, out, hd, static_cast<hipStream_t>(stream), lse));
+  SF_HIP(launch_attention_f32_mfma(q, hd, kv, 2 * hd, B, L, heads, out, hd, static_cast<hipStream_t>(stream), lse, dtype == SF_F32X));
   return SF_OK;
   SF_API_END
 }

@@ -88,6 +88,22 @@ template <int MODE> __device__ __forceinline__ void x3_split(const f32x4 p, cons
     lo[4 + e] = l;
   }
 }
+// four consecutive channels c0 .. c0 + 3 (c0 % 4 == 0) of an activation row in the pre-split layout [C / 32][hi 32 | lo' 32] fp16 (mode 1):
+// what ConvGemmArgs::src_x3 reads.  `row` points at the row's first byte (the row is C * 4 bytes long, as in fp32).
+__device__ __forceinline__ void st4_x3(void *row, int c0, const f32x4 v) {
+  typedef f16 f16x4_s __attribute__((ext_vector_type(4)));
+  f16x4_s h, l;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    f16 a, b;
+    x3_split1<X3_F16>(v[e], a, b);
+    h[e] = a;
+    l[e] = b;
+  }
+  unsigned char *p = static_cast<unsigned char *>(row) + (c0 >> 5) * 128 + (c0 & 31) * 2;
+  *reinterpret_cast<f16x4_s *>(p) = h;
+  *reinterpret_cast<f16x4_s *>(p + 64) = l;
+}
 // the three products of one 32x32x16 step
 template <int MODE>
 __device__ __forceinline__ void x3_mfma(const typename X3P<MODE>::v8 ah, const typename X3P<MODE>::v8 al, const typename X3P<MODE>::v8 bh,

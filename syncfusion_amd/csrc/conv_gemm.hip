@@ -549,6 +549,7 @@ bool conv_gemm_emits_gnpart(int dt, const ConvGemmArgs &a) {
 
 hipError_t launch_conv_gemm(int dt, const ConvGemmArgs &a, hipStream_t s) {
   if (!conv_gemm_supported(dt, a)) return hipErrorInvalidValue;
+  if (a.src_x3 && (dt != F32 || g_conv_gemm_force.path != 0 || !conv_gemm_src_x3_ok(a))) return hipErrorInvalidValue;   // only the macro tiles read pre-split rows
   const ConvGemmForce &f = g_conv_gemm_force;
   if (f.path == 6) return launch_conv_gemm_mt(dt, a, s);
   if (f.path == 0 && conv_gemm_mt_wanted(dt, a)) return launch_conv_gemm_mt(dt, a, s);

@@ -57,7 +57,7 @@ __device__ unsigned long long g_mt_stamps[8][8];
 // X3 (T = float): the weights are the split-fp16 image (ConvGemmArgs::wx, the same 128 bytes per row and K step: 32 hi | 32 lo'), the fp32
 // activation fragments are split in registers after the LDS read, three v_mfma_f32_32x32x16_f16 per product into two accumulators
 // (common.h, x3_split): fp32-grade results at 16-bit matrix rates.  DMA ring, swizzle and epilogue are those of the fp32 instantiation.
-template <typename T, int BM, int BN, int WM, int WN, int GEOM, bool CAT, int NST = NSTAGE, int EP = 1, bool LNE = false, bool PRE = false, int X3 = 0>
+template <typename T, int BM, int BN, int WM, int WN, int GEOM, bool CAT, int NST = NSTAGE, int EP = 1, bool LNE = false, bool PRE = false, int X3 = 0, bool AX = false>
 __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a, const int mtiles, const int ntiles, const unsigned bytesA,
                                                            const unsigned bytesA2, const unsigned bytesW) {
   constexpr int ES = sizeof(T);   // fp32 (training, the parity engine's long activations): same byte geometry, v_mfma_f32_32x32x2_f32
@@ -318,9 +318,14 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
         xv ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-          const f32x4 p = *reinterpret_cast<const f32x4 *>(slot + offA[i] + (unsigned)(((4 * s2 + 2 * fh) ^ sw) * 16));
-          const f32x4 q = *reinterpret_cast<const f32x4 *>(slot + offA[i] + (unsigned)(((4 * s2 + 2 * fh + 1) ^ sw) * 16));
-          x3_split<X3 ? X3 : 1>(p, q, ah[i], al[i]);
+          if constexpr (AX) {   // the producer wrote the rows already split (ConvGemmArgs::src_x3): same chunk geometry as the weights
+            ah[i] = *reinterpret_cast<const xv *>(slot + offA[i] + (unsigned)(((2 * s2 + fh) ^ sw) * 16));
+            al[i] = *reinterpret_cast<const xv *>(slot + offA[i] + (unsigned)(((4 + 2 * s2 + fh) ^ sw) * 16));
+          } else {
+            const f32x4 p = *reinterpret_cast<const f32x4 *>(slot + offA[i] + (unsigned)(((4 * s2 + 2 * fh) ^ sw) * 16));
+            const f32x4 q = *reinterpret_cast<const f32x4 *>(slot + offA[i] + (unsigned)(((4 * s2 + 2 * fh + 1) ^ sw) * 16));
+            x3_split<X3 ? X3 : 1>(p, q, ah[i], al[i]);
+          }
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -559,7 +564,7 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
 #endif
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int GEOM, bool CAT, int NST = NSTAGE, int EP = 1, bool LNE = false, bool PRE = false, int X3 = 0>
+template <typename T, int BM, int BN, int WM, int WN, int GEOM, bool CAT, int NST = NSTAGE, int EP = 1, bool LNE = false, bool PRE = false, int X3 = 0, bool AX = false>
 hipError_t launch_mt(const ConvGemmArgs &a, hipStream_t s) {
   constexpr size_t ring = (size_t)NST * (BM + BN) * ROWB;
   constexpr size_t redb = (size_t)8 * (BM / WM / EP) * (BN / WN + 4) * sizeof(float) + (size_t)BM * 2 * sizeof(float);   // parking area + rowstat
@@ -571,7 +576,7 @@ hipError_t launch_mt(const ConvGemmArgs &a, hipStream_t s) {
   else bA = (size_t)((a.M + a.To * a.Ho * a.Wo - 1) / (a.To * a.Ho * a.Wo)) * a.Ti * a.Hi * a.Wi * a.src_ld * sizeof(T);
   const size_t bW = (size_t)a.N * a.K * sizeof(T);
   const size_t bA2 = CAT ? (size_t)a.M * a.src2_ld * sizeof(T) : 0;
-  auto kern = conv_gemm_mt_kernel<T, BM, BN, WM, WN, GEOM, CAT, NST, EP, LNE, PRE, X3>;
+  auto kern = conv_gemm_mt_kernel<T, BM, BN, WM, WN, GEOM, CAT, NST, EP, LNE, PRE, X3, AX>;
   static bool en = false;
   if (!en) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -616,12 +621,12 @@ template <typename T, int GEOM, bool CAT> hipError_t launch_mt_v(const ConvGemmA
 }
 
 // split mode (fp32 activations x split-fp16 weights): wave tiles of at least 32 x 64, so that a split activation fragment feeds six MFMAs
-template <bool CAT, int MODE> hipError_t launch_mt_x3(const ConvGemmArgs &a, int v, hipStream_t s) {
+template <bool CAT, int MODE, bool AX = false> hipError_t launch_mt_x3(const ConvGemmArgs &a, int v, hipStream_t s) {
   switch (v) {
-    case 0: return launch_mt<float, 256, 128, 4, 2, 0, CAT, 3, 1, false, false, MODE>(a, s);   // wave tile 64 x 64, one workgroup per CU
-    case 1: return launch_mt<float, 128, 128, 4, 2, 0, CAT, 3, 1, false, false, MODE>(a, s);   // wave tile 32 x 64, three slots (96 KB)
-    case 5: return launch_mt<float, 128, 128, 4, 2, 0, CAT, 2, 2, false, false, MODE>(a, s);   // the same with two slots (64 KB): two workgroups per CU
-    case 7: return launch_mt<float, 128, 64, 4, 2, 0, CAT, 3, 1, false, false, MODE>(a, s);    // wave tile 32 x 32 (72 KB): two workgroups per CU
+    case 0: return launch_mt<float, 256, 128, 4, 2, 0, CAT, 3, 1, false, false, MODE, AX>(a, s);   // wave tile 64 x 64, one workgroup per CU
+    case 1: return launch_mt<float, 128, 128, 4, 2, 0, CAT, 3, 1, false, false, MODE, AX>(a, s);   // wave tile 32 x 64, three slots (96 KB)
+    case 5: return launch_mt<float, 128, 128, 4, 2, 0, CAT, 2, 2, false, false, MODE, AX>(a, s);   // the same with two slots (64 KB): two workgroups per CU
+    case 7: return launch_mt<float, 128, 64, 4, 2, 0, CAT, 3, 1, false, false, MODE, AX>(a, s);    // wave tile 32 x 32 (72 KB): two workgroups per CU
     default: return hipErrorInvalidValue;
   }
 }
@@ -636,6 +641,7 @@ bool conv_gemm_mt_ok(int dt, const ConvGemmArgs &a) {
   if (dt == F32 && a.geom != 0) return false;                // fp32: the U-Net's 1-D geometry only (training, parity engine)
   if (a.pro != 0 || (a.cin % bke) || (a.cin2 % bke) || a.taps < 1 || a.K != a.taps * a.cin + a.cin2) return false;
   if (a.wx && a.wx_mode == X3_BF16 && a.cin2) return false;
+  if (a.src_x3 && (dt != F32 || !a.wx || a.wx_mode != X3_F16 || a.cin2 || a.geom != 0)) return false;
   if (a.cin2 && (a.geom != 0 || !a.src2 || (a.src2_ld % vec) || a.src2_ld < a.cin2 || (size_t)a.M * a.src2_ld * es >= 0x7FFFFFF0ull)) return false;
   if (a.out_f32 || a.act > 1 || a.ln_ss || a.res_ln) return false;
   if (a.rowpart_out && (dt == F32 || a.geom != 0 || (a.n_store % 32) || a.rowpart_nt * 32 != a.n_store || a.N != a.n_store)) return false;
@@ -680,11 +686,18 @@ static bool conv_gemm_prefers_mt_x3(const ConvGemmArgs &a) {
 static int conv_gemm_mt_x3_variant(const ConvGemmArgs &a) {
   static const int forced = [] { const char *e = tune_env("SF_MT_X3_VARIANT"); return e ? atoi(e) : -1; }();   // tuning hook: 0, 1, 5, 7
   if (forced >= 0) return forced;
-  const long t128 = (long)((a.M + 127) / 128) * ((a.n_store + 127) / 128), t256 = (long)((a.M + 255) / 256) * ((a.n_store + 127) / 128);
-  if (a.n_store % 128 && a.n_store % 64 == 0 && a.n_store <= 192) return 7;
-  if (t256 >= 512) return 0;        // two full rounds of 256x128 tiles
-  if (t128 >= 256) return 5;        // 128x128, two workgroups per CU
-  return a.n_store % 64 == 0 ? 7 : 5;
+  // 128x128 with two slots (two workgroups per CU, wave tile 32 x 64: a split activation fragment feeds six MFMAs) wherever the column
+  // count allows it: same-box A/B on configs[2], 128x128 everywhere 93.5 vs 91.0 steps/s with 128x64 below 256 tiles (profiles/r6_c_ab_x3.txt);
+  // 256x128 from two full rounds of them
+  const long t256 = (long)((a.M + 255) / 256) * ((a.n_store + 127) / 128);
+  if (a.n_store <= 64 || ((a.n_store % 128) && (a.n_store % 128) <= 64 && a.n_store % 64 == 0 && a.n_store <= 192)) return 7;
+  if (t256 >= 512) return 0;
+  return 5;
+}
+bool conv_gemm_src_x3_ok(const ConvGemmArgs &a) {
+  ConvGemmArgs p = a;
+  p.src_x3 = 0;
+  return a.wx && a.wx_mode == X3_F16 && !a.cin2 && a.geom == 0 && conv_gemm_mt_wanted(F32, p);
 }
 bool conv_gemm_mt_wanted(int dt, const ConvGemmArgs &a) {
   if (!conv_gemm_mt_ok(dt, a)) return false;
@@ -780,7 +793,8 @@ hipError_t launch_conv_gemm_mt(int dt, const ConvGemmArgs &a, hipStream_t s) {
   if (!conv_gemm_mt_ok(dt, a)) return hipErrorInvalidValue;
   if (dt == F32 && a.wx) {
     const int v = conv_gemm_mt_x3_variant(a);
-    if (a.wx_mode == X3_BF16) return a.cin2 ? hipErrorInvalidValue : launch_mt_x3<false, X3_BF16>(a, v, s);   // (gradient GEMMs have one source)
+    if (a.wx_mode == X3_BF16) return (a.cin2 || a.src_x3) ? hipErrorInvalidValue : launch_mt_x3<false, X3_BF16>(a, v, s);   // (gradient GEMMs have one source)
+    if (a.src_x3) return a.cin2 ? hipErrorInvalidValue : launch_mt_x3<false, X3_F16, true>(a, v, s);
     return a.cin2 ? launch_mt_x3<true, X3_F16>(a, v, s) : launch_mt_x3<false, X3_F16>(a, v, s);
   }
   if (dt == F32) {

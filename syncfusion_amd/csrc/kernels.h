@@ -59,6 +59,10 @@ struct ConvGemmArgs {
   // v_mfma_f32_32x32x16_f16 per product (common.h, x3_split); every other kernel ignores it and multiplies `w` in fp32.
   const void *wx = nullptr;
   int wx_mode = 1;              // 1: fp16 hi + 2048-scaled fp16 lo (forward passes); 2: bf16 hi + bf16 lo (gradients: no range restriction)
+  // the first source is ALREADY split (mode 1): rows of [cin / 32][hi 32 | lo' 32] fp16 -- the same bytes per row as fp32 -- written by a
+  // producer whose output only this GEMM reads (launch_gn_silu with xfmt): the kernel then spends no vector instruction on the operand.
+  // Honoured by the macro-tile kernel only (conv_gemm_src_x3_ok).
+  int src_x3 = 0;
   void *out = nullptr;
   const float *bias = nullptr, *gamma = nullptr, *beta = nullptr, *stats = nullptr;
   const float *badd = nullptr, *bscale = nullptr;
@@ -105,6 +109,8 @@ hipError_t launch_conv_gemm(int dt, const ConvGemmArgs &a, hipStream_t s);
 bool conv_gemm_mt_ok(int dt, const ConvGemmArgs &a);
 bool conv_gemm_prefers_mt(const ConvGemmArgs &a);
 bool conv_gemm_mt_wanted(int dt, const ConvGemmArgs &a);   // eligible AND preferred (the fp32 rule differs: conv_gemm_mt.hip)
+// true when launch_conv_gemm(F32, a) would run on a kernel that can read its first source pre-split (ConvGemmArgs::src_x3)
+bool conv_gemm_src_x3_ok(const ConvGemmArgs &a);
 hipError_t launch_conv_gemm_mt(int dt, const ConvGemmArgs &a, hipStream_t s);
 const char *conv_gemm_mt_name(const ConvGemmArgs &a);   // label of the tile variant it picks (bf16 spelling)
 // process-wide switch of the macro-tile row-LayerNorm fusion (SF_MT_LN=1; -1 = not read yet); sf_op_inject_prenorm_proj turns it on for its call
@@ -246,19 +252,22 @@ hipError_t launch_gn_stats(int dt, const void *x, int ld, int B, int L, int C, i
                            hipStream_t s);
 
 // y = silu(GroupNorm_G(x; gamma, beta, eps)) materialised in one launch (statistics + apply, one workgroup per (clip, group))
+// xfmt (fp32 only, C % 32 == 0, out_ld == C): the output rows are written as split fp16 operands [C / 32][hi 32 | lo' 32] for a GEMM that
+// takes ConvGemmArgs::src_x3
 hipError_t launch_gn_silu(int dt, const void *x, int ld, int B, int L, int C, int G, const float *gamma, const float *beta, float eps,
-                          void *out, int out_ld, hipStream_t s, Prefetch pf = Prefetch());
+                          void *out, int out_ld, hipStream_t s, Prefetch pf = Prefetch(), bool xfmt = false);
 hipError_t launch_gn_silu_ws(int dt, const void *x, int ld, int B, int L, int C, int G, const float *gamma, const float *beta, float eps, void *out,
                              int out_ld, float *slab, int64_t slab_floats, hipStream_t s);
 
 // y = LN_C(x; eps) * (1 + scale[b][c]) + shift[b][c]   (ss == nullptr: plain normalise);  ss:(B, ss_ld) = [scale | shift]
 hipError_t launch_ln_modulate(int dt, const void *x, int ld, const float *ss, int ss_ld, float eps, int B, int L, int C,
-                              void *out, int out_ld, hipStream_t s, Prefetch pf = Prefetch());
+                              void *out, int out_ld, hipStream_t s, Prefetch pf = Prefetch(), bool xfmt = false /* as launch_gn_silu */);
 
 // Multi-head softmax attention on packed projections.  q row stride ldq, k/v inside kv with row stride ldkv
 // (k at column 0, v at column H*D).  out row stride ldo.
+// x3 (dt == F32 only): the products from split fp16 operands (the fp32x engine)
 hipError_t launch_attention(int dt, const void *q, int ldq, const void *kv, int ldkv, int B, int L, int H, int D,
-                            void *out, int ldo, hipStream_t s);
+                            void *out, int ldo, hipStream_t s, bool x3 = false, bool xfmt = false /* x3 only, ldo == H * D: output rows pre-split */);
 
 // ---------------------------------------------------------------------------------------
 // Element-wise / layout helpers
@@ -403,7 +412,7 @@ hipError_t launch_attention_bwd(const float *q, const float *kv, const float *o,
 // fp32 attention forward on the matrix cores that also keeps log-sum-exp of the scaled scores, (B, H, L), for launch_attention_bwd(lse_fwd)
 bool attention_f32_mfma_ok(int ldq, int ldkv, int ldo, int B, int H);
 hipError_t launch_attention_f32_mfma(const float *q, int ldq, const float *kv, int ldkv, int B, int L, int H, float *out, int ldo, hipStream_t s,
-                                     float *lse_out);
+                                     float *lse_out, bool x3 = false, bool xfmt = false);
 
 // BatchNorm (eval) -> per-channel scale / shift
 hipError_t launch_bn_fold(const float *gamma, const float *beta, const float *mean, const float *var, float eps, int C,

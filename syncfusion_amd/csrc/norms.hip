@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T *__restrict__ x, 
 template <typename T, int VPT>
 __global__ __launch_bounds__(256) void ln_modulate_kernel(const T *__restrict__ x, int ld, const float *__restrict__ ss,
                                                           int ss_ld, float eps, int rows, int L, int C, int tpr,
-                                                          T *__restrict__ out, int out_ld, const int nreal, const Prefetch pf) {
+                                                          T *__restrict__ out, int out_ld, const int nreal, const Prefetch pf, const int xfmt) {
   constexpr int V = Vec16<T>::N;
   const int tid = threadIdx.x;
   if ((int)blockIdx.x >= nreal) {   // hosted weight prefetch for the GEMM that follows (kernels.h, Prefetch)
@@ -225,6 +225,12 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const T *__restrict__ 
       if (ss) y = fmaf(y, 1.0f + sc[i][j >> 2][j & 3], sh[i][j >> 2][j & 3]);
       o.set(j, y);
     }
+    if constexpr (sizeof(T) == 4) {
+      if (xfmt) {   // pre-split rows for the GEMM that follows (common.h, st4_x3)
+        st4_x3(out + (size_t)row * out_ld, c0, o.v);
+        continue;
+      }
+    }
     st16<T>(out + (size_t)row * out_ld + c0, o);
   }
 }
@@ -238,7 +244,7 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const T *__restrict__ 
 template <typename T, int VW>
 __global__ __launch_bounds__(512) void gn_silu_kernel(const T *__restrict__ x, int ld, int L, int C, int G,
                                                       const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
-                                                      T *__restrict__ out, int out_ld) {
+                                                      T *__restrict__ out, int out_ld, const int xfmt) {
   constexpr bool FAST = sizeof(T) == 2;
   __shared__ float red_s[512], red_q[512];
   __shared__ float stat[2];
@@ -293,6 +299,12 @@ __global__ __launch_bounds__(512) void gn_silu_kernel(const T *__restrict__ x, i
       const float sc = rstd * gamma[c];
       o[j] = from_f<T>(silu_t<FAST>(fmaf(to_f(v[j]) - mean, sc, beta[c])));
     }
+    if constexpr (sizeof(T) == 4 && VW == 4) {
+      if (xfmt) {   // pre-split rows for the GEMM that follows (common.h, st4_x3)
+        st4_x3(out + ((size_t)b * L + r) * out_ld, g * cpg + cv * VW, f32x4{o[0], o[1], o[2], o[3]});
+        continue;
+      }
+    }
     __builtin_memcpy(__builtin_assume_aligned(obase + (size_t)r * out_ld + cv * VW, VW * sizeof(T)), o, VW * sizeof(T));
   }
 }
@@ -303,7 +315,7 @@ __global__ __launch_bounds__(512) void gn_silu_kernel(const T *__restrict__ x, i
 template <typename T, int RV>
 __global__ __launch_bounds__(512) void gn_silu_reg_kernel(const T *__restrict__ x, int ld, int L, int C, int G,
                                                           const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
-                                                          T *__restrict__ out, int out_ld, const int nslab, const Prefetch pf) {
+                                                          T *__restrict__ out, int out_ld, const int nslab, const Prefetch pf, const int xfmt) {
   constexpr bool FAST = sizeof(T) == 2;
   constexpr int V = Vec16<T>::N;
   __shared__ float red[2][8];
@@ -378,6 +390,12 @@ __global__ __launch_bounds__(512) void gn_silu_reg_kernel(const T *__restrict__ 
       Vec16<T> o;
 #pragma unroll
       for (int j = 0; j < V; ++j) o.set(j, silu_t<FAST>(fmaf(v[i].get(j), sc[j], sh[j])));
+      if constexpr (sizeof(T) == 4) {
+        if (xfmt) {
+          st4_x3(out + ((size_t)b * L + rr[i]) * out_ld, g * cpg + cv * V, o.v);
+          continue;
+        }
+      }
       st16<T>(obase + (size_t)rr[i] * out_ld + cv * V, o);
     }
   }
@@ -391,7 +409,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void gn_silu_apply_kernel(const T *__restrict__ x, int ld, int L, int C, int G, const float *__restrict__ slab,
                                                             int nch, int chunk_rows, const float *__restrict__ gamma,
                                                             const float *__restrict__ beta, float eps, int rows_per_wg, T *__restrict__ out,
-                                                            int out_ld) {
+                                                            int out_ld, const int xfmt = 0) {
   constexpr bool FAST = sizeof(T) == 2;
   constexpr int V = Vec16<T>::N;
   __shared__ float mean_s[64], rstd_s[64];
@@ -429,20 +447,28 @@ __global__ __launch_bounds__(256) void gn_silu_apply_kernel(const T *__restrict_
     Vec16<T> o;
 #pragma unroll
     for (int j = 0; j < V; ++j) o.set(j, silu_t<FAST>(fmaf(v.get(j), sc[j], sh[j])));
+    if constexpr (sizeof(T) == 4) {
+      if (xfmt) {
+        st4_x3(out + ((size_t)b * L + r) * out_ld, cv * V, o.v);
+        continue;
+      }
+    }
     st16<T>(ob + (size_t)r * out_ld, o);
   }
 }
 
 template <typename T>
 hipError_t gn_silu_go(const void *x, int ld, int B, int L, int C, int G, const float *gamma, const float *beta, float eps, void *out,
-                      int out_ld, hipStream_t s, Prefetch pf = Prefetch()) {
+                      int out_ld, hipStream_t s, Prefetch pf = Prefetch(), bool xfmt = false) {
   if (C % G) return hipErrorInvalidValue;
+  const int xf = xfmt ? 1 : 0;
+  if (xfmt && (sizeof(T) != 4 || (C % 32) || out_ld != C || (ld % 4) || ((C / G) % 4))) return hipErrorInvalidValue;
   const int cpg = C / G;
   constexpr int V = Vec16<T>::N;
   const T *xp = static_cast<const T *>(x);
   T *op = static_cast<T *>(out);
   dim3 grid(B * G);
-#define SF_GNS(VW) hipLaunchKernelGGL((gn_silu_kernel<T, VW>), grid, dim3(512), 0, s, xp, ld, L, C, G, gamma, beta, eps, op, out_ld)
+#define SF_GNS(VW) hipLaunchKernelGGL((gn_silu_kernel<T, VW>), grid, dim3(512), 0, s, xp, ld, L, C, G, gamma, beta, eps, op, out_ld, xf)
   const bool al = (ld % V == 0) && (out_ld % V == 0);
   // slab fits the registers of one workgroup: up to 16 vectors of 16 bytes per thread (64 data registers of the 256 a wave of a
   // 512-thread workgroup may hold).  8 and 16 cover the 2^18-sample clips (65 K elements per slab at depths 3-6), which the two-pass
@@ -452,7 +478,7 @@ hipError_t gn_silu_go(const void *x, int ld, int B, int L, int C, int G, const f
     const int64_t nv = (int64_t)L * (cpg / V);
     const int nslab = B * G;
     const dim3 gridp(nslab + (pf.ptr && pf.bytes >= 16 ? pf.wgs : 0));
-#define SF_GNR(RV) hipLaunchKernelGGL((gn_silu_reg_kernel<T, RV>), gridp, dim3(512), 0, s, xp, ld, L, C, G, gamma, beta, eps, op, out_ld, nslab, pf)
+#define SF_GNR(RV) hipLaunchKernelGGL((gn_silu_reg_kernel<T, RV>), gridp, dim3(512), 0, s, xp, ld, L, C, G, gamma, beta, eps, op, out_ld, nslab, pf, xf)
     if (nv <= 2 * 512) SF_GNR(2);
     else if (nv <= 4 * 512) SF_GNR(4);
     else if (nv <= 8 * 512) SF_GNR(8);
@@ -470,9 +496,11 @@ hipError_t gn_silu_go(const void *x, int ld, int B, int L, int C, int G, const f
 
 template <typename T>
 hipError_t ln_go(const void *x, int ld, const float *ss, int ss_ld, float eps, int B, int L, int C, void *out, int out_ld,
-                 hipStream_t s, Prefetch pf = Prefetch()) {
+                 hipStream_t s, Prefetch pf = Prefetch(), bool xfmt = false) {
   constexpr int V = Vec16<T>::N;
   if (C % V) return hipErrorInvalidValue;
+  if (xfmt && (sizeof(T) != 4 || (C % 32) || out_ld != C)) return hipErrorInvalidValue;
+  const int xf = xfmt ? 1 : 0;
   if (ss && ((ss_ld % 4) || (reinterpret_cast<uintptr_t>(ss) % 16))) return hipErrorInvalidValue;   // 16-byte scale/shift loads
   int vpr = C / V;
   int tpr = 1;
@@ -486,10 +514,10 @@ hipError_t ln_go(const void *x, int ld, const float *ss, int ss_ld, float eps, i
   const T *xp = static_cast<const T *>(x);
   T *op = static_cast<T *>(out);
   switch (vpt) {
-    case 1: hipLaunchKernelGGL((ln_modulate_kernel<T, 1>), grid, dim3(256), 0, s, xp, ld, ss, ss_ld, eps, rows, L, C, tpr, op, out_ld, nreal, pf); break;
-    case 2: hipLaunchKernelGGL((ln_modulate_kernel<T, 2>), grid, dim3(256), 0, s, xp, ld, ss, ss_ld, eps, rows, L, C, tpr, op, out_ld, nreal, pf); break;
-    case 4: hipLaunchKernelGGL((ln_modulate_kernel<T, 4>), grid, dim3(256), 0, s, xp, ld, ss, ss_ld, eps, rows, L, C, tpr, op, out_ld, nreal, pf); break;
-    case 8: hipLaunchKernelGGL((ln_modulate_kernel<T, 8>), grid, dim3(256), 0, s, xp, ld, ss, ss_ld, eps, rows, L, C, tpr, op, out_ld, nreal, pf); break;
+    case 1: hipLaunchKernelGGL((ln_modulate_kernel<T, 1>), grid, dim3(256), 0, s, xp, ld, ss, ss_ld, eps, rows, L, C, tpr, op, out_ld, nreal, pf, xf); break;
+    case 2: hipLaunchKernelGGL((ln_modulate_kernel<T, 2>), grid, dim3(256), 0, s, xp, ld, ss, ss_ld, eps, rows, L, C, tpr, op, out_ld, nreal, pf, xf); break;
+    case 4: hipLaunchKernelGGL((ln_modulate_kernel<T, 4>), grid, dim3(256), 0, s, xp, ld, ss, ss_ld, eps, rows, L, C, tpr, op, out_ld, nreal, pf, xf); break;
+    case 8: hipLaunchKernelGGL((ln_modulate_kernel<T, 8>), grid, dim3(256), 0, s, xp, ld, ss, ss_ld, eps, rows, L, C, tpr, op, out_ld, nreal, pf, xf); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -556,13 +584,15 @@ hipError_t launch_gn_silu_ws(int dt, const void *x, int ld, int B, int L, int C,
 }
 
 hipError_t launch_gn_silu(int dt, const void *x, int ld, int B, int L, int C, int G, const float *gamma, const float *beta, float eps,
-                          void *out, int out_ld, hipStream_t s, Prefetch pf) {
-  return SF_DISPATCH_T(dt, gn_silu_go<T>(x, ld, B, L, C, G, gamma, beta, eps, out, out_ld, s, pf));
+                          void *out, int out_ld, hipStream_t s, Prefetch pf, bool xfmt) {
+  if (xfmt && dt != F32) return hipErrorInvalidValue;
+  return SF_DISPATCH_T(dt, gn_silu_go<T>(x, ld, B, L, C, G, gamma, beta, eps, out, out_ld, s, pf, xfmt));
 }
 
 hipError_t launch_ln_modulate(int dt, const void *x, int ld, const float *ss, int ss_ld, float eps, int B, int L, int C,
-                              void *out, int out_ld, hipStream_t s, Prefetch pf) {
-  return SF_DISPATCH_T(dt, ln_go<T>(x, ld, ss, ss_ld, eps, B, L, C, out, out_ld, s, pf));
+                              void *out, int out_ld, hipStream_t s, Prefetch pf, bool xfmt) {
+  if (xfmt && dt != F32) return hipErrorInvalidValue;
+  return SF_DISPATCH_T(dt, ln_go<T>(x, ld, ss, ss_ld, eps, B, L, C, out, out_ld, s, pf, xfmt));
 }
 
 }  // namespace sf

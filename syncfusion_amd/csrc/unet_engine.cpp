@@ -927,10 +927,6 @@ struct Exec {
         a.beta = bet;
         a.eps = 1e-5f;
       } else {
-        // (the chunked two-launch form of launch_gn_silu_ws was measured on the 2^18-sample shape: 97.4 vs 98.4 steps/s -- the second
-        // launch costs what the better CU fill saves -- so the engine keeps the single launch)
-        timed("gn_silu", 12.0 * l.rows * C, 3.0 * l.rows * C * dsize(u.dt),
-              [&] { SF_HIP(launch_gn_silu(u.dt, in, C, p.Bt, l.L, C, G, gam, bet, 1e-5f, l.act, C, s, pf_for(w, p.Bt * G))); });
         a.src = l.act;
       }
       a.src_ld = C;
@@ -942,6 +938,16 @@ struct Exec {
       a.out_ld = C;
       a.res = res;
       a.res_ld = C;
+      if (!fuse_act) {
+        // fp32x: when the convolution runs on the macro tiles, GroupNorm+SiLU writes its rows already split into fp16 (hi, lo') -- the
+        // activated tensor has no other reader -- and the GEMM spends no vector instruction on its activation operand
+        const bool xf = u.x3 && (C % 32) == 0 && conv_gemm_src_x3_ok(filled(w, a));
+        // (the chunked two-launch form of launch_gn_silu_ws was measured on the 2^18-sample shape: 97.4 vs 98.4 steps/s -- the second
+        // launch costs what the better CU fill saves -- so the engine keeps the single launch)
+        timed("gn_silu", 12.0 * l.rows * C, 3.0 * l.rows * C * dsize(u.dt),
+              [&] { SF_HIP(launch_gn_silu(u.dt, in, C, p.Bt, l.L, C, G, gam, bet, 1e-5f, l.act, C, s, pf_for(w, p.Bt * G), xf)); });
+        a.src_x3 = xf ? 1 : 0;
+      }
       conv(w, a, u.dt, u.dt);
     };
     // Wide levels: the two LayerNorms of an item (Modulation before InjectChannels, the attention pre-norm) are not
@@ -1123,9 +1129,13 @@ struct Exec {
         a.pf = pf_for(g.attn_out, (int)((l.rows + 31) / 32) * (3 * u.hd / 32), l.rows);
         conv(g.qkv, a, u.dt, u.dt, /*ln=*/true);
       } else {
+        ConvGemmArgs aq = qkv_args(tA);
+        // fp32x on the macro tiles: the pre-norm's rows have no other reader and are written pre-split (kernels.h, ConvGemmArgs::src_x3)
+        const bool xf = u.x3 && (C % 32) == 0 && conv_gemm_src_x3_ok(filled(g.qkv, aq));
         timed("ln_modulate", 6.0 * l.rows * C, 2.0 * l.rows * C * dsize(u.dt),
-              [&] { SF_HIP(launch_ln_modulate(u.dt, tB, C, nullptr, 0, 1e-5f, p.Bt, l.L, C, tA, C, s)); });
-        conv(g.qkv, qkv_args(tA), u.dt, u.dt);
+              [&] { SF_HIP(launch_ln_modulate(u.dt, tB, C, nullptr, 0, 1e-5f, p.Bt, l.L, C, tA, C, s, Prefetch(), xf)); });
+        aq.src_x3 = xf ? 1 : 0;
+        conv(g.qkv, aq, u.dt, u.dt);
       }
       attention_tail(g, d, cur, tB, next);
       u.dbg.tap(tapname, u.dt, cur, C, l.rows, C, s);
@@ -1169,10 +1179,6 @@ struct Exec {
     const Level &l = p.lv[d];
     const int C = l.C;
     const size_t es = dsize(u.dt);
-    timed("attention", 4.0 * p.Bt * (double)l.L * l.L * u.hd, 4.0 * l.rows * u.hd * es, [&] {
-      SF_HIP(launch_attention(u.dt, l.qkv, 3 * u.hd, static_cast<char *>(l.qkv) + (size_t)u.hd * es, 3 * u.hd, p.Bt, l.L,
-                              u.cfg.attention_heads, u.cfg.attention_features, l.ao, u.hd, s));
-    });
     ConvGemmArgs a;
     a.src = l.ao;
     a.src_ld = u.hd;
@@ -1186,6 +1192,14 @@ struct Exec {
       a.badd = p.ca_all + g.ca_off;
       a.badd_ld = u.ca_ld;
     }
+    // fp32x on the macro tiles: the attention kernel writes its output rows pre-split for the projection (the only reader)
+    const bool xf = u.x3 && (u.hd % 32) == 0 && attention_f32_mfma_ok(3 * u.hd, 3 * u.hd, u.hd, p.Bt, u.cfg.attention_heads) &&
+                    conv_gemm_src_x3_ok(filled(g.attn_out, a));
+    timed("attention", 4.0 * p.Bt * (double)l.L * l.L * u.hd, 4.0 * l.rows * u.hd * es, [&] {
+      SF_HIP(launch_attention(u.dt, l.qkv, 3 * u.hd, static_cast<char *>(l.qkv) + (size_t)u.hd * es, 3 * u.hd, p.Bt, l.L,
+                              u.cfg.attention_heads, u.cfg.attention_features, l.ao, u.hd, s, u.x3, xf));
+    });
+    a.src_x3 = xf ? 1 : 0;
     gnpart_of = nullptr;
     if (next && arm_gnpart(g.attn_out, a, d)) {
       gnpart_of = out;

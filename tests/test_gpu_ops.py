@@ -14,7 +14,7 @@ from helpers import rel_l2
 pytestmark = pytest.mark.gpu
 
 TOL = {"fp32": 2e-5, "bf16": 2e-2, "fp16": 4e-3}
-TD = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
+TD = {"fp32": torch.float32, "fp32x": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
 
 
 def _lib():
@@ -203,7 +203,7 @@ def test_gn_silu_materialised(cuda, dtype, B, L, C, with_ws):
     assert rel_l2(out.float().cpu(), ref) < (2e-6 if dtype == "fp32" else 6e-3)
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("dtype", ["fp32", "fp32x", "bf16", "fp16"])
 @pytest.mark.parametrize("L", [1, 44, 64, 100, 352])
 def test_attention(cuda, dtype, L):
     _l, lib = _lib()
@@ -223,10 +223,10 @@ def test_attention(cuda, dtype, L):
     _l.check(lib.sf_op_attention(_l.DTYPES[dtype], qd.data_ptr(), kvd.data_ptr(), B, L, H, D, out.data_ptr(), _l.stream_ptr(cuda)),
              "sf_op_attention")
     torch.cuda.synchronize()
-    assert rel_l2(out.float().cpu(), ref) < (1e-5 if dtype == "fp32" else 8e-3)
+    assert rel_l2(out.float().cpu(), ref) < (1e-5 if dtype in ("fp32", "fp32x") else 8e-3)
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "fp16", "fp32"])
+@pytest.mark.parametrize("dtype", ["bf16", "fp16", "fp32", "fp32x"])
 @pytest.mark.parametrize("B,H,L", [(4, 8, 2048), (9, 8, 1100), (40, 8, 300)])
 def test_attention_long_sequences(cuda, dtype, B, H, L):
     """Enough (clip, head, query-tile) work that the 16-bit types take the 4-wave kernel with hardware-transposed V reads
@@ -248,7 +248,7 @@ def test_attention_long_sequences(cuda, dtype, B, H, L):
         kf, vf = k.reshape(L, H, D).transpose(0, 1), v.reshape(L, H, D).transpose(0, 1)
         ref = ((qf @ kf.transpose(-1, -2)) * D ** -0.5).softmax(-1) @ vf
         ref = ref.transpose(0, 1).reshape(L, H * D)
-        assert rel_l2(out[b].float().cpu(), ref.cpu()) < (1e-5 if dtype == "fp32" else 8e-3)
+        assert rel_l2(out[b].float().cpu(), ref.cpu()) < (1e-5 if dtype in ("fp32", "fp32x") else 8e-3)
 
 
 def test_onsets_to_track_matches_reference_formatting(cuda):
