@@ -333,9 +333,9 @@ int sf_bench_conv1d(int dtype, int B, int L, int C, int N, int taps, int upsampl
 int64_t sf_op_resnet_mod_cb_workspace_bytes(int B, int L, int C) {
   Workspace dry(nullptr, 0);
   const int64_t M = (int64_t)B * L;
-  dry.alloc(2 * (int64_t)C * C * 3 * 2);
-  dry.alloc(M * C * 2);
-  dry.alloc(M * C * 2);
+  dry.alloc(2 * (int64_t)C * C * 3 * 4);   // (sized for SF_F32X: 4 bytes per weight / activation)
+  dry.alloc(M * C * 4);
+  dry.alloc(M * C * 4);
   dry.alloc((int64_t)(C / 128) * M * C * 4);
   dry.alloc((int64_t)B * 32 * 64 * 2 * 4);
   return dry.used();
@@ -353,15 +353,18 @@ int sf_op_resnet_mod_cb(int dtype, const void *x, const float *w1, const float *
   const int64_t M = (int64_t)B * L;
   const int S = C / 128 / kb;
   if (kb == 2 && ((C / 128) % 2 || C / groups < 32)) fail(SF_ERR_UNSUPPORTED, "two channel blocks per workgroup need C a multiple of 256 and >= 32 channels per group");
-  char *wp = static_cast<char *>(wk.alloc(2 * (int64_t)C * C * 3 * 2));
-  void *wp1 = wp, *wp2 = wp + (int64_t)C * C * 3 * 2;
-  void *act = wk.alloc(M * C * 2);
-  void *h = h_out ? h_out : wk.alloc(M * C * 2);
+  if (kb == 2 && dtype == SF_F32X) fail(SF_ERR_UNSUPPORTED, "the split-operand form takes one channel block per workgroup");
+  const int64_t es = (int64_t)dsize(dtype);
+  const int adt = dtype == SF_F32X ? (int)F32 : dtype;   // activations / reducers of the fp32x chain are plain fp32
+  char *wp = static_cast<char *>(wk.alloc(2 * (int64_t)C * C * 3 * es));
+  void *wp1 = wp, *wp2 = wp + (int64_t)C * C * 3 * es;
+  void *act = wk.alloc(M * C * es);
+  void *h = h_out ? h_out : wk.alloc(M * C * es);
   float *slab = static_cast<float *>(wk.alloc((int64_t)S * M * C * 4));
   float *stats = static_cast<float *>(wk.alloc((int64_t)B * 32 * 64 * 2 * 4));
   SF_HIP(launch_pack_conv_cb(dtype, w1, C, C, wp1, s));
   SF_HIP(launch_pack_conv_cb(dtype, w2, C, C, wp2, s));
-  SF_HIP(launch_gn_silu(dtype, x, C, B, L, C, groups, gn1_g, gn1_b, eps_gn, act, C, s));
+  SF_HIP(launch_gn_silu(adt, x, C, B, L, C, groups, gn1_g, gn1_b, eps_gn, act, C, s));
   ConvCbArgs a;
   a.src = act;
   a.src_ld = C;
@@ -373,7 +376,7 @@ int sf_op_resnet_mod_cb(int dtype, const void *x, const float *w1, const float *
   a.kb = kb;
   SF_HIP(launch_conv_cb(dtype, a, s));
   const CbGnPlan gp = cb_gn_plan(L);
-  SF_HIP(launch_cb_reduce_gn(dtype, slab, S, B, L, C, b1, h, C, groups, stats, gp, s));
+  SF_HIP(launch_cb_reduce_gn(adt, slab, S, B, L, C, b1, h, C, groups, stats, gp, s));
   a.src = h;
   a.wp = wp2;
   a.pro = 1;
@@ -385,7 +388,7 @@ int sf_op_resnet_mod_cb(int dtype, const void *x, const float *w1, const float *
   a.beta = gn2_b;
   a.eps = eps_gn;
   SF_HIP(launch_conv_cb(dtype, a, s));
-  SF_HIP(launch_cb_reduce_ln(dtype, slab, S, B, L, C, b2, x, C, scale_shift, 2 * C, eps_ln, m_out, C, s));
+  SF_HIP(launch_cb_reduce_ln(adt, slab, S, B, L, C, b2, x, C, scale_shift, 2 * C, eps_ln, m_out, C, s));
   return SF_OK;
   SF_API_END
 }

@@ -223,6 +223,202 @@ __global__ __launch_bounds__(256) void conv_cb_kernel(const ConvCbArgs a, const 
   }
 }
 
+// The same workgroup on split fp16 operands (the fp32x engine: fp32 activations in HBM, fp32 partial slabs out).  The panel is fetched as
+// fp32 (32 threads per row), GroupNorm+SiLU'd in fp32 and SPLIT ONCE per element on the way into two fp16 LDS images (hi, lo'): every
+// fragment the three taps and the four waves read afterwards is a plain 16-byte row read, no vector instruction in the MFMA loop.  The
+// weight slice arrives as (hi, lo') fragment pairs, 48 x 1 KB contiguous per wave; three MFMAs per product into two accumulators.
+// One 128-channel block per workgroup (the two LDS images of a two-block panel would not fit the static 64 KB).
+template <int MT, bool PRO>
+__global__ __launch_bounds__(256) void conv_cb_x3_kernel(const ConvCbArgs a, const int mtiles, const unsigned bytes_src) {
+  using frag = f16x8;
+  constexpr int PITCHW = KC + 8, TPR = KC / 4, RPP = 256 / TPR;   // LDS pitch (fp16 elements), threads per panel row (16 B of fp32 each), rows per pass
+  constexpr int BM = 32 * MT, PR = BM + 2, NV = (PR + RPP - 1) / RPP;
+  __shared__ __attribute__((aligned(16))) f16 panelH[PR * PITCHW], panelL[PR * PITCHW];
+  __shared__ float2 gstat[NSLOT][8];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nws = (int)gridDim.x;
+  if ((int)blockIdx.y >= mtiles) {
+    prefetch_slice(a.pf, ((int)blockIdx.y - mtiles) * nws + (int)blockIdx.x, 256);
+    return;
+  }
+  const int mt = (int)blockIdx.y, ws = (int)blockIdx.x;
+  const int nt = ws >> a.log2S, cb = ws & ((1 << a.log2S) - 1);
+  const int r0 = mt * BM, M = a.B * a.L;
+  auto divL = [&](int x) { return (int)__umulhi((unsigned)x, a.magicL); };
+
+  // ---- 1. activation panel (fp32): rows r0 - 1 .. r0 + BM of channel block cb ----------------------------------------------------------
+  const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.src), 0, bytes_src, 0x00020000);
+  const int cv = tid % TPR, pr = tid / TPR;
+  f32x4 pv[NV];
+  const unsigned col_b = (unsigned)((cb * KC + cv * 4) * 4), row_b = (unsigned)(a.src_ld * 4);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int j = pr + RPP * i, r = r0 - 1 + j;
+    const bool ok = j < PR && r >= 0 && r < M;
+    pv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rS, ok ? (unsigned)r * row_b + col_b : OOB, 0, 0));
+  }
+  // ---- 2. GroupNorm operands (as in conv_cb_kernel; this thread owns a channel QUAD) ----------------------------------------------------
+  const int gshift = KC_LOG2 - a.log2cpg;
+  const int clip0 = divL(max(r0 - 1, 0));
+  const int nclip = PRO ? (divL(min(r0 + BM, M - 1)) - clip0 + 1) : 0;
+  const int npair = nclip << gshift;
+  f32x4 ga = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
+  float2 cs[4];
+  int lim = 0;
+  const int sub = tid & 7;
+  if constexpr (PRO) {
+    const int G = a.C >> a.log2cpg;
+    ga = *reinterpret_cast<const f32x4 *>(a.gamma + cb * KC + cv * 4);
+    be = *reinterpret_cast<const f32x4 *>(a.beta + cb * KC + cv * 4);
+    const bool tiles = a.pro == 2;
+    const int ltpg = a.log2cpg - 5, ct = a.C >> 5;
+    const int p = min(tid >> 3, npair - 1);
+    const int slot = p >> gshift, gi = p & ((1 << gshift) - 1);
+    const int clip = clip0 + slot;
+    const int mt_lo = (clip * a.L) >> 5, nmt = ((clip * a.L + a.L - 1) >> 5) - mt_lo + 1;
+    lim = tiles ? (nmt << max(ltpg, 0)) : a.nch;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int kc = min(sub + 8 * k, lim - 1);
+      const int mtile = mt_lo + (kc >> max(ltpg, 0));
+      const int tile = (((cb << gshift) + gi) << max(ltpg, 0)) + (kc & ((1 << max(ltpg, 0)) - 1));
+      const unsigned off2 = (unsigned)(((mtile * ct + tile) * 2 + (clip - divL(mtile << 5))) * 2);
+      const unsigned off1 = (unsigned)((((clip * a.nch + kc) * G) + (cb << gshift) + gi) * 2);
+      cs[k] = *reinterpret_cast<const float2 *>(a.stats + (tiles ? off2 : off1));
+    }
+  }
+  // ---- 3. the wave's weight slice: 24 (hi, lo') fragment pairs, 48 KB contiguous per wave, independent of the producer kernel -----------
+  __builtin_amdgcn_sched_barrier(0);
+  frag wh[24], wl[24];
+  {
+    const frag *wp = reinterpret_cast<const frag *>(a.wp) + ((size_t)(cb * (a.N >> 5) + (nt * 4 + wave)) * 48) * 64;   // uniform
+#pragma unroll
+    for (int s = 0; s < 24; ++s) {
+      wh[s] = wp[(2 * s) * 64 + lane];
+      wl[s] = wp[(2 * s + 1) * 64 + lane];
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (PRO) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(cs[k].x), "+v"(cs[k].y));
+  }
+  // ---- 4. statistics of the touched (clip, group) pairs -> LDS ---------------------------------------------------------------------------
+  if constexpr (PRO) {
+    const float rn = 1.0f / ((float)a.L * (float)(1 << a.log2cpg));
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (sub + 8 * k < lim) {
+        s1 += cs[k].x;
+        s2 += cs[k].y;
+      }
+    s1 = sum8_dpp(s1);
+    s2 = sum8_dpp(s2);
+    const int p = tid >> 3;
+    if (sub == 0 && p < npair) {
+      const float mean = s1 * rn;
+      gstat[p >> gshift][p & ((1 << gshift) - 1)] = make_float2(mean, rsqrtf(fmaxf(fmaf(s2, rn, -mean * mean), 0.f) + a.eps));
+    }
+    __syncthreads();
+  }
+  // ---- 5. panel -> LDS: GroupNorm + SiLU in fp32, then split into the two fp16 images ----------------------------------------------------
+  typedef f16 f16x4_c __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int j = pr + RPP * i, r = r0 - 1 + j;
+    if (j < PR) {
+      f32x4 o = pv[i];
+      if (PRO && r >= 0 && r < M) {
+        const float2 st = gstat[divL(r) - clip0][(cv * 4) >> a.log2cpg];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float sc = st.y * ga[e];
+          const float sh = fmaf(-st.x, sc, be[e]);
+          o[e] = silu_t<false>(fmaf(pv[i][e], sc, sh));
+        }
+      }
+      f16x4_c h, l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        f16 x, y;
+        x3_split1<X3_F16>(o[e], x, y);
+        h[e] = x;
+        l[e] = y;
+      }
+      *reinterpret_cast<f16x4_c *>(panelH + j * PITCHW + cv * 4) = h;
+      *reinterpret_cast<f16x4_c *>(panelL + j * PITCHW + cv * 4) = l;
+    }
+  }
+  __syncthreads();
+  // ---- 6. D^T[n][m] += W[n][k] * act[m + tap - 1][k] -------------------------------------------------------------------------------------
+  const int fr = lane & 31, fh = lane >> 5;
+  bool ok0[MT], ok2[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int m = r0 + t * 32 + fr, l = m - divL(m) * a.L;
+    ok0[t] = l > 0;
+    ok2[t] = l < a.L - 1;
+  }
+  f32x16 acc[MT], accL[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = accL[t][r] = 0.f;
+  const frag zf = __builtin_bit_cast(frag, u32x4{0u, 0u, 0u, 0u});
+#pragma unroll
+  for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        const int o = (t * 32 + fr + tap) * PITCHW + ks * 16 + fh * 8;
+        frag ah = *reinterpret_cast<const frag *>(panelH + o), al = *reinterpret_cast<const frag *>(panelL + o);
+        if (tap == 0) {
+          ah = ok0[t] ? ah : zf;
+          al = ok0[t] ? al : zf;
+        }
+        if (tap == 2) {
+          ah = ok2[t] ? ah : zf;
+          al = ok2[t] ? al : zf;
+        }
+        x3_mfma<X3_F16>(wh[tap * 8 + ks], wl[tap * 8 + ks], ah, al, acc[t], accL[t]);
+      }
+  // ---- 7. partial slab --------------------------------------------------------------------------------------------------------------------
+  float *sl = a.slab + (size_t)cb * M * a.N + nt * 128 + wave * 32 + 4 * fh;
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int m = r0 + t * 32 + fr;
+    if (m < M) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaf(accL[t][4 * g + e], X3P<X3_F16>::INV, acc[t][4 * g + e]);
+        *reinterpret_cast<f32x4 *>(sl + (unsigned)(m * a.N + 8 * g)) = v;
+      }
+    }
+  }
+}
+
+// the same weights as (hi, lo') fragment pairs for conv_cb_x3_kernel: [cb][n / 32][tap][ks][part][lane][8]
+__global__ void pack_conv_cb_x3_kernel(const float *__restrict__ w, int N, int C, f16 *__restrict__ out) {
+  const size_t total = (size_t)N * C * 3;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int q = (int)(e & 7), lane = (int)((e >> 3) & 63);
+    size_t t = e >> 9;
+    const int ks = (int)(t & 7);
+    t >>= 3;
+    const int tap = (int)(t % 3);
+    t /= 3;
+    const int nt32 = (int)(t % (N / 32)), cb = (int)(t / (N / 32));
+    const int n = nt32 * 32 + (lane & 31), c = cb * KC + ks * 16 + (lane >> 5) * 8 + q;
+    const size_t pair = (e >> 9) * 1024;   // 512 hi then 512 lo' per (cb, n / 32, tap, ks)
+    x3_split1<X3_F16>(w[((size_t)n * C + c) * 3 + tap], out[pair + (e & 511)], out[pair + 512 + (e & 511)]);
+  }
+}
+
 // Conv1d weight (N, C, 3) fp32 -> fragment order [cb][n / 32][tap][ks][lane][8]:
 //   lane holds W[n = 32 * (n / 32) + lane % 32][tap][c = 128 cb + 16 ks + 8 (lane / 32) + 0..7]
 template <typename T>
@@ -285,7 +481,7 @@ __global__ __launch_bounds__(256) void cb_reduce_gn_kernel(const float *__restri
         s1 += xo;
         s2 = fmaf(xo, xo, s2);
       }
-      __builtin_memcpy(__builtin_assume_aligned(out + ((size_t)b * L + l0 + lr) * out_ld + c, 8), o, 8);
+      __builtin_memcpy(__builtin_assume_aligned(out + ((size_t)b * L + l0 + lr) * out_ld + c, 4 * sizeof(T)), o, 4 * sizeof(T));
     }
   }
   // group totals: lanes of one group are `span` consecutive channel quads; lane ^ 32 is the same quad one row further
@@ -337,7 +533,7 @@ __global__ __launch_bounds__(256) void cb_reduce_ln_kernel(const float *__restri
 #pragma unroll
   for (int s = 0; s < S; ++s) v[s] = *reinterpret_cast<const f32x4 *>(slab + ((size_t)s * M + m) * C + c);
   T rv[4];
-  __builtin_memcpy(rv, __builtin_assume_aligned(res + m * res_ld + c, 8), 8);
+  __builtin_memcpy(rv, __builtin_assume_aligned(res + m * res_ld + c, 4 * sizeof(T)), 4 * sizeof(T));
   const f32x4 bi = *reinterpret_cast<const f32x4 *>(bias + c);
   f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
   if (ss) {
@@ -380,7 +576,7 @@ __global__ __launch_bounds__(256) void cb_reduce_ln_kernel(const float *__restri
     if (ss) z = fmaf(z, 1.0f + sc[e], sh[e]);
     o[e] = from_f<T>(z);
   }
-  __builtin_memcpy(__builtin_assume_aligned(out + (size_t)row * out_ld + c, 8), o, 8);
+  __builtin_memcpy(__builtin_assume_aligned(out + (size_t)row * out_ld + c, 4 * sizeof(T)), o, 4 * sizeof(T));
 }
 
 int cb_min_wgs() {
@@ -396,7 +592,7 @@ int cb_min_wgs() {
 size_t conv_cb_weight_elems(int N, int C) { return (size_t)N * C * 3; }
 
 bool conv_cb_shape_ok(int dt, int B, int L, int C, int N, int G) {
-  if (dt == F32) return false;
+  if (dt == F32) return false;   // (F32X: the split-operand form)
   if (C < KC || (C % KC) || (N % 128) || C / KC > 8 || ((C / KC) & (C / KC - 1))) return false;
   if (L < 44 || (int64_t)B * L * (int64_t)(C > N ? C : N) * 4 >= 0x7FFFFFF0ll) return false;   // a 130-row panel touches <= NSLOT clips
   if ((uint64_t)B * L * (uint64_t)L >= (1ull << 32)) return false;   // row / L by multiply-high (magicL) is exact only while row * L < 2^32
@@ -435,7 +631,8 @@ hipError_t launch_pack_conv_cb(int dt, const float *w, int N, int C, void *out, 
   if (dt == F32 || (C % KC) || (N % 32)) return hipErrorInvalidValue;
   const size_t total = (size_t)N * C * 3;
   const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
-  if (dt == BF16) hipLaunchKernelGGL((pack_conv_cb_kernel<bf16>), dim3(blocks), dim3(256), 0, s, w, N, C, static_cast<bf16 *>(out));
+  if (dt == F32X) hipLaunchKernelGGL(pack_conv_cb_x3_kernel, dim3(blocks), dim3(256), 0, s, w, N, C, static_cast<f16 *>(out));
+  else if (dt == BF16) hipLaunchKernelGGL((pack_conv_cb_kernel<bf16>), dim3(blocks), dim3(256), 0, s, w, N, C, static_cast<bf16 *>(out));
   else hipLaunchKernelGGL((pack_conv_cb_kernel<f16>), dim3(blocks), dim3(256), 0, s, w, N, C, static_cast<f16 *>(out));
   return hipGetLastError();
 }
@@ -445,6 +642,7 @@ hipError_t launch_conv_cb(int dt, const ConvCbArgs &a0, hipStream_t s) {
   if (a0.pro == 1 && a0.nch > 32) return hipErrorInvalidValue;
   if (a0.pro == 2 && !conv_cb_tile_stats_ok(a0.L, a0.C, a0.G)) return hipErrorInvalidValue;
   ConvCbArgs a = a0;
+  if (dt == F32X && a.kb == 2) return hipErrorInvalidValue;   // one channel block per workgroup in the split-operand form
   const int kb = a.kb == 2 ? 2 : 1;
   const int M = a.B * a.L, S = a.C / KC / kb;   // partial slabs = workgroups along the input channels
   if (kb == 2 && ((a.C / KC) % 2 || (a.pro && a.C / a.G < 32))) return hipErrorInvalidValue;   // <= 8 groups inside a 256-channel range
@@ -455,12 +653,23 @@ hipError_t launch_conv_cb(int dt, const ConvCbArgs &a0, hipStream_t s) {
   while ((1 << a.log2cpg) < cpg) ++a.log2cpg;
   if ((1 << a.log2S) != S || (1 << a.log2cpg) != cpg) return hipErrorInvalidValue;
   a.magicL = (unsigned)((0x100000000ull + (unsigned)a.L - 1) / (unsigned)a.L);   // x / L == mulhi(x, magicL) while x * L < 2^32
-  const int mt = kb == 2 ? std::min(2, conv_cb_mt(M, a.N, a.C / 2)) : conv_cb_mt(M, a.N, a.C);
+  int mt = kb == 2 ? std::min(2, conv_cb_mt(M, a.N, a.C / 2)) : conv_cb_mt(M, a.N, a.C);
+  if (dt == F32X) mt = std::min(mt, 2);
   const int mtiles = (M + 32 * mt - 1) / (32 * mt), nws = (a.N / 128) * S;
   const int pf_rows = (a.pf.ptr && a.pf.bytes >= 16 && a.pf.wgs > 0) ? (a.pf.wgs + nws - 1) / nws : 0;
   a.pf.wgs = pf_rows * nws;
   const dim3 grid(nws, mtiles + pf_rows);
-  const unsigned bytes_src = (unsigned)((size_t)M * a.src_ld * 2);
+  const unsigned bytes_src = (unsigned)((size_t)M * a.src_ld * dsize(dt));
+  if (dt == F32X) {
+    if (a.pro) {
+      if (mt == 1) hipLaunchKernelGGL((conv_cb_x3_kernel<1, true>), grid, dim3(256), 0, s, a, mtiles, bytes_src);
+      else hipLaunchKernelGGL((conv_cb_x3_kernel<2, true>), grid, dim3(256), 0, s, a, mtiles, bytes_src);
+    } else {
+      if (mt == 1) hipLaunchKernelGGL((conv_cb_x3_kernel<1, false>), grid, dim3(256), 0, s, a, mtiles, bytes_src);
+      else hipLaunchKernelGGL((conv_cb_x3_kernel<2, false>), grid, dim3(256), 0, s, a, mtiles, bytes_src);
+    }
+    return hipGetLastError();
+  }
 #define SF_CB2(T, MT, KB_)                                                                                                \
   do {                                                                                                                    \
     if (a.pro) hipLaunchKernelGGL((conv_cb_kernel<T, MT, true, KB_>), grid, dim3(256), 0, s, a, mtiles, bytes_src);       \
@@ -497,7 +706,7 @@ CbGnPlan cb_gn_plan(int L) {
 
 hipError_t launch_cb_reduce_gn(int dt, const float *slab, int S, int B, int L, int N, const float *bias, void *out, int out_ld, int G, float *stats,
                                const CbGnPlan &gp, hipStream_t s, Prefetch pf) {
-  if (dt == F32 || (N % 128) || N % G || (N / G) < 16 || (N / G) > 128 || (128 % (N / G)) || gp.nch > 32 || (out_ld % 4)) return hipErrorInvalidValue;
+  if ((N % 128) || N % G || (N / G) < 16 || (N / G) > 128 || (128 % (N / G)) || gp.nch > 32 || (out_ld % 4)) return hipErrorInvalidValue;
   const int P = gp.chunk_rows / 8, M = B * L;
   const int nreal = B * gp.nch * (N / 128);
   const dim3 grid(nreal + (pf.ptr && pf.bytes >= 16 ? pf.wgs : 0));
@@ -519,7 +728,7 @@ hipError_t launch_cb_reduce_gn(int dt, const float *slab, int S, int B, int L, i
     case 8: SF_RG_P(T, 8) break;  \
     default: return hipErrorInvalidValue; \
   }
-  if (dt == BF16) { SF_RG_S(bf16) } else { SF_RG_S(f16) }
+  if (dt == BF16) { SF_RG_S(bf16) } else if (dt == F16) { SF_RG_S(f16) } else { SF_RG_S(float) }   // float: the fp32x engine's chain
 #undef SF_RG_S
 #undef SF_RG_P
 #undef SF_RG
@@ -529,7 +738,7 @@ hipError_t launch_cb_reduce_gn(int dt, const float *slab, int S, int B, int L, i
 hipError_t launch_cb_reduce_ln(int dt, const float *slab, int S, int B, int L, int C, const float *bias, const void *res, int res_ld, const float *ss,
                                int ss_ld, float eps, void *out, int out_ld, hipStream_t s, Prefetch pf) {
   const int tpr = C / 4;
-  if (dt == F32 || (C % 128) || (tpr != 32 && tpr != 64 && tpr != 128 && tpr != 256) || (res_ld % 4) || (out_ld % 4)) return hipErrorInvalidValue;
+  if ((C % 128) || (tpr != 32 && tpr != 64 && tpr != 128 && tpr != 256) || (res_ld % 4) || (out_ld % 4)) return hipErrorInvalidValue;
   if (ss && ((ss_ld % 4) || (reinterpret_cast<uintptr_t>(ss) % 16))) return hipErrorInvalidValue;
   const int M = B * L, rpb = 256 / tpr;
   const int nreal = (M + rpb - 1) / rpb;
@@ -552,7 +761,7 @@ hipError_t launch_cb_reduce_ln(int dt, const float *slab, int S, int B, int L, i
     case 8: SF_RL_T(T, 8) break;   \
     default: return hipErrorInvalidValue; \
   }
-  if (dt == BF16) { SF_RL_S(bf16) } else { SF_RL_S(f16) }
+  if (dt == BF16) { SF_RL_S(bf16) } else if (dt == F16) { SF_RL_S(f16) } else { SF_RL_S(float) }
 #undef SF_RL_S
 #undef SF_RL_T
 #undef SF_RL

@@ -18,10 +18,12 @@ inline const char *tune_env(const char *name) { return getenv(name); }
 inline const char *tune_env(const char *) { return nullptr; }
 #endif
 
-enum DType { F32 = 0, BF16 = 1, F16 = 2 };
-// split modes of the fp32x GEMMs (common.h, X3<MODE>): fp16 hi + 2048-scaled fp16 lo (forward), bf16 hi + bf16 lo (gradients)
+// F32X (the channel-block chain only: conv_cb_shape_ok / launch_pack_conv_cb / launch_conv_cb): fp32 activations, split fp16 weights and
+// panel (common.h, X3P<X3_F16>); every other launcher of the fp32x engine takes F32 plus ConvGemmArgs::wx
+enum DType { F32 = 0, BF16 = 1, F16 = 2, F32X = 3 };
+// split modes of the fp32x GEMMs (common.h, X3P<MODE>): fp16 hi + 2048-scaled fp16 lo (forward), bf16 hi + bf16 lo (gradients)
 constexpr int X3_F16 = 1, X3_BF16 = 2;
-inline size_t dsize(int dt) { return dt == F32 ? 4 : 2; }
+inline size_t dsize(int dt) { return (dt == F32 || dt == F32X) ? 4 : 2; }
 // three-way dispatch on the arithmetic type: SF_DISPATCH_T(dt, f<T>(args)) evaluates f with T = float / bf16 / f16;
 // SF_DISPATCH_STMT(dt, statement using T) is the statement form (kernel launches)
 #define SF_DISPATCH_T(dt, EXPR_T)             \

@@ -286,10 +286,11 @@ struct Builder {
       if (C2) SF_HIP(launch_pack_conv(u.dt, w, N, Ctot, C1, C2, 1, c2p, nullptr, c.wt, kt, (int64_t)taps * C1, s));
     }
     static const bool no_cb = getenv("SF_NO_CB") != nullptr;   // debugging / A-B aid: keep the wave-private GEMM chain everywhere
-    if (cb && !no_cb && !direct && taps == 3 && C2 == 0 && cin_pad == C1 && conv_cb_shape_ok(u.dt, 1, 64, C1, N, 0)) {
+    const int cbdt = u.x3 ? (int)F32X : u.dt;   // fp32x: (hi, lo') fp16 fragment pairs
+    if (cb && !no_cb && !direct && taps == 3 && C2 == 0 && cin_pad == C1 && conv_cb_shape_ok(cbdt, 1, 64, C1, N, 0)) {
       // second copy in MFMA fragment order for the channel-block split-K kernel (the small-batch engine of the deep levels)
-      c.wcb = u.arena.alloc((int64_t)conv_cb_weight_elems(N, C1) * dsize(u.dt));
-      SF_HIP(launch_pack_conv_cb(u.dt, w, N, C1, c.wcb, s));
+      c.wcb = u.arena.alloc((int64_t)conv_cb_weight_elems(N, C1) * dsize(cbdt));
+      SF_HIP(launch_pack_conv_cb(cbdt, w, N, C1, c.wcb, s));
     }
     pack_wfr(c);
     if (b) {
@@ -684,7 +685,7 @@ Plan make_plan(const sf_unet &u, Workspace &ws, int B, int L0, bool two, int num
       const int64_t rows = (int64_t)bt * l.L;
       const Block &b = u.blocks[d];
       const bool have_w = !b.down_items.empty() && b.down_items[0].conv1.wcb != nullptr;
-      const bool shape_ok = have_w && l.C >= cb_min_c && rows <= cb_max_rows && conv_cb_shape_ok(u.dt, bt, l.L, l.C, l.C, c.resnet_groups) &&
+      const bool shape_ok = have_w && l.C >= cb_min_c && rows <= cb_max_rows && conv_cb_shape_ok(u.x3 ? (int)F32X : u.dt, bt, l.L, l.C, l.C, c.resnet_groups) &&
                             cb_gn_plan(l.L).nch <= 32 && (int64_t)bt * 32 * c.resnet_groups * 2 <= p.slab_half;
       const double slab1 = (double)(l.C / 128) * rows * l.C * 4.0;   // bytes of the partial slabs with one channel block per workgroup
       static const bool no_kb2 = getenv("SF_CB_NO_KB2") != nullptr;   // A/B aid
@@ -695,7 +696,7 @@ Plan make_plan(const sf_unet &u, Workspace &ws, int B, int L0, bool two, int num
       l.cb = false;
       l.cb_kb = 1;
       if (shape_ok && slab1 <= cb_max_slab_mb * 1048576.0) l.cb = true;
-      else if (shape_ok && !no_kb2 && (l.C / 128) % 2 == 0 && l.C / c.resnet_groups >= 32 && slab1 * 0.5 <= cb_max_slab2_mb * 1048576.0) {
+      else if (shape_ok && !u.x3 && !no_kb2 && (l.C / 128) % 2 == 0 && l.C / c.resnet_groups >= 32 && slab1 * 0.5 <= cb_max_slab2_mb * 1048576.0) {
         l.cb = true;   // two channel blocks per workgroup: half the slabs (8-16 clips per branch at the 1024-channel levels)
         l.cb_kb = 2;
       }
@@ -1032,6 +1033,7 @@ struct Exec {
       const int mt = kb == 2 ? std::min(2, conv_cb_mt((int)l.rows, C, C / 2)) : conv_cb_mt((int)l.rows, C, C);
       const int cwgs = (int)((l.rows + 32 * mt - 1) / (32 * mt)) * (C / 128) * S;
       const CbGnPlan cgp = cb_gn_plan(l.L);
+      const int cbdt = u.x3 ? (int)F32X : u.dt;
       ConvCbArgs a;
       a.src_ld = C;
       a.wp = g.conv1.wcb;
@@ -1050,12 +1052,12 @@ struct Exec {
         a.stats = p.gnpart;
         a.gamma = g.gn1_g;
         a.beta = g.gn1_b;
-        timed("conv_cb", cflops + 12.0 * rc, cbytes, [&] { SF_HIP(launch_conv_cb(u.dt, a, s)); });
+        timed("conv_cb", cflops + 12.0 * rc, cbytes, [&] { SF_HIP(launch_conv_cb(cbdt, a, s)); });
       } else {
         timed("gn_silu", 12.0 * rc, 3.0 * rc * es,
               [&] { SF_HIP(launch_gn_silu(u.dt, cur, C, bt, l.L, C, G, g.gn1_g, g.gn1_b, 1e-5f, l.act, C, s, pf_cb(g.conv1, bt * G))); });
         a.src = l.act;
-        timed("conv_cb", cflops, cbytes, [&] { SF_HIP(launch_conv_cb(u.dt, a, s)); });
+        timed("conv_cb", cflops, cbytes, [&] { SF_HIP(launch_conv_cb(cbdt, a, s)); });
       }
       gnpart_of = nullptr;
       timed("cb_reduce_gn", 4.0 * rc, 2.0 * rc * es, [&] {
@@ -1070,7 +1072,7 @@ struct Exec {
       a.gamma = g.gn2_g;
       a.beta = g.gn2_b;
       a.pf = pf_for(g.inject, cwgs, l.rows);
-      timed("conv_cb", cflops + 12.0 * rc, cbytes, [&] { SF_HIP(launch_conv_cb(u.dt, a, s)); });
+      timed("conv_cb", cflops + 12.0 * rc, cbytes, [&] { SF_HIP(launch_conv_cb(cbdt, a, s)); });
       timed("cb_reduce_ln", 12.0 * rc, 3.0 * rc * es, [&] {
         SF_HIP(launch_cb_reduce_ln(u.dt, p.cbslab, S, bt, l.L, C, g.conv2.bias, cur, C, p.mod_all + g.mod_off, p.mod_stride, 1e-6f, tA, C, s,
                                    pf_for(g.inject, (int)(l.rows * (C / 4) / 256), l.rows)));

@@ -13,7 +13,7 @@ from helpers import rel_l2
 
 pytestmark = pytest.mark.gpu
 
-TOL = {"fp32": 2e-5, "bf16": 2e-2, "fp16": 4e-3}
+TOL = {"fp32": 2e-5, "fp32x": 2e-5, "bf16": 2e-2, "fp16": 4e-3}
 TD = {"fp32": torch.float32, "fp32x": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
 
 
@@ -330,7 +330,7 @@ def test_conv1d_register_staged_shapes(cuda, dtype, shape):
 # Channel-block split-K convolution chain of the deep levels (conv_cb.hip): gn_silu -> conv_cb -> slab reduction + GroupNorm sums ->
 # conv_cb with the GroupNorm+SiLU panel prologue -> slab reduction + residual + LayerNorm + Modulation.
 # ----------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("dtype", ["bf16", "fp16", "fp32x"])
 @pytest.mark.parametrize("shape", [
     # B, L, C, modulated, channel blocks per workgroup
     (4, 44, 1024, True, 1),     # depth 7 of configs[1] per branch: 176 rows, 8 channel blocks, one group per block
@@ -349,6 +349,8 @@ def test_conv_cb_chain(cuda, dtype, shape):
     CPU from the same 16-bit-rounded inputs: the intermediate h (after the first reduction) and the modulated output m."""
     _l, lib = _lib()
     B, L, C, mod, kb = shape
+    if dtype == "fp32x" and kb == 2:
+        pytest.skip("the split-operand form takes one channel block per workgroup")
     G = 8
     td = TD[dtype]
     g = torch.Generator().manual_seed(B * 1000 + L + C)

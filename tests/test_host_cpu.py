@@ -297,3 +297,69 @@ def test_params_version_sees_in_place_updates_replaced_buffers_and_unhooked_edit
     assert seen[-1] and not v.tensors
     m, v = fresh()
     assert not any(v.changed(m) for _ in range(3 * _engine._REWALK_EVERY))
+
+
+def test_importing_the_package_patches_nothing_in_torch():
+    """VERDICT r5 #6 / ADVICE: the staleness detection is scoped to the module an engine was built from -- importing the package must
+    leave torch.nn.Module._apply alone and install no global registration hook."""
+    import subprocess
+    import sys
+
+    code = ("import torch\n"
+            "orig = torch.nn.Module._apply\n"
+            "import torch.nn.modules.module as mm\n"
+            "before = [len(getattr(mm, n)) for n in ('_global_parameter_registration_hooks', '_global_buffer_registration_hooks', '_global_module_registration_hooks')]\n"
+            "import syncfusion_amd\n"
+            "from syncfusion_amd import _engine, diffusion, encoder1d, onset_net\n"
+            "after = [len(getattr(mm, n)) for n in ('_global_parameter_registration_hooks', '_global_buffer_registration_hooks', '_global_module_registration_hooks')]\n"
+            "assert torch.nn.Module._apply is orig, 'Module._apply was patched'\n"
+            "assert before == after, (before, after)\n"
+            "print('clean')\n")
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, timeout=300)
+    assert r.returncode == 0 and "clean" in r.stdout, r.stderr[-2000:]
+
+
+def test_params_version_sees_structural_edits_on_the_next_call():
+    """Every edit of the module tree shows up on the NEXT staleness check (no 16-call window): a deleted parameter, a parameter rebound to a
+    new object, a new parameter / buffer / submodule, a submodule swapped under the same name, load_state_dict(assign=True)."""
+    import torch
+
+    from helpers import small_unet_module
+    from syncfusion_amd import _engine
+
+    def fresh():
+        m = small_unet_module()
+        return m, _engine._params_version(m)
+
+    m, v = fresh()
+    assert not v.changed(m) and not v.changed(m)
+    name = next(iter(dict(m.named_parameters())))
+    owner = m
+    for part in name.split(".")[:-1]:
+        owner = owner._modules[part]
+    leaf = name.split(".")[-1]
+    delattr(owner, leaf)                                                  # del m.w
+    assert v.changed(m)
+    m, v = fresh()
+    setattr(owner := m, "extra", torch.nn.Parameter(torch.zeros(3)))      # a new parameter on the root
+    assert v.changed(m)
+    m, v = fresh()
+    m.register_buffer("extra_buf", torch.zeros(2))
+    assert v.changed(m)
+    m, v = fresh()
+    m.add_module("extra_mod", torch.nn.Linear(2, 2))
+    assert v.changed(m)
+    m, v = fresh()
+    first = next(iter(m._modules))
+    m._modules[first] = type(m._modules[first])() if not list(m._modules[first].parameters()) else torch.nn.Identity()   # same name, other object
+    assert v.changed(m)
+    m, v = fresh()
+    sd = {k: t.clone() for k, t in m.state_dict().items()}
+    m.load_state_dict(sd, assign=True)                                    # rebinds every Parameter object
+    assert v.changed(m)
+    m, v = fresh()
+    m.load_state_dict(sd)                                                 # in place: same objects, bumped versions
+    assert v.changed(m)
