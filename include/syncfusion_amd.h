@@ -314,7 +314,7 @@ int sf_op_resnet_mod_cb(int dtype, const void *x, const float *w1, const float *
  * The first GEMM's epilogue leaves per-row LayerNorm partials per 32-column tile, the second multiplies the RAW rows of z and
  * normalises its accumulator, rstd * (acc - mean * colsum) -- no LayerNorm launch in between.  Which kernel family runs (macro tiles at
  * long activations, the 32x32 families at short ones) follows the engine's dispatch, except that the macro-tile form is always offered
- * here (the engine takes it only with SF_MT_LN=1: in the two-branch step it measured no gain); SF_ERR_UNSUPPORTED where no kernel fits.
+ * here (the engine does not take it: in the two-branch step it measured no gain); SF_ERR_UNSUPPORTED where no kernel fits.
  * fused_out (optional): set to 1 when the fused pair ran, 0 when the op fell back to z -> ln_modulate -> plain projection. */
 int64_t sf_op_inject_prenorm_proj_workspace_bytes(int B, int L, int C, int C2, int N);
 int sf_op_inject_prenorm_proj(int dtype, const void *m, const void *ctx, const float *w_inj, const float *b_inj, const float *gamma,

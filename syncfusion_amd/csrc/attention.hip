@@ -163,7 +163,7 @@ hipError_t launch_attention(int dt, const void *q, int ldq, const void *kv, int 
   if (xfmt && (dt != F32 || !x3 || !attention_f32_mfma_ok(ldq, ldkv, ldo, B, H))) return hipErrorInvalidValue;
   if (dt != F32 && (ldq % 8) == 0 && (ldkv % 8) == 0 && (ldo % 8) == 0)   // matrix-core path (attention_mfma.hip)
     return launch_attention_mfma(dt, q, ldq, kv, ldkv, B, L, H, Dh, out, ldo, s);
-  if (dt == F32 && attention_f32_mfma_ok(ldq, ldkv, ldo, B, H) && !getenv("SF_ATTN_F32_VALU"))   // fp32 matrix cores (attention_bwd.hip)
+  if (dt == F32 && attention_f32_mfma_ok(ldq, ldkv, ldo, B, H) && !tune_env("SF_ATTN_F32_VALU"))   // fp32 matrix cores (attention_bwd.hip)
     return launch_attention_f32_mfma(static_cast<const float *>(q), ldq, static_cast<const float *>(kv), ldkv, B, L, H, static_cast<float *>(out), ldo, s,
                                      nullptr, x3, xfmt);
   return SF_DISPATCH_T(dt, go<T>(q, ldq, kv, ldkv, B, L, H, out, ldo, s));

@@ -507,13 +507,13 @@ static hipError_t attention_mfma_go(const void *q, int ldq, const void *kv, int 
   const long waves_plain = (long)((L + WAVES * QW - 1) / (WAVES * QW)) * H * B * WAVES;
   const long wgs4 = (long)((L + W4 * QW - 1) / (W4 * QW)) * H * B;   // workgroups of the 4-wave kernel
   static const long wgs4_min = [] {   // tuning hook: from this many 4-wave workgroups on the long-sequence kernel runs instead of the key split
-    const char *e = getenv("SF_ATTN_WGS4_MIN");
+    const char *e = tune_env("SF_ATTN_WGS4_MIN");
     const long v = e ? atol(e) : 0;
     return v > 0 ? v : 128L;
   }();
   const bool long_kernel = L >= 256 && wgs4 >= wgs4_min;
   static const long ksplit_waves = [] {   // tuning hook: the key-split kernel runs while the 2-wave kernel would launch fewer waves than this
-    const char *e = getenv("SF_ATTN_KSPLIT_WAVES");
+    const char *e = tune_env("SF_ATTN_KSPLIT_WAVES");
     const long v = e ? atol(e) : 0;
     return v > 0 ? v : 1024L;   // (2048 until round 5: at 32 evaluations per branch the 176-position level keeps 6 key-split workgroups per head
                                 // re-reading K and V; configs[2] +1.0 %, batch 32 without guidance +-0, profiles/r5_f_ab_attn_ksplit.txt)
@@ -524,7 +524,7 @@ static hipError_t attention_mfma_go(const void *q, int ldq, const void *kv, int 
                        L, H, static_cast<T *>(out), ldo, 1.0f / sqrtf((float)D));
     return hipGetLastError();
   }
-  static const bool two_wave = getenv("SF_ATTN_2WAVE") != nullptr;   // tuning hook: the 2-wave kernel for every length
+  static const bool two_wave = tune_env("SF_ATTN_2WAVE") != nullptr;   // tuning hook: the 2-wave kernel for every length
   if (!two_wave && L >= 256) {
     dim3 g4((L + W4 * QW - 1) / (W4 * QW), H, B);
     hipLaunchKernelGGL((attention_mfma4_kernel<T>), g4, dim3(256), 0, s, static_cast<const T *>(q), ldq, static_cast<const T *>(kv), ldkv, L, H,

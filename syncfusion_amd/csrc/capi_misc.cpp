@@ -243,7 +243,7 @@ int sf_bench_conv1d(int dtype, int B, int L, int C, int N, int taps, int upsampl
   // as inside a denoising step (430 MB of weights per step do not fit the 256 MB Infinity Cache)
   const size_t wbytes = (size_t)N * K * es;
   int ncopy = 1;
-  if (const char *e = getenv("SF_BENCH_COLD")) {
+  if (const char *e = tune_env("SF_BENCH_COLD")) {
     if (atoi(e) > 0) ncopy = (int)std::min<size_t>(1024, ((size_t)768 << 20) / wbytes + 1);
   }
   SF_HIP(hipMalloc(&w, wbytes * ncopy));
@@ -283,7 +283,7 @@ int sf_bench_conv1d(int dtype, int B, int L, int C, int N, int taps, int upsampl
   hipError_t err = hipSuccess;
   unsigned *sink = nullptr;   // the touch kernel's dedicated write sink (never a live buffer)
   void *wfr = nullptr;
-  if (dtype != F32 && (K % 64) == 0 && K <= 2048 && (N % 32) == 0 && (C % 16) == 0 && !getenv("SF_BENCH_NO_WFR")) {
+  if (dtype != F32 && (K % 64) == 0 && K <= 2048 && (N % 32) == 0 && (C % 16) == 0 && !tune_env("SF_BENCH_NO_WFR")) {
     SF_HIP(hipMalloc(&wfr, wbytes * ncopy));   // fragment-ordered copies, same rotation (the values are random either way)
     SF_HIP(hipMemcpy(wfr, w, wbytes * ncopy, hipMemcpyDeviceToDevice));
     a.wfr = wfr;
@@ -303,7 +303,7 @@ int sf_bench_conv1d(int dtype, int B, int L, int C, int N, int taps, int upsampl
     // SF_BENCH_PREFETCH=n: a `touch` kernel of n workgroups reads this launch's weights right before it (1000 + n: the touch kernel
     // alone) -- what an idle-CU prefetch in the PRECEDING kernel of the chain could buy
     int pre = 0;
-    if (const char *e = getenv("SF_BENCH_PREFETCH")) pre = atoi(e);
+    if (const char *e = tune_env("SF_BENCH_PREFETCH")) pre = atoi(e);
     if (pre > 0 && pre % 1000 == 0) fail(SF_ERR_INVALID, "SF_BENCH_PREFETCH=%d: the workgroup count (value mod 1000) must be >= 1", pre);
     if (pre > 0) SF_HIP(hipMalloc(reinterpret_cast<void **>(&sink), 64));
     for (int i = 0; i < iters && err == hipSuccess; ++i) {
@@ -456,11 +456,7 @@ int sf_op_inject_prenorm_proj(int dtype, const void *m, const void *ctx, const f
   ql.ln_nt = C / 32;
   ql.ln_eps = eps;
   ql.ln_colsum = colsum;
-  struct MtLnOn {   // the op always offers the macro-tile form (the engine only with SF_MT_LN=1, see conv_gemm.hip)
-    int prev;
-    MtLnOn() : prev(conv_gemm_mt_ln_enabled() ? 1 : 0) { g_conv_gemm_mt_ln = 1; }
-    ~MtLnOn() { g_conv_gemm_mt_ln = prev; }
-  } mt_ln_on;
+  ar.mt_ln = ql.mt_ln = 1;   // the op always offers the macro-tile form (the engine never does: kernels.h, ConvGemmArgs::mt_ln)
   const bool fused = conv_gemm_emits_rowpart(dtype, ar) && conv_gemm_ln_ok(dtype, ql);
   if (fused_out) *fused_out = fused ? 1 : 0;
   if (fused) {

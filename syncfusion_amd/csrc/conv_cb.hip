@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256) void cb_reduce_ln_kernel(const float *__restri
 
 int cb_min_wgs() {
   static const int v = [] {   // tuning hook: fewest workgroups a launch should have when choosing the rows per workgroup
-    const char *e = getenv("SF_CB_MIN_WGS");
+    const char *e = tune_env("SF_CB_MIN_WGS");
     return e && atoi(e) > 0 ? atoi(e) : 160;
   }();
   return v;
@@ -619,7 +619,7 @@ bool conv_cb_tile_stats_ok(int L, int C, int G) {
 // gives >= 160 workgroups, else one.
 int conv_cb_mt(int M, int N, int C) {
   static const int forced = [] {
-    const char *e = getenv("SF_CB_MT");
+    const char *e = tune_env("SF_CB_MT");
     return e ? atoi(e) : 0;
   }();
   if (forced >= 1 && forced <= 4) return forced;

@@ -401,7 +401,7 @@ __global__ __launch_bounds__(MAXT) void d0_tail_kernel(const ThinTailArgs a) {
 // waves per workgroup: tuning hook SF_D0_WAVES (4 ... 16)
 int d0_threads() {
   static const int t = [] {
-    const char *e = getenv("SF_D0_WAVES");
+    const char *e = tune_env("SF_D0_WAVES");
     int v = e ? atoi(e) : 4;
     if (v < 4) v = 4;
     if (v > 16) v = 16;
@@ -417,8 +417,8 @@ int d0_threads() {
 // per step measured -0.7 % with these kernels, 32-64 evaluations +0.3 ... +1.5 % (profiles/r3_j_ab_d0.txt).
 bool d0_enabled(int B, int L) {
   static const long min_rows = [] {
-    if (getenv("SF_NO_D0")) return -1L;
-    const char *e = getenv("SF_D0_MIN_ROWS");
+    if (tune_env("SF_NO_D0")) return -1L;
+    const char *e = tune_env("SF_D0_MIN_ROWS");
     return e ? atol(e) : 262144L;
   }();
   return min_rows >= 0 && (long)B * L >= min_rows;

@@ -445,7 +445,7 @@ const char *conv_gemm_variant_name(int dt, const ConvGemmArgs &a) {
 // needs a few steps to reach steady state.
 static long short_act_tiles() {   // tuning hook: below this many 64x64 tiles a GEMM goes to the wave-split-K / wave-private kernels
   static const long v = [] {
-    const char *e = getenv("SF_SHORT_TILES");
+    const char *e = tune_env("SF_SHORT_TILES");
     const long t = e ? atol(e) : 0;
     return t > 0 ? t : 500L;
   }();
@@ -454,13 +454,13 @@ static long short_act_tiles() {   // tuning hook: below this many 64x64 tiles a 
 
 bool conv_gemm_prefers_mt(const ConvGemmArgs &a) {
   static const int mode = [] {   // SF_MT=0 disables the kernel, SF_MT=2 prefers it wherever it is eligible (tuning / tests)
-    const char *e = getenv("SF_MT");
+    const char *e = tune_env("SF_MT");
     return e ? atoi(e) : 1;
   }();
   if (mode == 0) return false;
   if (mode == 2) return true;
   static const int min_tiles = [] {   // tuning hook
-    const char *e = getenv("SF_MT_TILES");
+    const char *e = tune_env("SF_MT_TILES");
     const int v = e ? atoi(e) : 0;
     return v > 0 ? v : 40;   // re-measured with the later tile variants: batch 32 without guidance 218 (80) -> 230 (40) steps/s, batch 16 335 -> 341,
                              // batch 32 with guidance and batch 8 unchanged
@@ -469,11 +469,8 @@ bool conv_gemm_prefers_mt(const ConvGemmArgs &a) {
   // temporal convolution); the 128x64 tile with two workgroups per CU (video geometry) wins (542 vs 770 us on that shape)
   if (a.n_store <= 64 && a.geom != 1) return false;
   const long tiles = (long)((a.M + 127) / 128) * ((a.n_store + 127) / 128);   // the 128x128 variant takes over below 160 tiles of 256x128
-  static const int kmin = [] {   // tuning hook: shortest 1-D reduction on the macro tiles
-    const char *e = getenv("SF_MT_KMIN");
-    return e && atoi(e) > 0 ? atoi(e) : 256;
-  }();
-  return tiles >= 2 * min_tiles && a.K >= (a.geom == 1 ? 128 : kmin);   // two workgroups per CU cover the short pipelines of the video geometry
+  // (shortest 1-D reduction: 256; 192 with the context padded to 64 columns was measured twice at -0.9 ... +1.6 % by workload and removed)
+  return tiles >= 2 * min_tiles && a.K >= (a.geom == 1 ? 128 : 256);   // two workgroups per CU cover the short pipelines of the video geometry
 }
 
 static const char *variant_name_bf16(int dt, const ConvGemmArgs &a) {
@@ -504,15 +501,8 @@ ConvGemmForce g_conv_gemm_force;
 
 // Row-LayerNorm fusion on the macro tiles (row partials in the epilogue, LayerNorm on the accumulator): parity-tested at op level, but in
 // the two-branch step the launches it removes were hidden under the other branch's kernels and its epilogue work is not -- same-box A/B
-// (profiles/r5_c_ab_mt_ln.txt): configs[2] 202 -> 203.5 steps/s, batch 32 without guidance 301 -> 291.  Off unless SF_MT_LN=1.
-int g_conv_gemm_mt_ln = -1;
-bool conv_gemm_mt_ln_enabled() {
-  if (g_conv_gemm_mt_ln < 0) {
-    const char *e = getenv("SF_MT_LN");
-    g_conv_gemm_mt_ln = (e && atoi(e) > 0) ? 1 : 0;
-  }
-  return g_conv_gemm_mt_ln > 0;
-}
+// (profiles/r5_c_ab_mt_ln.txt): configs[2] 202 -> 203.5 steps/s, batch 32 without guidance 301 -> 291.  Taken only when the caller asks
+// for it (ConvGemmArgs::mt_ln; the engine does not).
 
 bool conv_gemm_emits_rowpart(int dt, const ConvGemmArgs &a) {
   if (g_conv_gemm_force.path != 0 || !conv_gemm_supported(dt, a)) return false;
@@ -520,7 +510,7 @@ bool conv_gemm_emits_rowpart(int dt, const ConvGemmArgs &a) {
     ConvGemmArgs plain = a;
     plain.rowpart_out = nullptr;
     if (conv_gemm_mt_wanted(dt, plain)) {
-      const bool off = !conv_gemm_mt_ln_enabled();
+      const bool off = a.mt_ln == 0;
       ConvGemmArgs probe = a;   // (callers ask before they arm the launch)
       if (!probe.rowpart_out) {
         probe.rowpart_out = reinterpret_cast<float *>(16);

@@ -492,7 +492,7 @@ static bool ln_goes_mt(int dt, const ConvGemmArgs &a, bool *supported = nullptr)
   plain.rowpart_out = nullptr;
   plain.res_ln = 0;
   if (!conv_gemm_mt_wanted(dt, plain)) return false;
-  const bool off = !conv_gemm_mt_ln_enabled();
+  const bool off = a.mt_ln == 0;
   if (supported) *supported = !off && a.ln_part && a.ln_colsum && !a.ln_ss && !a.res_ln && conv_gemm_mt_ok(dt, a);
   return true;
 }
@@ -520,7 +520,7 @@ hipError_t launch_conv_gemm_wp(int dt, const ConvGemmArgs &a, int variant, hipSt
 static bool ln_goes_wp(int dt, const ConvGemmArgs &a) {
   // tuning hook: the wave-private kernel also carries the epilogue fold, but on the qkv projections of this model (288 tiles,
   // K = 1024) the staged kernel measured 1.2 % faster over a whole step (460 vs 455 steps/s), so it stays opt-in
-  static const bool use_wp = getenv("SF_LN_WP") != nullptr;
+  static const bool use_wp = tune_env("SF_LN_WP") != nullptr;
   return use_wp && a.ln_colsum && !a.ln_ss && !a.res_ln && !a.rowpart_out && conv_gemm_wp_ok(dt, a);
 }
 
@@ -538,7 +538,7 @@ const char *conv_gemm_ln_variant_name(int dt, const ConvGemmArgs &a) {
 bool conv_gemm_prefers_wp(const ConvGemmArgs &a);
 static bool ln_goes_rs(int dt, const ConvGemmArgs &a) {
   static const long max_tiles = [] {   // tuning hook: most 32x32 tiles a LayerNorm-folded projection may have and still take the register-staged kernel
-    const char *e = getenv("SF_RS_LN_TILES");
+    const char *e = tune_env("SF_RS_LN_TILES");
     return e ? atol(e) : 512L;
   }();
   const long tiles = (long)((a.M + 31) / 32) * ((a.n_store + 31) / 32);

@@ -609,7 +609,7 @@ template <typename T, int GEOM, bool CAT> hipError_t launch_mt_v(const ConvGemmA
     case 6: return launch_mt<T, 128, 192, 4, 2, GEOM, CAT, 2, 2>(a, s);   // the same for 192-wide column tiles (80 KB)
     case 7:                                                               // three-slot ring of a 128x64 tile (72 KB): two workgroups per CU
       if constexpr (GEOM == 0 && sizeof(T) == 2) {
-        static const bool no_pre = getenv("SF_MT_NO_PRE") != nullptr;      // A/B aid: epilogue operands loaded in the epilogue as before
+        static const bool no_pre = tune_env("SF_MT_NO_PRE") != nullptr;      // A/B aid: epilogue operands loaded in the epilogue as before
         if (!no_pre) return launch_mt<T, 128, 64, 4, 2, GEOM, CAT, 3, 1, false, true>(a, s);
       }
       return launch_mt<T, 128, 64, 4, 2, GEOM, CAT, 3, 1>(a, s);
@@ -668,7 +668,7 @@ bool conv_gemm_mt_ok(int dt, const ConvGemmArgs &a) {
 // 8192 x 1536 x 256 137.7 -> 62.0, 4096 x 1536 x 512 126.2 -> 58.6 us (110 TFLOP/s of the 157 fp32 peak).
 bool conv_gemm_prefers_mt_f32(const ConvGemmArgs &a) {
   static const long min_tiles = [] {   // tuning hook: SF_MT_F32_TILES=0 keeps fp32 off the macro tiles
-    const char *e = getenv("SF_MT_F32_TILES");
+    const char *e = tune_env("SF_MT_F32_TILES");
     return e ? atol(e) : 256L;   // a full round of 128x64 tiles: at 128 tiles the wave-split-K / 64x64 kernels win (41 vs 57 us, 71 vs 110 us)
   }();
   if (min_tiles <= 0 || a.geom != 0 || a.K < 256) return false;
@@ -710,13 +710,13 @@ bool conv_gemm_mt_wanted(int dt, const ConvGemmArgs &a) {
 //               7 = 128x64 with three slots (two workgroups per CU)
 int conv_gemm_mt_variant(const ConvGemmArgs &a) {
   static const int forced = [] {   // tuning hook
-    const char *e = getenv("SF_MT_VARIANT");
+    const char *e = tune_env("SF_MT_VARIANT");
     return e ? atoi(e) : -1;
   }();
   if (forced >= 0 && forced <= 10) return forced;
   auto cols = [&](int bn) { return (long)((a.n_store + bn - 1) / bn) * bn; };
   static const int rule = [] {   // tuning hook: 0 = three-slot rings only, 1 = two-slot rings for every geometry, default: video geometry only
-    const char *e = getenv("SF_MT_RULE");
+    const char *e = tune_env("SF_MT_RULE");
     return e ? atoi(e) : -1;
   }();
   // 192-wide tiles: column counts they cover without empty tiles (192, 576, 960), and short reductions on counts both tile
@@ -733,16 +733,16 @@ int conv_gemm_mt_variant(const ConvGemmArgs &a) {
     // Taller tiles with the same two-slot ring (80 KB, still two workgroups per CU) move 5/6 of the bytes per FLOP through the
     // L2 -> LDS fill: 192x128 for 128x128 (+2.8 % on the whole net), 256x64 for 128x64 (+1 %), profiles/r3_j_onset_variants.txt --
     // where the launch still has two rounds of them (the 7x7 and 14x14 stages keep the smaller tiles).
-    static const int v_thin = [] { const char *e = getenv("SF_MT_VIDEO_THIN"); return e ? atoi(e) : 9; }();   // tuning hooks
-    static const int v_sq = [] { const char *e = getenv("SF_MT_VIDEO_SQ"); return e ? atoi(e) : 8; }();
-    static const long tall_min = [] { const char *e = getenv("SF_MT_VIDEO_TALL_MIN"); return e ? atol(e) : 1024L; }();
+    static const int v_thin = [] { const char *e = tune_env("SF_MT_VIDEO_THIN"); return e ? atoi(e) : 9; }();   // tuning hooks
+    static const int v_sq = [] { const char *e = tune_env("SF_MT_VIDEO_SQ"); return e ? atoi(e) : 8; }();
+    static const long tall_min = [] { const char *e = tune_env("SF_MT_VIDEO_TALL_MIN"); return e ? atol(e) : 1024L; }();
     if (a.n_store <= 64) return (long)((a.M + 255) / 256) >= tall_min ? v_thin : 7;   // 128x64 tiles (three slots still fit twice)
     if (wide) return 6;
     return (long)((a.M + 191) / 192) * ((a.n_store + 127) / 128) >= tall_min ? v_sq : 5;
   }
   {
     static const int wide_small = [] {   // tuning hook: 192-wide candidates with at most this many 128x128 tiles take the 128x64 tile instead
-      const char *e = getenv("SF_MT_WIDE_SMALL");
+      const char *e = tune_env("SF_MT_WIDE_SMALL");
       return e ? atoi(e) : 176;   // the qkv projections of depths 6-7 at 16-32 evaluations per branch (1408 x 1536 x 1024: 88 tiles of 128x192)
     }();
     const long t128w = (long)((a.M + 127) / 128) * ((a.n_store + 127) / 128);
@@ -762,20 +762,20 @@ int conv_gemm_mt_variant(const ConvGemmArgs &a) {
       // runs, profiles/r3_f_ab_small_tiles*.txt).  The 176-tile launches of the guidance batch gain 4 % alone (34.1 -> 32.6 us) and
       // nothing in the step: the threshold stays below them.
       static const int thr = [] {   // tuning hook: largest 128x128 tile count that still switches to 128x64 (0 = never)
-        const char *e = getenv("SF_MT_SMALL_TILES");
+        const char *e = tune_env("SF_MT_SMALL_TILES");
         return e ? atoi(e) : 176;
       }();
       const long t128 = (long)((a.M + 127) / 128) * nt;
       static const int kmin = [] {   // tuning hook: shortest reduction that takes the rule
-        const char *e = getenv("SF_MT_SMALL_KMIN");
+        const char *e = tune_env("SF_MT_SMALL_KMIN");
         return e ? atoi(e) : 256;   // 256 (was 512): + the InjectChannels GEMMs of depth 4; with SF_MT_WIDE_SMALL: configs[2] +1.4 %, batch 32 +3.8 % (profiles/r5_b_ab_tiles.txt)
       }();
       if (t128 <= thr && a.K >= kmin && a.n_store % 64 == 0 && rule != 0) return 7;
     }
     auto cost = [&](int bm) { return (((long)((a.M + bm - 1) / bm) * nt + 255) / 256) * (bm + 128); };
     const long c256 = cost(256), c192 = cost(192), c128 = cost(128);
-    static const int v192 = [] { const char *e = getenv("SF_MT_V192"); return e ? atoi(e) : 3; }();   // tuning hooks: 8 / 5 = the two-slot forms
-    static const int v128 = [] { const char *e = getenv("SF_MT_V128"); return e ? atoi(e) : 1; }();
+    static const int v192 = [] { const char *e = tune_env("SF_MT_V192"); return e ? atoi(e) : 3; }();   // tuning hooks: 8 / 5 = the two-slot forms
+    static const int v128 = [] { const char *e = tune_env("SF_MT_V128"); return e ? atoi(e) : 1; }();
     if (c192 < c256 && c192 <= c128) return v192;
     return c128 < c256 ? v128 : 0;
   }
@@ -798,7 +798,7 @@ hipError_t launch_conv_gemm_mt(int dt, const ConvGemmArgs &a, hipStream_t s) {
     return a.cin2 ? launch_mt_x3<true, X3_F16>(a, v, s) : launch_mt_x3<false, X3_F16>(a, v, s);
   }
   if (dt == F32) {
-    static const int forced = [] { const char *e = getenv("SF_MT_F32_VARIANT"); return e ? atoi(e) : -1; }();   // tuning hook: 1, 5, 7
+    static const int forced = [] { const char *e = tune_env("SF_MT_F32_VARIANT"); return e ? atoi(e) : -1; }();   // tuning hook: 1, 5, 7
     const long t128 = (long)((a.M + 127) / 128) * ((a.n_store + 127) / 128);
     const int v = forced >= 0 ? forced : ((a.n_store % 64 == 0 && t128 < 512) ? 7 : 5);
     return a.cin2 ? launch_mt_v<float, 0, true>(a, v, s) : launch_mt_v<float, 0, false>(a, v, s);

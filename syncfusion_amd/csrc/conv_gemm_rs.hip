@@ -276,7 +276,7 @@ template <typename T, bool CAT> hipError_t launch_rs(const ConvGemmArgs &a, hipS
 // the launch takes the register-staged kernel: fragment-ordered weights at hand, a 16-bit type, 1-D geometry, no prologue, 32x32
 // tiles (the caller has decided that), K a multiple of 64 up to 2048, channel counts that are multiples of 16, whole 32-column tiles
 bool conv_gemm_rs_ok(int dt, const ConvGemmArgs &a) {
-  static const bool off = getenv("SF_NO_RS") != nullptr;   // A/B aid
+  static const bool off = tune_env("SF_NO_RS") != nullptr;   // A/B aid
   if (off || dt == F32 || !a.wfr || a.geom != 0 || a.pro != 0 || a.taps < 1) return false;
   if ((a.K % 64) || a.K > 2048 || (a.cin % 16) || (a.cin2 % 16) || (a.N % 32) || a.n_store != a.N) return false;
   if ((a.res && (a.res_ld % 4)) || (a.bscale && (a.bscale_ld % 4)) || (a.badd && (a.badd_ld % 4)) || (a.out_ld % 4)) return false;   // vector epilogue loads

@@ -362,7 +362,7 @@ int conv_gemm_sk_variant(const ConvGemmArgs &a) {
   // workgroups in flight matter more than operand reuse
   auto blocks = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.n_store + bn - 1) / bn); };
   static const int exp_rule = [] {   // tuning hook (tools/): alternative tile rules under the two-branch bench
-    const char *e = getenv("SF_SK_TILE_RULE");
+    const char *e = tune_env("SF_SK_TILE_RULE");
     return e ? atoi(e) : 0;
   }();
   if (exp_rule == 1 && blocks(32, 32) > 300 && a.K >= 512) return 1;
@@ -393,7 +393,7 @@ bool conv_gemm_rs_rows_ok(int64_t rows, int N) {
 // kernel's two barriers per chunk cost more than the operand sharing they buy.
 bool conv_gemm_prefers_wp(const ConvGemmArgs &a) {
   static const long max_tiles = [] {   // tuning hook
-    const char *e = getenv("SF_WP_TILES");
+    const char *e = tune_env("SF_WP_TILES");
     const long v = e ? atol(e) : 0;
     return v > 0 ? v : 512L;
   }();

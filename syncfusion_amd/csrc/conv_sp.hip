@@ -179,7 +179,7 @@ template <typename T> __global__ void pack_sp_kernel(const T *__restrict__ w, in
 
 // applicable: 16-bit type, (1,3,3) kernel, stride 1, padding 1, 64 input channels in 64-channel rows, output rows of >= 32 * ceil(N / 32) channels
 bool conv_sp_ok(int dt, int cin_real, int cin_ld, int cout, int out_ld) {
-  static const bool off = getenv("SF_NO_SP") != nullptr;   // A/B aid
+  static const bool off = tune_env("SF_NO_SP") != nullptr;   // A/B aid
   if (off || dt == F32 || cin_real != CIN || cin_ld != CIN || cout < 1) return false;
   const int ntiles = (cout + 31) / 32;
   return out_ld == 32 * ntiles && ntiles <= 8;   // every column of the output rows is written

@@ -33,12 +33,12 @@ namespace {
 // of 512-position chunks share a CU -- the kernels hold ~100 registers, so a CU takes 16-20 waves of them)
 static int thin_max_waves(int C) {
   static const int v32 = [] {
-    const char *e = getenv("SF_THIN_WAVES32");
+    const char *e = tune_env("SF_THIN_WAVES32");
     const int w = e ? atoi(e) : 8;
     return w >= 16 ? 16 : (w >= 8 ? 8 : 4);
   }();
   static const int v64 = [] {
-    const char *e = getenv("SF_THIN_WAVES64");
+    const char *e = tune_env("SF_THIN_WAVES64");
     const int w = e ? atoi(e) : 8;
     return w >= 16 ? 16 : (w >= 8 ? 8 : 4);
   }();
@@ -943,14 +943,14 @@ hipError_t launch_thin_tail(int dt, const ThinTailArgs &a, hipStream_t s) {
 ThinPlan conv_thin_plan(int B, int L, int C) {
   ThinPlan p;
   static const int rows8 = [] {   // tuning hook: positions per workgroup on the 8-channel level
-    const char *e = getenv("SF_THIN_ROWS8");
+    const char *e = tune_env("SF_THIN_ROWS8");
     const int v = e ? atoi(e) : 0;
     return v > 0 ? v : 0;
   }();
   // a wave's fixed cost (weights, prologue table, epilogue bookkeeping) is amortised over 32 positions x C channels
   // per tile: the 8-channel level gives each wave several tiles
   static const int rows_cap = [] {   // tuning hook: upper bound of positions per workgroup above 8 channels
-    const char *e = getenv("SF_THIN_MAXROWS");
+    const char *e = tune_env("SF_THIN_MAXROWS");
     const int v = e ? atoi(e) : 0;
     return v > 0 ? v : 352;   // 64 channels: 352 positions x 8 waves (two workgroups per CU; 6 staged vectors per thread bound the chunk);
                                // one workgroup of 16 waves x 1024 positions measured 1.4 % slower on configs[2] and the 2^18-sample shape
@@ -960,13 +960,13 @@ ThinPlan conv_thin_plan(int B, int L, int C) {
   // convolution that shares the chunking; against 2048 it measured +1.6 % on 32 evaluations per step and no change on 64
   // (profiles/r3_j_ab_d0.txt).  The MFMA formulation prefers the long chunk.
   static const int rows32 = [] {   // tuning hook: the same bound on the 32-channel level alone
-    const char *e = getenv("SF_THIN_MAXROWS32");
+    const char *e = tune_env("SF_THIN_MAXROWS32");
     const int v = e ? atoi(e) : 0;
     return v > 0 ? v : 512;
   }();
   const int max_rows = C <= 8 ? (rows8 > 0 ? rows8 : (d0_enabled(B, L) ? 992 : 2048)) : (C == 32 && rows32 > 0 ? rows32 : rows_cap);
   static const int wgs = [] {   // tuning hook: workgroups a launch aims for
-    const char *e = getenv("SF_THIN_WGS");
+    const char *e = tune_env("SF_THIN_WGS");
     const int v = e ? atoi(e) : 0;
     return v > 0 ? v : 256;
   }();

@@ -177,7 +177,7 @@ int tw_ksteps(int cin_real) { return cin_real <= 64 ? 4 : (cin_real <= 160 ? 10 
 
 // applicable: 16-bit type, 64 output channels, (3,1,1) kernel with temporal padding 1, channel counts the two instantiations cover
 bool conv_tw_ok(int dt, int cin_real, int cin_ld, int cout, int out_ld, int res_ld) {
-  static const bool off = getenv("SF_NO_TW") != nullptr;   // A/B aid
+  static const bool off = tune_env("SF_NO_TW") != nullptr;   // A/B aid
   if (off || dt == F32 || cout != 64 || out_ld < 64 || (out_ld % 4) || (res_ld % 4)) return false;
   const int ks = tw_ksteps(cin_real);
   return ks > 0 && 16 * ks <= cin_ld && (cin_ld % 8) == 0;

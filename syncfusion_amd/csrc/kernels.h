@@ -99,6 +99,10 @@ struct ConvGemmArgs {
   const float *ln_part = nullptr, *ln_ss = nullptr;
   int ln_nt = 0, ln_ss_ld = 0, res_ln = 0;
   float ln_eps = 1e-5f;
+  // the caller allows the row-LayerNorm fusion on the MACRO tiles too (row partials in their epilogue, LayerNorm on the accumulator).  The
+  // engine never sets it: in the two-branch step it measured -3.5 ... +0.9 % (profiles/r5_c_ab_mt_ln.txt); sf_op_inject_prenorm_proj does,
+  // so that the kernels stay parity-tested.  An explicit argument: no process-wide switch for the dispatch to disagree with itself about.
+  int mt_ln = 0;
 };
 struct V2Plan {
   int variant = 2;  // 0: 128x128, 1: 128x64, 2: 64x64
@@ -115,9 +119,6 @@ bool conv_gemm_mt_wanted(int dt, const ConvGemmArgs &a);   // eligible AND prefe
 bool conv_gemm_src_x3_ok(const ConvGemmArgs &a);
 hipError_t launch_conv_gemm_mt(int dt, const ConvGemmArgs &a, hipStream_t s);
 const char *conv_gemm_mt_name(const ConvGemmArgs &a);   // label of the tile variant it picks (bf16 spelling)
-// process-wide switch of the macro-tile row-LayerNorm fusion (SF_MT_LN=1; -1 = not read yet); sf_op_inject_prenorm_proj turns it on for its call
-extern int g_conv_gemm_mt_ln;
-bool conv_gemm_mt_ln_enabled();
 // true when launch_conv_gemm would run `a` on a kernel that honours rowpart_out (fast / wp, 32x32 tiles; macro tiles with SF_MT_LN=1)
 bool conv_gemm_emits_rowpart(int dt, const ConvGemmArgs &a);
 // register-staged kernel (conv_gemm_rs.hip): 32x32 tiles, all operand fragments of a wave in flight, fragment-ordered weights

@@ -31,7 +31,7 @@ namespace {
 // 4 / 8 / 16); shared by gn_silu_go and gn_silu_ws_go so that an A/B with the hook compares exactly two paths
 int gn_reg_max_rv() {
   static const int v = [] {
-    const char *e = getenv("SF_GN_REG_MAXV");
+    const char *e = tune_env("SF_GN_REG_MAXV");
     const int x = e ? atoi(e) : 16;
     return x >= 16 ? 16 : (x >= 8 ? 8 : 4);
   }();
@@ -574,7 +574,7 @@ static hipError_t gn_silu_ws_go(const void *x, int ld, int B, int L, int C, int 
 
 hipError_t launch_gn_silu_ws(int dt, const void *x, int ld, int B, int L, int C, int G, const float *gamma, const float *beta, float eps, void *out,
                              int out_ld, float *slab, int64_t slab_floats, hipStream_t s) {
-  static const bool off = getenv("SF_NO_GN_CHUNKED") != nullptr;   // tuning hook
+  static const bool off = tune_env("SF_NO_GN_CHUNKED") != nullptr;   // tuning hook
   if (slab && !off) {
     bool done = false;
     hipError_t e = SF_DISPATCH_T(dt, gn_silu_ws_go<T>(x, ld, B, L, C, G, gamma, beta, eps, out, out_ld, slab, slab_floats, s, done));

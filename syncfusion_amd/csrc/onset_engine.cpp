@@ -165,7 +165,7 @@ struct OnsetExec {
     // Column counts that neither 128- nor 192-wide macro tiles cover well (layer 2's 288 mid channels in 320-channel rows: 384 computed
     // columns either way, 25 % of the launch on padding): whole 192-wide tiles first, the remaining <= 128 columns as a second launch
     // (192 + 128 = 320 computed columns).  692 -> ~600 us per convolution at 32 clips.
-    static const bool no_split = getenv("SF_ONSET_NO_NSPLIT") != nullptr;   // A/B aid
+    static const bool no_split = tune_env("SF_ONSET_NO_NSPLIT") != nullptr;   // A/B aid
     const int q192 = c.cout / 192, rest = c.cout_ld - 192 * q192;
     const int cols_now = std::min((c.cout_ld + 127) / 128 * 128, (c.cout_ld + 191) / 192 * 192);
     if (!no_split && o.dt != F32 && q192 >= 1 && rest > 0 && rest <= 128 && c.cout > 192 * q192 && 192 * q192 + 128 < cols_now) {
@@ -214,7 +214,7 @@ int sf_onsetnet_create(const sf_tensor *weights, int n_weights, int dtype, void 
   const std::string m = "net.model.";
   o->stem_s = make_conv(*o, pk, m + "stem.0", m + "stem.1", 3, 45, 1, 7, 7, 2, 0, 3);
   o->stem_t = make_conv(*o, pk, m + "stem.3", m + "stem.4", 45, 64, 3, 1, 1, 1, 1, 0);
-  if (dtype != SF_F32 && getenv("SF_NO_ONSET_STEM") == nullptr) {
+  if (dtype != SF_F32 && tune_env("SF_NO_ONSET_STEM") == nullptr) {
     o->stem_wk = o->arena.alloc((int64_t)onset_stem_weight_elems() * dsize(dtype));
     SF_HIP(launch_onset_stem_repack(dtype, o->stem_s.w.w, o->stem_s.cout, o->stem_s.w.K, o->stem_wk, s));
   }

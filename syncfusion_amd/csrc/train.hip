@@ -910,7 +910,7 @@ int conv_wgrad_splits(int64_t rows, int C, int N, int taps) {
   const int T = fam ? 64 * fam : 32;
   const int64_t tiles = (int64_t)((N + T - 1) / T) * ((Q + T - 1) / T);
   static const int64_t target = [] {   // tuning hook: workgroups per launch the row splits aim at (LDS-staged families)
-    const char *e = getenv("SF_WGRAD_TARGET");
+    const char *e = tune_env("SF_WGRAD_TARGET");
     return e ? (int64_t)atol(e) : 512;
   }();
   int64_t S = std::max<int64_t>(1, (fam ? target : 2048) / std::max<int64_t>(tiles, 1));

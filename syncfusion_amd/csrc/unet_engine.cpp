@@ -123,9 +123,9 @@ struct sf_unet {
   }
   std::vector<std::pair<std::string, int64_t>> names;
   // graph cache for sf_vsample
-  bool no_ln_fusion = getenv("SF_NO_LN_FUSION") != nullptr;   // debugging aid: launch every LayerNorm separately
-  bool no_indep_branches = getenv("SF_NO_INDEP_BRANCHES") != nullptr;   // debugging aid: fork / join the branches inside every step
-  bool no_thin_tail = getenv("SF_NO_THIN_TAIL") != nullptr;   // debugging aid: conv2 / inject of the thin levels as two launches
+  bool no_ln_fusion = tune_env("SF_NO_LN_FUSION") != nullptr;   // debugging aid: launch every LayerNorm separately
+  bool no_indep_branches = tune_env("SF_NO_INDEP_BRANCHES") != nullptr;   // debugging aid: fork / join the branches inside every step
+  bool no_thin_tail = tune_env("SF_NO_THIN_TAIL") != nullptr;   // debugging aid: conv2 / inject of the thin levels as two launches
   hipGraphExec_t gexec = nullptr;
   hipGraphExec_t gexec_br[8] = {};   // independent-branch pipelines: one single-stream step graph per branch
   bool gexec_indep = false;
@@ -285,7 +285,7 @@ struct Builder {
       SF_HIP(launch_pack_conv(u.dt, w, N, Ctot, 0, C1, taps, C1, nullptr, c.wt, kt, 0, s));
       if (C2) SF_HIP(launch_pack_conv(u.dt, w, N, Ctot, C1, C2, 1, c2p, nullptr, c.wt, kt, (int64_t)taps * C1, s));
     }
-    static const bool no_cb = getenv("SF_NO_CB") != nullptr;   // debugging / A-B aid: keep the wave-private GEMM chain everywhere
+    static const bool no_cb = tune_env("SF_NO_CB") != nullptr;   // debugging / A-B aid: keep the wave-private GEMM chain everywhere
     const int cbdt = u.x3 ? (int)F32X : u.dt;   // fp32x: (hi, lo') fp16 fragment pairs
     if (cb && !no_cb && !direct && taps == 3 && C2 == 0 && cin_pad == C1 && conv_cb_shape_ok(cbdt, 1, 64, C1, N, 0)) {
       // second copy in MFMA fragment order for the channel-block split-K kernel (the small-batch engine of the deep levels)
@@ -302,7 +302,7 @@ struct Builder {
 
   // second copy of a packed [N][K] matrix in MFMA fragment order for the register-staged small-batch GEMM (conv_gemm_rs.hip)
   void pack_wfr(ConvW &c) {
-    static const bool off = getenv("SF_NO_RS") != nullptr;
+    static const bool off = tune_env("SF_NO_RS") != nullptr;
     if (off || u.listing || c.direct || u.dt == F32 || !c.w || (c.K % 64) || c.K > 2048 || (c.N % 32) || (c.cin % 16) || (c.cin2 % 16)) return;
     c.wfr = u.arena.alloc((int64_t)c.N * c.K * dsize(u.dt));
     SF_HIP(launch_pack_wfr(u.dt, c.w, c.N, c.K, c.wfr, s));
@@ -355,8 +355,7 @@ void build_group(Builder &bd, Group &g, const std::string &pre, int d, int &mod_
   g.mod_off = mod_cols;
   mod_cols = pad_to(mod_cols + 2 * C, 4);
   const int ctx = c.context_channels[d];
-  static const bool ctx_pad64 = getenv("SF_CTX_PAD64") != nullptr;
-  g.inject = bd.conv(pre + ".inject.conv", C, C, 1, ctx, true, thin, C, pad_to(ctx, (ctx_pad64 && !thin && C >= 128 && C % 64 == 0) ? 64 : 32));
+  g.inject = bd.conv(pre + ".inject.conv", C, C, 1, ctx, true, thin, C, pad_to(ctx, 32));
   g.attn = c.attentions[d] != 0;
   g.cross = c.cross_attentions[d] != 0;
   const int hd = u.hd;
@@ -454,10 +453,8 @@ void build(sf_unet &u, const WeightMap *wm, hipStream_t s) {
     b.ctx = c.context_channels[d];
     while ((1 << b.up_shift) < b.factor) ++b.up_shift;
     const bool thin = (b.C % 32) != 0;
-    // (pad columns are zero-filled by the layout conversion.)  Tuning hook SF_CTX_PAD64=1: from 128 channels up the context is padded to 64
-    // columns, so that the K = C + ctx reduction of InjectChannels is whole 64-element steps of the macro-tile kernel at depth 3 too
-    static const bool ctx_pad64 = getenv("SF_CTX_PAD64") != nullptr;
-    b.ctx_ld = thin ? pad_to(b.ctx, 8) : pad_to(b.ctx, (ctx_pad64 && b.C >= 128 && b.C % 64 == 0) ? 64 : 32);
+    // (pad columns are zero-filled by the layout conversion)
+    b.ctx_ld = thin ? pad_to(b.ctx, 8) : pad_to(b.ctx, 32);
     const std::string pre = "net.blocks." + std::to_string(d);
     // Downsample: Conv1d(cin, C, kernel=f, stride=f).  As a GEMM it is a plain matrix product over the
     // (rows/f, f*cin) view of the input when that width is MFMA-friendly; else the direct kernel.
@@ -533,7 +530,7 @@ void build(sf_unet &u, const WeightMap *wm, hipStream_t s) {
       }
     }
   }
-  if (!u.listing && u.n_ca > 0 && !getenv("SF_NO_CA_GROUPED")) {   // table of the per-item projections (conditioning() runs them as one launch)
+  if (!u.listing && u.n_ca > 0 && !tune_env("SF_NO_CA_GROUPED")) {   // table of the per-item projections (conditioning() runs them as one launch)
     std::vector<CrossOutItem> items;
     std::vector<int2> blks;
     for (int d = 0; d < c.n_layers; ++d)
@@ -623,7 +620,7 @@ Plan make_plan(const sf_unet &u, Workspace &ws, int B, int L0, bool two, int num
     // with guidance, BASELINE configs[2] -- 168.2 -> 182.0 steps/s with two branches; 96 evaluations 113.7 -> 131.6; 128 evaluations
     // 101.5 -> 108.3; four branches at 64 evaluations 166: profiles/r3_g_ab_branches.txt)
     static const int two_max = [] {   // tuning hook: largest number of evaluations per step that still runs as two branches
-      const char *e = getenv("SF_TWO_BRANCH_MAX");
+      const char *e = tune_env("SF_TWO_BRANCH_MAX");
       return e ? atoi(e) : 128;
     }();
     int want = u.branches_override > 0 ? u.branches_override : ((p.Bt >= 4 && p.Bt <= two_max) ? 2 : 1);
@@ -667,15 +664,15 @@ Plan make_plan(const sf_unet &u, Workspace &ws, int B, int L0, bool two, int num
     // Footprint limit swept at batch 12 / 16 / 32 with and without guidance (profiles/r4_d_ab_cb_slab.txt): 12 MB is never behind "off"
     // beyond run-to-run noise and +1.5 % at batch 12-16.
     static const int cb_max_rows = [] {   // tuning hook: most rows per branch a level may have and still take the chain (0: never)
-      const char *e = getenv("SF_CB_MAX_ROWS");
+      const char *e = tune_env("SF_CB_MAX_ROWS");
       return e ? atoi(e) : 1408;
     }();
     static const double cb_max_slab_mb = [] {   // tuning hook: largest partial-slab footprint (MB per branch and level)
-      const char *e = getenv("SF_CB_MAX_SLAB_MB");
+      const char *e = tune_env("SF_CB_MAX_SLAB_MB");
       return e ? atof(e) : 12.0;
     }();
     static const int cb_min_c = [] {      // tuning hook: narrowest level that takes the chain
-      const char *e = getenv("SF_CB_MIN_C");
+      const char *e = tune_env("SF_CB_MIN_C");
       return e ? atoi(e) : 256;
     }();
     int64_t need = 0, need_gp = 0;
@@ -688,9 +685,9 @@ Plan make_plan(const sf_unet &u, Workspace &ws, int B, int L0, bool two, int num
       const bool shape_ok = have_w && l.C >= cb_min_c && rows <= cb_max_rows && conv_cb_shape_ok(u.x3 ? (int)F32X : u.dt, bt, l.L, l.C, l.C, c.resnet_groups) &&
                             cb_gn_plan(l.L).nch <= 32 && (int64_t)bt * 32 * c.resnet_groups * 2 <= p.slab_half;
       const double slab1 = (double)(l.C / 128) * rows * l.C * 4.0;   // bytes of the partial slabs with one channel block per workgroup
-      static const bool no_kb2 = getenv("SF_CB_NO_KB2") != nullptr;   // A/B aid
+      static const bool no_kb2 = tune_env("SF_CB_NO_KB2") != nullptr;   // A/B aid
       static const double cb_max_slab2_mb = [] {   // tuning hook: the same limit for the two-block form
-        const char *e = getenv("SF_CB_MAX_SLAB2_MB");
+        const char *e = tune_env("SF_CB_MAX_SLAB2_MB");
         return e ? atof(e) : 12.0;
       }();
       l.cb = false;
@@ -741,12 +738,13 @@ struct Exec {
   int cur_depth = -1;               // depth tag of the launches being issued (profile records, roofline.depth_groups)
 
   template <class F> void timed(const char *label, double flops, double bytes, F &&f) {
+#ifdef SF_TUNING_HOOKS   // (does not exist in the product library: a leaked variable would silently corrupt audio)
     {
       // measurement aid (phase removal): SF_SKIP_LABELS=gn_silu,ln_modulate,... drops every launch whose label starts with one of the
       // listed prefixes -- results are garbage, the step's wall time shows what that kernel family costs inside the two-branch step
       static const std::vector<std::string> skip = [] {
         std::vector<std::string> v;
-        if (const char *e = getenv("SF_SKIP_LABELS")) {
+        if (const char *e = tune_env("SF_SKIP_LABELS")) {
           std::string all(e);
           size_t a = 0;
           while (a <= all.size()) {
@@ -762,6 +760,7 @@ struct Exec {
       for (const std::string &t : skip)
         if (strncmp(label, t.c_str(), t.size()) == 0) return;
     }
+#endif
     ++u.launches;
     if (!u.prof_on) {
       f();
@@ -786,10 +785,10 @@ struct Exec {
   }
   Prefetch pf_cb(const ConvW &w, int host_wgs) const { return pf_bytes(w.wcb, conv_cb_weight_elems(w.N, w.cin) * dsize(u.dt), host_wgs); }
   Prefetch pf_bytes(const void *ptr, size_t bytes, int host_wgs) const {
-    static const bool off = getenv("SF_NO_PREFETCH") != nullptr;
+    static const bool off = tune_env("SF_NO_PREFETCH") != nullptr;
     Prefetch pf;
     static const int host_max = [] {   // tuning hook: hosts with more workgroups than this lend nothing
-      const char *e = getenv("SF_PF_HOST_MAX");
+      const char *e = tune_env("SF_PF_HOST_MAX");
       return e ? atoi(e) : 1024;   // (208 at first: batch 32 without guidance 277.2 -> 281.1 steps/s with 1024, configs[2] unchanged)
     }();
     if (off || !ptr || host_wgs > host_max) return pf;   // a host that fills the chip has no idle CUs to lend
@@ -797,11 +796,11 @@ struct Exec {
     pf.ptr = ptr;
     pf.bytes = (unsigned)bytes;
     static const int cap = [] {   // tuning hook: upper bound of prefetch workgroups per host launch
-      const char *e = getenv("SF_PF_WGS");
+      const char *e = tune_env("SF_PF_WGS");
       return e && atoi(e) > 0 ? atoi(e) : 224;
     }();
     static const int mult = [] {
-      const char *e = getenv("SF_PF_MULT");
+      const char *e = tune_env("SF_PF_MULT");
       return e && atoi(e) > 0 ? atoi(e) : 1;
     }();
     pf.wgs = std::max(std::min(48, cap), std::min(cap, mult * (256 - host_wgs)));
@@ -810,7 +809,7 @@ struct Exec {
 
   // the producer of an item input of level d should leave GroupNorm tile sums (ConvGemmArgs::gnpart_out) for conv_cb's prologue
   bool wants_gnpart(int d) const {
-    static const bool off = getenv("SF_NO_CB_TILESTATS") != nullptr;   // A/B aid: keep the gn_silu launch in front of conv1
+    static const bool off = tune_env("SF_NO_CB_TILESTATS") != nullptr;   // A/B aid: keep the gn_silu launch in front of conv1
     if (off || d < 0 || d >= (int)p.lv.size()) return false;
     const Level &l = p.lv[d];
     return l.cb && p.gnpart && conv_cb_tile_stats_ok(l.L, l.C, u.cfg.resnet_groups);
@@ -853,7 +852,7 @@ struct Exec {
       // measurement aid: SF_TOUCH=n reads this GEMM's weights with an n-workgroup kernel right before it,
       // to price what a weight prefetch hosted by the preceding kernel's idle CUs could save inside the real two-branch step
       static const int touch = [] {
-        const char *e = getenv("SF_TOUCH");
+        const char *e = tune_env("SF_TOUCH");
         return e ? atoi(e) : 0;
       }();
       if (touch > 0 && !u.prof_on) SF_HIP(launch_touch(w.w, (size_t)w.N * w.K * dsize(u.dt), touch, reinterpret_cast<unsigned *>(p.step + 8), s));
@@ -987,7 +986,7 @@ struct Exec {
     bool fuse_mod = false;
     // (measured: normalising the operand while staging costs more than the separate launch once the row is 1024 wide)
     static const int ln_fuse_maxc = [] {   // tuning hook: widest level whose Modulation LayerNorm is folded into the InjectChannels GEMM
-      const char *e = getenv("SF_LN_FUSE_MAXC");
+      const char *e = tune_env("SF_LN_FUSE_MAXC");
       return e ? atoi(e) : 512;
     }();
     if (!fuse_act && C % 32 == 0 && C <= ln_fuse_maxc && !u.no_ln_fusion) {
@@ -1927,7 +1926,7 @@ int sf_vsample(sf_unet *h, float *x, const float *const *ctx, const float *emb, 
     }
     {
       static const double stagger_us = [] {   // tuning aid: start branch b  b * stagger microseconds late
-        const char *e = getenv("SF_BRANCH_STAGGER_US");
+        const char *e = tune_env("SF_BRANCH_STAGGER_US");
         return e ? atof(e) : 0.0;
       }();
       if (stagger_us > 0.0)

@@ -75,7 +75,7 @@ class UNetV0(nn.Module):
                  modulation_features: int = 1024, embedding_max_length: Optional[int] = None,
                  use_time_conditioning: bool = True, use_embedding_cfg: bool = False, use_text_conditioning: bool = False,
                  out_channels: Optional[int] = None, upsample_mode: str = "nearest", dtype: str = "fp32", seed: Optional[int] = None,
-                 time_fourier_features: Optional[int] = None, time_first_activation: bool = True, attention_out_bias: bool = False):
+                 time_fourier_features: Optional[int] = None, time_first_activation: Optional[bool] = None, attention_out_bias: bool = False):
         super().__init__()
         n = len(channels)
         assert dim == 1, "only the 1-D U-Net of the reference config is implemented"
@@ -102,6 +102,10 @@ class UNetV0(nn.Module):
             assert attention_features is not None and attention_heads is not None, "attention requires features and heads"
         if any(cross_attentions):
             assert embedding_features is not None, "cross attention requires embedding_features"
+        # None = "not stated": the default (GELU on) applies, and a checkpoint that shows the NumberEmbedder layout may
+        # switch it off on load (Model.load_state_dict); an explicit True / False is never overridden
+        self.time_first_activation_explicit = time_first_activation is not None
+        time_first_activation = True if time_first_activation is None else time_first_activation
         self.hparams = dict(in_channels=in_channels, channels=list(channels), factors=list(factors), items=list(items),
                             attentions=attentions, cross_attentions=cross_attentions, context_channels=context_channels,
                             attention_heads=attention_heads or 0, attention_features=attention_features or 0,
@@ -185,14 +189,24 @@ class UNetV0(nn.Module):
             return False
         hp = dict(self.hparams, **new)
         dev = next(self.parameters()).device
-        fresh = UNetV0(dim=1, use_embedding_cfg=True, dtype=self.compute_dtype, **hp)
+        # Only the parameters whose EXISTENCE or SHAPE the facts change are (re-)registered; every other Parameter OBJECT stays where it
+        # is, so optimizers, EMA copies or DDP wrappers created before load_state_dict keep pointing at the live tensors and
+        # requires_grad flags survive.  New / re-shaped tensors get a seeded torch-default initialisation (they are about to be loaded).
+        fresh = UNetV0(dim=1, use_embedding_cfg=True, dtype=self.compute_dtype, seed=0,
+                       **{k: v for k, v in hp.items() if k != "time_first_activation"}, time_first_activation=hp["time_first_activation"])
         old = dict(self.named_parameters())
-        with torch.no_grad():
-            for k, t in fresh.named_parameters():
-                if k in old and old[k].shape == t.shape:
-                    t.copy_(old[k])
-        fresh = fresh.to(dev)
-        self._modules, self._parameters, self.hparams, self._engine = fresh._modules, fresh._parameters, fresh.hparams, None
+        want = dict(fresh.named_parameters())
+        for k in [k for k in old if k not in want]:                      # e.g. `to_out.bias` when attention_out_bias goes off
+            owner = self
+            for part in k.split(".")[:-1]:
+                owner = owner._modules[part]
+            del owner._parameters[k.split(".")[-1]]
+        for k, t in want.items():
+            if k in old and old[k].shape == t.shape:
+                continue
+            rg = old[k].requires_grad if k in old else True
+            _register(self, k, nn.Parameter(t.detach().to(dev), requires_grad=rg))
+        self.hparams, self._engine = fresh.hparams, None
         return True
 
     # -- execution ------------------------------------------------------------------------------

@@ -77,6 +77,9 @@ class RandomEmbedder(nn.Module):
         return self._embed(feats.to(self.proj.device) + 1e-3)
 
 
+VARIANTS_KEY = "syncfusion_amd.unet_variants"   # checkpoint entry next to `state_dict`: the three [RECALLED] facts of the U-Net
+
+
 class Model(_Base):
     def __init__(self, lr: float, lr_beta1: float, lr_beta2: float, lr_eps: float, lr_weight_decay: float,
                  model: nn.Module, onsets_encoder: nn.Module, embedder: nn.Module, embedder_checkpoint: Optional[str]):
@@ -108,7 +111,30 @@ class Model(_Base):
         # checkpoint's own tensors decide them differently from how this model was built, the U-Net re-registers those parameters first
         net_sd = _strip({k: v for k, v in state_dict.items() if not _DUP_NET.match(k)}, "model.net.")
         if net_sd and hasattr(self.model.net, "adopt_variants"):
-            self.model.net.adopt_variants(**infer_variants(net_sd, self.model.net.hparams))
+            net = self.model.net
+            if True:
+                facts = infer_variants(net_sd, net.hparams)
+                # The third [RECALLED] fact has no parameters.  A checkpoint whose time embedder has the NumberEmbedder layout (F learned
+                # frequencies, Linear(2 F + 1 -> features), F != features / 2) was written by a-unet's embedder, which -- as recalled -- is
+                # LearnedPositionalEmbedding -> Linear with NO activation in front of the two (Linear, GELU) layers.  Unless the caller
+                # stated time_first_activation explicitly, follow the layout, and say so: the alternative is a silently different time
+                # embedding in engine, training composition and oracle.
+                deviates = {k: v for k, v in facts.items() if net.hparams.get(k) != v}
+                if "time_fourier_features" in deviates and not getattr(net, "time_first_activation_explicit", False) and net.hparams.get("time_first_activation", True):
+                    facts["time_first_activation"] = False
+                    import warnings
+
+                    warnings.warn(f"checkpoint shows a-unet's NumberEmbedder layout (time_fourier_features={facts['time_fourier_features']}): "
+                                  "time_first_activation was not stated and is switched OFF to match it (a-unet's embedder has no activation behind its "
+                                  "Linear, [RECALLED]); pass net_t(time_first_activation=True/False) to decide it yourself, or run tools/pin_upstream.py",
+                                  stacklevel=2)
+                elif deviates:
+                    import warnings
+
+                    warnings.warn(f"checkpoint tensors decide {deviates} differently from how this model was built; the affected parameters are "
+                                  "re-registered.  time_first_activation has no parameters and stays "
+                                  f"{net.hparams.get('time_first_activation', True)} (state it explicitly if the checkpoint needs otherwise)", stacklevel=2)
+                net.adopt_variants(**facts)
         own = super().state_dict()
         try:
             mapped = translate_state_dict(state_dict, self, hypothesis)
@@ -127,6 +153,19 @@ class Model(_Base):
                 mapped[k] = state_dict[k] if k in state_dict and tuple(state_dict[k].shape) == tuple(own[k].shape) else own[k]
         mapped.update(extra)
         return super().load_state_dict(mapped, strict=strict, assign=assign)
+
+    # Lightning's checkpoint hooks (called by the Trainer around state_dict save / load; call them yourself around torch.save / torch.load
+    # without a Trainer): the three [RECALLED] facts this U-Net was built with travel in the checkpoint NEXT TO `state_dict`, so a reload is
+    # deterministic -- time_first_activation has no parameters it could be inferred from.
+    def on_save_checkpoint(self, checkpoint: dict) -> None:
+        net = self.model.net
+        checkpoint[VARIANTS_KEY] = {k: net.hparams.get(k) for k in ("time_fourier_features", "time_first_activation", "attention_out_bias")}
+
+    def on_load_checkpoint(self, checkpoint: dict) -> None:
+        saved = checkpoint.get(VARIANTS_KEY)
+        if isinstance(saved, dict) and hasattr(self.model.net, "adopt_variants"):
+            self.model.net.adopt_variants(**{k: saved[k] for k in ("time_fourier_features", "time_first_activation", "attention_out_bias") if k in saved})
+            self.model.net.time_first_activation_explicit = True     # decided by the checkpoint: load_state_dict must not second-guess it
 
     def configure_optimizers(self):
         """main/module_diffusion.py:53-61: AdamW over the U-Net and the onset encoder.  On the GPU the single-kernel (``fused``)

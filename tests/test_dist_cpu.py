@@ -54,6 +54,42 @@ def test_broadcast_and_gather_world2():
     assert out0 == [0.0, 1.0, 2.0, 3.0, 4.0], "gathered clips are not the rank-order concatenation"
 
 
+def test_shard_range_partitions_every_total_exactly():
+    """Contiguous shards cover [0, total) once, in rank order, sizes differing by at most one -- for every world size of one node and
+    totals around the configuration's 256 clips (uneven ones included)."""
+    from syncfusion_amd.dist import shard_range
+
+    for world in (1, 2, 3, 4, 8):
+        for total in (0, 1, 7, 8, 9, 250, 255, 256, 257):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1 and sorted(sizes, reverse=True) == sizes
+
+
+@pytest.mark.timeout(600)
+def test_broadcast_and_gather_world8_uneven_total():
+    """The configuration that will eventually run (BASELINE configs[3]: 8 ranks of one node) with a clip count that does NOT divide:
+    250 clips over 8 ranks = two ranks of 32 and six of 31.  Flat weight broadcast from rank 0, every rank produces its own shard, the
+    padded gather returns the rank-order concatenation on rank 0 only (main/generation.py:16,44 is single-device: the split is ours)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    total, world, port = 250, 8, 29617
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=500) for _ in range(world))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    weights = [r[2] for r in res]
+    assert all(w == weights[0] for w in weights), "weights differ after broadcast"
+    assert len({r[1] for r in res}) == 1 and res[0][1] > 0
+    assert all(r[3] is None for r in res[1:])
+    assert res[0][3] == [float(i) for i in range(total)], "gathered clips are not the rank-order concatenation"
+
+
 def _grad_worker(rank: int, world: int, port: int, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))

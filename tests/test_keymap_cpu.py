@@ -178,3 +178,66 @@ def test_checkpoint_shapes_decide_the_time_embedder_width_and_the_attention_outp
     for k in a:
         if not k.startswith("clap."):
             assert torch.equal(a[k], b[k]), k
+
+
+def test_loading_a_number_embedder_checkpoint_switches_the_first_activation_off_with_a_warning_and_keeps_parameter_objects():
+    """(a) the third [RECALLED] fact, time_first_activation, has no parameters -- a checkpoint with the NumberEmbedder layout
+    switches it OFF (a-unet's embedder, as recalled) unless the caller stated it, and WARNS instead of silently computing another time
+    embedding; (b) adopt_variants re-registers only the affected parameters: every other Parameter object (and its requires_grad flag)
+    survives, so an optimizer created before load_state_dict keeps updating the live model; (c) the Lightning checkpoint hooks carry the
+    three facts next to state_dict and restore them deterministically."""
+    import warnings
+
+    from syncfusion_amd import DiffusionModel, Encoder1d, Model, RandomEmbedder, UNetV0, VDiffusion, VSampler, keymap
+    from syncfusion_amd.module import VARIANTS_KEY
+
+    def build(seed, **kw):
+        dm = DiffusionModel(net_t=functools.partial(UNetV0, seed=seed, **kw), diffusion_t=VDiffusion, sampler_t=VSampler, use_embedding_cfg=True, **SMALL_UNET)
+        m = Model(1e-4, 0.95, 0.999, 1e-6, 1e-3, dm, Encoder1d(seed=seed, **SMALL_ENCODER), RandomEmbedder(SMALL_UNET["embedding_features"]), None)
+        m.load_state_dict(seeded_state(m, seed))
+        return m
+
+    src = build(11, time_fourier_features=16, time_first_activation=False, attention_out_bias=True)
+    up = keymap.to_upstream_layout(src, keymap.OrderHypothesis())
+    # (a) + (b): defaults, nothing stated
+    dst = build(22)
+    frozen = "blocks.1.items_down.0.resnet.conv1.weight"
+    dict(dst.model.net.named_parameters())[frozen].requires_grad_(False)
+    before = dict(dst.model.net.named_parameters())
+    opt = torch.optim.SGD([p for p in dst.model.net.parameters() if p.requires_grad], lr=0.1)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        dst.load_state_dict(up)
+    assert any("NumberEmbedder" in str(w.message) and "switched OFF" in str(w.message) for w in rec)
+    hp = dst.model.net.hparams
+    assert hp["time_fourier_features"] == 16 and hp["attention_out_bias"] is True and hp["time_first_activation"] is False
+    after = dict(dst.model.net.named_parameters())
+    changed = {k for k in after if k not in before or after[k] is not before[k]}
+    assert changed and all(k.startswith("time.") or k.endswith("to_out.bias") for k in changed), sorted(changed)[:5]
+    assert after[frozen] is before[frozen] and not after[frozen].requires_grad
+    live = {id(p) for p in dst.model.net.parameters()}
+    kept = [p for g in opt.param_groups for p in g["params"] if id(p) in live]
+    assert len(kept) >= len(before) - len(changed) - 1          # the optimizer still holds the live tensors
+    for k, v in src.state_dict().items():
+        if not k.startswith("clap."):
+            assert torch.equal(v, dst.state_dict()[k]), k
+    # an explicit statement is never overridden (and the layout still adapts)
+    dst2 = build(23, time_first_activation=True)
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        dst2.load_state_dict(up)
+    assert dst2.model.net.hparams["time_first_activation"] is True and dst2.model.net.hparams["time_fourier_features"] == 16
+    # (c) checkpoint hooks
+    ckpt = {"state_dict": src.state_dict()}
+    src.on_save_checkpoint(ckpt)
+    assert ckpt[VARIANTS_KEY] == dict(time_fourier_features=16, time_first_activation=False, attention_out_bias=True)
+    dst3 = build(24)
+    with warnings.catch_warnings(record=True) as rec3:
+        warnings.simplefilter("always")
+        dst3.on_load_checkpoint(ckpt)
+        dst3.load_state_dict(ckpt["state_dict"])
+    assert not any("NumberEmbedder" in str(w.message) for w in rec3)
+    assert dst3.model.net.hparams["time_first_activation"] is False
+    for k, v in src.state_dict().items():
+        if not k.startswith("clap."):
+            assert torch.equal(v, dst3.state_dict()[k]), k

@@ -2,6 +2,8 @@
 # Run ON the GPU box: A/B of HIP-library builds (SF_LIB_PATH), alternating, two rounds, on three workloads:
 # configs[1] (bench.py), configs[2] (batch 32, guidance 2.0) and one GPU's share of configs[3] (batch 32, no guidance).
 #   bash tools/ab_libs.sh name1=path1 name2=path2 ...   (paths relative to the repo root)
+# the SF_* hooks exist only in the tuning build of the library (make -C syncfusion_amd/csrc tuning)
+export SF_LIB_PATH=${SF_LIB_PATH:-${GRAFT_REPO_ROOT:-$(pwd)}/syncfusion_amd/lib/libsyncfusion_amd_tuning.so}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 for rep in $(seq 1 ${AB_REPS:-2}); do
   for spec in "$@"; do

@@ -1,6 +1,8 @@
 #!/bin/bash
 # Run ON the GPU box: alternating A/B of HIP-library builds (SF_LIB_PATH) on the batch-32 legs + the headline.
 #   bash tools/ab_libs_b32.sh name1=path1 name2=path2 ...   (paths relative to the repo root)
+# the SF_* hooks exist only in the tuning build of the library (make -C syncfusion_amd/csrc tuning)
+export SF_LIB_PATH=${SF_LIB_PATH:-${GRAFT_REPO_ROOT:-$(pwd)}/syncfusion_amd/lib/libsyncfusion_amd_tuning.so}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 for rep in $(seq 1 ${AB_REPS:-2}); do
   for spec in "$@"; do

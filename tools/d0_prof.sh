@@ -1,5 +1,7 @@
 #!/bin/bash
 # Run ON the GPU box: per-kernel durations of the 8-channel level under different knobs (single branch: clean durations).
+# the SF_* hooks exist only in the tuning build of the library (make -C syncfusion_amd/csrc tuning)
+export SF_LIB_PATH=${SF_LIB_PATH:-${GRAFT_REPO_ROOT:-$(pwd)}/syncfusion_amd/lib/libsyncfusion_amd_tuning.so}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/d0prof; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 export SF_TWO_BRANCH_MAX=0

@@ -1,5 +1,7 @@
 #!/bin/bash
 # Run ON the GPU box: LDS-array counters per kernel for one sample_one.py workload (eager launches):  bash tools/lds_state.sh tag B scale steps dtype [L0]
+# the SF_* hooks exist only in the tuning build of the library (make -C syncfusion_amd/csrc tuning)
+export SF_LIB_PATH=${SF_LIB_PATH:-${GRAFT_REPO_ROOT:-$(pwd)}/syncfusion_amd/lib/libsyncfusion_amd_tuning.so}
 T=$1; shift
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/wstate; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && export SF_NO_GRAPH=1

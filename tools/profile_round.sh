@@ -1,5 +1,7 @@
 #!/bin/bash
 # Run ON the GPU box (gpurun): rocprofv3 kernel stats + separate PMC passes of the bench command, summaries under gpurun_out/$1
+# the SF_* hooks exist only in the tuning build of the library (make -C syncfusion_amd/csrc tuning)
+export SF_LIB_PATH=${SF_LIB_PATH:-${GRAFT_REPO_ROOT:-$(pwd)}/syncfusion_amd/lib/libsyncfusion_amd_tuning.so}
 set -u
 TAG=${1:-prof}
 R=${GRAFT_REPO_ROOT:-$(pwd)}

@@ -1,6 +1,8 @@
 #!/bin/bash
 # Run ON the GPU box: SQ wave-state counters per kernel for one sample_one.py workload (eager launches), e.g.
 #   bash tools/wave_state.sh cfg2 32 2.0 3 bf16 45056
+# the SF_* hooks exist only in the tuning build of the library (make -C syncfusion_amd/csrc tuning)
+export SF_LIB_PATH=${SF_LIB_PATH:-${GRAFT_REPO_ROOT:-$(pwd)}/syncfusion_amd/lib/libsyncfusion_amd_tuning.so}
 T=$1; shift
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/wstate; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && export SF_NO_GRAPH=1
