@@ -212,10 +212,28 @@ struct sf_unet {
   hipStream_t bstream[kMaxBranches] = {};
   hipEvent_t ev_fork = nullptr, ev_join[kMaxBranches] = {};
   int branches_override = 0;
+  // Tuning hook (tuning build only) SF_BRANCH_CUMASK=d: the stream of branch b is created with a CU mask that holds the mask bits k with
+  // (k / d) % branches == b (hipExtStreamCreateWithCUMask) -- the round-6 A/B of CU-partitioned clip-parallel branches
+  // (profiles/r6_d_cumask_branches.txt; tools/r6_probes.hip shows what a mask bit is on this machine).  0 / unset: plain streams.
+  static hipError_t make_branch_stream(hipStream_t *st, int branch, int nbr) {
+    static const int div = [] { const char *e = tune_env("SF_BRANCH_CUMASK"); return e ? atoi(e) : 0; }();
+    if (div <= 0 || nbr < 2) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    hipDeviceProp_t prop;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) return e;
+    const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
+    std::vector<uint32_t> mask(words, 0u);
+    for (int k = 0; k < ncu; ++k)
+      if ((k / div) % nbr == branch) mask[k / 32] |= 1u << (k % 32);
+    return hipExtStreamCreateWithCUMask(st, (uint32_t)words, mask.data());
+  }
+  int stream_nbr = 0;   // branch count the masked streams were created for
   void ensure_branch_streams(int n) {
     if (!ev_fork) SF_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
     for (int i = 1; i < n; ++i) {
-      if (!bstream[i]) SF_HIP(hipStreamCreateWithFlags(&bstream[i], hipStreamNonBlocking));
+      if (!bstream[i]) SF_HIP(make_branch_stream(&bstream[i], i, n));
       if (!ev_join[i]) SF_HIP(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
     }
 
@@ -1768,7 +1786,7 @@ int sf_vsample(sf_unet *h, float *x, const float *const *ctx, const float *emb, 
   hipStream_t s = user;
   if (use_graph && num_steps > 1) {
     if (!h->own_stream) {
-      SF_HIP(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+      SF_HIP(sf_unet::make_branch_stream(&h->own_stream, 0, p.nbr));
       SF_HIP(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
       SF_HIP(hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming));
     }

@@ -44,23 +44,30 @@ __global__ void k_mfma_bf16(float va, float vb, float *out) {
   if (threadIdx.x == 0) out[0] = c[0];
 }
 
-// one record per workgroup: the XCD it ran on; spins a little so that the workgroups of a launch coexist
+// one record per workgroup: the XCD it ran on (bits 0-3) and its HW_ID bits 8-15 (cu_id, sh_id, se_id) in bits 8-15; spins a little so
+// that the workgroups of a launch coexist
 __global__ void k_xcc(int *out, int spin) {
   if (threadIdx.x == 0) {
     unsigned id = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (3 << 11));   // bits [3:0]
-    out[blockIdx.x] = (int)(id & 15);
+    unsigned hw = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (8 << 6) | (7 << 11));     // bits [15:8]: cu_id[11:8], sh_id[12], se_id[15:13]
+    out[blockIdx.x] = (int)((id & 15) | ((hw & 255) << 8));
   }
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)spin) {
   }
 }
 
+#include <set>
 static void histo(const char *what, const std::vector<int> &v) {
   int h[16] = {0};
-  for (int x : v) h[x & 15]++;
+  std::set<int> cus;
+  for (int x : v) {
+    h[x & 15]++;
+    cus.insert(x & 0xffff);
+  }
   printf("  %-58s XCD histogram:", what);
   for (int i = 0; i < 8; ++i) printf(" %d", h[i]);
-  printf("\n");
+  printf("   distinct (xcd, se, sh, cu): %d\n", (int)cus.size());
 }
 
 int main() {
@@ -152,6 +159,26 @@ int main() {
       }
       (void)hipStreamDestroy(sm);
     }
+  }
+  // which CU is mask bit k?  single-bit masks (every workgroup of the launch must then run on that one CU)
+  printf("== 3. single-bit CU masks: where do the workgroups run? (xcd, se, sh, cu) ==\n");
+  for (int k : {0, 1, 2, 7, 8, 9, 16, 31, 32, 33, 64, 128, 255}) {
+    std::vector<uint32_t> mask(words, 0);
+    mask[k / 32] = 1u << (k % 32);
+    hipStream_t sm;
+    if (hipExtStreamCreateWithCUMask(&sm, (uint32_t)words, mask.data()) != hipSuccess) break;
+    CK(hipMemsetAsync(dx, 0xff, 64 * sizeof(int), sm));
+    hipLaunchKernelGGL(k_xcc, dim3(64), dim3(64), 0, sm, dx, 2000);
+    CK(hipStreamSynchronize(sm));
+    CK(hipMemcpy(hx.data(), dx, 64 * sizeof(int), hipMemcpyDeviceToHost));
+    std::set<int> where(hx.begin(), hx.begin() + 64);
+    printf("  bit %3d ->", k);
+    int n = 0;
+    for (int w : where) {
+      if (n++ < 6) printf(" (x%d se%d sh%d cu%d)", w & 15, (w >> 13) & 7, (w >> 12) & 1, (w >> 8) & 15);
+    }
+    printf("%s  [%d distinct]\n", where.size() > 6 ? " ..." : "", (int)where.size());
+    (void)hipStreamDestroy(sm);
   }
   return 0;
 }
