@@ -117,6 +117,40 @@ __device__ __forceinline__ void mma_step(f32x16 &acc, const K8<float> &a, const 
   for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.get(j), b.get(j), acc, 0, 0, 0);
 }
 
+// fp32x (the split-operand mode of the fp32 engine, common.h X3P<X3_F16>): eight consecutive channels as (hi, lo') fp16 halves.  The staged
+// rows and the staged weights are split ONCE on their way into LDS (two fp16 images in the bytes of the fp32 one); operands that come
+// from registers or straight from global memory (weights of conv_thin, second source, an accumulator fed back) are split where used.
+struct K8x {
+  f16x8 h, l;
+  __device__ __forceinline__ static K8x from(const K8<float> &v) {
+    K8x r;
+    x3_split<X3_F16>(v.v[0], v.v[1], r.h, r.l);
+    return r;
+  }
+  __device__ __forceinline__ static K8x load(const f16 *ph, const f16 *pl) {
+    K8x r;
+    r.h = *reinterpret_cast<const f16x8 *>(ph);
+    r.l = *reinterpret_cast<const f16x8 *>(pl);
+    return r;
+  }
+  __device__ __forceinline__ void store(f16 *ph, f16 *pl) const {
+    *reinterpret_cast<f16x8 *>(ph) = h;
+    *reinterpret_cast<f16x8 *>(pl) = l;
+  }
+  __device__ __forceinline__ static K8x zero() {
+    K8x r;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    r.h = __builtin_bit_cast(f16x8, z);
+    r.l = r.h;
+    return r;
+  }
+};
+__device__ __forceinline__ void mma_step_x3(f32x16 &accM, f32x16 &accL, const K8x &a, const K8x &b) { x3_mfma<X3_F16>(a.h, a.l, b.h, b.l, accM, accL); }
+__device__ __forceinline__ void x3_fold(f32x16 &accM, const f32x16 &accL) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) accM[i] = fmaf(accL[i], X3P<X3_F16>::INV, accM[i]);
+}
+
 // Sum over the 32 lanes of each half-wave with DPP row operations (VALU only: no LDS crossbar traffic, unlike
 // __shfl_xor = ds_bpermute); every lane receives the total of its own half.  Fixed order -> deterministic.
 template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_mov(float v) {
@@ -211,8 +245,10 @@ template <> struct K4<float> {
 };
 
 // CIN: channels of a staged source row; NOUT: output channels (8, 32, 64); C2: channels of the concatenated second source
-template <typename T, int CIN, int TAPS, int C2, int PRO, int NOUT>
-__global__ __launch_bounds__(1024) void conv_thin_kernel(const ConvThinArgs a) {
+// (the split mode carries a second accumulator set: its instantiations are built for at most 8 waves, 256 registers each)
+template <typename T, int CIN, int TAPS, int C2, int PRO, int NOUT, bool X3 = false>
+__global__ __launch_bounds__(X3 ? 512 : 1024) void conv_thin_kernel(const ConvThinArgs a) {
+  static_assert(!X3 || sizeof(T) == 4, "split mode: fp32 activations");
   constexpr int E = 8;
   constexpr int QC = CIN / E;               // channel octets of a staged row
   constexpr int S1 = TAPS * QC, S2 = C2 / E, S = S1 + S2, NSTEP = (S + 1) / 2;
@@ -233,6 +269,9 @@ __global__ __launch_bounds__(1024) void conv_thin_kernel(const ConvThinArgs a) {
   float *ep = sh + CIN;     // epilogue vectors: bias | per-clip scale | per-clip add, 64 floats each (fetched up front)
   float *part = ep + 192;   // [tile][G][2]
   T *tile = reinterpret_cast<T *>(part + kThinMaxTiles * kThinMaxG * 2);
+  // split mode: the staged rows as two fp16 images in the same bytes (thin_lds_bytes reserves (rw >> up_shift) + 2 HALO + 2 rows)
+  f16 *tileH = reinterpret_cast<f16 *>(tile);
+  f16 *tileL = tileH + (size_t)((a.rw >> a.up_shift) + 2 * HALO + 2) * SROW;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = blockDim.x >> 6;
   const int half = lane >> 5, l32 = lane & 31;
@@ -360,7 +399,8 @@ __global__ __launch_bounds__(1024) void conv_thin_kernel(const ConvThinArgs a) {
           v.set(e, fmaf(y, sc[q * E + e], sh[q * E + e]));
         }
       }
-      v.store(tile + rr * SROW + q * E);
+      if constexpr (X3) K8x::from(v).store(tileH + rr * SROW + q * E, tileL + rr * SROW + q * E);
+      else v.store(tile + rr * SROW + q * E);
     }
   }
   __syncthreads();
@@ -387,6 +427,29 @@ __global__ __launch_bounds__(1024) void conv_thin_kernel(const ConvThinArgs a) {
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    if constexpr (X3) {
+      f32x16 accL;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) accL[i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < NSTEP; ++s) {
+        K8x bf;
+        if (s < NL || (MIX && s == NL)) {
+          const int slot = min(2 * s + half, S1 - 1);
+          const int tap = slot / QC, q = slot - tap * QC;
+          const int jj = ((prow + tap) >> a.up_shift) - j0;
+          bf = K8x::load(tileH + jj * SROW + q * E, tileL + jj * SROW + q * E);
+          if (MIX && s == NL) {
+            const K8x s2 = K8x::from(s2f[0]);
+            if (half) bf = s2;
+          }
+        } else {
+          bf = K8x::from(s2f[NS2 > 0 ? s - NL : 0]);
+        }
+        mma_step_x3(acc, accL, K8x::from(wload(s)), bf);
+      }
+      x3_fold(acc, accL);
+    } else {
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) {
       K8<T> bf;
@@ -404,6 +467,7 @@ __global__ __launch_bounds__(1024) void conv_thin_kernel(const ConvThinArgs a) {
       if constexpr (KEEP_W) mma_step(acc, wf[s], bf);
       else mma_step(acc, wload(s), bf);
     }
+    }
 
     // ---- epilogue: lane = position row_l, registers 4v..4v+3 = channels cb*32 + half*4 + 8v + {0..3} -----------
     float xs[4][4];
@@ -416,9 +480,17 @@ __global__ __launch_bounds__(1024) void conv_thin_kernel(const ConvThinArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) val[e] = (acc[4 * v + e] + bias[e]) * bs[e];
       if (a.res_self) {   // residual = the staged (modulated) input itself (CIN == NOUT, no upsampling)
-        const K4<T> rp = K4<T>::load(tile + (row_l + HALO) * SROW + c0);
+        if constexpr (X3) {   // (reassembled from its two halves: 22 significant bits)
+          typedef f16 f16x4_t __attribute__((ext_vector_type(4)));
+          const f16x4_t rh = *reinterpret_cast<const f16x4_t *>(tileH + (row_l + HALO) * SROW + c0);
+          const f16x4_t rl = *reinterpret_cast<const f16x4_t *>(tileL + (row_l + HALO) * SROW + c0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) val[e] += rp.get(e);
+          for (int e = 0; e < 4; ++e) val[e] += fmaf((float)rl[e], X3P<X3_F16>::INV, (float)rh[e]);
+        } else {
+          const K4<T> rp = K4<T>::load(tile + (row_l + HALO) * SROW + c0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) val[e] += rp.get(e);
+        }
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) val[e] += resf[v].get(e);
@@ -522,9 +594,9 @@ template <typename T> size_t thin_lds_bytes(int cin, int taps, int rw, int up_sh
   return (size_t)(2 * cin + 192 + kThinMaxTiles * kThinMaxG * 2) * sizeof(float) + rows * (cin + 8) * sizeof(T);
 }
 
-template <typename T, int CIN, int TAPS, int C2, int PRO, int NOUT> hipError_t thin_go(const ConvThinArgs &a, hipStream_t s) {
+template <typename T, int CIN, int TAPS, int C2, int PRO, int NOUT, bool X3 = false> hipError_t thin_go(const ConvThinArgs &a, hipStream_t s) {
   const size_t lds = thin_lds_bytes<T>(CIN, TAPS, a.rw, a.up_shift);
-  auto kern = conv_thin_kernel<T, CIN, TAPS, C2, PRO, NOUT>;
+  auto kern = conv_thin_kernel<T, CIN, TAPS, C2, PRO, NOUT, X3>;
   if (lds > 64 * 1024) {
     static bool raised = false;   // per instantiation
     if (!raised) {
@@ -536,6 +608,7 @@ template <typename T, int CIN, int TAPS, int C2, int PRO, int NOUT> hipError_t t
   constexpr int NCB = (NOUT + 31) / 32;
   int nw = ((a.rw + 31) / 32) * NCB;
   if (nw > thin_max_waves(NOUT)) nw = thin_max_waves(NOUT);
+  if (X3 && nw > 8) nw = 8;
   nw = (nw / NCB) * NCB;
   // staging registers: the source rows of a workgroup (<= rw + 2) * CIN/8 vectors must fit NV = 6 per thread
   if (((a.rw >> a.up_shift) + 3) * (CIN / 8) > 6 * nw * 64) return hipErrorInvalidValue;
@@ -556,6 +629,24 @@ constexpr ThinShape kThinShapes[] = {
     // nearest-upsample + conv3 up convolutions
     {32, 3, 0, 0, 8},  {64, 3, 0, 0, 32},  {64, 3, 0, 0, 64},
 };
+
+// the split-operand instantiations (fp32x engine): the MFMA levels (32 / 64 channels); the 8-channel level stays on the vector kernels
+static hipError_t thin_dispatch_x3(const ConvThinArgs &a, hipStream_t s) {
+#define SF_THINX(CC, TT, C22, PP, NN) \
+  if (a.C == CC && a.taps == TT && a.C2 == C22 && a.pro == PP && a.N == NN) return thin_go<float, CC, TT, C22, PP, NN, true>(a, s)
+  SF_THINX(32, 3, 0, 1, 32);
+  SF_THINX(64, 3, 0, 1, 64);
+  SF_THINX(32, 1, 32, 2, 32);
+  SF_THINX(64, 1, 32, 2, 64);
+  SF_THINX(64, 1, 64, 2, 64);
+  SF_THINX(32, 1, 0, 0, 32);
+  SF_THINX(64, 1, 0, 0, 64);
+  SF_THINX(128, 1, 0, 0, 64);
+  SF_THINX(64, 3, 0, 0, 32);
+  SF_THINX(64, 3, 0, 0, 64);
+#undef SF_THINX
+  return hipErrorInvalidValue;
+}
 
 template <typename T> hipError_t thin_dispatch(const ConvThinArgs &a, hipStream_t s) {
 #define SF_THIN(CC, TT, C22, PP, NN) \
@@ -586,8 +677,9 @@ template <typename T> hipError_t thin_dispatch(const ConvThinArgs &a, hipStream_
 // the order 16s + 8*(j >> 2) + 4*half + (j & 3), so the weight rows (A operand, staged in LDS) are read with the same
 // permutation.  The context channels follow as ordinary 8-channel slots.
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T, int C, int C2>
-__global__ __launch_bounds__(1024) void thin_tail_kernel(const ThinTailArgs a) {
+template <typename T, int C, int C2, bool X3 = false>
+__global__ __launch_bounds__(X3 ? 512 : 1024) void thin_tail_kernel(const ThinTailArgs a) {
+  static_assert(!X3 || sizeof(T) == 4, "split mode: fp32 activations");
   constexpr int E = 8;
   constexpr int QC = C / E;
   constexpr int S2 = 3 * QC, NST2 = (S2 + 1) / 2;     // conv2: slots / MFMA steps
@@ -610,6 +702,10 @@ __global__ __launch_bounds__(1024) void thin_tail_kernel(const ThinTailArgs a) {
   T *w2s = reinterpret_cast<T *>(part + kThinMaxTiles * kThinMaxG * 2);
   T *w3s = w2s + C * P2;
   T *tile = w3s + C * P3;
+  // split mode: each staged fp32 region holds two fp16 images (hi, lo') instead
+  f16 *w2H = reinterpret_cast<f16 *>(w2s), *w2L = w2H + C * P2;
+  f16 *w3H = reinterpret_cast<f16 *>(w3s), *w3L = w3H + C * P3;
+  f16 *tileH = reinterpret_cast<f16 *>(tile), *tileL = tileH + (size_t)(a.rw + 4) * SROW;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = blockDim.x >> 6;
   const int half = lane >> 5, l32 = lane & 31;
@@ -634,11 +730,15 @@ __global__ __launch_bounds__(1024) void thin_tail_kernel(const ThinTailArgs a) {
   // weights -> LDS (rows of the packed [C][K] matrices, 8 elements per thread and pass)
   for (int i = tid; i < C * (K2 / E); i += blockDim.x) {
     const int r = i / (K2 / E), v = i - r * (K2 / E);
-    K8<T>::load(static_cast<const T *>(a.w2) + (size_t)r * K2 + v * E).store(w2s + r * P2 + v * E);
+    const K8<T> w = K8<T>::load(static_cast<const T *>(a.w2) + (size_t)r * K2 + v * E);
+    if constexpr (X3) K8x::from(w).store(w2H + r * P2 + v * E, w2L + r * P2 + v * E);
+    else w.store(w2s + r * P2 + v * E);
   }
   for (int i = tid; i < C * (K3 / E); i += blockDim.x) {
     const int r = i / (K3 / E), v = i - r * (K3 / E);
-    K8<T>::load(static_cast<const T *>(a.w3) + (size_t)r * K3 + v * E).store(w3s + r * P3 + v * E);
+    const K8<T> w = K8<T>::load(static_cast<const T *>(a.w3) + (size_t)r * K3 + v * E);
+    if constexpr (X3) K8x::from(w).store(w3H + r * P3 + v * E, w3L + r * P3 + v * E);
+    else w.store(w3s + r * P3 + v * E);
   }
   // GroupNorm statistics of h, modulation vectors
   for (int g = tid >> 5; g < a.G; g += blockDim.x >> 5) {
@@ -670,7 +770,8 @@ __global__ __launch_bounds__(1024) void thin_tail_kernel(const ThinTailArgs a) {
         const float y = fmaf(v.get(e), sc[q * E + e], sh[q * E + e]);
         v.set(e, ok ? silu_t<FAST>(y) : 0.f);
       }
-      v.store(tile + rr * SROW + q * E);
+      if constexpr (X3) K8x::from(v).store(tileH + rr * SROW + q * E, tileL + rr * SROW + q * E);
+      else v.store(tile + rr * SROW + q * E);
     }
   }
   __syncthreads();
@@ -701,6 +802,30 @@ __global__ __launch_bounds__(1024) void thin_tail_kernel(const ThinTailArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[cb][i] = 0.f;
     const int prow = rvalid ? row_l : 0;
+    if constexpr (X3) {
+      f32x16 accL[NCB];
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accL[cb][i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < NST2; ++s) {
+        const int slot = min(2 * s + half, S2 - 1);
+        const bool sv = 2 * s + half < S2;
+        const int tap = slot / QC, q = slot - tap * QC;
+        K8x bf = K8x::load(tileH + (prow + tap) * SROW + q * E, tileL + (prow + tap) * SROW + q * E);
+        if (!sv) bf = K8x::zero();
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+          const int c = cb * 32 + l32;
+          K8x af = K8x::load(w2H + min(c, C - 1) * P2 + slot * E, w2L + min(c, C - 1) * P2 + slot * E);
+          if (c >= C || !sv) af = K8x::zero();
+          mma_step_x3(acc[cb], accL[cb], af, bf);
+        }
+      }
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) x3_fold(acc[cb], accL[cb]);
+    } else {
 #pragma unroll
     for (int s = 0; s < NST2; ++s) {
       const int slot = min(2 * s + half, S2 - 1);
@@ -715,6 +840,7 @@ __global__ __launch_bounds__(1024) void thin_tail_kernel(const ThinTailArgs a) {
         if (c >= C || !sv) af = K8<T>::zero();
         mma_step(acc[cb], af, bf);
       }
+    }
     }
     // ---- y = conv2 + bias + x;  LayerNorm over the C channels of the position; modulate ------------------------------
     float sum = 0.f;
@@ -771,6 +897,53 @@ __global__ __launch_bounds__(1024) void thin_tail_kernel(const ThinTailArgs a) {
     for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) zc[cb][i] = 0.f;
+    if constexpr (X3) {
+      typedef f16 f16x4_t __attribute__((ext_vector_type(4)));
+      f32x16 zl[NCB];
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) zl[cb][i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < NSTM; ++s) {
+        K8<float> bf32;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bf32.set(j, acc[s >> 1][8 * (s & 1) + j]);
+        const K8x bf = K8x::from(bf32);   // the modulated tile, split in registers
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+          const int c = cb * 32 + l32;
+          const int o = min(c, C - 1) * P3 + 16 * s + 4 * half;
+          const f16x4_t h0 = *reinterpret_cast<const f16x4_t *>(w3H + o), h1 = *reinterpret_cast<const f16x4_t *>(w3H + o + 8);
+          const f16x4_t l0 = *reinterpret_cast<const f16x4_t *>(w3L + o), l1 = *reinterpret_cast<const f16x4_t *>(w3L + o + 8);
+          K8x af;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const bool k0 = c < C && 16 * s + 4 * half + j < C, k1 = c < C && 16 * s + 8 + 4 * half + j < C;
+            af.h[j] = k0 ? h0[j] : (f16)0.f;
+            af.l[j] = k0 ? l0[j] : (f16)0.f;
+            af.h[4 + j] = k1 ? h1[j] : (f16)0.f;
+            af.l[4 + j] = k1 ? l1[j] : (f16)0.f;
+          }
+          mma_step_x3(zc[cb], zl[cb], af, bf);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NSTC; ++i) {
+        const int q2 = 2 * i + half;
+        const K8x cx = K8x::from(cf[i]);
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+          const int c = cb * 32 + l32;
+          const int o = min(c, C - 1) * P3 + C + min(q2, SC - 1) * E;
+          K8x af = K8x::load(w3H + o, w3L + o);
+          if (c >= C || q2 >= SC) af = K8x::zero();
+          mma_step_x3(zc[cb], zl[cb], af, cx);
+        }
+      }
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) x3_fold(zc[cb], zl[cb]);
+    } else {
 #pragma unroll
     for (int s = 0; s < NSTM; ++s) {
       // B operand: registers 8*(s&1) ... +7 of block s >> 1  <->  channels 16 s + 8 (j >> 2) + 4 half + (j & 3)
@@ -801,6 +974,7 @@ __global__ __launch_bounds__(1024) void thin_tail_kernel(const ThinTailArgs a) {
         if (c >= C || q2 >= SC) af = K8<T>::zero();
         mma_step(zc[cb], af, cf[i]);
       }
+    }
     }
     // ---- epilogue: + bias + m (+ per-clip bias), store, GroupNorm partial of the stored values ------------------------------
     float xs[NCB][4][4];
@@ -890,9 +1064,9 @@ template <typename T> size_t tail_lds_bytes(int C, int C2, int rw) {
          ((size_t)C * (3 * C + 8) + (size_t)C * (C + C2 + 8) + (size_t)(rw + 4) * (C + 8)) * sizeof(T);
 }
 
-template <typename T, int C, int C2> hipError_t tail_go(const ThinTailArgs &a, hipStream_t s) {
+template <typename T, int C, int C2, bool X3 = false> hipError_t tail_go(const ThinTailArgs &a, hipStream_t s) {
   const size_t lds = tail_lds_bytes<T>(C, C2, a.rw);
-  auto kern = thin_tail_kernel<T, C, C2>;
+  auto kern = thin_tail_kernel<T, C, C2, X3>;
   if (lds > 64 * 1024) {
     static bool raised = false;
     if (!raised) {
@@ -903,6 +1077,7 @@ template <typename T, int C, int C2> hipError_t tail_go(const ThinTailArgs &a, h
   }
   int nw = (a.rw + 31) / 32;
   if (nw > thin_max_waves(C)) nw = thin_max_waves(C);
+  if (X3 && nw > 8) nw = 8;
   if ((a.rw + 2) * (C / 8) > 6 * nw * 64) return hipErrorInvalidValue;
   hipLaunchKernelGGL(kern, dim3(a.B * a.nchw), dim3(nw * 64), lds, s, a);
   return hipGetLastError();
@@ -937,6 +1112,11 @@ bool thin_tail_supported(int dt, const ThinTailArgs &a) {
 hipError_t launch_thin_tail(int dt, const ThinTailArgs &a, hipStream_t s) {
   if (!thin_tail_supported(dt, a)) return hipErrorInvalidValue;
   if (d0_tail_supported(a)) return launch_d0_tail(dt, a, s);
+  if (dt == F32 && a.x3) {   // split-operand instantiations (the 8-channel level stays on the vector / fp32 kernels)
+    if (a.C == 32 && a.C2 == 32) return tail_go<float, 32, 32, true>(a, s);
+    if (a.C == 64 && a.C2 == 32) return tail_go<float, 64, 32, true>(a, s);
+    if (a.C == 64 && a.C2 == 64) return tail_go<float, 64, 64, true>(a, s);
+  }
   return SF_DISPATCH_T(dt, tail_dispatch<T>(a, s));
 }
 
@@ -1005,6 +1185,10 @@ bool conv_thin_supported(int dt, const ConvThinArgs &a) {
 hipError_t launch_conv_thin(int dt, const ConvThinArgs &a, hipStream_t s) {
   if (!conv_thin_supported(dt, a)) return hipErrorInvalidValue;
   if (d0_conv_supported(a)) return launch_d0_conv(dt, a, s);
+  if (dt == F32 && a.x3) {
+    const hipError_t e = thin_dispatch_x3(a, s);
+    if (e != hipErrorInvalidValue) return e;   // (shapes without a split instantiation run in fp32)
+  }
   return SF_DISPATCH_T(dt, thin_dispatch<T>(a, s));
 }
 

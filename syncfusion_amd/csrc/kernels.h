@@ -170,6 +170,7 @@ struct ConvThinArgs {
   int pro = 0, res_self = 0, G = 1, nch_in = 1, chunk_in = 1;
   float eps = 1e-5f;
   int rw = 32, nchw = 1;
+  int x3 = 0;   // fp32 launches: products from split fp16 operands (the fp32x engine)
 };
 struct ThinPlan {
   int rw = 32, nchw = 1;
@@ -188,6 +189,7 @@ struct ThinTailArgs {
   int B = 0, L = 0, C = 0, C2 = 0, ctx_ld = 0, ss_ld = 0, badd_ld = 0, G = 1, nch_in = 1, chunk_in = 1;
   float eps_gn = 1e-5f, eps_ln = 1e-6f;
   int rw = 32, nchw = 1;
+  int x3 = 0;   // fp32 launches: products from split fp16 operands (the fp32x engine)
 };
 bool thin_tail_supported(int dt, const ThinTailArgs &a);
 hipError_t launch_thin_tail(int dt, const ThinTailArgs &a, hipStream_t s);

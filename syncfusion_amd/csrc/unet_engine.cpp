@@ -1250,6 +1250,7 @@ struct Exec {
     base.nch_in = tp.nchw;
     base.chunk_in = tp.rw;
     base.src_ld = base.out_ld = base.res_ld = C;
+    base.x3 = u.x3 ? 1 : 0;
     ConvThinArgs a1 = base, a3 = base;
     a1.taps = 3;
     a1.pro = 1;
@@ -1278,6 +1279,7 @@ struct Exec {
     // conv2 + Modulation + InjectChannels in one launch when the fused tail covers the shape
     {
       ThinTailArgs t;
+      t.x3 = u.x3 ? 1 : 0;
       t.h = tA;
       t.x = cur;
       t.ctx = l.ctx;
@@ -1386,6 +1388,7 @@ struct Exec {
     if (!b.down.direct && xin_dt == u.dt) {   // patchify conv on the (rows/f, f*cin) view as a thin-level kernel
       const ThinPlan tp = conv_thin_plan(p.Bt, l.L, l.C);
       ConvThinArgs a;
+      a.x3 = u.x3 ? 1 : 0;
       a.B = p.Bt;
       a.L = a.Ls = l.L;
       a.C = b.factor * b.cin;
@@ -1476,6 +1479,7 @@ struct Exec {
     if (!up_done && !b.up.direct && xout_dt == u.dt && xin_dt == u.dt) {   // nearest-upsample + conv3 + SkipModulate as a thin-level kernel
       const ThinPlan tp = conv_thin_plan(p.Bt, Lprev, b.cin);
       ConvThinArgs a;
+      a.x3 = u.x3 ? 1 : 0;
       a.B = p.Bt;
       a.L = Lprev;
       a.Ls = l.L;
