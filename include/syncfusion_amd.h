@@ -290,6 +290,9 @@ int sf_op_attention_fwd_lse(const float *q, const float *kv, int B, int L, int h
 int sf_op_attention_fwd_lse_x(int dtype, const float *q, const float *kv, int B, int L, int heads, int head_dim, float *out, float *lse, void *stream);
 int sf_op_attention_bwd_lse(const float *q, const float *kv, const float *out, const float *dout, const float *lse, int B, int L, int heads, int head_dim,
                             float *dq, float *dkv, void *ws, int64_t ws_bytes, void *stream);
+/* the same with the arithmetic chosen by `dtype` (SF_F32, or SF_F32X: scores from split fp16 operands, the gradient products from split bf16 operands) */
+int sf_op_attention_bwd_lse_x(int dtype, const float *q, const float *kv, const float *out, const float *dout, const float *lse, int B, int L, int heads,
+                              int head_dim, float *dq, float *dkv, void *ws, int64_t ws_bytes, void *stream);
 /* Kernel tuning aid: average milliseconds of `iters` back-to-back launches of one channels-last conv1d
  * (x:(B,L,C) -> (B,L*upsample,N), `taps` taps, bias + residual epilogue) with a forced kernel family
  * (path 0 auto, 1 classic, 2 wave-split-K, 4 v2), tile variant (-1 auto) and grid split-K factor (-1 auto). */

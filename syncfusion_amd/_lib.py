@@ -106,6 +106,7 @@ SYMBOLS = {
     "sf_op_attention_fwd_lse": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "sf_op_attention_fwd_lse_x": (_I, [_I, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "sf_op_attention_bwd_lse": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _L, _P]),
+    "sf_op_attention_bwd_lse_x": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _L, _P]),
     "sf_op_length_sums_workspace_bytes": (_L, [_I, _I, _I]),
     "sf_op_length_sums": (_I, [_P, _P, _I, _I, _I, _P, _P, _L, _P]),
     "sf_bench_conv1d": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_float)]),

@@ -265,8 +265,9 @@ class _AttentionFn(torch.autograd.Function):
             doc = _lib.f32c(dout)
             dq, dkv = torch.empty_like(qc), torch.empty_like(kc)
             ws = torch.empty(B * H * L * 4 + 256, dtype=torch.uint8, device=dev)
-            _lib.check(lib.sf_op_attention_bwd_lse(qc.data_ptr(), kc.data_ptr(), out.data_ptr(), doc.data_ptr(), lse.data_ptr(), B, L, H, D, dq.data_ptr(),
-                                                   dkv.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)), "sf_op_attention_bwd_lse")
+            _lib.check(lib.sf_op_attention_bwd_lse_x(_lib.DTYPES[GEMM_DTYPE], qc.data_ptr(), kc.data_ptr(), out.data_ptr(), doc.data_ptr(), lse.data_ptr(), B, L, H,
+                                                     D, dq.data_ptr(), dkv.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)),
+                       "sf_op_attention_bwd_lse_x")
         return dq, dkv, None
 
 

@@ -490,6 +490,242 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_mfma_kernel(const float *__re
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The backward pass on split 16-bit operands (SF_F32X).  Same tiling and the same accumulator-as-operand trick as the fp32 kernels above;
+// 48 MFMAs of 32 cycles per 32 x 32 tile and wave instead of 96 / 128 of 64.  Which split a product takes follows its operands:
+//   S  = q k^T   : both are forward activations -> fp16 hi / 2048-scaled lo (22 bits per operand): P = exp(S / 8 - lse) amplifies the absolute
+//                  error of S, so the scores get the accurate mode;
+//   dP, dQ, dK, dV: one operand is a gradient (dO, dS), which spans the whole fp32 exponent range -> bf16 hi / lo (no range restriction).
+// Tiles that are read row-wise (a row per lane, 8 consecutive head dims: the A operand of S and dP) sit in LDS at a 144-byte pitch, tiles
+// that are read column-wise (the B operand of dQ / dK / dV: 8 consecutive rows of one head dim per lane) at a 192-byte pitch and are
+// gathered by the hardware transpose read; a tile that is read both ways is staged twice.  Requires the forward pass's log-sum-exp.
+// ---------------------------------------------------------------------------------------------------------------
+typedef bf16 bf16x4_a __attribute__((ext_vector_type(4)));
+template <int MODE> __device__ __forceinline__ void tile_store_split(typename X3P<MODE>::elem *hi, typename X3P<MODE>::elem *lo, const TileRegs &t, int tid,
+                                                                    int pitch) {
+  using E = typename X3P<MODE>::elem;
+  typedef E E4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int idx = tid + 256 * e, r = idx >> 4, c4 = idx & 15;
+    E4 h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      E a, b;
+      x3_split1<MODE>(t.v[e][j], a, b);
+      h[j] = a;
+      l[j] = b;
+    }
+    *reinterpret_cast<E4 *>(hi + r * pitch + 4 * c4) = h;
+    *reinterpret_cast<E4 *>(lo + r * pitch + 4 * c4) = l;
+  }
+}
+// a lane's 64 values of one row (head dims 16 s + 8 hf .. + 7 of step s) as split B-operand fragments
+template <int MODE>
+__device__ __forceinline__ void row_frags(const float *p, bool valid, float mul, typename X3P<MODE>::v8 (&hi)[4], typename X3P<MODE>::v8 (&lo)[4]) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    f32x4 a = valid ? *reinterpret_cast<const f32x4 *>(p + 16 * s) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 c = valid ? *reinterpret_cast<const f32x4 *>(p + 16 * s + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      a[e] *= mul;
+      c[e] *= mul;
+    }
+    x3_split<MODE>(a, c, hi[s], lo[s]);
+  }
+}
+template <int MODE> __device__ __forceinline__ void split8(const float *v, typename X3P<MODE>::v8 &hi, typename X3P<MODE>::v8 &lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    typename X3P<MODE>::elem a, b;
+    x3_split1<MODE>(v[j], a, b);
+    hi[j] = a;
+    lo[j] = b;
+  }
+}
+__device__ __forceinline__ bf16x8 tr_frag_bf16(const bf16 *base, int pitch) {
+  const v4i16_a a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_a *)(base));
+  const v4i16_a c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_a *)(base + 8 * pitch));
+  const v8i16_a both = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+  return __builtin_bit_cast(bf16x8, both);
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_q_x3_kernel(const float *__restrict__ q, const float *__restrict__ kv, const float *__restrict__ o,
+                                                            const float *__restrict__ dout, int L, int H, float scale, float *__restrict__ dq,
+                                                            float *__restrict__ dsum_out, const float *__restrict__ lse_in) {
+  __shared__ __attribute__((aligned(16))) f16 KrH[TILE * KP16], KrL[TILE * KP16];       // K rows, fp16 split: S^T = K q^T
+  __shared__ __attribute__((aligned(16))) bf16 VrH[TILE * KP16], VrL[TILE * KP16];      // V rows, bf16 split: dP^T = V dO^T
+  __shared__ __attribute__((aligned(16))) bf16 KcH[TILE * VP16], KcL[TILE * VP16];      // K again, bf16 split, column reads: dQ += dS K
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, hf = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int ldq = H * HD, ldkv = 2 * H * HD;
+  const size_t rb = (size_t)b * L;
+  const int qbase = blockIdx.x * 128 + wave * 32;
+  const int qi = qbase + li;
+  const bool qv = qi < L;
+  f16x8 qh[4], ql[4];
+  bf16x8 doh[4], dol[4];
+  float dd = 0.f;
+  {
+    const size_t off = (rb + (qv ? qi : 0)) * ldq + h * HD + 8 * hf;
+    row_frags<X3_F16>(q + off, qv, scale, qh, ql);      // the scores come out already scaled by 1 / 8
+    row_frags<X3_BF16>(dout + off, qv, 1.0f, doh, dol);
+    if (qv) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dd = fmaf(dout[off + 16 * s + e], o[off + 16 * s + e], dd);   // D_i = dO_i . O_i (this half's 32 head dims)
+    }
+  }
+  dd += __shfl_xor(dd, 32);
+  const float lse = qv ? lse_in[((size_t)b * H + h) * L + qi] : 0.f;
+  if (hf == 0 && qv) dsum_out[((size_t)b * H + h) * L + qi] = dd;
+  const int nkt = (L + TILE - 1) / TILE;
+  TileRegs pk, pv;
+  f32x16 acc0 = zero16(), acc1 = zero16();   // (bf16 products: one accumulator each, x3_mfma1_bf16)
+  tile_fetch(pk, kv, rb, 0, L, ldkv, h * HD, tid);
+  tile_fetch(pv, kv, rb, 0, L, ldkv, (H + h) * HD, tid);
+  const int tr_off = (4 * hf + ((lane & 15) >> 2)) * VP16 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();
+    tile_store_split<X3_F16>(KrH, KrL, pk, tid, KP16);
+    tile_store_split<X3_BF16>(KcH, KcL, pk, tid, VP16);
+    tile_store_split<X3_BF16>(VrH, VrL, pv, tid, KP16);
+    __syncthreads();
+    if (kt + 1 < nkt) {
+      tile_fetch(pk, kv, rb, (kt + 1) * TILE, L, ldkv, h * HD, tid);
+      tile_fetch(pv, kv, rb, (kt + 1) * TILE, L, ldkv, (H + h) * HD, tid);
+    }
+    f32x16 sm = zero16(), sl = zero16(), dpm = zero16();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int o16 = li * KP16 + 16 * s + 8 * hf;
+      x3_mfma<X3_F16>(*reinterpret_cast<const f16x8 *>(KrH + o16), *reinterpret_cast<const f16x8 *>(KrL + o16), qh[s], ql[s], sm, sl);
+      x3_mfma1_bf16(*reinterpret_cast<const bf16x8 *>(VrH + o16), *reinterpret_cast<const bf16x8 *>(VrL + o16), doh[s], dol[s], dpm);
+    }
+    float ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float sc = fmaf(sl[r], X3P<X3_F16>::INV, sm[r]);
+      const float p = (kt * TILE + acc_row(r, hf) < L) ? expf(sc - lse) : 0.f;
+      ds[r] = p * (dpm[r] - dd) * scale;
+    }
+    // dQ += dS K: the lane's dS values in accumulator order are its A operand (keys 16 s + 8 (j / 4) + 4 hf + j % 4), K columns by two
+    // transposed reads per fragment
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 dh, dl;
+      split8<X3_BF16>(ds + 8 * s, dh, dl);
+      const int ob = (16 * s) * VP16 + tr_off;
+      x3_mfma1_bf16(dh, dl, tr_frag_bf16(KcH + ob, VP16), tr_frag_bf16(KcL + ob, VP16), acc0);
+      x3_mfma1_bf16(dh, dl, tr_frag_bf16(KcH + ob + 32, VP16), tr_frag_bf16(KcL + ob + 32, VP16), acc1);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = qbase + acc_row(r, hf);
+    if (row < L) {
+      float *p = dq + (rb + row) * ldq + h * HD + li;
+      p[0] = acc0[r];
+      p[32] = acc1[r];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_kv_x3_kernel(const float *__restrict__ q, const float *__restrict__ kv, const float *__restrict__ dout,
+                                                             const float *__restrict__ lse, const float *__restrict__ dsum, int L, int H, float scale,
+                                                             float *__restrict__ dkv) {
+  __shared__ __attribute__((aligned(16))) f16 QrH[TILE * KP16], QrL[TILE * KP16];       // Q rows, fp16 split: S = Q k^T
+  __shared__ __attribute__((aligned(16))) bf16 OrH[TILE * KP16], OrL[TILE * KP16];      // dO rows, bf16 split: dP = dO v^T
+  __shared__ __attribute__((aligned(16))) bf16 QcH[TILE * VP16], QcL[TILE * VP16];      // Q again, bf16 split, column reads: dK += dS^T Q
+  __shared__ __attribute__((aligned(16))) bf16 OcH[TILE * VP16], OcL[TILE * VP16];      // dO again, column reads: dV += P^T dO
+  __shared__ float lse_s[TILE], dsum_s[TILE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, hf = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int ldq = H * HD, ldkv = 2 * H * HD;
+  const size_t rb = (size_t)b * L;
+  const int kbase = blockIdx.x * 128 + wave * 32;
+  const int kj = kbase + li;
+  const bool kvld = kj < L;
+  f16x8 kh[4], kl[4];
+  bf16x8 vh[4], vl[4];
+  {
+    const size_t off = (rb + (kvld ? kj : 0)) * ldkv + h * HD + 8 * hf;
+    row_frags<X3_F16>(kv + off, kvld, scale, kh, kl);
+    row_frags<X3_BF16>(kv + off + H * HD, kvld, 1.0f, vh, vl);
+  }
+  const float *lp = lse + ((size_t)b * H + h) * L, *dp_ = dsum + ((size_t)b * H + h) * L;
+  f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();   // (bf16 products: one accumulator each)
+  const int nqt = (L + TILE - 1) / TILE;
+  TileRegs pq, po;
+  float pl = 0.f, pd = 0.f;
+  tile_fetch(pq, q, rb, 0, L, ldq, h * HD, tid);
+  tile_fetch(po, dout, rb, 0, L, ldq, h * HD, tid);
+  if (tid < TILE) {
+    pl = tid < L ? lp[tid] : INFINITY;
+    pd = tid < L ? dp_[tid] : 0.f;
+  }
+  const int tr_off = (4 * hf + ((lane & 15) >> 2)) * VP16 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  for (int qt = 0; qt < nqt; ++qt) {
+    __syncthreads();
+    tile_store_split<X3_F16>(QrH, QrL, pq, tid, KP16);
+    tile_store_split<X3_BF16>(QcH, QcL, pq, tid, VP16);
+    tile_store_split<X3_BF16>(OrH, OrL, po, tid, KP16);
+    tile_store_split<X3_BF16>(OcH, OcL, po, tid, VP16);
+    if (tid < TILE) {
+      lse_s[tid] = pl;
+      dsum_s[tid] = pd;
+    }
+    __syncthreads();
+    if (qt + 1 < nqt) {
+      tile_fetch(pq, q, rb, (qt + 1) * TILE, L, ldq, h * HD, tid);
+      tile_fetch(po, dout, rb, (qt + 1) * TILE, L, ldq, h * HD, tid);
+      if (tid < TILE) {
+        const int i = (qt + 1) * TILE + tid;
+        pl = i < L ? lp[i] : INFINITY;
+        pd = i < L ? dp_[i] : 0.f;
+      }
+    }
+    f32x16 sm = zero16(), sl = zero16(), dpm = zero16();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int o16 = li * KP16 + 16 * s + 8 * hf;
+      x3_mfma<X3_F16>(*reinterpret_cast<const f16x8 *>(QrH + o16), *reinterpret_cast<const f16x8 *>(QrL + o16), kh[s], kl[s], sm, sl);
+      x3_mfma1_bf16(*reinterpret_cast<const bf16x8 *>(OrH + o16), *reinterpret_cast<const bf16x8 *>(OrL + o16), vh[s], vl[s], dpm);
+    }
+    float p[16], ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = acc_row(r, hf);
+      p[r] = expf(fmaf(sl[r], X3P<X3_F16>::INV, sm[r]) - lse_s[i]);
+      ds[r] = p[r] * (dpm[r] - dsum_s[i]) * scale;
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 ph, pl8, dh, dl;
+      split8<X3_BF16>(p + 8 * s, ph, pl8);
+      split8<X3_BF16>(ds + 8 * s, dh, dl);
+      const int ob = (16 * s) * VP16 + tr_off;
+      x3_mfma1_bf16(ph, pl8, tr_frag_bf16(OcH + ob, VP16), tr_frag_bf16(OcL + ob, VP16), dv0);
+      x3_mfma1_bf16(ph, pl8, tr_frag_bf16(OcH + ob + 32, VP16), tr_frag_bf16(OcL + ob + 32, VP16), dv1);
+      x3_mfma1_bf16(dh, dl, tr_frag_bf16(QcH + ob, VP16), tr_frag_bf16(QcL + ob, VP16), dk0);
+      x3_mfma1_bf16(dh, dl, tr_frag_bf16(QcH + ob + 32, VP16), tr_frag_bf16(QcL + ob + 32, VP16), dk1);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = kbase + acc_row(r, hf);
+    if (row < L) {
+      float *pk_ = dkv + (rb + row) * ldkv + h * HD + li;
+      pk_[0] = dk0[r];
+      pk_[32] = dk1[r];
+      pk_[H * HD] = dv0[r];
+      pk_[H * HD + 32] = dv1[r];
+    }
+  }
+}
+
 }  // namespace
 
 bool attention_f32_mfma_ok(int ldq, int ldkv, int ldo, int B, int H) { return (ldkv % 4) == 0 && (ldo % 4) == 0 && ldq > 0 && B <= 65535 && H <= 65535; }
@@ -509,10 +745,15 @@ hipError_t launch_attention_f32_mfma(const float *q, int ldq, const float *kv, i
 
 // q, o, dout, dq: (B, L, H*64);  kv, dkv: (B, L, 2*H*64);  lse, dsum: (B, H, L) scratch
 hipError_t launch_attention_bwd(const float *q, const float *kv, const float *o, const float *dout, int B, int L, int H, int D, float *dq, float *dkv,
-                                float *lse, float *dsum, hipStream_t s, const float *lse_fwd) {
+                                float *lse, float *dsum, hipStream_t s, const float *lse_fwd, bool x3) {
   if (D != HD || L < 1 || B < 1 || H < 1 || H > 65535 || B > 65535) return hipErrorInvalidValue;
   const float scale = 1.0f / sqrtf((float)HD);
   const dim3 grid((L + 127) / 128, H, B);
+  if (x3 && lse_fwd) {   // split-operand kernels (they take the forward pass's log-sum-exp)
+    hipLaunchKernelGGL(attn_bwd_q_x3_kernel, grid, dim3(256), 0, s, q, kv, o, dout, L, H, scale, dq, dsum, lse_fwd);
+    hipLaunchKernelGGL(attn_bwd_kv_x3_kernel, grid, dim3(256), 0, s, q, kv, dout, lse_fwd, dsum, L, H, scale, dkv);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(attn_bwd_q_mfma_kernel, grid, dim3(256), 0, s, q, kv, o, dout, L, H, scale, dq, lse, dsum, lse_fwd);
   hipLaunchKernelGGL(attn_bwd_kv_mfma_kernel, grid, dim3(256), 0, s, q, kv, dout, lse_fwd ? lse_fwd : lse, dsum, L, H, scale, dkv);
   return hipGetLastError();

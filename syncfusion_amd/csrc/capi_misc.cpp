@@ -164,9 +164,15 @@ int sf_op_conv1d_cl(int dtype, const void *x, const float *w, const float *bias,
   const int K = taps * C;
   const void *wp = w;   // fp32 1x1 convolutions: the PyTorch layout (N, C, 1) IS the GEMM's [N][K] (60 % of the training step's convolutions)
   // (the kernels read weights as 16-byte vectors: a view at a storage offset that is not a multiple of 4 floats is packed like the rest)
+  void *wx_done = nullptr;
   if (!(taps == 1 && wdt == F32 && (reinterpret_cast<uintptr_t>(w) % 16) == 0)) {
     void *packed = wk.alloc((int64_t)N * K * dsize(wdt));
-    SF_HIP(launch_pack_conv(wdt, w, N, C, 0, C, taps, C, nullptr, packed, K, 0, s));
+    if (x3 && !direct && (K % 32) == 0) {   // fp32 matrix and its split image in one pass
+      wx_done = wk.alloc((int64_t)N * K * 4);
+      SF_HIP(launch_pack_conv_x(w, N, C, taps, static_cast<float *>(packed), wx_done, X3_F16, s));
+    } else {
+      SF_HIP(launch_pack_conv(wdt, w, N, C, 0, C, taps, C, nullptr, packed, K, 0, s));
+    }
     wp = packed;
   }
   ConvGemmArgs a;
@@ -175,7 +181,8 @@ int sf_op_conv1d_cl(int dtype, const void *x, const float *w, const float *bias,
     SF_HIP(launch_pack_wfr(dtype, wp, N, K, wfr, s));
     a.wfr = wfr;
   }
-  if (x3 && !direct && (K % 32) == 0) {
+  if (wx_done) a.wx = wx_done;
+  else if (x3 && !direct && (K % 32) == 0) {
     void *wx = wk.alloc((int64_t)N * K * 4);
     SF_HIP(launch_pack_wx(static_cast<const float *>(wp), N, K, wx, s));
     a.wx = wx;
@@ -199,6 +206,7 @@ int sf_op_conv1d_cl(int dtype, const void *x, const float *w, const float *bias,
   a.n_store = N;
   a.res = residual;
   a.res_ld = N;
+  a.solo = 1;   // op-level entry (the training step's single stream)
   if (groups > 0) {
     GnPlan gp = gn_plan(B, L, C);
     float *slab = wk.alloc_n<float>((int64_t)B * gp.nch * groups * 2);

@@ -81,7 +81,9 @@ static int conv1d_bwd_impl(int dtype, const float *x, const float *act_saved, co
   // (dx == NULL: the input needs no gradient -- the first convolution on the raw waveform, a frozen trunk -- and without a GroupNorm
   // in front nothing else depends on da: the whole data gradient is skipped; likewise dw == NULL skips the weight gradient)
   if (dx || groups > 0) {
-    SF_HIP(launch_pack_dgrad(w, N, C, taps, p.ldn, p.wd, s));
+    const bool direct_dg = (N % 32) != 0;
+    const bool wx_dg = x3 && !direct_dg && ((taps * p.ldn) % 32) == 0;
+    SF_HIP(launch_pack_dgrad(w, N, C, taps, p.ldn, p.wd, s, wx_dg ? p.wdx : nullptr));
     ConvGemmArgs a;
     a.src = dy;
     a.src_ld = N;
@@ -97,10 +99,10 @@ static int conv1d_bwd_impl(int dtype, const float *x, const float *act_saved, co
     a.out = groups > 0 ? p.da : dx;
     a.out_ld = C;
     a.n_store = C;
+    a.solo = 1;
     const bool direct = (N % 32) != 0;
     if (direct && C > 32) fail(SF_ERR_UNSUPPORTED, "dgrad of a thin convolution (N %% 32 != 0) needs C <= 32");
-    if (x3 && !direct && (a.K % 32) == 0) {   // fp32-accurate products from split fp16 operands (kernels.h, ConvGemmArgs::wx)
-      SF_HIP(launch_pack_wx(p.wd, C, a.K, p.wdx, s, X3_BF16));   // gradients span the whole fp32 exponent range: the bf16 split
+    if (wx_dg) {   // products from split bf16 operands (gradients span the whole fp32 exponent range); image written by launch_pack_dgrad
       a.wx = p.wdx;
       a.wx_mode = X3_BF16;
     }
@@ -220,16 +222,27 @@ static int attention_fwd_lse_impl(int dtype, const float *q, const float *kv, in
   SF_API_END
 }
 
+static int attention_bwd_lse_impl(int dtype, const float *q, const float *kv, const float *out, const float *dout, const float *lse, int B, int L, int heads,
+                                  int head_dim, float *dq, float *dkv, void *ws, int64_t ws_bytes, void *stream);
 int sf_op_attention_bwd_lse(const float *q, const float *kv, const float *out, const float *dout, const float *lse, int B, int L, int heads, int head_dim,
                             float *dq, float *dkv, void *ws, int64_t ws_bytes, void *stream) {
+  return attention_bwd_lse_impl(SF_F32, q, kv, out, dout, lse, B, L, heads, head_dim, dq, dkv, ws, ws_bytes, stream);
+}
+int sf_op_attention_bwd_lse_x(int dtype, const float *q, const float *kv, const float *out, const float *dout, const float *lse, int B, int L, int heads,
+                              int head_dim, float *dq, float *dkv, void *ws, int64_t ws_bytes, void *stream) {
+  return attention_bwd_lse_impl(dtype, q, kv, out, dout, lse, B, L, heads, head_dim, dq, dkv, ws, ws_bytes, stream);
+}
+static int attention_bwd_lse_impl(int dtype, const float *q, const float *kv, const float *out, const float *dout, const float *lse, int B, int L, int heads,
+                                  int head_dim, float *dq, float *dkv, void *ws, int64_t ws_bytes, void *stream) {
   SF_API_BEGIN
+  if (dtype != SF_F32 && dtype != SF_F32X) fail(SF_ERR_INVALID, "dtype must be SF_F32 or SF_F32X");
   if (!q || !kv || !out || !dout || !lse || !dq || !dkv || !ws) fail(SF_ERR_INVALID, "null argument");
   if (head_dim != 64) fail(SF_ERR_UNSUPPORTED, "head_dim must be 64");
   if (B < 1 || L < 1 || heads < 1) fail(SF_ERR_INVALID, "B, L and heads must be positive");
   const int64_t need = (int64_t)B * heads * L * (int64_t)sizeof(float);
   if (ws_bytes < need) fail(SF_ERR_WORKSPACE, "workspace too small: need %lld bytes", (long long)need);
   float *dsum = static_cast<float *>(ws);
-  SF_HIP(launch_attention_bwd(q, kv, out, dout, B, L, heads, head_dim, dq, dkv, nullptr, dsum, static_cast<hipStream_t>(stream), lse));
+  SF_HIP(launch_attention_bwd(q, kv, out, dout, B, L, heads, head_dim, dq, dkv, nullptr, dsum, static_cast<hipStream_t>(stream), lse, dtype == SF_F32X));
   return SF_OK;
   SF_API_END
 }

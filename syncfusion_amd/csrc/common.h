@@ -88,6 +88,12 @@ template <int MODE> __device__ __forceinline__ void x3_split(const f32x4 p, cons
     lo[4 + e] = l;
   }
 }
+// the bf16 split needs no scale, so its three products can share ONE accumulator (half the accumulator registers: a second workgroup per CU)
+__device__ __forceinline__ void x3_mfma1_bf16(const bf16x8 ah, const bf16x8 al, const bf16x8 bh, const bf16x8 bl, f32x16 &acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);   // small terms first
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+}
 // four consecutive channels c0 .. c0 + 3 (c0 % 4 == 0) of an activation row in the pre-split layout [C / 32][hi 32 | lo' 32] fp16 (mode 1):
 // what ConvGemmArgs::src_x3 reads.  `row` points at the row's first byte (the row is C * 4 bytes long, as in fp32).
 __device__ __forceinline__ void st4_x3(void *row, int c0, const f32x4 v) {

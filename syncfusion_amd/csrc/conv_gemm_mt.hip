@@ -184,7 +184,7 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
   };
 
   f32x16 acc[TM][TN];
-  f32x16 accL[X3 ? TM : 1][X3 ? TN : 1];   // split mode: the cross terms hi lo' + lo' hi (scaled by 2048)
+  f32x16 accL[X3 == X3_F16 ? TM : 1][X3 == X3_F16 ? TN : 1];   // fp16 split: the cross terms hi lo' + lo' hi (scaled by 2048); bf16 split: one accumulator
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         acc[i][j][r] = 0.f;
-        if constexpr (X3) accL[i][j][r] = 0.f;
+        if constexpr (X3 == X3_F16) accL[i][j][r] = 0.f;
       }
 
   // fragment read offsets inside a slot: row-dependent part once, the k sub-step enters through the XOR
@@ -335,7 +335,10 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) x3_mfma<X3 ? X3 : 1>(ah[i], al[i], bh[j], bl[j], acc[i][j], accL[i][j]);
+          for (int j = 0; j < TN; ++j) {
+            if constexpr (X3 == X3_BF16) x3_mfma1_bf16(ah[i], al[i], bh[j], bl[j], acc[i][j]);
+            else x3_mfma<X3_F16>(ah[i], al[i], bh[j], bl[j], acc[i][j], accL[i][j]);
+          }
       }
     } else {
 #pragma unroll
@@ -419,7 +422,7 @@ __global__ __launch_bounds__(512) void conv_gemm_mt_kernel(const ConvGemmArgs a,
       for (int r = 0; r < 16; ++r) {
         if (EP == 2 && (r >> 3) != pass) continue;   // registers 0-7 = rows 0-15 of the tile, 8-15 = rows 16-31
         const int lr = EP == 1 ? (r & 3) + 8 * (r >> 2) + 4 * fh : (r & 3) + 8 * ((r >> 2) & 1) + 4 * fh;
-        if constexpr (X3) red[(i * RPT + lr) * LDR + j * 32 + fr] = fmaf(accL[i][j][r], X3P<X3 ? X3 : 1>::INV, acc[i][j][r]);
+        if constexpr (X3 == X3_F16) red[(i * RPT + lr) * LDR + j * 32 + fr] = fmaf(accL[i][j][r], X3P<X3_F16>::INV, acc[i][j][r]);
         else red[(i * RPT + lr) * LDR + j * 32 + fr] = acc[i][j][r];
       }
   __builtin_amdgcn_wave_barrier();   // same-wave LDS operations execute in order; this only pins the compiler
@@ -692,6 +695,9 @@ static int conv_gemm_mt_x3_variant(const ConvGemmArgs &a) {
   const long t256 = (long)((a.M + 255) / 256) * ((a.n_store + 127) / 128);
   if (a.n_store <= 64 || ((a.n_store % 128) && (a.n_store % 128) <= 64 && a.n_store % 64 == 0 && a.n_store <= 192)) return 7;
   if (t256 >= 512) return 0;
+  // alone on the chip (training: one stream) a launch of fewer than 256 tiles of 128x128 leaves CUs without work: 128x64 tiles there
+  // (training step, same box: 30.9 vs 35.8 us per launch, profiles/r6_e_train_kernel_stats.csv vs r6_f)
+  if (a.solo && (long)((a.M + 127) / 128) * ((a.n_store + 127) / 128) < 256 && a.n_store % 64 == 0) return 7;
   return 5;
 }
 bool conv_gemm_src_x3_ok(const ConvGemmArgs &a) {

@@ -65,6 +65,9 @@ struct ConvGemmArgs {
   // producer whose output only this GEMM reads (launch_gn_silu with xfmt): the kernel then spends no vector instruction on the operand.
   // Honoured by the macro-tile kernel only (conv_gemm_src_x3_ok).
   int src_x3 = 0;
+  // hint: nothing else runs beside this launch (the training step's single stream, an engine without clip-parallel branches) -- tile
+  // choices that rely on a second stream filling the CUs a launch leaves idle do not apply
+  int solo = 0;
   void *out = nullptr;
   const float *bias = nullptr, *gamma = nullptr, *beta = nullptr, *stats = nullptr;
   const float *badd = nullptr, *bscale = nullptr;
@@ -128,6 +131,8 @@ hipError_t launch_conv_gemm_rs(int dt, const ConvGemmArgs &a, hipStream_t s);
 hipError_t launch_pack_wfr(int dt, const void *w /* [N][K], compute type */, int N, int K, void *out, hipStream_t s);
 // split-fp16 image of a packed fp32 [N][K] matrix (K % 32 == 0): out[n][k / 32][0][k % 32] = hi, [1][k % 32] = lo' (common.h, x3_split)
 hipError_t launch_pack_wx(const float *w, int N, int K, void *out, hipStream_t s, int mode = 1);
+// Conv1d weight (N, C, taps) fp32 -> out[n][tap * C + c] fp32 and the split image of the same matrix, one pass ((taps * C) % 32 == 0)
+hipError_t launch_pack_conv_x(const float *w, int N, int C, int taps, float *out, void *outx, int mode, hipStream_t s);
 // true when launch_conv_gemm would run `a` on the kernel that honours gnpart_out (wp, 32x32 tiles)
 bool conv_gemm_emits_gnpart(int dt, const ConvGemmArgs &a);
 // GEMM whose first source is LayerNorm-modulated on the fly from producer-side row partials (see ConvGemmArgs)
@@ -386,7 +391,8 @@ hipError_t launch_times_to_track(const double *times, const int *clip_of, int n_
 // Training backward, first slice (train.hip): fp32, channels-last
 // ---------------------------------------------------------------------------------------
 // Conv1d weight (N, C, taps) -> dgrad matrix [c][t' * ldn + n] = W[n][c][taps-1-t'] (the forward kernels then compute da from dy)
-hipError_t launch_pack_dgrad(const float *w, int N, int C, int taps, int ldn, float *out, hipStream_t s);
+// outx (optional, (taps * ldn) % 32 == 0): the split bf16 image of the same matrix, written in the same pass
+hipError_t launch_pack_dgrad(const float *w, int N, int C, int taps, int ldn, float *out, hipStream_t s, void *outx = nullptr);
 // dw (N, C, taps) = sum_rows dy[row][n] * act[row + t - pad][c];  partial: [S][N][taps*C] scratch, S = conv_wgrad_splits(...)
 int conv_wgrad_splits(int64_t rows, int C, int N, int taps);
 // x3: the products from split fp16 operands (both operands are activations: split while they are staged)
@@ -413,7 +419,7 @@ hipError_t launch_ln_modulate_bwd(const float *x, const float *ss, const float *
                                   float *dss, hipStream_t s);
 // backward of softmax attention on packed projections (head dim 64): dq (B,L,H*64), dkv (B,L,2*H*64); lse, dsum: (B,H,L) scratch
 hipError_t launch_attention_bwd(const float *q, const float *kv, const float *o, const float *dout, int B, int L, int H, int D, float *dq, float *dkv,
-                                float *lse, float *dsum, hipStream_t s, const float *lse_fwd = nullptr);
+                                float *lse, float *dsum, hipStream_t s, const float *lse_fwd = nullptr, bool x3 = false);
 // fp32 attention forward on the matrix cores that also keeps log-sum-exp of the scaled scores, (B, H, L), for launch_attention_bwd(lse_fwd)
 bool attention_f32_mfma_ok(int ldq, int ldkv, int ldo, int B, int H);
 hipError_t launch_attention_f32_mfma(const float *q, int ldq, const float *kv, int ldkv, int B, int L, int H, float *out, int ldo, hipStream_t s,

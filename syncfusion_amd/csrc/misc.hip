@@ -183,6 +183,19 @@ __global__ void pack_conv_kernel(const float *__restrict__ w, int N, int Ctot, i
     out[(size_t)n * out_row + col0 + (size_t)tap * cin_pad + ci] = from_f<T>(v);
   }
 }
+// the op-level convolution weight (N, C, taps) -> fp32 [N][taps * C] AND its split 16-bit image in one pass (training: the weights change
+// every step, both copies are rebuilt per call)
+template <int MODE>
+__global__ void pack_conv_x_kernel(const float *__restrict__ w, int N, int C, int taps, float *__restrict__ out, typename X3P<MODE>::elem *__restrict__ outx) {
+  SF_GRID_STRIDE(i, (int64_t)N * taps * C) {
+    const int ci = (int)(i % C);
+    const int64_t r = i / C;
+    const int tap = (int)(r % taps), n = (int)(r / taps);
+    const float v = w[((size_t)n * C + ci) * taps + tap];
+    out[i] = v;
+    x3_split1<MODE>(v, outx[(i >> 5) * 64 + (i & 31)], outx[(i >> 5) * 64 + 32 + (i & 31)]);
+  }
+}
 template <typename T>
 __global__ void pack_rows_kernel(const float *__restrict__ in, int64_t rows, int cols, int64_t ldi, const float *__restrict__ cscale,
                                  T *__restrict__ out, int64_t ldo) {
@@ -401,6 +414,13 @@ hipError_t launch_pack_conv(int dt, const float *w, int N, int Ctot, int c_off, 
                             void *out, int64_t out_row, int64_t col0, hipStream_t s) {
   dim3 g = grid_for((int64_t)N * taps * cin_pad);
   SF_DISPATCH_STMT(dt, hipLaunchKernelGGL((pack_conv_kernel<T>), g, dim3(TPB), 0, s, w, N, Ctot, c_off, Cin, taps, cin_pad, nscale, (T *)out, out_row, col0));
+  return hipGetLastError();
+}
+hipError_t launch_pack_conv_x(const float *w, int N, int C, int taps, float *out, void *outx, int mode, hipStream_t s) {
+  if (((int64_t)taps * C) % 32) return hipErrorInvalidValue;
+  dim3 g = grid_for((int64_t)N * taps * C);
+  if (mode == X3_BF16) hipLaunchKernelGGL(pack_conv_x_kernel<X3_BF16>, g, dim3(TPB), 0, s, w, N, C, taps, out, static_cast<bf16 *>(outx));
+  else hipLaunchKernelGGL(pack_conv_x_kernel<X3_F16>, g, dim3(TPB), 0, s, w, N, C, taps, out, static_cast<f16 *>(outx));
   return hipGetLastError();
 }
 // ConvTranspose1d weight (Cin, Cout, f) -> the GEMM matrix of its "un-patchify" form: out[(t * Cout + o) * out_row + c] = w[c][o][t]

@@ -19,13 +19,15 @@ namespace sf {
 namespace {
 
 // Conv1d weight (N, C, taps) -> dgrad weight matrix [c][t' * ldn + n] = W[n][c][taps-1-t']  (rows padded to ldn columns per tap)
-__global__ void pack_dgrad_kernel(const float *__restrict__ w, int N, int C, int taps, int ldn, float *__restrict__ out) {
+__global__ void pack_dgrad_kernel(const float *__restrict__ w, int N, int C, int taps, int ldn, float *__restrict__ out, bf16 *__restrict__ outx) {
   const int64_t total = (int64_t)C * taps * ldn;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int n = (int)(i % ldn);
     const int64_t r = i / ldn;
     const int t = (int)(r % taps), c = (int)(r / taps);
-    out[i] = n < N ? w[((int64_t)n * C + c) * taps + (taps - 1 - t)] : 0.f;
+    const float v = n < N ? w[((int64_t)n * C + c) * taps + (taps - 1 - t)] : 0.f;
+    out[i] = v;
+    if (outx) x3_split1<X3_BF16>(v, outx[(i >> 5) * 64 + (i & 31)], outx[(i >> 5) * 64 + 32 + (i & 31)]);   // split bf16 image, same pass
   }
 }
 
@@ -273,13 +275,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const float *__restr
     coff[j] = single ? (wq * TW + j) * 32 : (qok[j] ? qs - t * C : 0);
   }
   const int r_begin = blockIdx.z * rows_per_split, r_end = min(rows, r_begin + rows_per_split);
-  f32x16 acc[TW][TW], accL[TW][TW];
+  constexpr bool ONE = MODE == X3_BF16;   // no scale between the parts: one accumulator per tile
+  f32x16 acc[TW][TW], accL[ONE ? 1 : TW][ONE ? 1 : TW];
 #pragma unroll
   for (int i = 0; i < TW; ++i)
 #pragma unroll
     for (int j = 0; j < TW; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = accL[i][j][e] = 0.f;
+      for (int e = 0; e < 16; ++e) {
+        acc[i][j][e] = 0.f;
+        if constexpr (!ONE) accL[i][j][e] = 0.f;
+      }
   constexpr int DYV = KR * TILE / 4 / 256;
   constexpr int ACV = (NRMAX * TILE / 4 + 255) / 256;
   f32x4 pdy[DYV], pac[ACV];
@@ -380,7 +386,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const float *__restr
 #pragma unroll
       for (int i = 0; i < TW; ++i)
 #pragma unroll
-        for (int j = 0; j < TW; ++j) x3_mfma<MODE>(ah[i], al[i], bh[j], bl[j], acc[i][j], accL[i][j]);
+        for (int j = 0; j < TW; ++j) {
+          if constexpr (ONE) x3_mfma1_bf16(ah[i], al[i], bh[j], bl[j], acc[i][j]);
+          else x3_mfma<MODE>(ah[i], al[i], bh[j], bl[j], acc[i][j], accL[i][j]);
+        }
     }
   }
 #pragma unroll
@@ -394,7 +403,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const float *__restr
       for (int e = 0; e < 16; ++e) {
         const int nn = n0 + (wn * TW + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
         if (nn < N) {
-          const float v = fmaf(accL[i][j][e], X3P<MODE>::INV, acc[i][j][e]);
+          float v = acc[i][j][e];
+          if constexpr (!ONE) v = fmaf(accL[i][j][e], X3P<MODE>::INV, v);
           if (dw_direct) dw_direct[((size_t)nn * C + cc) * taps + t] = v;
           else partial[((size_t)blockIdx.z * N + nn) * Q + qq] = v;
         }
@@ -888,10 +898,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__
 
 }  // namespace
 
-hipError_t launch_pack_dgrad(const float *w, int N, int C, int taps, int ldn, float *out, hipStream_t s) {
+hipError_t launch_pack_dgrad(const float *w, int N, int C, int taps, int ldn, float *out, hipStream_t s, void *outx) {
   const int64_t total = (int64_t)C * taps * ldn;
+  if (outx && (((int64_t)taps * ldn) % 32)) return hipErrorInvalidValue;
   const int grid = (int)std::min<int64_t>((total + 255) / 256, 2048);
-  hipLaunchKernelGGL(pack_dgrad_kernel, dim3(grid), dim3(256), 0, s, w, N, C, taps, ldn, out);
+  hipLaunchKernelGGL(pack_dgrad_kernel, dim3(grid), dim3(256), 0, s, w, N, C, taps, ldn, out, static_cast<bf16 *>(outx));
   return hipGetLastError();
 }
 

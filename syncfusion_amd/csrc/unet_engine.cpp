@@ -65,6 +65,7 @@ struct Plan {  // everything carved out of the caller's workspace for one (B, L0
   void *four = nullptr, *f1 = nullptr, *f2 = nullptr, *sf = nullptr, *emb_t = nullptr, *xhat_e = nullptr, *v_all = nullptr;
   int *step = nullptr;
   int nbr = 1;                 // clip-parallel branches
+  int nbr_total = 1;           // ... of the whole plan (a branch view keeps it: the solo hint of its launches)
   int64_t slab_stride = 0;     // floats of GroupNorm scratch per branch
   int64_t slab_half = 0;       // second statistics slab of a branch starts here
   float *rowpart = nullptr;    // per-row LayerNorm partials of the wide levels: two buffers per branch (y and z of an item)
@@ -645,6 +646,7 @@ Plan make_plan(const sf_unet &u, Workspace &ws, int B, int L0, bool two, int num
     if (want > sf_unet::kMaxBranches) want = sf_unet::kMaxBranches;
     while (want > 1 && p.Bt % want) --want;
     p.nbr = u.dbg.buf ? 1 : want;
+    p.nbr_total = p.nbr;
     // GroupNorm partial-statistics scratch per branch: two slabs (statistics of x and of the hidden activation),
     // each [clips][chunks][groups][2]; the thin levels chunk by their workgroup tile (conv_thin_plan)
     int64_t one = (int64_t)(p.Bt / p.nbr) * 32 * c.resnet_groups * 2;
@@ -845,6 +847,7 @@ struct Exec {
     a.w = w.w;
     a.wfr = w.wfr;
     a.wx = w.wx;
+    a.solo = p.nbr_total <= 1 ? 1 : 0;
     a.bias = w.bias;
     a.N = w.N;
     a.K = w.K;
