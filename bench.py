@@ -465,9 +465,44 @@ def extra_workloads(model, device, args, noise, channels, emb) -> dict:
             model.load_state_dict(saved, strict=False)
             torch.cuda.empty_cache()
         assert all(math.isfinite(v) for v in losses) and losses[-1] < losses[0], losses
-        return dict(workload="training step (exp/train_diffusion_gh.yaml): fp32, batch 4 x 2**18 samples, v-objective loss -> backward -> AdamW",
-                    ms_per_step=round(1e3 * dt, 2), ms_per_step_spread=spread(group_ms), clips_per_s=round(B / dt, 2), dtype="fp32", timed_steps=iters,
-                    losses=losses)
+        from syncfusion_amd import autograd as sfa
+
+        res = dict(workload="training step (exp/train_diffusion_gh.yaml): fp32 tensors, batch 4 x 2**18 samples, v-objective loss -> backward -> AdamW; "
+                            f"GEMM arithmetic {sfa.GEMM_DTYPE} (fp32x = products from split 16-bit operands, gradient tests at unchanged tolerances)",
+                   ms_per_step=round(1e3 * dt, 2), ms_per_step_spread=spread(group_ms), clips_per_s=round(B / dt, 2), dtype=sfa.GEMM_DTYPE, timed_steps=iters,
+                   losses=losses, mode="eager (Python issues ~4400 launches per step)")
+        # the same step with forward + backward captured once in a HIP graph (syncfusion_amd.training.GraphedTrainStep): the eager step is
+        # host-bound once the GEMMs run on the split operands
+        try:
+            from syncfusion_amd.training import GraphedTrainStep
+
+            saved2 = {k: v.detach().clone() for k, v in model.state_dict().items() if not k.startswith("clap.")}
+            opt2 = model.configure_optimizers()
+            try:
+                with torch.enable_grad():
+                    gs = GraphedTrainStep(model, (x, y, x, None, None))
+                    glosses, marks = [], []
+                    for it in range(iters + 1):
+                        if it >= 1 and (it - 1) % 3 == 0:
+                            torch.cuda.synchronize(device)
+                            marks.append(time.perf_counter())
+                        glosses.append(gs.step().detach().clone())
+                        opt2.step()
+                    torch.cuda.synchronize(device)
+                    marks.append(time.perf_counter())
+                gms = [1e3 * (b_ - a_) / 3 for a_, b_ in zip(marks[:-1], marks[1:])]
+                glosses = [round(float(v), 5) for v in glosses]
+                assert all(math.isfinite(v) for v in glosses) and glosses[-1] < glosses[0], glosses
+                res["graph_replay"] = dict(ms_per_step=round(sorted(gms)[len(gms) // 2], 2), ms_per_step_spread=spread(gms), losses=glosses,
+                                           note="forward + backward replayed from one HIP graph, AdamW eager")
+            finally:
+                del opt2
+                model.zero_grad(set_to_none=True)
+                model.load_state_dict(saved2, strict=False)
+                torch.cuda.empty_cache()
+        except Exception as e:  # noqa: BLE001
+            res["graph_replay"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        return res
 
     def transpose_up_legs():
         # The OTHER candidate network (SURVEY 8f-1 cannot be settled offline): upsample_mode="transpose", a-unet's `Upsample` =

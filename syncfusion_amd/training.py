@@ -394,6 +394,72 @@ def allreduce_gradients(module: torch.nn.Module, bucket_bytes: int = 256 << 20) 
 # ---------------------------------------------------------------------------------------------------------------------------
 # the optimisation step as exp/train_diffusion_gh.yaml configures Lightning's Trainer for it
 # ---------------------------------------------------------------------------------------------------------------------------
+class GraphedTrainStep:
+    """``Model.training_step`` + ``loss.backward()`` captured ONCE in a HIP graph and replayed per step (static batch shape).
+
+    The training composition issues ~4400 launches per step from Python; with the fp32x GEMMs the GPU finishes a step in ~52 ms and
+    the host needs ~60 ms to issue it, so the eager step is host-bound.  Replay removes the host from the step: one graph launch, then the
+    optimizer.  What is captured is exactly ``Model.step`` (CLAP embedding of ``z``, onset encoder, v-objective loss on ``x``) and its
+    backward; the per-step randomness of ``VDiffusion.forward`` (sigmas ~ U(0, 1), noise ~ N(0, 1): a-unet VDiffusion)
+    lives in two static tensors that are refilled before every replay with torch's generator, so the step draws fresh values like the eager
+    one.  Gradients land in the parameters' ``.grad`` tensors that the capture allocated (every replay overwrites them): call the optimizer
+    (and ``allreduce_gradients`` / clipping) after ``step()`` as usual, and do NOT ``zero_grad(set_to_none=True)`` afterwards -- that would
+    drop the tensors the graph writes.
+
+        gs = GraphedTrainStep(model, example_batch)       # captures; the batch tensors are copied into static buffers
+        for batch in loader:
+            loss = gs.step(batch)                         # copy-in, refill randomness, replay
+            optimizer.step()
+    """
+
+    def __init__(self, model, batch, warmup: int = 2):
+        x, y, z = batch[0], batch[1], batch[2]
+        self.model = model
+        self.x, self.y, self.z = x.clone(), y.clone(), (x if z is x else z).clone()
+        if z is x:
+            self.z = self.x
+        self.sig = torch.rand(x.shape[0], device=x.device)
+        self.noise = torch.randn_like(x)
+        params = [p for p in model.parameters() if p.requires_grad]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), training_step_scope():   # warm-up on a side stream: allocator pools, lazy kernel loads, .grad allocation
+            for _ in range(max(1, warmup)):
+                for p in params:
+                    p.grad = None
+                self._fwd_bwd()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        for p in params:
+            p.grad = None
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), training_step_scope():
+            self.loss = self._fwd_bwd()
+
+    def _fwd_bwd(self) -> Tensor:
+        m = self.model
+        emb = m.clap_encode_audio(self.z)
+        _, info = m.onsets_encoder(self.y, with_info=True)
+        loss = m.model(self.x, channels=info["xs"][2:-1], embedding=emb, sigmas=self.sig, noise=self.noise)
+        loss.backward()
+        return loss
+
+    def step(self, batch=None, resample: bool = True) -> Tensor:
+        """Copy ``batch`` (same shapes as the example) into the static buffers, draw this step's sigmas / noise (``resample=False``: keep
+        what ``self.sig`` / ``self.noise`` hold), replay.  Returns the static loss tensor (a device scalar: read it after the step, not
+        inside a timed loop)."""
+        if batch is not None:
+            self.x.copy_(batch[0])
+            self.y.copy_(batch[1])
+            if self.z is not self.x:
+                self.z.copy_(batch[2])
+        if resample:
+            self.sig.uniform_()
+            self.noise.normal_()
+        self.graph.replay()
+        return self.loss
+
+
 def fit_batches(model, optimizer, batches, *, accumulate_grad_batches: int = 2, gradient_clip_val: Optional[float] = 0.5,
                 on_step=None) -> List[float]:
     """Run ``Model.training_step`` over ``batches`` the way the reference's trainer section does

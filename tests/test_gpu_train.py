@@ -591,3 +591,44 @@ def test_train_checkpoint_generate_round_trip(cuda, tmp_path):
     for i, f in enumerate(files):
         got, rate = load_wav(f)              # 32-bit float wav, as torchaudio.save writes it: the samples keep their bits
         assert rate == 22050 and torch.equal(got, want[i].cpu())
+
+
+def test_graphed_train_step_equals_the_eager_step(cuda):
+    """training.GraphedTrainStep (forward + backward captured once in a HIP graph, replayed per step) against the eager
+    Model.step -> backward on the same batch, sigmas and noise: the loss and every gradient bit for bit (same kernels, same order), over
+    two replays with different data, and an optimizer step in between moves the weights the graph reads."""
+    import functools
+
+    from helpers import SMALL_ENCODER
+    from syncfusion_amd import DiffusionModel, Encoder1d, Model, RandomEmbedder, UNetV0, VDiffusion, VSampler
+    from syncfusion_amd.training import GraphedTrainStep, training_step_scope
+
+    torch.manual_seed(3)
+    dm = DiffusionModel(net_t=functools.partial(UNetV0, seed=5), diffusion_t=VDiffusion, sampler_t=VSampler, use_embedding_cfg=True, **SMALL_UNET)
+    model = Model(1e-3, 0.95, 0.999, 1e-6, 1e-3, dm, Encoder1d(seed=6, **SMALL_ENCODER), RandomEmbedder(SMALL_UNET["embedding_features"]), None).to(cuda)
+    B, L0 = 2, 16 * 24
+    g = torch.Generator().manual_seed(9)
+    batches = [(torch.randn(B, 1, L0, generator=g).to(cuda), (torch.rand(B, 1, L0, generator=g) < 0.02).float().to(cuda)) for _ in range(2)]
+    gs = GraphedTrainStep(model, (batches[0][0], batches[0][1], batches[0][0], None, None))
+    opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=1e-2)
+    for it, (x, y) in enumerate(batches):
+        gs.sig.copy_(torch.rand(B, generator=g).to(cuda))
+        gs.noise.copy_(torch.randn(B, 1, L0, generator=g).to(cuda))
+        loss_g = float(gs.step((x, y, x, None, None), resample=False).detach())
+        grads_g = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+        # eager, same inputs: fresh .grad tensors (the graph's own are put back afterwards)
+        keep = {k: p.grad for k, p in model.named_parameters()}
+        for p in model.parameters():
+            p.grad = None
+        with training_step_scope():
+            emb = model.clap_encode_audio(x)
+            _, info = model.onsets_encoder(y, with_info=True)
+            loss_e = model.model(x, channels=info["xs"][2:-1], embedding=emb, sigmas=gs.sig.clone(), noise=gs.noise.clone())
+            loss_e.backward()
+        assert float(loss_e) == loss_g
+        for k, p in model.named_parameters():
+            if p.grad is not None:
+                assert torch.equal(p.grad, grads_g[k]), k
+            p.grad = keep[k]
+        opt.step()    # the next replay must see the moved weights (it reads the parameter tensors, not a snapshot)
+    assert len(grads_g) > 100

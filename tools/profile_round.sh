@@ -1,7 +1,6 @@
 #!/bin/bash
 # Run ON the GPU box (gpurun): rocprofv3 kernel stats + separate PMC passes of the bench command, summaries under gpurun_out/$1
-# the SF_* hooks exist only in the tuning build of the library (make -C syncfusion_amd/csrc tuning)
-export SF_LIB_PATH=${SF_LIB_PATH:-${GRAFT_REPO_ROOT:-$(pwd)}/syncfusion_amd/lib/libsyncfusion_amd_tuning.so}
+# (every pass runs on the PRODUCT library except the two traffic passes, which need the SF_NO_PREFETCH hook of the tuning build)
 set -u
 TAG=${1:-prof}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -12,10 +11,10 @@ if [ "${SF_PROFILE_PRIMARY:-1}" = "1" ]; then
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra > $O/bench_under_profiler.json 2> $O/stats.log
 # traffic passes WITHOUT the hosted weight prefetch: a prefetch workgroup's reads are charged to the launch that hosts it (the NEXT GEMM's
 # weights), which would triple the apparent traffic of the small-batch GEMMs; the timed runs keep the prefetch on
-export SF_NO_PREFETCH=1
+export SF_NO_PREFETCH=1 SF_LIB_PATH=$R/syncfusion_amd/lib/libsyncfusion_amd_tuning.so
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- python3 $R/bench.py --no-cpu-baseline --no-extra --steps 3 --warmup 1 --no-graph > /dev/null 2> $O/fetch.log
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- python3 $R/bench.py --no-cpu-baseline --no-extra --steps 3 --warmup 1 --no-graph > /dev/null 2> $O/write.log
-unset SF_NO_PREFETCH
+unset SF_NO_PREFETCH SF_LIB_PATH
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $O/mfma -- python3 $R/bench.py --no-cpu-baseline --no-extra --steps 3 --warmup 1 --no-graph > /dev/null 2> $O/mfma.log
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $O/mfma_onset -- python3 $R/tools/onset_one.py 32 bf16 3 > /dev/null 2> $O/mfma_onset.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/onset_stats -- python3 $R/tools/onset_one.py 32 bf16 5 > /dev/null 2> $O/onset_stats.log
@@ -45,6 +44,9 @@ if [ "${SF_PROFILE_SECONDARY:-1}" = "1" ]; then
   sec cfg2_b32_cfg 32 2.0 6 bf16 45056
   sec cfg3share_b32 32 1.0 6 bf16 45056
   sec refshape_b10_2p18 10 2.0 4 bf16 262144
+  # the parity-grade fast path (fp32 activations, products from split 16-bit operands)
+  sec x3_cfg1_b8 8 1.0 20 fp32x 45056
+  sec x3_cfg2_b32_cfg 32 2.0 6 fp32x 45056
 fi
 rm -rf $O/stats $O/fetch $O/write $O/mfma $O/mfma_onset $O/onset_stats $O/train_stats
 ls -la $O
