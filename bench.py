@@ -438,6 +438,46 @@ def extra_workloads(model, device, args, noise, channels, emb) -> dict:
         g = torch.Generator().manual_seed(5)
         x = torch.randn(B, 1, L, generator=g).to(device)
         y = (torch.rand(B, 1, L, generator=g) < 0.0005).float().to(device)
+        def graph_part():
+            # forward + backward captured once in a HIP graph (syncfusion_amd.training.GraphedTrainStep): the eager step is host-bound once
+            # the GEMMs run on the split operands.  Runs FIRST: capture needs a process whose autograd nodes were not yet created on the
+            # default stream by an eager backward.
+            import gc
+
+            from syncfusion_amd.training import GraphedTrainStep
+
+            saved2 = {k: v.detach().clone() for k, v in model.state_dict().items() if not k.startswith("clap.")}
+            opt2 = model.configure_optimizers()
+            gs = None
+            try:
+                with torch.enable_grad():
+                    gs = GraphedTrainStep(model, (x, y, x, None, None))
+                    glosses, marks = [], []
+                    for it in range(iters + 1):
+                        if it >= 1 and (it - 1) % 3 == 0:
+                            torch.cuda.synchronize(device)
+                            marks.append(time.perf_counter())
+                        glosses.append(gs.step().detach().clone())
+                        opt2.step()
+                    torch.cuda.synchronize(device)
+                    marks.append(time.perf_counter())
+                gms = [1e3 * (b_ - a_) / 3 for a_, b_ in zip(marks[:-1], marks[1:])]
+                glosses = [round(float(v), 5) for v in glosses]
+                assert all(math.isfinite(v) for v in glosses) and glosses[-1] < glosses[0], glosses
+                return dict(ms_per_step=round(sorted(gms)[len(gms) // 2], 2), ms_per_step_spread=spread(gms), losses=glosses,
+                            note="forward + backward replayed from one HIP graph (training.GraphedTrainStep), AdamW eager")
+            finally:
+                del opt2, gs
+                model.zero_grad(set_to_none=True)
+                model.load_state_dict(saved2, strict=False)
+                gc.collect()
+                torch.cuda.synchronize(device)
+                torch.cuda.empty_cache()
+
+        try:
+            graph_res = graph_part()
+        except Exception as e:  # noqa: BLE001
+            graph_res = {"error": f"{type(e).__name__}: {e}"[:300]}
         saved = {k: v.detach().clone() for k, v in model.state_dict().items() if not k.startswith("clap.")}   # the step moves the weights
         opt = model.configure_optimizers()
         losses = []
@@ -470,38 +510,7 @@ def extra_workloads(model, device, args, noise, channels, emb) -> dict:
         res = dict(workload="training step (exp/train_diffusion_gh.yaml): fp32 tensors, batch 4 x 2**18 samples, v-objective loss -> backward -> AdamW; "
                             f"GEMM arithmetic {sfa.GEMM_DTYPE} (fp32x = products from split 16-bit operands, gradient tests at unchanged tolerances)",
                    ms_per_step=round(1e3 * dt, 2), ms_per_step_spread=spread(group_ms), clips_per_s=round(B / dt, 2), dtype=sfa.GEMM_DTYPE, timed_steps=iters,
-                   losses=losses, mode="eager (Python issues ~4400 launches per step)")
-        # the same step with forward + backward captured once in a HIP graph (syncfusion_amd.training.GraphedTrainStep): the eager step is
-        # host-bound once the GEMMs run on the split operands
-        try:
-            from syncfusion_amd.training import GraphedTrainStep
-
-            saved2 = {k: v.detach().clone() for k, v in model.state_dict().items() if not k.startswith("clap.")}
-            opt2 = model.configure_optimizers()
-            try:
-                with torch.enable_grad():
-                    gs = GraphedTrainStep(model, (x, y, x, None, None))
-                    glosses, marks = [], []
-                    for it in range(iters + 1):
-                        if it >= 1 and (it - 1) % 3 == 0:
-                            torch.cuda.synchronize(device)
-                            marks.append(time.perf_counter())
-                        glosses.append(gs.step().detach().clone())
-                        opt2.step()
-                    torch.cuda.synchronize(device)
-                    marks.append(time.perf_counter())
-                gms = [1e3 * (b_ - a_) / 3 for a_, b_ in zip(marks[:-1], marks[1:])]
-                glosses = [round(float(v), 5) for v in glosses]
-                assert all(math.isfinite(v) for v in glosses) and glosses[-1] < glosses[0], glosses
-                res["graph_replay"] = dict(ms_per_step=round(sorted(gms)[len(gms) // 2], 2), ms_per_step_spread=spread(gms), losses=glosses,
-                                           note="forward + backward replayed from one HIP graph, AdamW eager")
-            finally:
-                del opt2
-                model.zero_grad(set_to_none=True)
-                model.load_state_dict(saved2, strict=False)
-                torch.cuda.empty_cache()
-        except Exception as e:  # noqa: BLE001
-            res["graph_replay"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                   losses=losses, mode="eager (Python issues ~4400 launches per step)", graph_replay=graph_res)
         return res
 
     def transpose_up_legs():

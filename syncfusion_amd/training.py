@@ -406,6 +406,10 @@ class GraphedTrainStep:
     (and ``allreduce_gradients`` / clipping) after ``step()`` as usual, and do NOT ``zero_grad(set_to_none=True)`` afterwards -- that would
     drop the tensors the graph writes.
 
+    Build it BEFORE the first eager ``backward()`` of the process on these parameters (or after every reference to such a graph is gone):
+    autograd's AccumulateGrad nodes remember the stream they were created on, and nodes left over from an eager backward on the default
+    stream make the capture synchronise -- which HIP graph capture does not survive.
+
         gs = GraphedTrainStep(model, example_batch)       # captures; the batch tensors are copied into static buffers
         for batch in loader:
             loss = gs.step(batch)                         # copy-in, refill randomness, replay
