@@ -80,7 +80,7 @@ class _ConvBlockFn(torch.autograd.Function):
             g = _lib.f32c(gamma) if groups > 0 else None
             be = _lib.f32c(beta) if groups > 0 else None
             out = torch.empty(B, L, N, dtype=torch.float32, device=x.device)
-            ws = torch.empty(max(256, 8 * N * Cc * taps + 8 * B * 64 * groups + (1 << 16)), dtype=torch.uint8, device=x.device)
+            ws = torch.empty(max(256, 12 * N * Cc * taps + 8 * B * 64 * groups + (1 << 16)), dtype=torch.uint8, device=x.device)
             # residual: added in the convolution's epilogue (one pass less over the tensor than a separate add); its gradient is dy itself
             res_cl, res_late = None, None
             if residual is not None:

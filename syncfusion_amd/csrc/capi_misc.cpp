@@ -187,6 +187,11 @@ int sf_op_conv1d_cl(int dtype, const void *x, const float *w, const float *bias,
     SF_HIP(launch_pack_wx(static_cast<const float *>(wp), N, K, wx, s));
     a.wx = wx;
   }
+  if (a.wx && (K % 64) == 0 && K <= 1280 && (N % 32) == 0 && (C % 16) == 0) {   // as the engine packs it: fragment order for the register-staged kernel
+    void *wfrx = wk.alloc((int64_t)N * K * 4);
+    SF_HIP(launch_pack_wfrx(static_cast<const float *>(wp), N, K, wfrx, s));
+    a.wfrx = wfrx;
+  }
   a.src = x;
   a.src_ld = C;
   a.w = wp;

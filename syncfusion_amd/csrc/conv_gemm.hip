@@ -490,7 +490,7 @@ static const char *variant_name_bf16(int dt, const ConvGemmArgs &a) {
   static const char *wp_names[2][3] = {{"conv_gemm_wp<f32,32x32>", "conv_gemm_wp<f32,32x32>", "conv_gemm_wp<f32,32x32>"},
                                        {"conv_gemm_wp<bf16,64x64>", "conv_gemm_wp<bf16,64x32>", "conv_gemm_wp<bf16,32x32>"}};
   if ((short_act || use_sk(a)) && conv_gemm_prefers_wp(a) && conv_gemm_sk_variant(a) == 2 && g_conv_gemm_force.path == 0 && conv_gemm_rs_ok(dt, a))
-    return "conv_gemm_rs<bf16,32x32>";
+    return dt == F32 ? "conv_gemm_rs<x3,32x32>" : "conv_gemm_rs<bf16,32x32>";
   if ((short_act || use_sk(a)) && conv_gemm_prefers_wp(a) && conv_gemm_wp_ok(dt, a)) return wp_names[dt == F32 ? 0 : 1][conv_gemm_sk_variant(a)];
   if (short_act || use_sk(a)) return (conv_gemm_fast_ok(dt, a) ? fast_names : sk_names)[dt == F32 ? 0 : 1][conv_gemm_sk_variant(a)];
   int v = pick_variant(a);

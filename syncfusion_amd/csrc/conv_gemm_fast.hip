@@ -527,7 +527,7 @@ static bool ln_goes_wp(int dt, const ConvGemmArgs &a) {
 static bool ln_goes_rs(int dt, const ConvGemmArgs &a);
 const char *conv_gemm_ln_variant_name(int dt, const ConvGemmArgs &a) {
   if (ln_goes_mt(dt, a)) return label_for_dtype(dt, conv_gemm_mt_name(a));
-  if (ln_goes_rs(dt, a)) return label_for_dtype(dt, "conv_gemm_rs<bf16,32x32>");
+  if (ln_goes_rs(dt, a)) return dt == F32 ? "conv_gemm_rs<x3,32x32>" : label_for_dtype(dt, "conv_gemm_rs<bf16,32x32>");
   if (dt == F32 && a.wx && a.wx_mode == X3_F16) return ln_goes_wp(dt, a) ? "conv_gemm_wp<x3,32x32>" : "conv_gemm_fast<x3,32x32>";
   if (dt == F32) return ln_goes_wp(dt, a) ? "conv_gemm_wp<f32,32x32>" : "conv_gemm_fast<f32,32x32>";
   return label_for_dtype(dt, ln_goes_wp(dt, a) ? "conv_gemm_wp<bf16,32x32>" : "conv_gemm_fast<bf16,32x32>");

@@ -14,6 +14,7 @@
 // is bound by the CU's fill rate (~70 GB/s -> ~2 us).  Used for the 1x1 InjectChannels convolution over cat[x, ctx], the attention
 // projections, and the patchify / up convolutions that fit (a-unet InjectChannelsItem / AttentionItem / Downsample).
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "kernels.h"
@@ -25,11 +26,16 @@ constexpr unsigned OOB = 0x80000000u;
 constexpr int LDR = 36;   // row pitch of a partial tile in LDS (floats)
 
 // T1: one tap (1x1 / Linear), a compile-time switch so that the two address schemes do not meet at a join
-template <typename T, bool CAT, int NFD, bool T1>
+// X3 (T = float, the fp32x engine): fp32 activation fragments (two 16-byte loads per lane and 16 k), weights from the fragment-ordered
+// split image ConvGemmArgs::wfrx = [N / 32][K / 16][hi | lo'][64 lanes][8] (2 KB contiguous per wave and fragment); every fragment is split
+// in registers when it is multiplied (common.h, X3P<X3_F16>), three MFMAs per product, two accumulators.  16 registers per fragment in
+// flight: K <= 1280.
+template <typename T, bool CAT, int NFD, bool T1, bool X3 = false>
 __global__ __launch_bounds__(256) void conv_gemm_rs_kernel(const ConvGemmArgs a, const int mtiles, const int ntiles, const int swz, const unsigned bytesA,
                                                            const unsigned bytesA2, const unsigned bytesW) {
-  using frag = typename Frag16<T>::type;
-  constexpr int ES = 2;
+  using frag = typename std::conditional<X3, f16x8, typename Frag16<T>::type>::type;
+  constexpr int ES = X3 ? 4 : 2;
+  static_assert(!X3 || sizeof(T) == 4, "split mode: fp32 activations");
   __shared__ __attribute__((aligned(16))) float red[4 * 32 * LDR + 4 * 32];   // four partial tiles | (mean, rstd) per row | (sum, sumsq) per row
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -57,14 +63,15 @@ __global__ __launch_bounds__(256) void conv_gemm_rs_kernel(const ConvGemmArgs a,
   // ---- the wave's K quarter: all fragments in flight ----------------------------------------------------------------------------
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.src), 0, bytesA, 0x00020000);
   const __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(CAT ? a.src2 : a.src), 0, CAT ? bytesA2 : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rF = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.wfr), 0, bytesW, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rF = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(X3 ? a.wfrx : a.wfr), 0, bytesW, 0x00020000);
   const int F = a.K >> 4, nf = F >> 2, f0 = wave * nf;          // K % 64 == 0: every wave takes F / 4 fragments of 16 k
-  f32x16 acc;
+  f32x16 acc, accL;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int r = 0; r < 16; ++r) acc[r] = accL[r] = 0.f;
   typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
   f32x4 eb, es_, ea, ec;
   u32x2 er, lp[4];
+  u32x4 er4 = {0u, 0u, 0u, 0u};   // split mode: the residual quad in fp32
   {
     const int m = m0 + fr;
     const bool vm = m < a.M;
@@ -72,8 +79,9 @@ __global__ __launch_bounds__(256) void conv_gemm_rs_kernel(const ConvGemmArgs a,
     const int b = mm / a.Lout, l = mm - b * a.Lout;
     const int rb = b * a.Lsrc, p0 = l * a.stride - a.pad;
     const int pmax = (a.Lsrc << a.up_shift) - 1;
-    const unsigned vmask = vm ? 0u : OOB, lane_b = (unsigned)(fh * 16);
-    const unsigned wbase = (unsigned)((((size_t)nt * F + f0) * 64 + lane) * 16);
+    const unsigned vmask = vm ? 0u : OOB, lane_b = (unsigned)(fh * 8 * ES);
+    const unsigned wbase = X3 ? (unsigned)((((size_t)nt * F + f0) * 128 + lane) * 16) : (unsigned)((((size_t)nt * F + f0) * 64 + lane) * 16);
+    constexpr unsigned WSTEP = X3 ? 2048u : 1024u;   // bytes of one weight fragment (pair)
     const int k_taps = a.taps * a.cin;
     // (tap, channel) of the wave's first fragment, then streamed: all of it wave-uniform (scalar registers)
     int k = f0 * 16;
@@ -86,7 +94,9 @@ __global__ __launch_bounds__(256) void conv_gemm_rs_kernel(const ConvGemmArgs a,
     };
     unsigned cur = row_off(tap);
     const unsigned cur2 = CAT ? (((unsigned)(mm * a.src2_ld * ES) + lane_b) | vmask) : OOB;
-    frag af[NFD], wf[NFD];
+    frag af[X3 ? 1 : NFD], wf[NFD];
+    frag wl[X3 ? NFD : 1];            // split mode: the lo' halves of the weight fragments ...
+    f32x4 ax[X3 ? NFD : 1][2];        // ... and the activation fragments as fp32 (8 consecutive k per lane)
     if constexpr (T1) {
       // 1x1 / Linear (+ concatenated second source): no tap bookkeeping, the k offset of fragment i is an instruction immediate
       const int kk = f0 * 16;
@@ -96,17 +106,36 @@ __global__ __launch_bounds__(256) void conv_gemm_rs_kernel(const ConvGemmArgs a,
         const bool sec = CAT && (kk + 16 * i) >= k_taps;   // wave-uniform: scalar selects, one load instruction
         const unsigned off = sec ? cur2 + (unsigned)((kk - k_taps) * ES) : cur + (unsigned)(kk * ES);
         const __amdgpu_buffer_rsrc_t rs = sec ? rA2 : rA;
-        af[i] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rs, (off + (unsigned)(i * 16 * ES)) | dead, 0, 0));
-        wf[i] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rF, (wbase + (unsigned)(i * 1024)) | dead, 0, 0));
+        if constexpr (X3) {
+          ax[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (off + (unsigned)(i * 16 * ES)) | dead, 0, 0));
+          ax[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (off + (unsigned)(i * 16 * ES) + 16u) | dead, 0, 0));
+          wl[i] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rF, (wbase + (unsigned)(i * WSTEP) + 1024u) | dead, 0, 0));
+        } else {
+          af[i] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rs, (off + (unsigned)(i * 16 * ES)) | dead, 0, 0));
+        }
+        wf[i] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rF, (wbase + (unsigned)(i * WSTEP)) | dead, 0, 0));
       }
     } else {
 #pragma unroll
       for (int i = 0; i < NFD; ++i) {
         const unsigned dead = i < nf ? 0u : OOB;
-        if (CAT && k >= k_taps)
-          af[i] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rA2, (cur2 + (unsigned)((k - k_taps) * ES)) | dead, 0, 0));
-        else af[i] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rA, (cur + (unsigned)(c * ES)) | dead, 0, 0));
-        wf[i] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rF, (wbase + (unsigned)(i * 1024)) | dead, 0, 0));
+        if constexpr (X3) {
+          if (CAT && k >= k_taps) {
+            const unsigned aoff = (cur2 + (unsigned)((k - k_taps) * ES)) | dead;
+            ax[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA2, aoff, 0, 0));
+            ax[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA2, aoff + 16u, 0, 0));
+          } else {
+            const unsigned aoff = (cur + (unsigned)(c * ES)) | dead;
+            ax[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, aoff, 0, 0));
+            ax[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, aoff + 16u, 0, 0));
+          }
+          wl[i] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rF, (wbase + (unsigned)(i * WSTEP) + 1024u) | dead, 0, 0));
+        } else {
+          if (CAT && k >= k_taps)
+            af[i] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rA2, (cur2 + (unsigned)((k - k_taps) * ES)) | dead, 0, 0));
+          else af[i] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rA, (cur + (unsigned)(c * ES)) | dead, 0, 0));
+        }
+        wf[i] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rF, (wbase + (unsigned)(i * WSTEP)) | dead, 0, 0));
         k += 16;
         c += 16;
         if (c >= a.cin && k < k_taps) {
@@ -127,7 +156,8 @@ __global__ __launch_bounds__(256) void conv_gemm_rs_kernel(const ConvGemmArgs a,
       es_ = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc(a.bscale), (unsigned)((bb * a.bscale_ld + nc) * 4), 0, 0));
       ea = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc(a.badd), (unsigned)((bb * a.badd_ld + nc) * 4), 0, 0));
       ec = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc(a.ln_colsum), (unsigned)(nc * 4), 0, 0));
-      er = __builtin_amdgcn_raw_buffer_load_b64(rsrc(a.res), (unsigned)((mc * a.res_ld + nc) * ES), 0, 0);
+      if constexpr (X3) er4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc(a.res), (unsigned)((mc * a.res_ld + nc) * ES), 0, 0);
+      else er = __builtin_amdgcn_raw_buffer_load_b64(rsrc(a.res), (unsigned)((mc * a.res_ld + nc) * ES), 0, 0);
       const __amdgpu_buffer_rsrc_t rl = rsrc(a.ln_part);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -135,13 +165,25 @@ __global__ __launch_bounds__(256) void conv_gemm_rs_kernel(const ConvGemmArgs a,
         lp[j] = __builtin_amdgcn_raw_buffer_load_b64(rl, pidx < a.ln_nt ? (unsigned)((mc * a.ln_nt + pidx) * 8) : OOB, 0, 0);
       }
     }
+    if constexpr (X3) {
 #pragma unroll
-    for (int i = 0; i < NFD; ++i) acc = mfma32x16(af[i], wf[i], acc);
+      for (int i = 0; i < NFD; ++i) {
+        f16x8 ah, al;
+        x3_split<X3_F16>(ax[i][0], ax[i][1], ah, al);
+        x3_mfma<X3_F16>(ah, al, wf[i], wl[i], acc, accL);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = fmaf(accL[r], X3P<X3_F16>::INV, acc[r]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NFD; ++i) acc = mfma32x16(af[i], wf[i], acc);
+    }
   }
   float bi[4], rv[4], sv[4], av[4], cu[4], ln_mp[4], ln_qp[4];
   {
     T rt[4];
-    __builtin_memcpy(rt, &er, 8);
+    if constexpr (X3) __builtin_memcpy(rt, &er4, 16);
+    else __builtin_memcpy(rt, &er, 8);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       bi[e] = eb[e];
@@ -201,7 +243,7 @@ __global__ __launch_bounds__(256) void conv_gemm_rs_kernel(const ConvGemmArgs a,
   }
   if (live && !a.out_f32) {
     T *op = static_cast<T *>(a.out) + (size_t)em * a.out_ld + enb;
-    if (enb + 3 < a.n_store && (a.out_ld & 3) == 0) __builtin_memcpy(__builtin_assume_aligned(op, 8), ob, 8);
+    if (enb + 3 < a.n_store && (a.out_ld & 3) == 0) __builtin_memcpy(__builtin_assume_aligned(op, 4 * sizeof(T)), ob, 4 * sizeof(T));
     else
       for (int e = 0; e < 4; ++e)
         if (enb + e < a.n_store) op[e] = ob[e];
@@ -250,6 +292,39 @@ template <typename T> __global__ void pack_wfr_kernel(const T *__restrict__ w, i
   }
 }
 
+// packed fp32 [N][K] -> split fragment order [N / 32][K / 16][hi | lo'][64][8] (the fp32x engine)
+__global__ void pack_wfrx_kernel(const float *__restrict__ w, int N, int K, f16 *__restrict__ out) {
+  const size_t total = (size_t)N * K;
+  const int F = K >> 4;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int q = (int)(e & 7), lane = (int)((e >> 3) & 63);
+    const size_t t = e >> 9;
+    const int f = (int)(t % F), nt = (int)(t / F);
+    x3_split1<X3_F16>(w[(size_t)(nt * 32 + (lane & 31)) * K + f * 16 + (lane >> 5) * 8 + q], out[t * 1024 + (e & 511)], out[t * 1024 + 512 + (e & 511)]);
+  }
+}
+
+template <bool CAT> hipError_t launch_rs_x3(const ConvGemmArgs &a, hipStream_t s) {
+  const int mtiles = (a.M + 31) / 32, ntiles = (a.n_store + 31) / 32;
+  const int swz = (ntiles % 8 == 0) ? 1 : 0;
+  const size_t bA = (size_t)(a.M / a.Lout + (a.M % a.Lout ? 1 : 0)) * a.Lsrc * a.src_ld * 4;
+  const size_t bA2 = CAT ? (size_t)a.M * a.src2_ld * 4 : 0;
+  const size_t bW = (size_t)a.N * a.K * 4;
+  const dim3 grid(mtiles * ntiles + (a.pf.ptr && a.pf.bytes >= 16 ? a.pf.wgs : 0));
+  const int nf = a.K / 64;
+#define SF_RSX(NFD)                                                                                                                                      \
+  do {                                                                                                                                                   \
+    if (a.taps == 1) hipLaunchKernelGGL((conv_gemm_rs_kernel<float, CAT, NFD, true, true>), grid, dim3(256), 0, s, a, mtiles, ntiles, swz, (unsigned)bA, (unsigned)bA2, (unsigned)bW); \
+    else hipLaunchKernelGGL((conv_gemm_rs_kernel<float, CAT, NFD, false, true>), grid, dim3(256), 0, s, a, mtiles, ntiles, swz, (unsigned)bA, (unsigned)bA2, (unsigned)bW); \
+  } while (0)
+  if (nf <= 8) SF_RSX(8);
+  else if (nf <= 12) SF_RSX(12);
+  else if (nf <= 16) SF_RSX(16);
+  else SF_RSX(20);
+#undef SF_RSX
+  return hipGetLastError();
+}
+
 template <typename T, bool CAT> hipError_t launch_rs(const ConvGemmArgs &a, hipStream_t s) {
   const int mtiles = (a.M + 31) / 32, ntiles = (a.n_store + 31) / 32;
   const int swz = (ntiles % 8 == 0) ? 1 : 0;
@@ -277,20 +352,32 @@ template <typename T, bool CAT> hipError_t launch_rs(const ConvGemmArgs &a, hipS
 // tiles (the caller has decided that), K a multiple of 64 up to 2048, channel counts that are multiples of 16, whole 32-column tiles
 bool conv_gemm_rs_ok(int dt, const ConvGemmArgs &a) {
   static const bool off = tune_env("SF_NO_RS") != nullptr;   // A/B aid
-  if (off || dt == F32 || !a.wfr || a.geom != 0 || a.pro != 0 || a.taps < 1) return false;
-  if ((a.K % 64) || a.K > 2048 || (a.cin % 16) || (a.cin2 % 16) || (a.N % 32) || a.n_store != a.N) return false;
+  const bool x3 = dt == F32 && a.wfrx != nullptr && a.wx_mode == X3_F16;   // the split-operand form (fp32 activations)
+  const size_t es = x3 ? 4 : 2;
+  if (off || (dt == F32 && !x3) || (!x3 && !a.wfr) || a.geom != 0 || a.pro != 0 || a.taps < 1) return false;
+  if ((a.K % 64) || a.K > (x3 ? 1280 : 2048) || (a.cin % 16) || (a.cin2 % 16) || (a.N % 32) || a.n_store != a.N) return false;
+  if (x3 && ((a.src_ld % 4) || (a.cin2 && (a.src2_ld % 4)) || a.out_f32)) return false;   // 16-byte fp32 fragment loads
   if ((a.res && (a.res_ld % 4)) || (a.bscale && (a.bscale_ld % 4)) || (a.badd && (a.badd_ld % 4)) || (a.out_ld % 4)) return false;   // vector epilogue loads
   if (a.ln_ss || a.res_ln) return false;   // the operand-side LayerNorm (Modulation folded into InjectChannels) stays on conv_gemm_fast
   if (a.ln_colsum && (!a.ln_part || a.ln_nt * 32 != a.cin || a.ln_nt > 32 || a.cin2)) return false;
   const size_t lim = 0x7FFFFFF0ull;
-  if ((size_t)(a.M / a.Lout + 1) * a.Lsrc * a.src_ld * 2 >= lim) return false;
-  if ((size_t)a.M * (a.src2_ld > 0 ? a.src2_ld : 1) * 2 >= lim) return false;
-  if ((size_t)a.N * a.K * 2 >= lim) return false;
+  if ((size_t)(a.M / a.Lout + 1) * a.Lsrc * a.src_ld * es >= lim) return false;
+  if ((size_t)a.M * (a.src2_ld > 0 ? a.src2_ld : 1) * es >= lim) return false;
+  if ((size_t)a.N * a.K * es >= lim) return false;
   return true;
+}
+
+hipError_t launch_pack_wfrx(const float *w, int N, int K, void *out, hipStream_t s) {
+  if ((N % 32) || (K % 16)) return hipErrorInvalidValue;
+  const size_t total = (size_t)N * K;
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(pack_wfrx_kernel, dim3(blocks), dim3(256), 0, s, w, N, K, static_cast<f16 *>(out));
+  return hipGetLastError();
 }
 
 hipError_t launch_conv_gemm_rs(int dt, const ConvGemmArgs &a, hipStream_t s) {
   if (!conv_gemm_rs_ok(dt, a)) return hipErrorInvalidValue;
+  if (dt == F32) return a.cin2 ? launch_rs_x3<true>(a, s) : launch_rs_x3<false>(a, s);
   if (dt == BF16) return a.cin2 ? launch_rs<bf16, true>(a, s) : launch_rs<bf16, false>(a, s);
   return a.cin2 ? launch_rs<f16, true>(a, s) : launch_rs<f16, false>(a, s);
 }

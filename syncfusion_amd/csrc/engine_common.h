@@ -106,6 +106,7 @@ struct ConvW {
   void *wt = nullptr;      // direct layers only: the same [N][K] matrix in the compute type (conv_thin's MFMA operand)
   void *wcb = nullptr;     // k = 3 convolutions of the deep levels: the same weights in MFMA fragment order (conv_cb.hip)
   void *wfr = nullptr;     // the [N][K] matrix in MFMA fragment order [N / 32][K / 16][64][8] (conv_gemm_rs.hip), K <= 2048
+  void *wfrx = nullptr;    // fp32x engine: the split weights in MFMA fragment order (conv_gemm_rs.hip), K <= 1280
   void *wx = nullptr;      // fp32x engine: the fp32 [N][K] matrix as split fp16 operands [N][K / 32][hi 32 | lo' 32] (launch_pack_wx)
 };
 

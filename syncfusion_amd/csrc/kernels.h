@@ -60,6 +60,7 @@ struct ConvGemmArgs {
   // the same bytes per row as fp32).  When set, the kernels that carry the split mode multiply fp32 activations against it with three
   // v_mfma_f32_32x32x16_f16 per product (common.h, x3_split); every other kernel ignores it and multiplies `w` in fp32.
   const void *wx = nullptr;
+  const void *wfrx = nullptr;   // the same split weights in MFMA fragment order [N / 32][K / 16][hi | lo'][64][8] (conv_gemm_rs.hip, K <= 1280)
   int wx_mode = 1;              // 1: fp16 hi + 2048-scaled fp16 lo (forward passes); 2: bf16 hi + bf16 lo (gradients: no range restriction)
   // the first source is ALREADY split (mode 1): rows of [cin / 32][hi 32 | lo' 32] fp16 -- the same bytes per row as fp32 -- written by a
   // producer whose output only this GEMM reads (launch_gn_silu with xfmt): the kernel then spends no vector instruction on the operand.
@@ -129,6 +130,7 @@ bool conv_gemm_rs_ok(int dt, const ConvGemmArgs &a);
 bool conv_gemm_rs_rows_ok(int64_t rows, int N);   // few enough 32x32 tiles for the small-batch kernels (the rule launch_conv_gemm applies)
 hipError_t launch_conv_gemm_rs(int dt, const ConvGemmArgs &a, hipStream_t s);
 hipError_t launch_pack_wfr(int dt, const void *w /* [N][K], compute type */, int N, int K, void *out, hipStream_t s);
+hipError_t launch_pack_wfrx(const float *w /* [N][K] fp32 */, int N, int K, void *out, hipStream_t s);   // split fragment order (ConvGemmArgs::wfrx)
 // split-fp16 image of a packed fp32 [N][K] matrix (K % 32 == 0): out[n][k / 32][0][k % 32] = hi, [1][k % 32] = lo' (common.h, x3_split)
 hipError_t launch_pack_wx(const float *w, int N, int K, void *out, hipStream_t s, int mode = 1);
 // Conv1d weight (N, C, taps) fp32 -> out[n][tap * C + c] fp32 and the split image of the same matrix, one pass ((taps * C) % 32 == 0)

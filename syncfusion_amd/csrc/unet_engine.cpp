@@ -581,6 +581,11 @@ void build(sf_unet &u, const WeightMap *wm, hipStream_t s) {
       if (w.direct || !w.w || (w.K % 32)) return;   // (the kernels check the channel counts of the launch they are given)
       w.wx = u.arena.alloc((int64_t)w.N * w.K * 4);
       SF_HIP(launch_pack_wx(static_cast<const float *>(w.w), w.N, w.K, w.wx, s));
+      // ... and in fragment order for the register-staged small-batch GEMM (InjectChannels, attention projections, down / up convolutions)
+      if ((w.K % 64) == 0 && w.K <= 1280 && (w.N % 32) == 0 && (w.cin % 16) == 0 && (w.cin2 % 16) == 0) {
+        w.wfrx = u.arena.alloc((int64_t)w.N * w.K * 4);
+        SF_HIP(launch_pack_wfrx(static_cast<const float *>(w.w), w.N, w.K, w.wfrx, s));
+      }
     };
     for (ConvW *w : {&u.lin0, &u.mlp0, &u.mlp1, &u.mod, &u.wv_cat}) split(*w);
     for (Block &b : u.blocks) {
@@ -800,8 +805,8 @@ struct Exec {
   // `rows` = output rows of the GEMM that will read the weights: short activations run on the register-staged kernel, which reads
   // the fragment-ordered copy (conv_gemm_rs.hip)
   Prefetch pf_for(const ConvW &w, int host_wgs, int64_t rows = -1) const {
-    const bool rs = w.wfr && rows >= 0 && conv_gemm_rs_rows_ok(rows, w.N);
-    return pf_bytes(w.direct ? nullptr : (rs ? w.wfr : (w.wx ? w.wx : w.w)), (size_t)w.N * w.K * dsize(u.dt), host_wgs);
+    const bool rs = (w.wfr || w.wfrx) && rows >= 0 && conv_gemm_rs_rows_ok(rows, w.N);
+    return pf_bytes(w.direct ? nullptr : (rs ? (w.wfrx ? w.wfrx : w.wfr) : (w.wx ? w.wx : w.w)), (size_t)w.N * w.K * dsize(u.dt), host_wgs);
   }
   Prefetch pf_cb(const ConvW &w, int host_wgs) const { return pf_bytes(w.wcb, conv_cb_weight_elems(w.N, w.cin) * dsize(u.dt), host_wgs); }
   Prefetch pf_bytes(const void *ptr, size_t bytes, int host_wgs) const {
@@ -847,6 +852,7 @@ struct Exec {
     a.w = w.w;
     a.wfr = w.wfr;
     a.wx = w.wx;
+    a.wfrx = w.wfrx;
     a.solo = p.nbr_total <= 1 ? 1 : 0;
     a.bias = w.bias;
     a.N = w.N;

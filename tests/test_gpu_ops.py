@@ -125,7 +125,11 @@ def _conv_x3_case(cuda, dtype, B, L, C, N, taps, up, residual, seed=0):
     (32, 176, 1024, 1024, 3, 1, True),    # the deepest level at the guidance batch: K = 3072
     (32, 176, 1024, 1536, 1, 1, False),   # qkv projection
     (64, 512, 256, 256, 3, 1, True),      # 256x128 macro tiles (two full rounds)
-    (4, 88, 1024, 1024, 3, 1, True),      # few rows: wave-private 32x32 split-K
+    (4, 88, 1024, 1024, 3, 1, True),      # few rows, K = 3072: wave-private 32x32 split-K
+    (4, 88, 1024, 1024, 1, 1, True),      # few rows, K = 1024: register-staged 32x32 kernel (fragment-ordered split weights), residual
+    (4, 44, 1024, 1536, 1, 1, False),     # qkv projection at the deepest level
+    (4, 176, 512, 512, 1, 1, True),       # attention output projection shape
+    (5, 61, 256, 256, 3, 1, True),        # K = 768 with taps: the register-staged kernel's tap bookkeeping, ragged rows
     (8, 44, 512, 256, 3, 1, True),        # clips shorter than a tile
     (2, 100, 256, 320, 1, 1, False),      # ragged M and N on the 32x32 kernels
     (4, 352, 256, 256, 3, 1, True),       # staged 32x32 kernel
