@@ -250,14 +250,15 @@ def extra_workloads(model, device, args, noise, channels, emb) -> dict:
         return float((a.double() - b.double()).norm() / b.double().norm())
 
     def parity_twin(dt, nz, ch, e, scale, steps, lowp_out, L):
-        """The workload of a 16-bit leg again on a parity-grade engine (`dt` = fp32 or fp32x): its rate, its roofline fraction against the fp32
-        MFMA peak, and the distance of the 16-bit engine's final sample from it after the configuration's own step count."""
+        """The workload of a 16-bit leg again on a parity-grade engine (`dt` = fp32 or fp32x): its rate, its roofline fraction against the MFMA
+        peak of ITS arithmetic (fp32 MFMA for fp32; a third of the 16-bit peak for fp32x: three 16-bit products per product), and the distance of the 16-bit engine's final sample from it after the configuration's own step count."""
         with engine_dtype(dt):
             rate, o, sp = timed_sample(model, device, nz, ch, e, scale, steps, warm=2, repeats=REPEATS)
         ms = 1e3 / rate
         B_ = nz.shape[0]
         return dict(steps_per_s=round(rate, 2), steps_per_s_spread=sp, ms_per_step=round(ms, 3), dtype=dt, timed_steps=steps,
-                    step_roofline_frac_vs_fp32_peak=round(roof_ms(B_, 1 if scale == 1.0 else 2, L, "fp32") / ms, 4),
+                    step_roofline_frac=round(roof_ms(B_, 1 if scale == 1.0 else 2, L, dt) / ms, 4),
+                    step_roofline_peak_tflops={"fp32": PEAK_F32_TFLOPS, "fp32x": PEAK_X3_TFLOPS}[dt],
                     lowp_dtype=args.dtype, lowp_final_sample_rel_l2=float(f"{rel_l2(lowp_out, o):.3e}"), rel_l2_steps=steps,
                     gate_1e4_met_by_lowp=bool(rel_l2(lowp_out, o) < 1e-4)), o
 

@@ -215,7 +215,7 @@ struct sf_unet {
   int branches_override = 0;
   // Tuning hook (tuning build only) SF_BRANCH_CUMASK=d: the stream of branch b is created with a CU mask that holds the mask bits k with
   // (k / d) % branches == b (hipExtStreamCreateWithCUMask) -- the round-6 A/B of CU-partitioned clip-parallel branches
-  // (profiles/r6_d_cumask_branches.txt; tools/r6_probes.hip shows what a mask bit is on this machine).  0 / unset: plain streams.
+  // (profiles/r6_d_xcd_branches.txt; tools/r6_probes.hip shows what a mask bit is on this machine).  0 / unset: plain streams.
   static hipError_t make_branch_stream(hipStream_t *st, int branch, int nbr) {
     static const int div = [] { const char *e = tune_env("SF_BRANCH_CUMASK"); return e ? atoi(e) : 0; }();
     if (div <= 0 || nbr < 2) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
