@@ -268,6 +268,19 @@ int sf_op_conv1d_bwd_cl_act(const float *x, const float *act, const float *stats
 int sf_op_conv1d_bwd_cl_x(int dtype, const float *x, const float *act, const float *stats, const float *w, const float *gamma, const float *beta,
                           int groups, float eps, const float *dy, int B, int L, int C, int N, int taps, int pad, float *dx, float *dw, float *db,
                           float *dgb, void *ws, int64_t ws_bytes, void *stream);
+/* One weight-pack launch per convolution and training step.  sf_op_conv1d_train_fwd = sf_op_conv1d_cl for fp32 tensors (dtype SF_F32 /
+ * SF_F32X, stride 1, no upsampling, taps <= 9) that ALSO writes the images of `w` the data-gradient GEMM of the backward pass reads into
+ * dgrad_pack (>= sf_op_conv1d_dgrad_pack_bytes(C, N, taps) bytes: the flipped / transposed matrix [C][taps][N] in fp32, then its split
+ * bf16 image); dgrad_pack may be NULL (then it is sf_op_conv1d_cl).  sf_op_conv1d_bwd_cl_p = sf_op_conv1d_bwd_cl_x reading those
+ * images instead of packing its own (dgrad_pack NULL: packs its own).  The caller keeps dgrad_pack alive and `w` unchanged between the
+ * two calls (the reference's training step: main/module_diffusion.py:79-82, optimizer step after backward). */
+int64_t sf_op_conv1d_dgrad_pack_bytes(int C, int N, int taps);
+int sf_op_conv1d_train_fwd(int dtype, const float *x, const float *w, const float *bias, const float *gamma, const float *beta, int groups, float eps,
+                           const float *residual, int B, int L, int C, int N, int taps, int pad, float *out, void *dgrad_pack, int64_t dgrad_pack_bytes,
+                           void *ws, int64_t ws_bytes, void *stream);
+int sf_op_conv1d_bwd_cl_p(int dtype, const float *x, const float *act, const float *stats, const float *w, const void *dgrad_pack, const float *gamma,
+                          const float *beta, int groups, float eps, const float *dy, int B, int L, int C, int N, int taps, int pad, float *dx, float *dw,
+                          float *db, float *dgb, void *ws, int64_t ws_bytes, void *stream);
 /* Length reductions of the training composition (fp32, channels-last): out[b][c] = sum_l x[b][l][c] * (y ? y[b][l][c] : 1) -- the
  * gradient of a per-clip broadcast add (cross-attention over one context token) and of the SkipModulate scale
  * (a-unet SkipModulate: x + scale[:, None, :] * h).  Two deterministic stages, no atomics.

@@ -40,6 +40,7 @@ def _cl(x: Tensor) -> Tensor:
 # both settings meet the gradient tests' unchanged tolerances.
 GEMM_DTYPE = os.environ.get("SF_TRAIN_GEMM", "fp32x")
 
+_SELF_PACK = os.environ.get("SF_TRAIN_SELF_PACK") == "1"  # A/B aid: the backward pass packs the data-gradient weight images itself (one more launch per convolution)
 _FUSED_GN = os.environ.get("SF_TRAIN_FUSED_GN") == "1"   # A/B aid: GroupNorm+SiLU as the convolution kernel's prologue, recomputed in backward
 
 
@@ -102,13 +103,20 @@ class _ConvBlockFn(torch.autograd.Function):
                 _lib.check(lib.sf_op_gn_silu_train(x_cl.data_ptr(), g.data_ptr(), be.data_ptr(), int(groups), float(eps), B, L, Cc, act.data_ptr(),
                                                    stats.data_ptr() if nst > 0 else None, _lib.stream_ptr(x.device)), "sf_op_gn_silu_train")
             src, gr = (act, 0) if act is not None else (x_cl, int(groups))
-            _lib.check(lib.sf_op_conv1d_cl(_lib.DTYPES[GEMM_DTYPE], src.data_ptr(), w.data_ptr(), b.data_ptr() if b is not None else None,
-                                           g.data_ptr() if gr > 0 else None, be.data_ptr() if gr > 0 else None, gr, float(eps),
-                                           res_cl.data_ptr() if res_cl is not None else None, B, L, Cc, N, taps, 1, pad, 1, out.data_ptr(), ws.data_ptr(),
-                                           ws.numel(), _lib.stream_ptr(x.device)),
-                       "sf_op_conv1d_cl")
+            # the weight images of the backward pass's data-gradient GEMM come out of the SAME pack launch as the forward images (one launch
+            # per weight and step; the backward pass packs nothing), when a data gradient will be asked for
+            dgp = None
+            if taps <= 9 and (groups > 0 or ctx.needs_input_grad[0]) and not _SELF_PACK:
+                dgp = torch.empty(int(lib.sf_op_conv1d_dgrad_pack_bytes(Cc, N, taps)), dtype=torch.uint8, device=x.device)
+            _lib.check(lib.sf_op_conv1d_train_fwd(_lib.DTYPES[GEMM_DTYPE], src.data_ptr(), w.data_ptr(), b.data_ptr() if b is not None else None,
+                                                  g.data_ptr() if gr > 0 else None, be.data_ptr() if gr > 0 else None, gr, float(eps),
+                                                  res_cl.data_ptr() if res_cl is not None else None, B, L, Cc, N, taps, pad, out.data_ptr(),
+                                                  dgp.data_ptr() if dgp is not None else None, dgp.numel() if dgp is not None else 0, ws.data_ptr(),
+                                                  ws.numel(), _lib.stream_ptr(x.device)),
+                       "sf_op_conv1d_train_fwd")
         ctx.save_for_backward(x_cl, w, g if g is not None else x_cl.new_empty(0), be if be is not None else x_cl.new_empty(0),
-                              act if act is not None else x_cl.new_empty(0), stats if stats is not None else x_cl.new_empty(0))
+                              act if act is not None else x_cl.new_empty(0), stats if stats is not None else x_cl.new_empty(0),
+                              dgp if dgp is not None else x_cl.new_empty(0))
         ctx.meta = (B, L, Cc, N, taps, pad, int(groups), float(eps), bias is not None, c_real, n_real, bool(channels_last))
         if n_real != N:
             out = out[:, :, :n_real]
@@ -119,7 +127,7 @@ class _ConvBlockFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy: Tensor):
         lib = _lib.load()
-        x_cl, w, g, be, act, stats = ctx.saved_tensors
+        x_cl, w, g, be, act, stats, dgp = ctx.saved_tensors
         B, L, Cc, N, taps, pad, groups, eps, has_bias, c_real, n_real, channels_last = ctx.meta
         dev = x_cl.device
         with torch.cuda.device(dev):
@@ -143,9 +151,10 @@ class _ConvBlockFn(torch.autograd.Function):
                     ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev))
             gp, bp = (g.data_ptr() if groups > 0 else None), (be.data_ptr() if groups > 0 else None)
             have_act = groups > 0 and act.numel() > 0
-            _lib.check(lib.sf_op_conv1d_bwd_cl_x(_lib.DTYPES[GEMM_DTYPE], x_cl.data_ptr(), act.data_ptr() if have_act else None,
-                                                 stats.data_ptr() if have_act and stats.numel() > 0 else None, w.data_ptr(), gp, bp, *tail),
-                       "sf_op_conv1d_bwd_cl_x")
+            _lib.check(lib.sf_op_conv1d_bwd_cl_p(_lib.DTYPES[GEMM_DTYPE], x_cl.data_ptr(), act.data_ptr() if have_act else None,
+                                                 stats.data_ptr() if have_act and stats.numel() > 0 else None, w.data_ptr(),
+                                                 dgp.data_ptr() if dgp.numel() > 0 else None, gp, bp, *tail),
+                       "sf_op_conv1d_bwd_cl_p")
         if c_real != Cc:
             dx = dx[:, :, :c_real] if dx is not None else None
             dw = dw[:, :c_real] if dw is not None else None

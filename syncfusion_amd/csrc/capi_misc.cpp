@@ -1,5 +1,6 @@
 // Version / error / device probes, the onset glue and the op-level test entry points of the C ABI.
 #include <algorithm>
+#include <cstring>
 #include <cstdlib>
 #include <cmath>
 #include <exception>
@@ -148,9 +149,11 @@ int sf_resampler_forward(sf_resampler *h, const float *x, int R, int L, float *o
   SF_API_END
 }
 
-int sf_op_conv1d_cl(int dtype, const void *x, const float *w, const float *bias, const float *gamma, const float *beta, int groups,
-                    float eps, const void *residual, int B, int L, int C, int N, int taps, int stride, int pad, int upsample,
-                    void *out, void *ws, int64_t ws_bytes, void *stream) {
+// (dgp: the training forward also writes the data-gradient images of the weight, [C][taps][N] fp32 then its split bf16 image, for
+// sf_op_conv1d_bwd_cl_p -- one pack launch per weight and step instead of one per GEMM)
+static int conv1d_cl_impl(int dtype, const void *x, const float *w, const float *bias, const float *gamma, const float *beta, int groups,
+                          float eps, const void *residual, int B, int L, int C, int N, int taps, int stride, int pad, int upsample,
+                          void *out, void *ws, int64_t ws_bytes, void *stream, void *dgp) {
   SF_API_BEGIN
   if (!x || !w || !out || !ws) fail(SF_ERR_INVALID, "null argument");
   if (upsample < 1 || (upsample & (upsample - 1))) fail(SF_ERR_UNSUPPORTED, "upsample must be a power of two");
@@ -162,39 +165,10 @@ int sf_op_conv1d_cl(int dtype, const void *x, const float *w, const float *bias,
   if (direct && N > 32) fail(SF_ERR_UNSUPPORTED, "thin convolution with N > 32");
   const int wdt = direct ? F32 : dtype;
   const int K = taps * C;
-  const void *wp = w;   // fp32 1x1 convolutions: the PyTorch layout (N, C, 1) IS the GEMM's [N][K] (60 % of the training step's convolutions)
-  // (the kernels read weights as 16-byte vectors: a view at a storage offset that is not a multiple of 4 floats is packed like the rest)
-  void *wx_done = nullptr;
-  if (!(taps == 1 && wdt == F32 && (reinterpret_cast<uintptr_t>(w) % 16) == 0)) {
-    void *packed = wk.alloc((int64_t)N * K * dsize(wdt));
-    if (x3 && !direct && (K % 32) == 0) {   // fp32 matrix and its split image in one pass
-      wx_done = wk.alloc((int64_t)N * K * 4);
-      SF_HIP(launch_pack_conv_x(w, N, C, taps, static_cast<float *>(packed), wx_done, X3_F16, s));
-    } else {
-      SF_HIP(launch_pack_conv(wdt, w, N, C, 0, C, taps, C, nullptr, packed, K, 0, s));
-    }
-    wp = packed;
-  }
+  // ---- the launch, without its weight images ---------------------------------------------------------------------------------------------
   ConvGemmArgs a;
-  if (!direct && dtype != F32 && (K % 64) == 0 && K <= 2048 && (N % 32) == 0 && (C % 16) == 0) {   // as the engine packs it (conv_gemm_rs.hip)
-    void *wfr = wk.alloc((int64_t)N * K * dsize(wdt));
-    SF_HIP(launch_pack_wfr(dtype, wp, N, K, wfr, s));
-    a.wfr = wfr;
-  }
-  if (wx_done) a.wx = wx_done;
-  else if (x3 && !direct && (K % 32) == 0) {
-    void *wx = wk.alloc((int64_t)N * K * 4);
-    SF_HIP(launch_pack_wx(static_cast<const float *>(wp), N, K, wx, s));
-    a.wx = wx;
-  }
-  if (a.wx && (K % 64) == 0 && K <= 1280 && (N % 32) == 0 && (C % 16) == 0) {   // as the engine packs it: fragment order for the register-staged kernel
-    void *wfrx = wk.alloc((int64_t)N * K * 4);
-    SF_HIP(launch_pack_wfrx(static_cast<const float *>(wp), N, K, wfrx, s));
-    a.wfrx = wfrx;
-  }
   a.src = x;
   a.src_ld = C;
-  a.w = wp;
   a.bias = bias;
   a.N = N;
   a.K = K;
@@ -225,10 +199,87 @@ int sf_op_conv1d_cl(int dtype, const void *x, const float *w, const float *bias,
     a.beta = beta;
     a.eps = eps;
   }
+  // ---- weight images -------------------------------------------------------------------------------------------------------------------------
+  const void *wp = w;   // fp32 1x1 convolutions: the PyTorch layout (N, C, 1) IS the GEMM's [N][K] (60 % of the training step's convolutions)
+  // (the kernels read weights as 16-byte vectors: a view at a storage offset that is not a multiple of 4 floats is packed like the rest)
+  const bool need_fw = !(taps == 1 && wdt == F32 && (reinterpret_cast<uintptr_t>(w) % 16) == 0);
+  const bool wx_ok = x3 && !direct && (K % 32) == 0;
+  // fragment order for the register-staged kernel, as the engine packs it -- but only when THIS launch would take that kernel (the long rows
+  // of the training step go to the macro tiles: 131 of these packs per step were written and never read)
+  bool want_rs = false;
+  if (wx_ok && groups == 0 && (K % 64) == 0 && K <= 1280 && (N % 32) == 0 && (C % 16) == 0) {
+    ConvGemmArgs pa = a;
+    pa.w = pa.wx = pa.wfrx = reinterpret_cast<const void *>(16);   // probe
+    want_rs = strncmp(conv_gemm_variant_name(dtype, pa), "conv_gemm_rs", 12) == 0;
+  }
+  void *wx_done = nullptr;
+  if (dgp) {   // training forward (fp32 tensors): every image of this weight the step reads, in one launch, and only those
+    if (dtype != F32 || stride != 1 || upsample != 1 || taps > 9) fail(SF_ERR_UNSUPPORTED, "data-gradient images: fp32 / fp32x stride-1 convolutions of at most 9 taps");
+    const bool fw_read = !wx_ok || want_rs || !conv_gemm_reads_split_only(dtype, a);   // (the fragment-order pack reads the fp32 image)
+    float *fw = need_fw && fw_read ? wk.alloc_n<float>((int64_t)N * K) : nullptr;
+    if (wx_ok) wx_done = wk.alloc((int64_t)N * K * 4);
+    float *dg = static_cast<float *>(dgp);
+    void *dgx = conv1d_dgrad_split_ok(x3, N, taps) ? static_cast<void *>(dg + (int64_t)C * taps * N) : nullptr;
+    const bool dg_read = !dgx || !conv_gemm_reads_split_only(F32, conv1d_dgrad_args(nullptr, B, L, C, N, taps, pad, nullptr));
+    SF_HIP(launch_pack_train(w, N, C, taps, fw, wx_done, dg_read ? dg : nullptr, dgx, s));
+    if (fw) wp = fw;
+    else if (need_fw) wp = nullptr;   // nobody reads it
+  } else if (need_fw) {
+    void *packed = wk.alloc((int64_t)N * K * dsize(wdt));
+    if (wx_ok) {   // fp32 matrix and its split image in one pass
+      wx_done = wk.alloc((int64_t)N * K * 4);
+      SF_HIP(launch_pack_conv_x(w, N, C, taps, static_cast<float *>(packed), wx_done, X3_F16, s));
+    } else {
+      SF_HIP(launch_pack_conv(wdt, w, N, C, 0, C, taps, C, nullptr, packed, K, 0, s));
+    }
+    wp = packed;
+  }
+  if (!direct && dtype != F32 && (K % 64) == 0 && K <= 2048 && (N % 32) == 0 && (C % 16) == 0) {   // as the engine packs it (conv_gemm_rs.hip)
+    void *wfr = wk.alloc((int64_t)N * K * dsize(wdt));
+    SF_HIP(launch_pack_wfr(dtype, wp, N, K, wfr, s));
+    a.wfr = wfr;
+  }
+  if (wx_done) a.wx = wx_done;
+  else if (wx_ok) {
+    void *wx = wk.alloc((int64_t)N * K * 4);
+    SF_HIP(launch_pack_wx(static_cast<const float *>(wp), N, K, wx, s));
+    a.wx = wx;
+  }
+  a.w = wp;
+  if (want_rs) {
+    void *wfrx = wk.alloc((int64_t)N * K * 4);
+    SF_HIP(launch_pack_wfrx(static_cast<const float *>(wp), N, K, wfrx, s));
+    a.wfrx = wfrx;
+  }
   if (direct) SF_HIP(launch_conv_direct(dtype, dtype, a, s));
   else SF_HIP(launch_conv_gemm(dtype, a, s));
   return SF_OK;
   SF_API_END
+}
+
+int sf_op_conv1d_cl(int dtype, const void *x, const float *w, const float *bias, const float *gamma, const float *beta, int groups,
+                    float eps, const void *residual, int B, int L, int C, int N, int taps, int stride, int pad, int upsample,
+                    void *out, void *ws, int64_t ws_bytes, void *stream) {
+  return conv1d_cl_impl(dtype, x, w, bias, gamma, beta, groups, eps, residual, B, L, C, N, taps, stride, pad, upsample, out, ws, ws_bytes, stream, nullptr);
+}
+
+int64_t sf_op_conv1d_dgrad_pack_bytes(int C, int N, int taps) {
+  if (C < 1 || N < 1 || taps < 1 || taps > 9) return -1;
+  return (int64_t)C * taps * N * 8;   // the fp32 matrix and its split bf16 image
+}
+
+int sf_op_conv1d_train_fwd(int dtype, const float *x, const float *w, const float *bias, const float *gamma, const float *beta, int groups, float eps,
+                           const float *residual, int B, int L, int C, int N, int taps, int pad, float *out, void *dgrad_pack, int64_t dgrad_pack_bytes,
+                           void *ws, int64_t ws_bytes, void *stream) {
+  if (dtype != SF_F32 && dtype != SF_F32X) {
+    set_error("sf_op_conv1d_train_fwd: dtype must be SF_F32 or SF_F32X");
+    return SF_ERR_INVALID;
+  }
+  if (dgrad_pack && dgrad_pack_bytes < sf_op_conv1d_dgrad_pack_bytes(C, N, taps)) {
+    set_error("sf_op_conv1d_train_fwd: dgrad_pack holds %lld bytes, %lld needed", (long long)dgrad_pack_bytes, (long long)sf_op_conv1d_dgrad_pack_bytes(C, N, taps));
+    return SF_ERR_INVALID;
+  }
+  return conv1d_cl_impl(dtype, x, w, bias, gamma, beta, groups, eps, residual, B, L, C, N, taps, 1, pad, 1, out, ws, ws_bytes, stream, dgrad_pack);
 }
 
 int sf_op_gn_silu(int dtype, const void *x, const float *gamma, const float *beta, int groups, float eps, int B, int L, int C, void *out,

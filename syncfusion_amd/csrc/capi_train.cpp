@@ -58,7 +58,8 @@ int64_t sf_op_conv1d_bwd_workspace_bytes(int B, int L, int C, int N, int taps, i
 }
 
 static int conv1d_bwd_impl(int dtype, const float *x, const float *act_saved, const float *stats_saved, const float *w, const float *gamma, const float *beta, int groups, float eps, const float *dy, int B, int L,
-                        int C, int N, int taps, int pad, float *dx, float *dw, float *db, float *dgb, void *ws, int64_t ws_bytes, void *stream) {
+                        int C, int N, int taps, int pad, float *dx, float *dw, float *db, float *dgb, void *ws, int64_t ws_bytes, void *stream,
+                        const void *dgrad_pack = nullptr /* sf_op_conv1d_train_fwd's images of w: nothing is packed here */) {
   SF_API_BEGIN
   if (!x || !w || !dy || !ws) fail(SF_ERR_INVALID, "null argument");
   if (dtype != SF_F32 && dtype != SF_F32X) fail(SF_ERR_INVALID, "dtype must be SF_F32 or SF_F32X");
@@ -81,31 +82,20 @@ static int conv1d_bwd_impl(int dtype, const float *x, const float *act_saved, co
   // (dx == NULL: the input needs no gradient -- the first convolution on the raw waveform, a frozen trunk -- and without a GroupNorm
   // in front nothing else depends on da: the whole data gradient is skipped; likewise dw == NULL skips the weight gradient)
   if (dx || groups > 0) {
-    const bool direct_dg = (N % 32) != 0;
-    const bool wx_dg = x3 && !direct_dg && ((taps * p.ldn) % 32) == 0;
-    SF_HIP(launch_pack_dgrad(w, N, C, taps, p.ldn, p.wd, s, wx_dg ? p.wdx : nullptr));
-    ConvGemmArgs a;
-    a.src = dy;
-    a.src_ld = N;
-    a.w = p.wd;
-    a.N = C;
-    a.K = taps * p.ldn;
-    a.cin = p.ldn;
-    a.taps = taps;
-    a.stride = 1;
-    a.pad = taps - 1 - pad;
-    a.Lsrc = a.Lout = L;
-    a.M = B * L;
-    a.out = groups > 0 ? p.da : dx;
-    a.out_ld = C;
-    a.n_store = C;
-    a.solo = 1;
     const bool direct = (N % 32) != 0;
     if (direct && C > 32) fail(SF_ERR_UNSUPPORTED, "dgrad of a thin convolution (N %% 32 != 0) needs C <= 32");
-    if (wx_dg) {   // products from split bf16 operands (gradients span the whole fp32 exponent range); image written by launch_pack_dgrad
-      a.wx = p.wdx;
-      a.wx_mode = X3_BF16;
+    const bool wx_dg = conv1d_dgrad_split_ok(x3, N, taps);
+    ConvGemmArgs a = conv1d_dgrad_args(dy, B, L, C, N, taps, pad, groups > 0 ? p.da : dx);
+    if (!wx_dg) a.wx_mode = X3_F16;   // (unused without a split image; the struct's default)
+    if (dgrad_pack) {   // images written by sf_op_conv1d_train_fwd: the fp32 matrix only if this launch reads it (the same predicate there)
+      p.wd = const_cast<float *>(static_cast<const float *>(dgrad_pack));
+      p.wdx = p.wd + (int64_t)C * taps * p.ldn;
+      if (wx_dg && conv_gemm_reads_split_only(F32, a)) p.wd = nullptr;
+    } else {
+      SF_HIP(launch_pack_dgrad(w, N, C, taps, p.ldn, p.wd, s, wx_dg ? p.wdx : nullptr));
     }
+    a.w = p.wd;
+    if (wx_dg) a.wx = p.wdx;   // products from split bf16 operands
     if (direct) SF_HIP(launch_conv_direct(F32, F32, a, s));
     else SF_HIP(launch_conv_gemm(F32, a, s));
   }
@@ -137,6 +127,12 @@ int sf_op_conv1d_bwd_cl_x(int dtype, const float *x, const float *act, const flo
                           int groups, float eps, const float *dy, int B, int L, int C, int N, int taps, int pad, float *dx, float *dw, float *db,
                           float *dgb, void *ws, int64_t ws_bytes, void *stream) {
   return conv1d_bwd_impl(dtype, x, act, stats, w, gamma, beta, groups, eps, dy, B, L, C, N, taps, pad, dx, dw, db, dgb, ws, ws_bytes, stream);
+}
+
+int sf_op_conv1d_bwd_cl_p(int dtype, const float *x, const float *act, const float *stats, const float *w, const void *dgrad_pack, const float *gamma,
+                          const float *beta, int groups, float eps, const float *dy, int B, int L, int C, int N, int taps, int pad, float *dx, float *dw,
+                          float *db, float *dgb, void *ws, int64_t ws_bytes, void *stream) {
+  return conv1d_bwd_impl(dtype, x, act, stats, w, gamma, beta, groups, eps, dy, B, L, C, N, taps, pad, dx, dw, db, dgb, ws, ws_bytes, stream, dgrad_pack);
 }
 
 int64_t sf_op_gn_silu_train_stats_floats(int B, int L, int C, int groups) {

@@ -1,6 +1,7 @@
 // Host-side plumbing shared by the engines behind the C ABI: error reporting, named-weight lookup,
 // a device arena for packed weights and a bump allocator over the caller's workspace.
 #pragma once
+#include <cstring>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -109,6 +110,36 @@ struct ConvW {
   void *wfrx = nullptr;    // fp32x engine: the split weights in MFMA fragment order (conv_gemm_rs.hip), K <= 1280
   void *wx = nullptr;      // fp32x engine: the fp32 [N][K] matrix as split fp16 operands [N][K / 32][hi 32 | lo' 32] (launch_pack_wx)
 };
+
+// ---- training step: the data-gradient GEMM of a stride-1 "same" convolution, shared by the forward entry that packs its weight images
+// (capi_misc.cpp) and the backward entry that launches it (capi_train.cpp): da[row][c] = sum over (tap', n) of dy[row + tap' - (taps - 1 - pad)][n]
+// * W[n][c][taps - 1 - tap'] ----
+inline bool conv1d_dgrad_split_ok(bool x3, int N, int taps) { return x3 && (N % 32) == 0 && (((int64_t)taps * N) % 32) == 0; }
+inline ConvGemmArgs conv1d_dgrad_args(const float *dy, int B, int L, int C, int N, int taps, int pad, float *out) {
+  ConvGemmArgs a;
+  a.src = dy;
+  a.src_ld = N;
+  a.N = C;
+  a.K = taps * N;
+  a.cin = N;
+  a.taps = taps;
+  a.stride = 1;
+  a.pad = taps - 1 - pad;
+  a.Lsrc = a.Lout = L;
+  a.M = B * L;
+  a.out = out;
+  a.out_ld = C;
+  a.n_store = C;
+  a.solo = 1;
+  a.wx_mode = X3_BF16;   // gradients span the whole fp32 exponent range: bf16 hi / lo
+  return a;
+}
+// would launch_conv_gemm(dt, a) with a split image at hand take a kernel that reads ONLY the split image (so that the fp32 image need not exist)?
+inline bool conv_gemm_reads_split_only(int dt, ConvGemmArgs a) {
+  a.w = a.wx = reinterpret_cast<const void *>(16);   // probe
+  const char *name = conv_gemm_variant_name(dt, a);
+  return std::strstr(name, "<x3") != nullptr;   // conv_gemm_mt<x3>, conv_gemm_wp<x3,..>, conv_gemm_fast<x3,..>, conv_gemm_rs<x3,..>
+}
 
 // Name lookup + packing helper shared by the Encoder1d and VideoOnsetNet engines.
 struct Packer {

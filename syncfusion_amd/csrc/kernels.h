@@ -395,6 +395,9 @@ hipError_t launch_times_to_track(const double *times, const int *clip_of, int n_
 // Conv1d weight (N, C, taps) -> dgrad matrix [c][t' * ldn + n] = W[n][c][taps-1-t'] (the forward kernels then compute da from dy)
 // outx (optional, (taps * ldn) % 32 == 0): the split bf16 image of the same matrix, written in the same pass
 hipError_t launch_pack_dgrad(const float *w, int N, int C, int taps, int ldn, float *out, hipStream_t s, void *outx = nullptr);
+// every weight image of one training convolution in one launch (train.hip): fw [N][taps][C] fp32, fwx its split fp16 image, dg the
+// data-gradient matrix [C][taps][N] (taps flipped) fp32, dgx its split bf16 image; null outputs are skipped; taps <= 9
+hipError_t launch_pack_train(const float *w, int N, int C, int taps, float *fw, void *fwx, float *dg, void *dgx, hipStream_t s);
 // dw (N, C, taps) = sum_rows dy[row][n] * act[row + t - pad][c];  partial: [S][N][taps*C] scratch, S = conv_wgrad_splits(...)
 int conv_wgrad_splits(int64_t rows, int C, int N, int taps);
 // x3: the products from split fp16 operands (both operands are activations: split while they are staged)

@@ -31,6 +31,50 @@ __global__ void pack_dgrad_kernel(const float *__restrict__ w, int N, int C, int
   }
 }
 
+// Every weight image one training convolution reads, in ONE launch per weight and step (the forward and the data-gradient GEMM used to pack
+// their own: 2 x 200 launches per step, the data-gradient one with reads strided by C * taps floats).  A workgroup takes a 32 (n) x 32 (c)
+// tile with all its taps through LDS: the (c, tap) run of a row is contiguous in the PyTorch layout, the forward images are written with c
+// fastest, the data-gradient images with n fastest.  Any of the four outputs may be null:
+//   fw  [n][tap][c] fp32                      fwx  its split fp16 image (hi | lo' per 32 columns; (taps * C) % 32 == 0)
+//   dg  [c][taps - 1 - tap][n] fp32            dgx  its split bf16 image ((taps * N) % 32 == 0)
+constexpr int PT_MAX_TAPS = 9;
+__global__ __launch_bounds__(256) void pack_train_kernel(const float *__restrict__ w, int N, int C, int taps, float *__restrict__ fw, f16 *__restrict__ fwx,
+                                                         float *__restrict__ dg, bf16 *__restrict__ dgx) {
+  __shared__ float tile[PT_MAX_TAPS * 32 * 33];
+  const int c0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const int cw = min(32, C - c0), nh = min(32, N - n0);
+  const int run = cw * taps;   // floats of one row's (c, tap) run inside the tile
+  for (int e = threadIdx.x; e < nh * run; e += 256) {
+    const int nl = e / run, rem = e - nl * run;
+    const int cl = rem / taps, tap = rem - cl * taps;
+    tile[(tap * 32 + nl) * 33 + cl] = w[((int64_t)(n0 + nl) * C + c0) * taps + rem];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;   // 8 groups of 32 lanes
+  if (fw || fwx) {
+    for (int r = grp; r < taps * nh; r += 8) {   // r -> (tap, nl); lanes along c
+      const int tap = r / nh, nl = r - tap * nh;
+      if (lane < cw) {
+        const float v = tile[(tap * 32 + nl) * 33 + lane];
+        const int64_t i = ((int64_t)(n0 + nl) * taps + tap) * C + c0 + lane;
+        if (fw) fw[i] = v;
+        if (fwx) x3_split1<X3_F16>(v, fwx[(i >> 5) * 64 + (i & 31)], fwx[(i >> 5) * 64 + 32 + (i & 31)]);
+      }
+    }
+  }
+  if (dg || dgx) {
+    for (int r = grp; r < taps * cw; r += 8) {   // r -> (tap, cl); lanes along n
+      const int tap = r / cw, cl = r - tap * cw;
+      if (lane < nh) {
+        const float v = tile[(tap * 32 + lane) * 33 + cl];
+        const int64_t j = ((int64_t)(c0 + cl) * taps + (taps - 1 - tap)) * N + n0 + lane;
+        if (dg) dg[j] = v;
+        if (dgx) x3_split1<X3_BF16>(v, dgx[(j >> 5) * 64 + (j & 31)], dgx[(j >> 5) * 64 + 32 + (j & 31)]);
+      }
+    }
+  }
+}
+
 // partial[s][n][q],  q = t * C + c:  sum over the rows of split s of dy[row][n] * a[row + t - pad][c]
 // A wave holds TN x TQ accumulator tiles of 32 x 32 (2 x 2 for the wide layers: one A and one B value per tile row / column feed
 // TN * TQ MFMAs, which halves the L2 traffic per flop); the 4 waves take interleaved row pairs and are summed through LDS.
@@ -897,6 +941,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__
 }
 
 }  // namespace
+
+hipError_t launch_pack_train(const float *w, int N, int C, int taps, float *fw, void *fwx, float *dg, void *dgx, hipStream_t s) {
+  if (taps < 1 || taps > PT_MAX_TAPS) return hipErrorInvalidValue;
+  if ((fwx && (((int64_t)taps * C) % 32)) || (dgx && (((int64_t)taps * N) % 32))) return hipErrorInvalidValue;
+  if (!fw && !fwx && !dg && !dgx) return hipSuccess;
+  hipLaunchKernelGGL(pack_train_kernel, dim3((C + 31) / 32, (N + 31) / 32), dim3(256), 0, s, w, N, C, taps, fw, static_cast<f16 *>(fwx), dg,
+                     static_cast<bf16 *>(dgx));
+  return hipGetLastError();
+}
 
 hipError_t launch_pack_dgrad(const float *w, int N, int C, int taps, int ldn, float *out, hipStream_t s, void *outx) {
   const int64_t total = (int64_t)C * taps * ldn;

@@ -86,8 +86,11 @@ def _pointwise(x: Tensor, w: Tensor, b: Optional[Tensor], residual: Optional[Ten
 
 def _affine_ln(x: Tensor, gamma: Tensor, beta: Tensor, eps: float) -> Tensor:
     """LayerNorm_C with affine parameters, as LN-modulate with scale = gamma - 1, shift = beta for every clip."""
-    ss = torch.cat([gamma - 1.0, beta])[None, :].expand(x.shape[0], -1)
-    return sfa.ln_modulate(x, ss, eps)
+    # every clip shares (gamma, beta): the (B, L, C) rows are ONE clip of B * L rows to the kernel -- no per-clip copy of the pair in forward,
+    # no sum over the clips in backward (the kernel's length reduction covers all rows)
+    B, L, C = x.shape
+    ss = torch.cat([gamma - 1.0, beta])[None, :]
+    return sfa.ln_modulate(x.reshape(1, B * L, C), ss, eps).reshape(B, L, C)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -118,7 +121,7 @@ def _self_attention(P, pre: str, x: Tensor, heads: int) -> Tensor:
 
 
 class _ZeroGradAnchor(torch.autograd.Function):
-    """``y = x``; the listed parameters join the graph and receive exactly-zero gradients in backward (one fill each) -- what upstream's
+    """``y = x``; the listed parameters join the graph and receive exactly-zero gradients in backward (one fill for all) -- what upstream's
     autograd gives parameters whose branch cannot influence the output.  (Anchoring them with ``0 * p.sum()`` terms cost a reduction per
     parameter in forward and an expand + multiply + accumulate in backward: 4 % of the training step in ATen reduce / fill kernels.)"""
 
@@ -129,7 +132,17 @@ class _ZeroGradAnchor(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return (g,) + tuple(torch.zeros(shape, dtype=dt, device=dev) for shape, dt, dev in ctx.meta)
+        # ONE fill for all of them: the gradients are views of a single zero buffer (per dtype / device)
+        pools, outs = {}, []
+        for shape, dt, dev in ctx.meta:
+            pools[(dt, dev)] = pools.get((dt, dev), 0) + (math.prod(shape) + 3) // 4 * 4
+        bufs = {k: [torch.zeros(n, dtype=k[0], device=k[1]), 0] for k, n in pools.items()}
+        for shape, dt, dev in ctx.meta:
+            buf = bufs[(dt, dev)]
+            n = math.prod(shape)
+            outs.append(buf[0][buf[1]:buf[1] + n].view(shape))
+            buf[1] += (n + 3) // 4 * 4
+        return (g,) + tuple(outs)
 
 
 _ATEN_SUMS = os.environ.get("SF_TRAIN_ATEN_SUMS") == "1"   # A/B aid: the length reductions through ATen as before
@@ -166,6 +179,22 @@ class _SkipModulate(torch.autograd.Function):
         return g, gs, gh
 
 
+_ITEM_MAJOR: Dict[tuple, Tensor] = {}
+
+
+def _item_major_index(B: int, sizes: tuple, device) -> Tensor:
+    """flat position of element (item i, clip b, column k) in a row-major (B, sum(sizes)) matrix, items outermost (cached per shape)"""
+    key = (B, sizes, str(device))
+    idx = _ITEM_MAJOR.get(key)
+    if idx is None:
+        total, off, parts = sum(sizes), 0, []
+        for sz in sizes:
+            parts.append((torch.arange(B)[:, None] * total + off + torch.arange(sz)[None, :]).reshape(-1))
+            off += sz
+        idx = _ITEM_MAJOR[key] = torch.cat(parts).to(device)
+    return idx
+
+
 def _modulation_outputs(P, hp, f_act: Tensor) -> Dict[str, Tensor]:
     """Every Modulation (to_scale_shift) and SkipModulate (to_scale) Linear of the net reads the same SiLU(time features): one Linear over
     the concatenated weights (the inference engine keeps them as one (34569 x 1024) matrix too), split into per-item views -- 42 small
@@ -179,9 +208,10 @@ def _modulation_outputs(P, hp, f_act: Tensor) -> Dict[str, Tensor]:
     b = torch.cat([P[n + ".bias"] for n in names])
     out = F.linear(f_act, w, b)
     sizes = [int(P[n + ".weight"].shape[0]) for n in names]
-    # the consumers read contiguous (B, width) rows: repack the column slices item-major in ONE copy (instead of one per consumer)
+    # the consumers read contiguous (B, width) rows: repack the column slices item-major with ONE gather (a permutation of out's elements;
+    # its backward is one scatter of unique indices: deterministic) instead of one strided copy per consumer and direction
     B = out.shape[0]
-    flat = torch.cat([v.reshape(-1) for v in out.split(sizes, dim=1)])
+    flat = out.reshape(-1).index_select(0, _item_major_index(B, tuple(sizes), out.device))
     return {n: v.reshape(B, sz) for n, v, sz in zip(names, flat.split([B * sz for sz in sizes]), sizes)}
 
 

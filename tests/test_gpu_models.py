@@ -761,7 +761,7 @@ def test_full_size_transposed_up_eval_parity_with_taps(cuda, full_model_transpos
     assert e_t < out_tol and e_o < out_tol
 
 
-@pytest.mark.parametrize("dtype,tol", [("fp32", FP32_TOL), ("bf16", LOWP_SAMPLE5_TOL["bf16"]), ("fp16", LOWP_SAMPLE5_TOL["fp16"])])
+@pytest.mark.parametrize("dtype,tol", [("fp32", FP32_TOL), ("fp32x", FP32_TOL), ("bf16", LOWP_SAMPLE5_TOL["bf16"]), ("fp16", LOWP_SAMPLE5_TOL["fp16"])])
 def test_full_size_transposed_up_multistep_sample_parity(cuda, full_model_transposed, dtype, tol):
     """5 sampler steps of the transposed-up 215 M-parameter model (B = 2, L0 = 45056, graph replay) against sampler_ref."""
     model = full_model_transposed
@@ -777,7 +777,7 @@ def test_full_size_transposed_up_multistep_sample_parity(cuda, full_model_transp
     assert e < tol
 
 
-@pytest.mark.parametrize("dtype", LOWP + ["fp32x"])
+@pytest.mark.parametrize("dtype", LOWP + PARITY)
 def test_config2_shape_lowp_parity(cuda, full_model, dtype):
     """BASELINE configs[2]: batch 32, guidance scale 2.0 (one 64-row batch per evaluation), conditioning from the REAL Encoder1d
     pyramid of seeded onset tracks and a unit-norm CLAP-shaped embedding.  The first two clips against the oracle."""
@@ -955,6 +955,9 @@ def test_config4_chain_fp16_index_and_audio_parity(cuda, full_model):
                                noise=noise.to(cuda))
     gen32 = generate_batch(full_model, tracks["fp32"], z, num_steps=steps, length=L0, embedding_scale=scale, cut_prefix=True, cut_length=cut,
                            noise=noise.to(cuda))
+    with _compute_dtype(full_model, "fp32x"):   # the fast parity-grade engine on the same chain
+        gen32x = generate_batch(full_model, tracks["fp32"], z, num_steps=steps, length=L0, embedding_scale=scale, cut_prefix=True, cut_length=cut,
+                                noise=noise.to(cuda))
     assert gen16.shape == (B, 1, cut) and torch.isfinite(gen16).all()
     enc = full_model.onsets_encoder
     with torch.no_grad():
@@ -965,7 +968,9 @@ def test_config4_chain_fp16_index_and_audio_parity(cuda, full_model):
     ref = ref[:, :, :cut]
     e32, e16 = rel_l2(gen32[:1].cpu(), ref), rel_l2(gen16[:1].cpu(), ref)
     e16_32 = rel_l2(gen16.cpu(), gen32.cpu())
-    print(f"configs[4] chain, {steps} guided steps: rel-L2 vs oracle fp32 {e32:.3e}, fp16 {e16:.3e}; fp16 vs fp32 engine (4 clips) {e16_32:.3e}")
+    e32x = rel_l2(gen32x[:1].cpu(), ref)
+    print(f"configs[4] chain, {steps} guided steps: rel-L2 vs oracle fp32 {e32:.3e}, fp32x {e32x:.3e}, fp16 {e16:.3e}; fp16 vs fp32 engine (4 clips) {e16_32:.3e}")
+    assert e32x < FP32_TOL
     assert float(gen16[0, :, :first].abs().max()) == 0.0
     assert e32 < FP32_TOL
     assert e16 < LOWP_CHAIN_TOL["fp16"] and e16_32 < LOWP_CHAIN_TOL["fp16"]

@@ -24,19 +24,52 @@ def step(i):
 for i in range(2):
     step(i)
 torch.cuda.synchronize()
-from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=False) as prof:
+import traceback
+from torch.utils._python_dispatch import TorchDispatchMode
+
+
+class Trace(TorchDispatchMode):
+    """every ATen call of one step with the innermost syncfusion_amd / tools source line that issued it (torch.profiler's with_stack gives
+    empty stacks on this build); calls made by C++ autograd nodes carry no Python frame and are listed by shape"""
+
+    def __init__(self):
+        super().__init__()
+        self.agg = collections.Counter()
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        out = func(*args, **(kwargs or {}))
+        name = str(func).replace("aten.", "")
+        if any(k in name for k in ("empty", "view", "reshape", "as_strided", "transpose", "slice", "select", "unsqueeze", "squeeze", "expand", "detach", "alias", "permute", "t.default", "_unsafe_view", "split", "unbind", "narrow", "sym_", "is_", "size", "stride", "numel", "item", "_local_scalar")):
+            return out
+        where = None
+        chain = []
+        for fr in reversed(traceback.extract_stack()[:-1]):
+            if ("syncfusion_amd" in fr.filename or "tools/" in fr.filename) and "train_aten_trace" not in fr.filename:
+                chain.append(f"{os.path.basename(fr.filename)}:{fr.lineno} {fr.name}")
+                if len(chain) == 3:
+                    break
+        if chain:
+            where = " <- ".join(chain)
+            if "clone" in name or "copy_" in name:
+                t = next((a for a in args if isinstance(a, torch.Tensor)), None)
+                if t is not None:
+                    where += f"  {tuple(t.shape)} strides {tuple(t.stride())}"
+        if where is None:
+            shp = [tuple(a.shape) for a in args if isinstance(a, torch.Tensor)][:2]
+            where = f"<autograd engine / torch> {shp}"
+        self.agg[(name, where)] += 1
+        return out
+
+
+with Trace() as tr:
     step(2)
 torch.cuda.synchronize()
-want = ("aten::fill_", "aten::zero_", "aten::zeros", "aten::sum", "aten::add", "aten::add_", "aten::copy_", "aten::mul", "aten::cat", "aten::zeros_like", "aten::clone")
-agg = collections.Counter()
-for ev in prof.events():
-    if ev.name in want:
-        where = "?"
-        for fr in (ev.stack or []):
-            if "syncfusion_amd" in fr or "tools/" in fr or "torch/optim" in fr or "autograd/" in fr:
-                where = fr.strip()[-110:]
-                break
-        agg[(ev.name, where)] += 1
-for (name, where), n in agg.most_common(40):
-    print(f"{n:5d}  {name:18s} {where}")
+tot = collections.Counter()
+for (name, where), n in tr.agg.items():
+    tot[name] += n
+print("== ATen calls of one training step by op ==")
+for name, n in tot.most_common(30):
+    print(f"{n:5d}  {name}")
+print("== by (op, source line) ==")
+for (name, where), n in tr.agg.most_common(90):
+    print(f"{n:5d}  {name:24s} {where}")
