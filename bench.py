@@ -510,8 +510,17 @@ def extra_workloads(model, device, args, noise, channels, emb) -> dict:
 
         res = dict(workload="training step (exp/train_diffusion_gh.yaml): fp32 tensors, batch 4 x 2**18 samples, v-objective loss -> backward -> AdamW; "
                             f"GEMM arithmetic {sfa.GEMM_DTYPE} (fp32x = products from split 16-bit operands, gradient tests at unchanged tolerances)",
-                   ms_per_step=round(1e3 * dt, 2), ms_per_step_spread=spread(group_ms), clips_per_s=round(B / dt, 2), dtype=sfa.GEMM_DTYPE, timed_steps=iters,
-                   losses=losses, mode="eager (Python issues ~4400 launches per step)", graph_replay=graph_res)
+                   dtype=sfa.GEMM_DTYPE, timed_steps=iters,
+                   eager=dict(ms_per_step=round(1e3 * dt, 2), ms_per_step_spread=spread(group_ms), losses=losses,
+                              note="Python issues ~4100 launches per step: host-bound on boxes with slow host cores"),
+                   graph_replay=graph_res)
+        # the step as a user runs it fastest: both modes are product API (Model.training_step + backward, or training.GraphedTrainStep)
+        g_ms = graph_res.get("ms_per_step")
+        if g_ms is not None and g_ms < 1e3 * dt:
+            res.update(ms_per_step=g_ms, ms_per_step_spread=graph_res["ms_per_step_spread"], clips_per_s=round(B / (g_ms / 1e3), 2),
+                       mode="graph replay (training.GraphedTrainStep: forward + backward from one HIP graph, AdamW eager)")
+        else:
+            res.update(ms_per_step=round(1e3 * dt, 2), ms_per_step_spread=spread(group_ms), clips_per_s=round(B / dt, 2), mode="eager")
         return res
 
     def transpose_up_legs():

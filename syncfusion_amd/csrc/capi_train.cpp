@@ -100,8 +100,11 @@ static int conv1d_bwd_impl(int dtype, const float *x, const float *act_saved, co
     else SF_HIP(launch_conv_gemm(F32, a, s));
   }
   // ---- wgrad / bias grad ------------------------------------------------------------------------------------------
-  if (dw) SF_HIP(launch_conv_wgrad(dy, act, B, L, C, N, taps, pad, p.wpart, p.S, dw, s, x3 ? X3_BF16 : 0));
-  if (db) SF_HIP(launch_col_sums(dy, (int64_t)B * L, N, p.bpart, p.Sb, db, s));
+  // (the bias gradient's slice sums first: their reduction rides on the weight gradient's reducer launch where there is one)
+  if (db) SF_HIP(launch_col_sums_part(dy, (int64_t)B * L, N, p.bpart, p.Sb, s));
+  bool db_done = false;
+  if (dw) SF_HIP(launch_conv_wgrad(dy, act, B, L, C, N, taps, pad, p.wpart, p.S, dw, s, x3 ? X3_BF16 : 0, db ? p.bpart : nullptr, p.Sb, db, &db_done));
+  if (db && !db_done) SF_HIP(launch_slices_reduce(p.bpart, p.Sb, N, db, s));
   // ---- GroupNorm + SiLU ----------------------------------------------------------------------------------------------
   if (groups > 0) SF_HIP(launch_gn_silu_bwd(x, p.da, gamma, beta, B, L, C, groups, eps, dx, p.gpart, dgb, s, act_saved ? stats_saved : nullptr));
   return SF_OK;

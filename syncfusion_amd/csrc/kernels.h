@@ -401,8 +401,13 @@ hipError_t launch_pack_train(const float *w, int N, int C, int taps, float *fw, 
 // dw (N, C, taps) = sum_rows dy[row][n] * act[row + t - pad][c];  partial: [S][N][taps*C] scratch, S = conv_wgrad_splits(...)
 int conv_wgrad_splits(int64_t rows, int C, int N, int taps);
 // x3: the products from split fp16 operands (both operands are activations: split while they are staged)
+// (bias_part / bias_slices / db: the bias gradient's slice sums, written by launch_col_sums_part BEFORE this call, are reduced by workgroups
+//  appended to the weight gradient's reducer; *bias_done tells whether that happened -- not with one row split or C % 4 != 0)
 hipError_t launch_conv_wgrad(const float *dy, const float *act, int B, int L, int C, int N, int taps, int pad, float *partial, int S, float *dw,
-                             hipStream_t s, int x3_mode = 0);
+                             hipStream_t s, int x3_mode = 0, const float *bias_part = nullptr, int bias_slices = 0, float *db = nullptr,
+                             bool *bias_done = nullptr);
+hipError_t launch_col_sums_part(const float *x, int64_t rows, int cols, float *part, int S, hipStream_t s);
+hipError_t launch_slices_reduce(const float *part, int S, int cols, float *out, hipStream_t s);
 // out[col] = sum_rows x[row][col]   (part: [S][cols] scratch)
 hipError_t launch_col_sums(const float *x, int64_t rows, int cols, float *part, int S, float *out, hipStream_t s);
 // out[b][c] = sum_l x[b][l][c] * (y ? y[b][l][c] : 1); part: B * length_sums_slices(B, L) * C floats

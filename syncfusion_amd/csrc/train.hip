@@ -38,9 +38,11 @@ __global__ void pack_dgrad_kernel(const float *__restrict__ w, int N, int C, int
 //   fw  [n][tap][c] fp32                      fwx  its split fp16 image (hi | lo' per 32 columns; (taps * C) % 32 == 0)
 //   dg  [c][taps - 1 - tap][n] fp32            dgx  its split bf16 image ((taps * N) % 32 == 0)
 constexpr int PT_MAX_TAPS = 9;
-__global__ __launch_bounds__(256) void pack_train_kernel(const float *__restrict__ w, int N, int C, int taps, float *__restrict__ fw, f16 *__restrict__ fwx,
+template <int TP /* compile-time tap count (1, 3), 0 = any up to PT_MAX_TAPS */>
+__global__ __launch_bounds__(256) void pack_train_kernel(const float *__restrict__ w, int N, int C, int taps_rt, float *__restrict__ fw, f16 *__restrict__ fwx,
                                                          float *__restrict__ dg, bf16 *__restrict__ dgx) {
-  __shared__ float tile[PT_MAX_TAPS * 32 * 33];
+  __shared__ float tile[(TP ? TP : PT_MAX_TAPS) * 32 * 33];
+  const int taps = TP ? TP : taps_rt;
   const int c0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
   const int cw = min(32, C - c0), nh = min(32, N - n0);
   const int run = cw * taps;   // floats of one row's (c, tap) run inside the tile
@@ -473,6 +475,21 @@ __device__ __forceinline__ float slice_sum_8(const float *__restrict__ part, int
   return t;
 }
 
+// A slice reduction riding on another launch: out[j] = sum_k part[k][j], 32 outputs per workgroup, done by the workgroups the host kernel
+// appends to its grid (the small reductions of the backward pass were 2 launches each: 250 launches of ~6 us per training step).
+struct TailReduce {
+  const float *part = nullptr;
+  float *out = nullptr;
+  int S = 0, cols = 0;
+  __host__ __device__ int blocks() const { return part ? (cols + 31) / 32 : 0; }
+};
+__device__ __forceinline__ void tail_reduce_block(const TailReduce &t, int block, float *sh /* [256] */) {
+  const int col = block * 32 + (threadIdx.x & 31);
+  const bool valid = col < t.cols;
+  const float v = slice_sum_8(t.part, t.S, (size_t)t.cols, (size_t)(valid ? col : 0), valid, sh);
+  if (threadIdx.x < 32 && valid) t.out[col] = v;
+}
+
 // dw[n][c][t] (PyTorch layout) = sum_s partial[s][n][t * C + c]
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ partial, int S, int N, int C, int taps, float *__restrict__ dw) {
   __shared__ float sh[256];
@@ -530,7 +547,13 @@ __global__ __launch_bounds__(256) void col_sums_vec_kernel(const float *__restri
 // the same for C % 4 == 0: a thread owns four consecutive channels of one (n, tap) and walks the slices with 16-byte loads along the
 // slabs' contiguous dimension (the kernel above gathers 4-byte elements C apart: 3.5 ms of a 76 ms training step); slices are added in
 // index order, four partial sums deep (fixed order: bit-reproducible)
-__global__ __launch_bounds__(256) void wgrad_reduce_vec_kernel(const float *__restrict__ partial, int S, int N, int C, int taps, float *__restrict__ dw) {
+__global__ __launch_bounds__(256) void wgrad_reduce_vec_kernel(const float *__restrict__ partial, int S, int N, int C, int taps, float *__restrict__ dw,
+                                                               const int nb_main, const TailReduce tail /* the bias gradient's slices */) {
+  __shared__ float sh[256];
+  if ((int)blockIdx.x >= nb_main) {
+    tail_reduce_block(tail, (int)blockIdx.x - nb_main, sh);
+    return;
+  }
   const int Q = taps * C;
   const int64_t NQ = (int64_t)N * Q;
   const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -847,8 +870,13 @@ template <int V>
 __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const float *__restrict__ x, const float *__restrict__ da, const float *__restrict__ gamma,
                                                         const float *__restrict__ beta, const float *__restrict__ slab,
                                                         const float *__restrict__ s12_part, int L, int C, int G, int nch, int chunk_rows, float eps,
-                                                        float *__restrict__ dx) {
+                                                        float *__restrict__ dx, const int B, const TailReduce tail /* dgamma | dbeta slices */) {
   __shared__ float mean_s[256], rstd_s[256], m1_s[256], m2_s[256];
+  if ((int)blockIdx.y >= B) {   // appended rows of the grid: the slice reduction of the affine gradients (written by gn_bwd_part_kernel)
+    const int blk = ((int)blockIdx.y - B) * nch + (int)blockIdx.x;
+    if (blk < tail.blocks()) tail_reduce_block(tail, blk, mean_s);
+    return;
+  }
   const int ch = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int cpg = C / G, vpr = C / V, cv = tid % vpr, rstep = 256 / vpr;
   gn_group_stats(slab + (size_t)b * nch * G * 2, nch, G, chunk_rows, L, cpg, eps, mean_s, rstd_s);
@@ -946,8 +974,10 @@ hipError_t launch_pack_train(const float *w, int N, int C, int taps, float *fw, 
   if (taps < 1 || taps > PT_MAX_TAPS) return hipErrorInvalidValue;
   if ((fwx && (((int64_t)taps * C) % 32)) || (dgx && (((int64_t)taps * N) % 32))) return hipErrorInvalidValue;
   if (!fw && !fwx && !dg && !dgx) return hipSuccess;
-  hipLaunchKernelGGL(pack_train_kernel, dim3((C + 31) / 32, (N + 31) / 32), dim3(256), 0, s, w, N, C, taps, fw, static_cast<f16 *>(fwx), dg,
-                     static_cast<bf16 *>(dgx));
+  const dim3 grid((C + 31) / 32, (N + 31) / 32);
+  if (taps == 1) hipLaunchKernelGGL(pack_train_kernel<1>, grid, dim3(256), 0, s, w, N, C, taps, fw, static_cast<f16 *>(fwx), dg, static_cast<bf16 *>(dgx));
+  else if (taps == 3) hipLaunchKernelGGL(pack_train_kernel<3>, grid, dim3(256), 0, s, w, N, C, taps, fw, static_cast<f16 *>(fwx), dg, static_cast<bf16 *>(dgx));
+  else hipLaunchKernelGGL(pack_train_kernel<0>, grid, dim3(256), 0, s, w, N, C, taps, fw, static_cast<f16 *>(fwx), dg, static_cast<bf16 *>(dgx));
   return hipGetLastError();
 }
 
@@ -983,7 +1013,8 @@ int conv_wgrad_splits(int64_t rows, int C, int N, int taps) {
 }
 
 hipError_t launch_conv_wgrad(const float *dy, const float *act, int B, int L, int C, int N, int taps, int pad, float *partial, int S, float *dw,
-                             hipStream_t s, int x3) {
+                             hipStream_t s, int x3, const float *bias_part, int bias_slices, float *db, bool *bias_done) {
+  if (bias_done) *bias_done = false;
   const int rows = B * L, Q = taps * C;
   int rps = (rows + S - 1) / S;
   rps = (rps + 31) / 32 * 32;
@@ -1002,8 +1033,20 @@ hipError_t launch_conv_wgrad(const float *dy, const float *act, int B, int L, in
     hipLaunchKernelGGL((conv_wgrad_kernel<1, 1>), dim3((N + 31) / 32, (Q + 31) / 32, S), dim3(256), 0, s, dy, act, rows, L, C, N, taps, pad, rps, partial, direct);
   if (!direct) {
     const int64_t total = (int64_t)N * Q;
-    if (C % 4 == 0) hipLaunchKernelGGL(wgrad_reduce_vec_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s, partial, S, N, C, taps, dw);
-    else hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, s, partial, S, N, C, taps, dw);
+    if (C % 4 == 0) {
+      TailReduce tail;   // the bias gradient's slice sums (launch_col_sums_part ran before this call) ride on the reducer
+      if (bias_part && db) {
+        tail.part = bias_part;
+        tail.out = db;
+        tail.S = bias_slices;
+        tail.cols = N;
+        if (bias_done) *bias_done = true;
+      }
+      const int nb = (int)((total / 4 + 255) / 256);
+      hipLaunchKernelGGL(wgrad_reduce_vec_kernel, dim3((unsigned)(nb + tail.blocks())), dim3(256), 0, s, partial, S, N, C, taps, dw, nb, tail);
+    } else {
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, s, partial, S, N, C, taps, dw);
+    }
   }
   return hipGetLastError();
 }
@@ -1098,13 +1141,22 @@ hipError_t launch_length_sums(const float *x, const float *y, int B, int L, int 
   return hipGetLastError();
 }
 
-hipError_t launch_col_sums(const float *x, int64_t rows, int cols, float *part, int S, float *out, hipStream_t s) {
+// the two stages of launch_col_sums apart: the slice sums, and their reduction (which the backward pass lets ride on the weight
+// gradient's reducer, launch_conv_wgrad)
+hipError_t launch_col_sums_part(const float *x, int64_t rows, int cols, float *part, int S, hipStream_t s) {
   const int64_t rps = (rows + S - 1) / S;
   if (cols % 4 == 0 && cols <= 1024 && (256 % (cols / 4)) == 0) hipLaunchKernelGGL(col_sums_vec_kernel<4>, dim3(S), dim3(256), 0, s, x, rows, cols, rps, part);
   else if (cols <= 256 && (256 % cols) == 0) hipLaunchKernelGGL(col_sums_vec_kernel<1>, dim3(S), dim3(256), 0, s, x, rows, cols, rps, part);
   else hipLaunchKernelGGL(col_sums_kernel, dim3((cols + 63) / 64, S), dim3(64), 0, s, x, rows, cols, rps, part);
+  return hipGetLastError();
+}
+hipError_t launch_slices_reduce(const float *part, int S, int cols, float *out, hipStream_t s) {
   hipLaunchKernelGGL(slices_reduce_kernel, dim3((cols + 31) / 32), dim3(256), 0, s, part, S, cols, out);
   return hipGetLastError();
+}
+hipError_t launch_col_sums(const float *x, int64_t rows, int cols, float *part, int S, float *out, hipStream_t s) {
+  hipError_t e = launch_col_sums_part(x, rows, cols, part, S, s);
+  return e != hipSuccess ? e : launch_slices_reduce(part, S, cols, out, s);
 }
 
 static int gn_bwd_vec(int C, int G) {   // columns per access of the chunked kernels; 0 = unsupported shape
@@ -1116,6 +1168,8 @@ static int gn_bwd_vec(int C, int G) {   // columns per access of the chunked ker
 static bool gn_bwd_chunked_ok(int C, int G) { return gn_bwd_vec(C, G) != 0; }
 
 static void gn_bwd_plan(int L, int C, int &nch, int &chunk_rows) {
+  // (>= 16 K elements per workgroup, <= 64 chunks per clip; 128 / 256 chunks and 8 K elements measured: the four GroupNorm kernels of the
+  //  training step 7.75 -> 8.0 / 8.1 / 9.1 ms, profiles/r6_g_prof_train_gn.txt)
   int64_t n = ((int64_t)L * C + 16383) / 16384;
   n = std::max<int64_t>(1, std::min<int64_t>(n, 64));
   chunk_rows = (int)((L + n - 1) / n);
@@ -1170,14 +1224,19 @@ hipError_t launch_gn_silu_bwd(const float *x, const float *da, const float *gamm
     gn_bwd_plan(L, C, nch, chunk_rows);
     float *dgb_part = ws + (size_t)B * nch * G * 2, *s12 = dgb_part + (size_t)B * nch * 2 * C;
     const float *slab = slab_in ? slab_in : ws;
+    TailReduce tail;   // [dgamma | dbeta] = column sums of the B * nch partial rows: rides on the dx launch (rows appended to its grid)
+    tail.part = dgb_part;
+    tail.out = dgb;
+    tail.S = B * nch;
+    tail.cols = 2 * C;
+    const int extra = (tail.blocks() + nch - 1) / nch;
     if (gn_bwd_vec(C, G) == 4) {
       hipLaunchKernelGGL(gn_bwd_part_kernel<4>, dim3(nch, B), dim3(256), 0, s, x, da, gamma, beta, slab, L, C, G, nch, chunk_rows, eps, dgb_part, s12);
-      hipLaunchKernelGGL(gn_bwd_dx_kernel<4>, dim3(nch, B), dim3(256), 0, s, x, da, gamma, beta, slab, s12, L, C, G, nch, chunk_rows, eps, dx);
+      hipLaunchKernelGGL(gn_bwd_dx_kernel<4>, dim3(nch, B + extra), dim3(256), 0, s, x, da, gamma, beta, slab, s12, L, C, G, nch, chunk_rows, eps, dx, B, tail);
     } else {
       hipLaunchKernelGGL(gn_bwd_part_kernel<1>, dim3(nch, B), dim3(256), 0, s, x, da, gamma, beta, slab, L, C, G, nch, chunk_rows, eps, dgb_part, s12);
-      hipLaunchKernelGGL(gn_bwd_dx_kernel<1>, dim3(nch, B), dim3(256), 0, s, x, da, gamma, beta, slab, s12, L, C, G, nch, chunk_rows, eps, dx);
+      hipLaunchKernelGGL(gn_bwd_dx_kernel<1>, dim3(nch, B + extra), dim3(256), 0, s, x, da, gamma, beta, slab, s12, L, C, G, nch, chunk_rows, eps, dx, B, tail);
     }
-    hipLaunchKernelGGL(slices_reduce_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, s, dgb_part, B * nch, 2 * C, dgb);
     return hipGetLastError();
   }
   const int cpg = C / G;
