@@ -279,8 +279,13 @@ int sf_op_conv1d_train_fwd(int dtype, const float *x, const float *w, const floa
                            const float *residual, int B, int L, int C, int N, int taps, int pad, float *out, void *dgrad_pack, int64_t dgrad_pack_bytes,
                            void *ws, int64_t ws_bytes, void *stream);
 int sf_op_conv1d_bwd_cl_p(int dtype, const float *x, const float *act, const float *stats, const float *w, const void *dgrad_pack, const float *gamma,
-                          const float *beta, int groups, float eps, const float *dy, int B, int L, int C, int N, int taps, int pad, float *dx, float *dw,
-                          float *db, float *dgb, void *ws, int64_t ws_bytes, void *stream);
+                          const float *beta, int groups, float eps, const float *dy, const float *dx_add, int B, int L, int C, int N, int taps, int pad,
+                          float *dx, float *dw, float *db, float *dgb, void *ws, int64_t ws_bytes, void *stream);
+/* dx_add (or NULL), in sf_op_conv1d_bwd_cl_p (GroupNorm convolutions only) and sf_op_ln_modulate_bwd_add: a second gradient of x -- the one
+ * arriving through the residual connection that bypasses the op (ResnetItem: x + conv2(...conv1(x)); attention: x + to_out(attn(LN(x)))) --
+ * is added to dx inside the normalisation backward's own pass over the tensor, instead of by a separate element-wise launch. */
+int sf_op_ln_modulate_bwd_add(const float *x, const float *scale_shift, const float *dy, const float *dx_add, float eps, int B, int L, int C, float *dx,
+                              float *dss, void *ws, int64_t ws_bytes, void *stream);
 /* Length reductions of the training composition (fp32, channels-last): out[b][c] = sum_l x[b][l][c] * (y ? y[b][l][c] : 1) -- the
  * gradient of a per-clip broadcast add (cross-attention over one context token) and of the SkipModulate scale
  * (a-unet SkipModulate: x + scale[:, None, :] * h).  Two deterministic stages, no atomics.

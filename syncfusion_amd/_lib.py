@@ -101,8 +101,9 @@ SYMBOLS = {
     "sf_op_conv1d_dgrad_pack_bytes": (_L, [_I, _I, _I]),
     # (dtype, x, w, bias, gamma, beta, groups, eps, residual, B, L, C, N, taps, pad, out, dgrad_pack, dgrad_pack_bytes, ws, ws_bytes, stream)
     "sf_op_conv1d_train_fwd": (_I, [_I, _P, _P, _P, _P, _P, _I, _F, _P, _I, _I, _I, _I, _I, _I, _P, _P, _L, _P, _L, _P]),
-    # (dtype, x, act, stats, w, dgrad_pack, gamma, beta, groups, eps, dy, B, L, C, N, taps, pad, dx, dw, db, dgb, ws, ws_bytes, stream)
-    "sf_op_conv1d_bwd_cl_p": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _L, _P]),
+    # (dtype, x, act, stats, w, dgrad_pack, gamma, beta, groups, eps, dy, dx_add, B, L, C, N, taps, pad, dx, dw, db, dgb, ws, ws_bytes, stream)
+    "sf_op_conv1d_bwd_cl_p": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _L, _P]),
+    "sf_op_ln_modulate_bwd_add": (_I, [_P, _P, _P, _P, _F, _I, _I, _I, _P, _P, _P, _L, _P]),
     "sf_op_gn_silu_train_stats_floats": (_L, [_I, _I, _I, _I]),
     "sf_op_gn_silu_train": (_I, [_P, _P, _P, _I, _F, _I, _I, _I, _P, _P, _P]),
     "sf_op_ln_modulate_bwd_workspace_bytes": (_L, [_I, _I, _I]),

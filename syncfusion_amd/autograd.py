@@ -47,8 +47,10 @@ _FUSED_GN = os.environ.get("SF_TRAIN_FUSED_GN") == "1"   # A/B aid: GroupNorm+Si
 class _ConvBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], gamma: Optional[Tensor], beta: Optional[Tensor], groups: int, eps: float,
-                channels_last: bool = False, residual: Optional[Tensor] = None):
+                channels_last: bool = False, residual: Optional[Tensor] = None, passthrough: bool = False):
         _lib.require_gpu_tensor(x, "syncfusion_amd.autograd")
+        ctx.set_materialize_grads(False)
+        ctx.passthrough = bool(passthrough)
         lib = _lib.load()
         if channels_last:
             B, L, Cc = x.shape
@@ -122,14 +124,23 @@ class _ConvBlockFn(torch.autograd.Function):
             out = out[:, :, :n_real]
             if res_late is not None:
                 out = out + res_late
-        return out if channels_last else out.transpose(1, 2)
+        out = out if channels_last else out.transpose(1, 2)
+        # passthrough: x again as a second output.  A residual connection that bypasses this op reads THAT tensor, so both gradients of x
+        # arrive in this node's backward and are summed inside the GroupNorm backward's pass (no element-wise launch by the autograd engine)
+        return (out, x.view_as(x)) if passthrough else out
 
     @staticmethod
-    def backward(ctx, dy: Tensor):
+    def backward(ctx, dy: Optional[Tensor], d_pass: Optional[Tensor] = None):
         lib = _lib.load()
         x_cl, w, g, be, act, stats, dgp = ctx.saved_tensors
         B, L, Cc, N, taps, pad, groups, eps, has_bias, c_real, n_real, channels_last = ctx.meta
         dev = x_cl.device
+        if dy is None:   # only the passthrough output was used
+            return (d_pass,) + (None,) * 9
+        add = None
+        if d_pass is not None:
+            add = _lib.f32c(d_pass) if channels_last else _cl(_lib.f32c(d_pass))
+        fused_add = add is not None and groups > 0 and c_real == Cc
         with torch.cuda.device(dev):
             dy_cl = _lib.f32c(dy) if channels_last else _cl(_lib.f32c(dy))
             if n_real != N:
@@ -146,38 +157,43 @@ class _ConvBlockFn(torch.autograd.Function):
             if n < 0:
                 raise _lib.SyncFusionAmdError(lib.sf_last_error().decode())
             ws = torch.empty(max(int(n), 256), dtype=torch.uint8, device=dev)
-            tail = (groups, eps, dy_cl.data_ptr(), B, L, Cc, N, taps, pad, dx.data_ptr() if dx is not None else None,
+            tail = (B, L, Cc, N, taps, pad, dx.data_ptr() if dx is not None else None,
                     dw.data_ptr() if dw is not None else None, db.data_ptr() if db is not None else None, dgb.data_ptr() if dgb is not None else None,
                     ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev))
             gp, bp = (g.data_ptr() if groups > 0 else None), (be.data_ptr() if groups > 0 else None)
             have_act = groups > 0 and act.numel() > 0
             _lib.check(lib.sf_op_conv1d_bwd_cl_p(_lib.DTYPES[GEMM_DTYPE], x_cl.data_ptr(), act.data_ptr() if have_act else None,
                                                  stats.data_ptr() if have_act and stats.numel() > 0 else None, w.data_ptr(),
-                                                 dgp.data_ptr() if dgp.numel() > 0 else None, gp, bp, *tail),
+                                                 dgp.data_ptr() if dgp.numel() > 0 else None, gp, bp, groups, eps, dy_cl.data_ptr(),
+                                                 add.data_ptr() if fused_add else None, *tail),
                        "sf_op_conv1d_bwd_cl_p")
         if c_real != Cc:
             dx = dx[:, :, :c_real] if dx is not None else None
             dw = dw[:, :c_real] if dw is not None else None
         if n_real != N:
             dw, db = (dw[:n_real] if dw is not None else None), (db[:n_real] if db is not None else None)
+        if add is not None and not fused_add and dx is not None:
+            dx = dx + add
         if dx is not None and not channels_last:
             dx = dx.transpose(1, 2)
         if not ctx.needs_input_grad[0]:
             dx = None
         return (dx, dw, db, dgb[:Cc] if dgb is not None else None, dgb[Cc:] if dgb is not None else None,
-                None, None, None, dy if ctx.needs_input_grad[8] else None)
+                None, None, None, dy if ctx.needs_input_grad[8] else None, None)
 
 
 def gn_silu_conv1d(x: Tensor, weight: Tensor, bias: Optional[Tensor], gamma: Tensor, beta: Tensor, groups: int, eps: float = 1e-5,
-                   channels_last: bool = False, residual: Optional[Tensor] = None) -> Tensor:
+                   channels_last: bool = False, residual: Optional[Tensor] = None, passthrough: bool = False):
     """``F.conv1d(F.silu(F.group_norm(x, groups, gamma, beta, eps)), weight, bias, padding=k//2) (+ residual)`` with HIP forward and
-    backward.  ``channels_last``: x, residual and the result are ``(B, L, C)`` instead of ``(B, C, L)`` (no transposes around the kernels)."""
-    return _ConvBlockFn.apply(x, weight, bias, gamma, beta, int(groups), float(eps), bool(channels_last), residual)
+    backward.  ``channels_last``: x, residual and the result are ``(B, L, C)`` instead of ``(B, C, L)`` (no transposes around the kernels).
+    ``passthrough``: returns ``(y, x')`` with ``x'`` = x; a residual branch around the op that reads ``x'`` has its gradient added to this
+    op's dx inside the GroupNorm backward kernel (one pass over the tensor less than the autograd engine's separate add)."""
+    return _ConvBlockFn.apply(x, weight, bias, gamma, beta, int(groups), float(eps), bool(channels_last), residual, bool(passthrough))
 
 
 def conv1d(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, channels_last: bool = False, residual: Optional[Tensor] = None) -> Tensor:
     """``F.conv1d(x, weight, bias, padding=k//2) (+ residual)`` (stride 1) with HIP forward and backward."""
-    return _ConvBlockFn.apply(x, weight, bias, None, None, 0, 0.0, bool(channels_last), residual)
+    return _ConvBlockFn.apply(x, weight, bias, None, None, 0, 0.0, bool(channels_last), residual, False)
 
 
 def length_sums(x: Tensor, y: Optional[Tensor] = None) -> Tensor:
@@ -205,9 +221,10 @@ class _LnModulateFn(torch.autograd.Function):
     """y = LayerNorm_C(x; eps, no affine) * (1 + ss[:, :C]) + ss[:, C:] on channels-last ``(B, L, C)`` rows (ss: ``(B, 2C)`` or None)."""
 
     @staticmethod
-    def forward(ctx, x: Tensor, ss: Optional[Tensor], eps: float):
+    def forward(ctx, x: Tensor, ss: Optional[Tensor], eps: float, passthrough: bool = False):
         _lib.require_gpu_tensor(x, "syncfusion_amd.autograd")
         lib = _lib.load()
+        ctx.set_materialize_grads(False)
         B, L, Cc = x.shape
         with torch.cuda.device(x.device):
             xc = _lib.f32c(x)
@@ -219,29 +236,33 @@ class _LnModulateFn(torch.autograd.Function):
                                              _lib.stream_ptr(x.device)), "sf_op_ln_modulate")
         ctx.save_for_backward(xc, sc if sc is not None else xc.new_empty(0))
         ctx.meta = (B, L, Cc, float(eps), ss is not None)
-        return out
+        return (out, x.view_as(x)) if passthrough else out   # (passthrough: see gn_silu_conv1d)
 
     @staticmethod
-    def backward(ctx, dy: Tensor):
+    def backward(ctx, dy: Optional[Tensor], d_pass: Optional[Tensor] = None):
         lib = _lib.load()
         xc, sc = ctx.saved_tensors
         B, L, Cc, eps, has_ss = ctx.meta
         dev = xc.device
+        if dy is None:   # only the passthrough output was used
+            return d_pass, None, None, None
         with torch.cuda.device(dev):
             dyc = _lib.f32c(dy)
+            add = _lib.f32c(d_pass) if d_pass is not None else None
             dx = torch.empty_like(xc)
             dss = torch.empty(B, 2 * Cc, dtype=torch.float32, device=dev) if has_ss else None
             ws = torch.empty(max(int(lib.sf_op_ln_modulate_bwd_workspace_bytes(B, L, Cc)), 256), dtype=torch.uint8, device=dev)
-            _lib.check(lib.sf_op_ln_modulate_bwd(xc.data_ptr(), sc.data_ptr() if has_ss else None, dyc.data_ptr(), eps, B, L, Cc, dx.data_ptr(),
-                                                 dss.data_ptr() if dss is not None else None, ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)),
-                       "sf_op_ln_modulate_bwd")
-        return dx, dss, None
+            _lib.check(lib.sf_op_ln_modulate_bwd_add(xc.data_ptr(), sc.data_ptr() if has_ss else None, dyc.data_ptr(),
+                                                     add.data_ptr() if add is not None else None, eps, B, L, Cc, dx.data_ptr(),
+                                                     dss.data_ptr() if dss is not None else None, ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)),
+                       "sf_op_ln_modulate_bwd_add")
+        return dx, dss, None, None
 
 
-def ln_modulate(x: Tensor, scale_shift: Optional[Tensor], eps: float) -> Tensor:
+def ln_modulate(x: Tensor, scale_shift: Optional[Tensor], eps: float, passthrough: bool = False):
     """Modulation / pre-norm LayerNorm on ``(B, L, C)`` rows with HIP forward and backward.  An affine LayerNorm ``LN(x) * g + b``
-    is ``ln_modulate(x, cat[g - 1, b] broadcast over the clips, eps)``."""
-    return _LnModulateFn.apply(x, scale_shift, float(eps))
+    is ``ln_modulate(x, cat[g - 1, b] broadcast over the clips, eps)``.  ``passthrough``: returns ``(y, x')`` (see ``gn_silu_conv1d``)."""
+    return _LnModulateFn.apply(x, scale_shift, float(eps), bool(passthrough))
 
 
 class _AttentionFn(torch.autograd.Function):

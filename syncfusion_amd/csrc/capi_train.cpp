@@ -59,13 +59,15 @@ int64_t sf_op_conv1d_bwd_workspace_bytes(int B, int L, int C, int N, int taps, i
 
 static int conv1d_bwd_impl(int dtype, const float *x, const float *act_saved, const float *stats_saved, const float *w, const float *gamma, const float *beta, int groups, float eps, const float *dy, int B, int L,
                         int C, int N, int taps, int pad, float *dx, float *dw, float *db, float *dgb, void *ws, int64_t ws_bytes, void *stream,
-                        const void *dgrad_pack = nullptr /* sf_op_conv1d_train_fwd's images of w: nothing is packed here */) {
+                        const void *dgrad_pack = nullptr /* sf_op_conv1d_train_fwd's images of w: nothing is packed here */,
+                        const float *dx_add = nullptr /* GroupNorm convolutions: dx = gradient + dx_add in the GroupNorm backward's own pass */) {
   SF_API_BEGIN
   if (!x || !w || !dy || !ws) fail(SF_ERR_INVALID, "null argument");
   if (dtype != SF_F32 && dtype != SF_F32X) fail(SF_ERR_INVALID, "dtype must be SF_F32 or SF_F32X");
   const bool x3 = dtype == SF_F32X;
   if (!dx && !dw && !db && !dgb) fail(SF_ERR_INVALID, "nothing to compute: dx, dw, db and dgb are all null");
   if (groups > 0 && (!gamma || !beta || !dgb || !dx)) fail(SF_ERR_INVALID, "GroupNorm backward needs gamma, beta, dgb and dx");
+  if (dx_add && groups <= 0) fail(SF_ERR_UNSUPPORTED, "dx_add: GroupNorm convolutions only");
   if (taps < 1 || pad < 0 || pad >= taps || 2 * pad != taps - 1) fail(SF_ERR_UNSUPPORTED, "stride-1 'same' convolutions only (2 * pad == taps - 1)");
   hipStream_t s = static_cast<hipStream_t>(stream);
   Workspace wk(ws, ws_bytes);
@@ -106,7 +108,7 @@ static int conv1d_bwd_impl(int dtype, const float *x, const float *act_saved, co
   if (dw) SF_HIP(launch_conv_wgrad(dy, act, B, L, C, N, taps, pad, p.wpart, p.S, dw, s, x3 ? X3_BF16 : 0, db ? p.bpart : nullptr, p.Sb, db, &db_done));
   if (db && !db_done) SF_HIP(launch_slices_reduce(p.bpart, p.Sb, N, db, s));
   // ---- GroupNorm + SiLU ----------------------------------------------------------------------------------------------
-  if (groups > 0) SF_HIP(launch_gn_silu_bwd(x, p.da, gamma, beta, B, L, C, groups, eps, dx, p.gpart, dgb, s, act_saved ? stats_saved : nullptr));
+  if (groups > 0) SF_HIP(launch_gn_silu_bwd(x, p.da, gamma, beta, B, L, C, groups, eps, dx, p.gpart, dgb, s, act_saved ? stats_saved : nullptr, dx_add));
   return SF_OK;
   SF_API_END
 }
@@ -133,9 +135,10 @@ int sf_op_conv1d_bwd_cl_x(int dtype, const float *x, const float *act, const flo
 }
 
 int sf_op_conv1d_bwd_cl_p(int dtype, const float *x, const float *act, const float *stats, const float *w, const void *dgrad_pack, const float *gamma,
-                          const float *beta, int groups, float eps, const float *dy, int B, int L, int C, int N, int taps, int pad, float *dx, float *dw,
-                          float *db, float *dgb, void *ws, int64_t ws_bytes, void *stream) {
-  return conv1d_bwd_impl(dtype, x, act, stats, w, gamma, beta, groups, eps, dy, B, L, C, N, taps, pad, dx, dw, db, dgb, ws, ws_bytes, stream, dgrad_pack);
+                          const float *beta, int groups, float eps, const float *dy, const float *dx_add, int B, int L, int C, int N, int taps, int pad,
+                          float *dx, float *dw, float *db, float *dgb, void *ws, int64_t ws_bytes, void *stream) {
+  return conv1d_bwd_impl(dtype, x, act, stats, w, gamma, beta, groups, eps, dy, B, L, C, N, taps, pad, dx, dw, db, dgb, ws, ws_bytes, stream, dgrad_pack,
+                         dx_add);
 }
 
 int64_t sf_op_gn_silu_train_stats_floats(int B, int L, int C, int groups) {
@@ -175,16 +178,26 @@ int64_t sf_op_ln_modulate_bwd_workspace_bytes(int B, int L, int C) {
   return (int64_t)B * ln_mod_bwd_chunks(L) * 2 * C * (int64_t)sizeof(float);
 }
 
-int sf_op_ln_modulate_bwd(const float *x, const float *scale_shift, const float *dy, float eps, int B, int L, int C, float *dx, float *dss, void *ws,
-                          int64_t ws_bytes, void *stream) {
+static int ln_modulate_bwd_impl(const float *x, const float *scale_shift, const float *dy, const float *dx_add, float eps, int B, int L, int C, float *dx,
+                                float *dss, void *ws, int64_t ws_bytes, void *stream) {
   SF_API_BEGIN
   if (!x || !dy || !dx || !ws) fail(SF_ERR_INVALID, "null argument");
   if (C < 4 || C > 1024 || (C & (C - 1))) fail(SF_ERR_UNSUPPORTED, "C must be a power of two in [4, 1024] (got %d)", C);
   const int64_t need = sf_op_ln_modulate_bwd_workspace_bytes(B, L, C);
   if (ws_bytes < need) fail(SF_ERR_WORKSPACE, "workspace too small: need %lld bytes", (long long)need);
-  SF_HIP(launch_ln_modulate_bwd(x, scale_shift, dy, eps, B, L, C, dx, static_cast<float *>(ws), dss, static_cast<hipStream_t>(stream)));
+  SF_HIP(launch_ln_modulate_bwd(x, scale_shift, dy, eps, B, L, C, dx, static_cast<float *>(ws), dss, static_cast<hipStream_t>(stream), dx_add));
   return SF_OK;
   SF_API_END
+}
+
+int sf_op_ln_modulate_bwd(const float *x, const float *scale_shift, const float *dy, float eps, int B, int L, int C, float *dx, float *dss, void *ws,
+                          int64_t ws_bytes, void *stream) {
+  return ln_modulate_bwd_impl(x, scale_shift, dy, nullptr, eps, B, L, C, dx, dss, ws, ws_bytes, stream);
+}
+
+int sf_op_ln_modulate_bwd_add(const float *x, const float *scale_shift, const float *dy, const float *dx_add, float eps, int B, int L, int C, float *dx,
+                              float *dss, void *ws, int64_t ws_bytes, void *stream) {
+  return ln_modulate_bwd_impl(x, scale_shift, dy, dx_add, eps, B, L, C, dx, dss, ws, ws_bytes, stream);
 }
 
 int sf_op_attention_bwd(const float *q, const float *kv, const float *out, const float *dout, int B, int L, int heads, int head_dim, float *dq,

@@ -415,7 +415,8 @@ int length_sums_slices(int B, int L);
 hipError_t launch_length_sums(const float *x, const float *y, int B, int L, int C, float *part, float *out, hipStream_t s);
 // backward of a = SiLU(GroupNorm_G(x; gamma, beta, eps)): dx, and dgb = [dgamma | dbeta]  (dgb_part: [B][2][C] scratch)
 hipError_t launch_gn_silu_bwd(const float *x, const float *da, const float *gamma, const float *beta, int B, int L, int C, int G, float eps,
-                              float *dx, float *dgb_part, float *dgb, hipStream_t s, const float *slab_in = nullptr);
+                              float *dx, float *dgb_part, float *dgb, hipStream_t s, const float *slab_in = nullptr,
+                              const float *dx_add = nullptr /* added to dx in the same pass: a residual branch's gradient of x */);
 int64_t gn_bwd_stats_floats(int B, int L, int C, int G);
 int64_t gn_silu_bwd_ws_floats(int B, int L, int C, int G);
 hipError_t launch_gn_silu_recompute(const float *x, const float *gamma, const float *beta, int B, int L, int C, int G, float eps, float *act,
@@ -426,7 +427,7 @@ hipError_t launch_gn_bwd_stats(const float *x, int B, int L, int C, int G, float
 // dss (B, 2C) = [dscale | dshift];  dss_part: [B][ln_mod_bwd_chunks(L)][2C] scratch
 int ln_mod_bwd_chunks(int L);
 hipError_t launch_ln_modulate_bwd(const float *x, const float *ss, const float *dy, float eps, int B, int L, int C, float *dx, float *dss_part,
-                                  float *dss, hipStream_t s);
+                                  float *dss, hipStream_t s, const float *dx_add = nullptr /* added to dx in the same pass */);
 // backward of softmax attention on packed projections (head dim 64): dq (B,L,H*64), dkv (B,L,2*H*64); lse, dsum: (B,H,L) scratch
 hipError_t launch_attention_bwd(const float *q, const float *kv, const float *o, const float *dout, int B, int L, int H, int D, float *dq, float *dkv,
                                 float *lse, float *dsum, hipStream_t s, const float *lse_fwd = nullptr, bool x3 = false);

@@ -600,7 +600,7 @@ __device__ __forceinline__ float block_sum_256(float v, float *sh) {   // every 
 // One workgroup per (clip, group).  cpg must divide 256 (a thread then always meets the same channel).
 __global__ __launch_bounds__(256) void gn_silu_bwd_kernel(const float *__restrict__ x, const float *__restrict__ da, const float *__restrict__ gamma,
                                                           const float *__restrict__ beta, int L, int C, int G, float eps, float *__restrict__ dx,
-                                                          float *__restrict__ dgb_part /* [B][2][C] */) {
+                                                          float *__restrict__ dgb_part /* [B][2][C] */, const float *__restrict__ dx_add /* or null */) {
   __shared__ float sh[4];
   __shared__ float chs[2][256];
   const int b = blockIdx.x / G, g = blockIdx.x - b * G;
@@ -610,6 +610,7 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_kernel(const float *__restric
   const float *xb = x + (size_t)b * L * C + g * cpg;
   const float *db = da + (size_t)b * L * C + g * cpg;
   float *ob = dx + (size_t)b * L * C + g * cpg;
+  const float *ab = dx_add ? dx_add + (size_t)b * L * C + g * cpg : nullptr;
   const int tc = threadIdx.x % cpg;   // this thread's channel inside the group (256 % cpg == 0)
   float s = 0.f;
   for (int i = threadIdx.x; i < n_el; i += 256) s += xb[(size_t)(i / cpg) * C + (i % cpg)];
@@ -653,7 +654,7 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_kernel(const float *__restric
     const float u = fmaf(xh, gam, bet);
     const float sg = 1.0f / (1.0f + expf(-u));
     const float g1 = db[off] * sg * (1.0f + u * (1.0f - sg)) * gam;
-    ob[off] = rstd * (g1 - m1 - xh * m2);
+    ob[off] = rstd * (g1 - m1 - xh * m2) + (ab ? ab[off] : 0.f);
   }
 }
 
@@ -670,7 +671,7 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_kernel(const float *__restric
 template <int TPR, int PER>
 __global__ __launch_bounds__(256) void ln_mod_bwd_vec_kernel(const float *__restrict__ x, const float *__restrict__ ss, int ss_ld,
                                                              const float *__restrict__ dy, int L, float eps, int rows_per_chunk, float *__restrict__ dx,
-                                                             float *__restrict__ dss_part /* [B][nchunk][2C] */) {
+                                                             float *__restrict__ dss_part /* [B][nchunk][2C] */, const float *__restrict__ dx_add /* or null */) {
   constexpr int C = 4 * TPR * PER, NG = 256 / TPR;
   __shared__ float red[2 * NG * C];
   const int tid = threadIdx.x, sub = tid % TPR, grp = tid / TPR;
@@ -729,6 +730,7 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_vec_kernel(const float *__rest
       f32x4 o;
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = rstd * (dv[k][j] - m1 - xv[k][j] * m2);
+      if (dx_add) o += *reinterpret_cast<const f32x4 *>(dx_add + row + 4 * (sub + TPR * k));
       *reinterpret_cast<f32x4 *>(dx + row + 4 * (sub + TPR * k)) = o;
     }
   }
@@ -870,7 +872,8 @@ template <int V>
 __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const float *__restrict__ x, const float *__restrict__ da, const float *__restrict__ gamma,
                                                         const float *__restrict__ beta, const float *__restrict__ slab,
                                                         const float *__restrict__ s12_part, int L, int C, int G, int nch, int chunk_rows, float eps,
-                                                        float *__restrict__ dx, const int B, const TailReduce tail /* dgamma | dbeta slices */) {
+                                                        float *__restrict__ dx, const int B, const TailReduce tail /* dgamma | dbeta slices */,
+                                                        const float *__restrict__ dx_add /* or null: a second gradient of x, added here */) {
   __shared__ float mean_s[256], rstd_s[256], m1_s[256], m2_s[256];
   if ((int)blockIdx.y >= B) {   // appended rows of the grid: the slice reduction of the affine gradients (written by gn_bwd_part_kernel)
     const int blk = ((int)blockIdx.y - B) * nch + (int)blockIdx.x;
@@ -925,6 +928,15 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const float *__restrict_
       const float sg = 1.0f / (1.0f + expf(-u));
       const float g1 = dv[j] * sg * (1.0f + u * (1.0f - sg)) * gam[j];
       o[j] = rs[j] * (g1 - m1[j] - xh * m2[j]);
+    }
+    if (dx_add) {
+      if constexpr (V == 4) {
+        const f32x4 a4 = *reinterpret_cast<const f32x4 *>(dx_add + base + (size_t)r * C);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] += a4[j];
+      } else {
+        o[0] += dx_add[base + (size_t)r * C];
+      }
     }
     if constexpr (V == 4) *reinterpret_cast<f32x4 *>(dx + base + (size_t)r * C) = f32x4{o[0], o[1], o[2], o[3]};
     else dx[base + (size_t)r * C] = o[0];
@@ -1217,7 +1229,8 @@ int64_t gn_bwd_stats_floats(int B, int L, int C, int G) {   // size of the chunk
 
 hipError_t launch_gn_silu_bwd(const float *x, const float *da, const float *gamma, const float *beta, int B, int L, int C, int G, float eps,
                               float *dx, float *ws /* statistics already there (launch_gn_silu_recompute) */, float *dgb /* [2C] = dgamma | dbeta */,
-                              hipStream_t s, const float *slab_in /* the statistics kept by the forward pass instead of those in ws */) {
+                              hipStream_t s, const float *slab_in /* the statistics kept by the forward pass instead of those in ws */,
+                              const float *dx_add /* dx = the GroupNorm gradient + this tensor (a residual branch's gradient of x), or null */) {
   if (G < 1 || C % G) return hipErrorInvalidValue;
   if (gn_bwd_chunked_ok(C, G)) {
     int nch, chunk_rows;
@@ -1232,16 +1245,16 @@ hipError_t launch_gn_silu_bwd(const float *x, const float *da, const float *gamm
     const int extra = (tail.blocks() + nch - 1) / nch;
     if (gn_bwd_vec(C, G) == 4) {
       hipLaunchKernelGGL(gn_bwd_part_kernel<4>, dim3(nch, B), dim3(256), 0, s, x, da, gamma, beta, slab, L, C, G, nch, chunk_rows, eps, dgb_part, s12);
-      hipLaunchKernelGGL(gn_bwd_dx_kernel<4>, dim3(nch, B + extra), dim3(256), 0, s, x, da, gamma, beta, slab, s12, L, C, G, nch, chunk_rows, eps, dx, B, tail);
+      hipLaunchKernelGGL(gn_bwd_dx_kernel<4>, dim3(nch, B + extra), dim3(256), 0, s, x, da, gamma, beta, slab, s12, L, C, G, nch, chunk_rows, eps, dx, B, tail, dx_add);
     } else {
       hipLaunchKernelGGL(gn_bwd_part_kernel<1>, dim3(nch, B), dim3(256), 0, s, x, da, gamma, beta, slab, L, C, G, nch, chunk_rows, eps, dgb_part, s12);
-      hipLaunchKernelGGL(gn_bwd_dx_kernel<1>, dim3(nch, B + extra), dim3(256), 0, s, x, da, gamma, beta, slab, s12, L, C, G, nch, chunk_rows, eps, dx, B, tail);
+      hipLaunchKernelGGL(gn_bwd_dx_kernel<1>, dim3(nch, B + extra), dim3(256), 0, s, x, da, gamma, beta, slab, s12, L, C, G, nch, chunk_rows, eps, dx, B, tail, dx_add);
     }
     return hipGetLastError();
   }
   const int cpg = C / G;
   if (cpg > 256 || (256 % cpg)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(gn_silu_bwd_kernel, dim3(B * G), dim3(256), 0, s, x, da, gamma, beta, L, C, G, eps, dx, ws);
+  hipLaunchKernelGGL(gn_silu_bwd_kernel, dim3(B * G), dim3(256), 0, s, x, da, gamma, beta, L, C, G, eps, dx, ws, dx_add);
   // ws is [B][2][C]: rows b, columns (2C) -> column sums give [dgamma | dbeta]
   hipLaunchKernelGGL(slices_reduce_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, s, ws, B, 2 * C, dgb);
   return hipGetLastError();
@@ -1250,10 +1263,10 @@ hipError_t launch_gn_silu_bwd(const float *x, const float *da, const float *gamm
 int ln_mod_bwd_chunks(int L) { return std::max(1, std::min(64, (L + 63) / 64)); }
 
 hipError_t launch_ln_modulate_bwd(const float *x, const float *ss, const float *dy, float eps, int B, int L, int C, float *dx, float *dss_part,
-                                  float *dss, hipStream_t s) {
+                                  float *dss, hipStream_t s, const float *dx_add) {
   const int nchunk = ln_mod_bwd_chunks(L);
   const int rpc = (L + nchunk - 1) / nchunk;
-#define SF_LNB(TPR, PER) hipLaunchKernelGGL((ln_mod_bwd_vec_kernel<TPR, PER>), dim3(B, nchunk), dim3(256), 0, s, x, ss, 2 * C, dy, L, eps, rpc, dx, dss_part)
+#define SF_LNB(TPR, PER) hipLaunchKernelGGL((ln_mod_bwd_vec_kernel<TPR, PER>), dim3(B, nchunk), dim3(256), 0, s, x, ss, 2 * C, dy, L, eps, rpc, dx, dss_part, dx_add)
   switch (C) {
     case 4: SF_LNB(1, 1); break;
     case 8: SF_LNB(2, 1); break;

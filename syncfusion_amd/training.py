@@ -84,12 +84,15 @@ def _pointwise(x: Tensor, w: Tensor, b: Optional[Tensor], residual: Optional[Ten
     return sfa.conv1d(x, w.reshape(w.shape[0], -1, 1), b, channels_last=True, residual=residual)
 
 
-def _affine_ln(x: Tensor, gamma: Tensor, beta: Tensor, eps: float) -> Tensor:
+def _affine_ln(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, passthrough: bool = False):
     """LayerNorm_C with affine parameters, as LN-modulate with scale = gamma - 1, shift = beta for every clip."""
     # every clip shares (gamma, beta): the (B, L, C) rows are ONE clip of B * L rows to the kernel -- no per-clip copy of the pair in forward,
     # no sum over the clips in backward (the kernel's length reduction covers all rows)
     B, L, C = x.shape
     ss = torch.cat([gamma - 1.0, beta])[None, :]
+    if passthrough:
+        y, xp = sfa.ln_modulate(x.reshape(1, B * L, C), ss, eps, passthrough=True)
+        return y.reshape(B, L, C), xp.reshape(B, L, C)
     return sfa.ln_modulate(x.reshape(1, B * L, C), ss, eps).reshape(B, L, C)
 
 
@@ -109,14 +112,20 @@ def _time_features(P, sigma: Tensor, first_act: bool = True) -> Tensor:
 
 
 def _resnet(P, pre: str, x: Tensor, groups: int) -> Tensor:
-    h = sfa.gn_silu_conv1d(x, P[pre + ".conv1.weight"], P[pre + ".conv1.bias"], P[pre + ".gn1.weight"], P[pre + ".gn1.bias"], groups, 1e-5, True)
+    # (x reaches the residual connection THROUGH conv1's node: both of its gradients meet in that node's GroupNorm backward kernel)
+    h, x = sfa.gn_silu_conv1d(x, P[pre + ".conv1.weight"], P[pre + ".conv1.bias"], P[pre + ".gn1.weight"], P[pre + ".gn1.bias"], groups, 1e-5, True,
+                              passthrough=True)
     return sfa.gn_silu_conv1d(h, P[pre + ".conv2.weight"], P[pre + ".conv2.bias"], P[pre + ".gn2.weight"], P[pre + ".gn2.bias"], groups, 1e-5, True,
                               residual=x)
 
 
 def _self_attention(P, pre: str, x: Tensor, heads: int) -> Tensor:
-    q = _pointwise(_affine_ln(x, P[pre + ".norm.weight"], P[pre + ".norm.bias"], 1e-5), P[pre + ".to_q.weight"], None)
-    kv = _pointwise(_affine_ln(x, P[pre + ".norm_context.weight"], P[pre + ".norm_context.bias"], 1e-5), P[pre + ".to_kv.weight"], None)
+    # (x is handed from node to node -- q norm, then k/v norm, then the residual: its three gradients are summed inside the two LayerNorm
+    #  backward kernels instead of by two element-wise launches of the autograd engine)
+    xq, x = _affine_ln(x, P[pre + ".norm.weight"], P[pre + ".norm.bias"], 1e-5, passthrough=True)
+    xkv, x = _affine_ln(x, P[pre + ".norm_context.weight"], P[pre + ".norm_context.bias"], 1e-5, passthrough=True)
+    q = _pointwise(xq, P[pre + ".to_q.weight"], None)
+    kv = _pointwise(xkv, P[pre + ".to_kv.weight"], None)
     return _pointwise(sfa.attention(q, kv, heads), P[pre + ".to_out.weight"], P.get(pre + ".to_out.bias"), residual=x)
 
 

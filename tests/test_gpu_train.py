@@ -129,10 +129,56 @@ def test_training_pack_launch_equals_the_self_packing_entries(cuda, dtype, B, L,
         if pack is None:
             _lib.check(lib.sf_op_conv1d_bwd_cl_x(dt, x.data_ptr(), None, None, w.data_ptr(), None, None, 0, 0.0, *args), "sf_op_conv1d_bwd_cl_x")
         else:
-            _lib.check(lib.sf_op_conv1d_bwd_cl_p(dt, x.data_ptr(), None, None, w.data_ptr(), pack.data_ptr(), None, None, 0, 0.0, *args), "sf_op_conv1d_bwd_cl_p")
+            _lib.check(lib.sf_op_conv1d_bwd_cl_p(dt, x.data_ptr(), None, None, w.data_ptr(), pack.data_ptr(), None, None, 0, 0.0, args[0], None, *args[1:]),
+                       "sf_op_conv1d_bwd_cl_p")
         res.append((dx, dw, db))
     for a, b_ in zip(*res):
         assert torch.equal(a, b_)
+
+
+@pytest.mark.parametrize("B,L,C", [(2, 352, 64), (3, 100, 128), (2, 2816, 8), (1, 9, 32), (2, 1024, 256)])
+def test_passthrough_outputs_sum_the_residual_gradient_inside_the_normalisation_backward(cuda, B, L, C):
+    """``gn_silu_conv1d(..., passthrough=True)`` / ``ln_modulate(..., passthrough=True)`` return x a second time; a residual branch that reads
+    that output has its gradient added to dx INSIDE the GroupNorm / LayerNorm backward kernel (``dx_add`` of sf_op_conv1d_bwd_cl_p /
+    sf_op_ln_modulate_bwd_add).  Same values as the autograd engine's own sum of the two gradients (one rounding per element either way:
+    bit-equal), and every other gradient untouched."""
+    from syncfusion_amd import autograd as sfa
+
+    g = torch.Generator().manual_seed(L + C)
+    x0 = torch.randn(B, L, C, generator=g).to(cuda)
+    w0 = (torch.randn(C, C, 3, generator=g) / (3 * C) ** 0.5).to(cuda)
+    ga0, be0 = (1 + 0.2 * torch.randn(C, generator=g)).to(cuda), (0.1 * torch.randn(C, generator=g)).to(cuda)
+    dy = torch.randn(B, L, C, generator=g).to(cuda)
+    side = torch.randn(B, L, C, generator=g).to(cuda)          # what the bypassing branch multiplies x by
+    res = []
+    for pt in (False, True):
+        x, w, ga, be = (t.clone().requires_grad_() for t in (x0, w0, ga0, be0))
+        if pt:
+            y, xp = sfa.gn_silu_conv1d(x, w, None, ga, be, 8, 1e-5, True, passthrough=True)
+        else:
+            y, xp = sfa.gn_silu_conv1d(x, w, None, ga, be, 8, 1e-5, True), x
+        (y * dy).sum().add((xp * side).sum()).backward()
+        res.append((x.grad, w.grad, ga.grad, be.grad))
+    for a, b_ in zip(*res):
+        assert torch.equal(a, b_)
+    if C >= 4 and (C & (C - 1)) == 0:
+        ss0 = (0.3 * torch.randn(B, 2 * C, generator=g)).to(cuda)
+        res = []
+        for pt in (False, True):
+            x, ss = x0.clone().requires_grad_(), ss0.clone().requires_grad_()
+            if pt:
+                y, xp = sfa.ln_modulate(x, ss, 1e-6, passthrough=True)
+            else:
+                y, xp = sfa.ln_modulate(x, ss, 1e-6), x
+            (y * dy).sum().add((xp * side).sum()).backward()
+            res.append((x.grad, ss.grad))
+        for a, b_ in zip(*res):
+            assert torch.equal(a, b_)
+        # the passthrough output alone (the op's own output unused): the gradient passes through untouched
+        x = x0.clone().requires_grad_()
+        _, xp = sfa.ln_modulate(x, ss0, 1e-6, passthrough=True)
+        (xp * side).sum().backward()
+        assert torch.equal(x.grad, side)
 
 
 @pytest.mark.parametrize("groups", [0, 8])
