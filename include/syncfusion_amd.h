@@ -281,6 +281,19 @@ int sf_op_conv1d_train_fwd(int dtype, const float *x, const float *w, const floa
 int sf_op_conv1d_bwd_cl_p(int dtype, const float *x, const float *act, const float *stats, const float *w, const void *dgrad_pack, const float *gamma,
                           const float *beta, int groups, float eps, const float *dy, const float *dx_add, int B, int L, int C, int N, int taps, int pad,
                           float *dx, float *dw, float *db, float *dgb, void *ws, int64_t ws_bytes, void *stream);
+/* The whole weight set of a training step in ONE pack launch.  sf_op_conv1d_train_images: which images of `w` the convolution (forward, and
+ * its data gradient) reads at this geometry -- bit 0 fw = [N][taps][C] fp32, bit 1 fwx = its split fp16 image, bit 2 dg = [C][taps][N] fp32
+ * (taps flipped), bit 3 dgx = its split bf16 image; bit 4: not plannable (the launch wants the fragment-ordered image: use
+ * sf_op_conv1d_train_fwd); < 0 on error.  `w` is read for its address alignment only (an aligned fp32 1x1 weight IS its own fw).
+ * sf_train_pack_many: desc_dev = n_items x 7 64-bit words in DEVICE memory per weight -- the addresses w, fw, fwx, dg, dgx (0 = not
+ * written), then N | C << 32, then taps | first_tile << 32 -- sorted by first_tile; a weight has ceil(C / 32) * ceil(N / 32) tiles,
+ * total_tiles is their sum.  sf_op_conv1d_train_fwd_pk = sf_op_conv1d_train_fwd reading fw / fwx instead of packing; the backward pass
+ * takes the weight's [dg | dgx] region (dgx at dg + 4 * C * taps * N bytes) as the dgrad_pack of sf_op_conv1d_bwd_cl_p. */
+int sf_op_conv1d_train_images(int dtype, const float *w, int B, int L, int C, int N, int taps, int pad, int groups);
+int sf_train_pack_many(const void *desc_dev, int n_items, int total_tiles, void *stream);
+int sf_op_conv1d_train_fwd_pk(int dtype, const float *x, const float *w, const float *fw, const void *fwx, const float *bias, const float *gamma,
+                              const float *beta, int groups, float eps, const float *residual, int B, int L, int C, int N, int taps, int pad, float *out,
+                              void *ws, int64_t ws_bytes, void *stream);
 /* dx_add (or NULL), in sf_op_conv1d_bwd_cl_p (GroupNorm convolutions only) and sf_op_ln_modulate_bwd_add: a second gradient of x -- the one
  * arriving through the residual connection that bypasses the op (ResnetItem: x + conv2(...conv1(x)); attention: x + to_out(attn(LN(x)))) --
  * is added to dx inside the normalisation backward's own pass over the tensor, instead of by a separate element-wise launch. */

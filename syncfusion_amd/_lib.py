@@ -103,6 +103,10 @@ SYMBOLS = {
     "sf_op_conv1d_train_fwd": (_I, [_I, _P, _P, _P, _P, _P, _I, _F, _P, _I, _I, _I, _I, _I, _I, _P, _P, _L, _P, _L, _P]),
     # (dtype, x, act, stats, w, dgrad_pack, gamma, beta, groups, eps, dy, dx_add, B, L, C, N, taps, pad, dx, dw, db, dgb, ws, ws_bytes, stream)
     "sf_op_conv1d_bwd_cl_p": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _L, _P]),
+    "sf_op_conv1d_train_images": (_I, [_I, _P, _I, _I, _I, _I, _I, _I, _I]),
+    "sf_train_pack_many": (_I, [_P, _I, _I, _P]),
+    # (dtype, x, w, fw, fwx, bias, gamma, beta, groups, eps, residual, B, L, C, N, taps, pad, out, ws, ws_bytes, stream)
+    "sf_op_conv1d_train_fwd_pk": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P, _I, _I, _I, _I, _I, _I, _P, _P, _L, _P]),
     "sf_op_ln_modulate_bwd_add": (_I, [_P, _P, _P, _P, _F, _I, _I, _I, _P, _P, _P, _L, _P]),
     "sf_op_gn_silu_train_stats_floats": (_L, [_I, _I, _I, _I]),
     "sf_op_gn_silu_train": (_I, [_P, _P, _P, _I, _F, _I, _I, _I, _P, _P, _P]),

@@ -44,6 +44,95 @@ _SELF_PACK = os.environ.get("SF_TRAIN_SELF_PACK") == "1"  # A/B aid: the backwar
 _FUSED_GN = os.environ.get("SF_TRAIN_FUSED_GN") == "1"   # A/B aid: GroupNorm+SiLU as the convolution kernel's prologue, recomputed in backward
 
 
+class PackPlan:
+    """The weight images of every convolution of one training forward, written by ONE launch at its start (``sf_train_pack_many``) instead of
+    one launch per convolution (240 launches of ~8 us per step, mostly launch latency).
+
+    ``with plan:`` around a forward pass.  The FIRST pass records which weights are convolved at which geometry (and packs per convolution,
+    as without a plan); at its end the plan allocates one persistent buffer for all images and a descriptor table in device memory.  Every
+    LATER pass packs all of them from the CURRENT weight values with one launch on entry -- nothing is cached across passes, so an optimizer
+    step, ``load_state_dict`` or any in-place update between passes is always seen -- and the convolutions read their images from the
+    buffer.  A convolution the plan does not know (other shapes, a temporary weight) packs its own as before; any miss makes the plan
+    re-record on the next pass.  The plan keeps the recorded weight tensors alive, so the addresses in its table stay valid."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.state, self.items, self.buf, self.desc, self.total_tiles, self.misses, self.n_packed = "record", {}, None, None, 0, 0, 0
+
+    @staticmethod
+    def _key(w, N, C, taps):
+        return (w.data_ptr(), int(N), int(C), int(taps))
+
+    def record(self, w, geom, mask, need_dg):
+        if self.state == "record" and not torch.cuda.is_current_stream_capturing():
+            self.items.setdefault(self._key(w, geom[3], geom[2], geom[4]), dict(w=w, geom=tuple(geom), mask=int(mask), need_dg=bool(need_dg)))
+
+    def lookup(self, w, geom, need_dg):
+        if self.state != "ready":
+            return None
+        it = self.items.get(self._key(w, geom[3], geom[2], geom[4]))
+        if it is None or it["geom"] != tuple(geom) or (need_dg and not it["need_dg"]):
+            self.misses += 1
+            return None
+        return None if it["mask"] < 0 else it   # (mask < 0: recorded as a convolution that packs its own images -- not a miss)
+
+    def __enter__(self):
+        global _ACTIVE_PLAN
+        self._outer, _ACTIVE_PLAN = _ACTIVE_PLAN, self
+        if self.state == "ready":
+            _lib.check(_lib.load().sf_train_pack_many(self.desc.data_ptr(), self.n_packed, self.total_tiles, _lib.stream_ptr(self.buf.device)),
+                       "sf_train_pack_many")
+        return self
+
+    def __exit__(self, *exc):
+        global _ACTIVE_PLAN
+        _ACTIVE_PLAN = self._outer
+        if exc[0] is not None:
+            self.reset()
+        elif self.state == "ready" and self.misses:
+            self.reset()
+        elif self.state == "record" and self.items and not torch.cuda.is_current_stream_capturing():
+            self._finalize()
+        return False
+
+    def _finalize(self):
+        packed = [it for it in self.items.values() if it["mask"] >= 0]
+        if not packed:
+            return
+        dev = packed[0]["w"].device
+        off, tiles, rows = 0, 0, []
+
+        def take(nbytes):
+            nonlocal off
+            o, off = off, off + (nbytes + 255) // 256 * 256
+            return o
+
+        for it in packed:
+            B, L, C, N, taps, pad, gr = it["geom"]
+            m, nk = it["mask"], 4 * N * C * taps
+            it["fw_off"] = take(nk) if m & 1 else None
+            it["fwx_off"] = take(nk) if m & 2 else None
+            it["dg_off"] = take(2 * nk) if it["need_dg"] else None   # [dg fp32 | dgx], as sf_op_conv1d_bwd_cl_p reads them
+            it["tile0"] = tiles
+            tiles += ((C + 31) // 32) * ((N + 31) // 32)
+        self.buf = torch.empty(max(off, 256), dtype=torch.uint8, device=dev)
+        base = self.buf.data_ptr()
+        for it in packed:
+            B, L, C, N, taps, pad, gr = it["geom"]
+            m, nk = it["mask"], 4 * N * C * taps
+            dg = base + it["dg_off"] if it["need_dg"] and m & 4 else 0
+            dgx = base + it["dg_off"] + nk if it["need_dg"] and m & 8 else 0
+            rows.append([it["w"].data_ptr(), base + it["fw_off"] if m & 1 else 0, base + it["fwx_off"] if m & 2 else 0, dg, dgx, N | (C << 32),
+                         taps | (it["tile0"] << 32)])
+        self.desc = torch.tensor(rows, dtype=torch.int64).to(dev)
+        self.total_tiles, self.n_packed, self.state, self.misses = tiles, len(packed), "ready", 0
+
+
+_ACTIVE_PLAN: Optional[PackPlan] = None
+
+
 class _ConvBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], gamma: Optional[Tensor], beta: Optional[Tensor], groups: int, eps: float,
@@ -108,14 +197,35 @@ class _ConvBlockFn(torch.autograd.Function):
             # the weight images of the backward pass's data-gradient GEMM come out of the SAME pack launch as the forward images (one launch
             # per weight and step; the backward pass packs nothing), when a data gradient will be asked for
             dgp = None
-            if taps <= 9 and (groups > 0 or ctx.needs_input_grad[0]) and not _SELF_PACK:
-                dgp = torch.empty(int(lib.sf_op_conv1d_dgrad_pack_bytes(Cc, N, taps)), dtype=torch.uint8, device=x.device)
-            _lib.check(lib.sf_op_conv1d_train_fwd(_lib.DTYPES[GEMM_DTYPE], src.data_ptr(), w.data_ptr(), b.data_ptr() if b is not None else None,
-                                                  g.data_ptr() if gr > 0 else None, be.data_ptr() if gr > 0 else None, gr, float(eps),
-                                                  res_cl.data_ptr() if res_cl is not None else None, B, L, Cc, N, taps, pad, out.data_ptr(),
-                                                  dgp.data_ptr() if dgp is not None else None, dgp.numel() if dgp is not None else 0, ws.data_ptr(),
-                                                  ws.numel(), _lib.stream_ptr(x.device)),
-                       "sf_op_conv1d_train_fwd")
+            need_dg = taps <= 9 and (groups > 0 or ctx.needs_input_grad[0]) and not _SELF_PACK
+            plan, geom = _ACTIVE_PLAN, (B, L, Cc, N, taps, pad, gr)
+            # (only weights that live across passes: a parameter or a view of one -- a matrix computed in this pass has a new address every time)
+            stable_w = weight.is_leaf or (weight._base is not None and weight._base.is_leaf)
+            plannable = plan is not None and not _SELF_PACK and c_real == Cc and n_real == N and taps <= 9 and stable_w and w.data_ptr() == weight.data_ptr()
+            it = plan.lookup(w, geom, need_dg) if plannable else None
+            if it is not None:   # images written by the plan's one launch at the start of this pass
+                base = plan.buf.data_ptr()
+                if need_dg:
+                    dgp = plan.buf[it["dg_off"]:it["dg_off"] + 8 * N * Cc * taps]
+                _lib.check(lib.sf_op_conv1d_train_fwd_pk(_lib.DTYPES[GEMM_DTYPE], src.data_ptr(), w.data_ptr(),
+                                                         base + it["fw_off"] if it["fw_off"] is not None else None,
+                                                         base + it["fwx_off"] if it["fwx_off"] is not None else None,
+                                                         b.data_ptr() if b is not None else None, g.data_ptr() if gr > 0 else None,
+                                                         be.data_ptr() if gr > 0 else None, gr, float(eps), res_cl.data_ptr() if res_cl is not None else None,
+                                                         B, L, Cc, N, taps, pad, out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr(x.device)),
+                           "sf_op_conv1d_train_fwd_pk")
+            else:
+                if plannable and plan.state == "record":
+                    mask = int(lib.sf_op_conv1d_train_images(_lib.DTYPES[GEMM_DTYPE], w.data_ptr(), B, L, Cc, N, taps, pad, gr))
+                    plan.record(w, geom, -1 if mask < 0 or mask & 16 else mask, need_dg)   # (-1: this launch keeps packing its own)
+                if need_dg:
+                    dgp = torch.empty(int(lib.sf_op_conv1d_dgrad_pack_bytes(Cc, N, taps)), dtype=torch.uint8, device=x.device)
+                _lib.check(lib.sf_op_conv1d_train_fwd(_lib.DTYPES[GEMM_DTYPE], src.data_ptr(), w.data_ptr(), b.data_ptr() if b is not None else None,
+                                                      g.data_ptr() if gr > 0 else None, be.data_ptr() if gr > 0 else None, gr, float(eps),
+                                                      res_cl.data_ptr() if res_cl is not None else None, B, L, Cc, N, taps, pad, out.data_ptr(),
+                                                      dgp.data_ptr() if dgp is not None else None, dgp.numel() if dgp is not None else 0, ws.data_ptr(),
+                                                      ws.numel(), _lib.stream_ptr(x.device)),
+                           "sf_op_conv1d_train_fwd")
         ctx.save_for_backward(x_cl, w, g if g is not None else x_cl.new_empty(0), be if be is not None else x_cl.new_empty(0),
                               act if act is not None else x_cl.new_empty(0), stats if stats is not None else x_cl.new_empty(0),
                               dgp if dgp is not None else x_cl.new_empty(0))

@@ -151,11 +151,15 @@ int sf_resampler_forward(sf_resampler *h, const float *x, int R, int L, float *o
 
 // (dgp: the training forward also writes the data-gradient images of the weight, [C][taps][N] fp32 then its split bf16 image, for
 // sf_op_conv1d_bwd_cl_p -- one pack launch per weight and step instead of one per GEMM)
+// (prepacked: the images come from sf_train_pack_many -- pk_fw / pk_fwx as sf_op_conv1d_train_images says; nothing is packed here.
+//  images_out: query only -- which images would the training forward (with / without a data gradient) read?  Nothing is launched.)
+enum { IMG_FW = 1, IMG_FWX = 2, IMG_DG = 4, IMG_DGX = 8, IMG_UNPLANNABLE = 16 };
 static int conv1d_cl_impl(int dtype, const void *x, const float *w, const float *bias, const float *gamma, const float *beta, int groups,
                           float eps, const void *residual, int B, int L, int C, int N, int taps, int stride, int pad, int upsample,
-                          void *out, void *ws, int64_t ws_bytes, void *stream, void *dgp) {
+                          void *out, void *ws, int64_t ws_bytes, void *stream, void *dgp, bool prepacked = false, const float *pk_fw = nullptr,
+                          const void *pk_fwx = nullptr, int *images_out = nullptr) {
   SF_API_BEGIN
-  if (!x || !w || !out || !ws) fail(SF_ERR_INVALID, "null argument");
+  if (!images_out && (!x || !w || !out || !ws)) fail(SF_ERR_INVALID, "null argument");
   if (upsample < 1 || (upsample & (upsample - 1))) fail(SF_ERR_UNSUPPORTED, "upsample must be a power of two");
   hipStream_t s = static_cast<hipStream_t>(stream);
   Workspace wk(ws, ws_bytes);
@@ -188,8 +192,8 @@ static int conv1d_cl_impl(int dtype, const void *x, const float *w, const float 
   a.solo = 1;   // op-level entry (the training step's single stream)
   if (groups > 0) {
     GnPlan gp = gn_plan(B, L, C);
-    float *slab = wk.alloc_n<float>((int64_t)B * gp.nch * groups * 2);
-    SF_HIP(launch_gn_stats(dtype, x, C, B, L, C, groups, gp.nch, gp.chunk_rows, slab, s));
+    float *slab = images_out ? nullptr : wk.alloc_n<float>((int64_t)B * gp.nch * groups * 2);
+    if (!images_out) SF_HIP(launch_gn_stats(dtype, x, C, B, L, C, groups, gp.nch, gp.chunk_rows, slab, s));
     a.pro = 1;
     a.G = groups;
     a.nch = gp.nch;
@@ -213,14 +217,28 @@ static int conv1d_cl_impl(int dtype, const void *x, const float *w, const float 
     want_rs = strncmp(conv_gemm_variant_name(dtype, pa), "conv_gemm_rs", 12) == 0;
   }
   void *wx_done = nullptr;
-  if (dgp) {   // training forward (fp32 tensors): every image of this weight the step reads, in one launch, and only those
+  // which images the training step reads of this weight: the fp32 [N][K] matrix only where the chosen kernel is not a split-operand one
+  // (or the fragment-order pack needs it as its source), likewise the fp32 data-gradient matrix
+  const bool fw_read = !wx_ok || want_rs || !conv_gemm_reads_split_only(dtype, a);
+  const bool dgx_ok = conv1d_dgrad_split_ok(x3, N, taps);
+  const bool dg_read = !dgx_ok || !conv_gemm_reads_split_only(F32, conv1d_dgrad_args(nullptr, B, L, C, N, taps, pad, nullptr));
+  if (images_out) {
+    *images_out = (need_fw && fw_read ? IMG_FW : 0) | (wx_ok ? IMG_FWX : 0) | (dg_read ? IMG_DG : 0) | (dgx_ok ? IMG_DGX : 0) |
+                  (want_rs || dtype != F32 || stride != 1 || upsample != 1 || taps > 9 ? IMG_UNPLANNABLE : 0);
+    return SF_OK;
+  }
+  if (prepacked) {   // images written by sf_train_pack_many at the start of the step
+    if (want_rs || dtype != F32) fail(SF_ERR_UNSUPPORTED, "prepacked images: not for this launch (sf_op_conv1d_train_images says so)");
+    if ((need_fw && fw_read && !pk_fw) || (wx_ok && !pk_fwx)) fail(SF_ERR_INVALID, "prepacked images missing (see sf_op_conv1d_train_images)");
+    if (need_fw) wp = fw_read ? pk_fw : nullptr;
+    wx_done = const_cast<void *>(pk_fwx);
+    if (!wx_ok) wx_done = nullptr;
+  } else if (dgp) {   // training forward (fp32 tensors): every image of this weight the step reads, in one launch, and only those
     if (dtype != F32 || stride != 1 || upsample != 1 || taps > 9) fail(SF_ERR_UNSUPPORTED, "data-gradient images: fp32 / fp32x stride-1 convolutions of at most 9 taps");
-    const bool fw_read = !wx_ok || want_rs || !conv_gemm_reads_split_only(dtype, a);   // (the fragment-order pack reads the fp32 image)
     float *fw = need_fw && fw_read ? wk.alloc_n<float>((int64_t)N * K) : nullptr;
     if (wx_ok) wx_done = wk.alloc((int64_t)N * K * 4);
     float *dg = static_cast<float *>(dgp);
-    void *dgx = conv1d_dgrad_split_ok(x3, N, taps) ? static_cast<void *>(dg + (int64_t)C * taps * N) : nullptr;
-    const bool dg_read = !dgx || !conv_gemm_reads_split_only(F32, conv1d_dgrad_args(nullptr, B, L, C, N, taps, pad, nullptr));
+    void *dgx = dgx_ok ? static_cast<void *>(dg + (int64_t)C * taps * N) : nullptr;
     SF_HIP(launch_pack_train(w, N, C, taps, fw, wx_done, dg_read ? dg : nullptr, dgx, s));
     if (fw) wp = fw;
     else if (need_fw) wp = nullptr;   // nobody reads it
@@ -280,6 +298,34 @@ int sf_op_conv1d_train_fwd(int dtype, const float *x, const float *w, const floa
     return SF_ERR_INVALID;
   }
   return conv1d_cl_impl(dtype, x, w, bias, gamma, beta, groups, eps, residual, B, L, C, N, taps, 1, pad, 1, out, ws, ws_bytes, stream, dgrad_pack);
+}
+
+int sf_op_conv1d_train_images(int dtype, const float *w, int B, int L, int C, int N, int taps, int pad, int groups) {
+  if (dtype != SF_F32 && dtype != SF_F32X) {
+    set_error("sf_op_conv1d_train_images: dtype must be SF_F32 or SF_F32X");
+    return -1;
+  }
+  int mask = 0;
+  const int rc = conv1d_cl_impl(dtype, nullptr, w, nullptr, nullptr, nullptr, groups, 0.f, nullptr, B, L, C, N, taps, 1, pad, 1, nullptr, nullptr, 0, nullptr, nullptr,
+                                false, nullptr, nullptr, &mask);
+  return rc == SF_OK ? mask : -1;
+}
+
+int sf_train_pack_many(const void *desc_dev, int n_items, int total_tiles, void *stream) {
+  SF_API_BEGIN
+  SF_HIP(launch_pack_train_many(desc_dev, n_items, total_tiles, static_cast<hipStream_t>(stream)));
+  return SF_OK;
+  SF_API_END
+}
+
+int sf_op_conv1d_train_fwd_pk(int dtype, const float *x, const float *w, const float *fw, const void *fwx, const float *bias, const float *gamma,
+                              const float *beta, int groups, float eps, const float *residual, int B, int L, int C, int N, int taps, int pad, float *out,
+                              void *ws, int64_t ws_bytes, void *stream) {
+  if (dtype != SF_F32 && dtype != SF_F32X) {
+    set_error("sf_op_conv1d_train_fwd_pk: dtype must be SF_F32 or SF_F32X");
+    return SF_ERR_INVALID;
+  }
+  return conv1d_cl_impl(dtype, x, w, bias, gamma, beta, groups, eps, residual, B, L, C, N, taps, 1, pad, 1, out, ws, ws_bytes, stream, nullptr, true, fw, fwx);
 }
 
 int sf_op_gn_silu(int dtype, const void *x, const float *gamma, const float *beta, int groups, float eps, int B, int L, int C, void *out,

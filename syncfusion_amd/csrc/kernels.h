@@ -398,6 +398,9 @@ hipError_t launch_pack_dgrad(const float *w, int N, int C, int taps, int ldn, fl
 // every weight image of one training convolution in one launch (train.hip): fw [N][taps][C] fp32, fwx its split fp16 image, dg the
 // data-gradient matrix [C][taps][N] (taps flipped) fp32, dgx its split bf16 image; null outputs are skipped; taps <= 9
 hipError_t launch_pack_train(const float *w, int N, int C, int taps, float *fw, void *fwx, float *dg, void *dgx, hipStream_t s);
+// the same for many weights in one launch: desc_dev = n_items x 7 64-bit words in device memory (w, fw, fwx, dg, dgx, N | C << 32,
+// taps | first_tile << 32), items sorted by first_tile, tiles of an item = ceil(C / 32) * ceil(N / 32), total_tiles their sum
+hipError_t launch_pack_train_many(const void *desc_dev, int n_items, int total_tiles, hipStream_t s);
 // dw (N, C, taps) = sum_rows dy[row][n] * act[row + t - pad][c];  partial: [S][N][taps*C] scratch, S = conv_wgrad_splits(...)
 int conv_wgrad_splits(int64_t rows, int C, int N, int taps);
 // x3: the products from split fp16 operands (both operands are activations: split while they are staged)

@@ -39,11 +39,9 @@ __global__ void pack_dgrad_kernel(const float *__restrict__ w, int N, int C, int
 //   dg  [c][taps - 1 - tap][n] fp32            dgx  its split bf16 image ((taps * N) % 32 == 0)
 constexpr int PT_MAX_TAPS = 9;
 template <int TP /* compile-time tap count (1, 3), 0 = any up to PT_MAX_TAPS */>
-__global__ __launch_bounds__(256) void pack_train_kernel(const float *__restrict__ w, int N, int C, int taps_rt, float *__restrict__ fw, f16 *__restrict__ fwx,
-                                                         float *__restrict__ dg, bf16 *__restrict__ dgx) {
-  __shared__ float tile[(TP ? TP : PT_MAX_TAPS) * 32 * 33];
+__device__ __forceinline__ void pack_train_tile(const float *__restrict__ w, int N, int C, int taps_rt, float *__restrict__ fw, f16 *__restrict__ fwx,
+                                                float *__restrict__ dg, bf16 *__restrict__ dgx, const int c0, const int n0, float *tile) {
   const int taps = TP ? TP : taps_rt;
-  const int c0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
   const int cw = min(32, C - c0), nh = min(32, N - n0);
   const int run = cw * taps;   // floats of one row's (c, tap) run inside the tile
   for (int e = threadIdx.x; e < nh * run; e += 256) {
@@ -75,6 +73,40 @@ __global__ __launch_bounds__(256) void pack_train_kernel(const float *__restrict
       }
     }
   }
+}
+template <int TP>
+__global__ __launch_bounds__(256) void pack_train_kernel(const float *__restrict__ w, int N, int C, int taps_rt, float *__restrict__ fw, f16 *__restrict__ fwx,
+                                                         float *__restrict__ dg, bf16 *__restrict__ dgx) {
+  __shared__ float tile[(TP ? TP : PT_MAX_TAPS) * 32 * 33];
+  pack_train_tile<TP>(w, N, C, taps_rt, fw, fwx, dg, dgx, blockIdx.x * 32, blockIdx.y * 32, tile);
+}
+
+// The same for MANY weights in one launch (the training step's whole weight set: 240 launches of ~8 us were mostly launch latency).  The
+// descriptor table lives in device memory, 7 64-bit words per weight: w, fw, fwx, dg, dgx (addresses; 0 = skipped), N | C << 32,
+// taps | first_tile << 32; a workgroup finds its weight by bisection over first_tile (items are sorted by it).
+constexpr int PACK_DESC_WORDS = 7;
+__global__ __launch_bounds__(256) void pack_train_many_kernel(const unsigned long long *__restrict__ desc, const int n_items) {
+  __shared__ float tile[PT_MAX_TAPS * 32 * 33];
+  const unsigned blk = blockIdx.x;
+  int lo = 0, hi = n_items - 1;   // the last item whose first_tile <= blk (uniform: scalar loads)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((unsigned)(desc[mid * PACK_DESC_WORDS + 6] >> 32) <= blk) lo = mid;
+    else hi = mid - 1;
+  }
+  const unsigned long long *d = desc + lo * PACK_DESC_WORDS;
+  const float *w = reinterpret_cast<const float *>(d[0]);
+  float *fw = reinterpret_cast<float *>(d[1]);
+  f16 *fwx = reinterpret_cast<f16 *>(d[2]);
+  float *dg = reinterpret_cast<float *>(d[3]);
+  bf16 *dgx = reinterpret_cast<bf16 *>(d[4]);
+  const int N = (int)(d[5] & 0xffffffffu), C = (int)(d[5] >> 32), taps = (int)(d[6] & 0xffffffffu);
+  const int t = (int)(blk - (unsigned)(d[6] >> 32)), ntx = (C + 31) / 32;
+  const int c0 = (t % ntx) * 32, n0 = (t / ntx) * 32;
+  if (n0 >= N) return;
+  if (taps == 1) pack_train_tile<1>(w, N, C, taps, fw, fwx, dg, dgx, c0, n0, tile);
+  else if (taps == 3) pack_train_tile<3>(w, N, C, taps, fw, fwx, dg, dgx, c0, n0, tile);
+  else pack_train_tile<0>(w, N, C, taps, fw, fwx, dg, dgx, c0, n0, tile);
 }
 
 // partial[s][n][q],  q = t * C + c:  sum over the rows of split s of dy[row][n] * a[row + t - pad][c]
@@ -990,6 +1022,12 @@ hipError_t launch_pack_train(const float *w, int N, int C, int taps, float *fw, 
   if (taps == 1) hipLaunchKernelGGL(pack_train_kernel<1>, grid, dim3(256), 0, s, w, N, C, taps, fw, static_cast<f16 *>(fwx), dg, static_cast<bf16 *>(dgx));
   else if (taps == 3) hipLaunchKernelGGL(pack_train_kernel<3>, grid, dim3(256), 0, s, w, N, C, taps, fw, static_cast<f16 *>(fwx), dg, static_cast<bf16 *>(dgx));
   else hipLaunchKernelGGL(pack_train_kernel<0>, grid, dim3(256), 0, s, w, N, C, taps, fw, static_cast<f16 *>(fwx), dg, static_cast<bf16 *>(dgx));
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_train_many(const void *desc_dev, int n_items, int total_tiles, hipStream_t s) {
+  if (!desc_dev || n_items < 1 || total_tiles < 1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pack_train_many_kernel, dim3((unsigned)total_tiles), dim3(256), 0, s, static_cast<const unsigned long long *>(desc_dev), n_items);
   return hipGetLastError();
 }
 

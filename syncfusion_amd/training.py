@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import math
 import os
+import weakref
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -188,7 +189,20 @@ class _SkipModulate(torch.autograd.Function):
         return g, gs, gh
 
 
+_PACK_PLANS: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
 _ITEM_MAJOR: Dict[tuple, Tensor] = {}
+
+
+def _pack_plan(module, x: Tensor) -> "sfa.PackPlan":
+    """every convolution weight of a pass through ``module`` packed by ONE launch at its start (``autograd.PackPlan``: recorded on the first
+    pass of an input shape; weakly keyed by the module -- the plans' buffers are no part of its state, copies or pickles)"""
+    plans = _PACK_PLANS.setdefault(module, {})
+    sig = (tuple(x.shape), str(x.device), sfa.GEMM_DTYPE, torch.is_grad_enabled())
+    if sig not in plans:
+        if len(plans) >= 4:
+            plans.clear()
+        plans[sig] = sfa.PackPlan()
+    return plans[sig]
 
 
 def _item_major_index(B: int, sizes: tuple, device) -> Tensor:
@@ -332,10 +346,11 @@ def unet_forward(net, x: Tensor, sigma: Tensor, *, embedding: Tensor, channels: 
         mask = torch.rand(B, 1, 1, device=x.device) < embedding_mask_proba
         emb = torch.where(mask, fixed, emb)
     x_cl = x.to(torch.float32).transpose(1, 2)
-    out = _block(P, hp, 0, x_cl, f_act, _cross_attention_outputs(P, hp, emb), ctx)
-    if embedding_scale != 1.0:
-        out_masked = _block(P, hp, 0, x_cl, f_act, _cross_attention_outputs(P, hp, fixed), ctx)
-        out = out_masked + (out - out_masked) * embedding_scale
+    with _pack_plan(net, x):
+        out = _block(P, hp, 0, x_cl, f_act, _cross_attention_outputs(P, hp, emb), ctx)
+        if embedding_scale != 1.0:
+            out_masked = _block(P, hp, 0, x_cl, f_act, _cross_attention_outputs(P, hp, fixed), ctx)
+            out = out_masked + (out - out_masked) * embedding_scale
     return out.transpose(1, 2)
 
 
@@ -360,19 +375,20 @@ def encoder1d_forward(enc, y: Tensor) -> Tuple[Tensor, Dict[str, List[Tensor]]]:
     P = _params(enc)
     x = y.to(torch.float32).transpose(1, 2)
     xs = [y]
-    x = _enc_resnet(P, "to_in", x, 1)
-    xs.append(x.transpose(1, 2))
-    for i, f in enumerate(hp["factors"]):
-        pre = f"downsamples.{i}"
-        w = P[pre + ".down.weight"]                                            # (N, C, 2f + 1), stride f, padding f
-        N, Cc, k = w.shape
-        cols = F.pad(x, (0, 0, f, f)).unfold(1, k, f)                           # (B, Lout, C, k) windows
-        Bq, Lout = cols.shape[:2]
-        cols = cols.permute(0, 1, 3, 2).reshape(Bq, Lout, k * Cc)
-        x = _pointwise(cols, w.permute(0, 2, 1).reshape(N, k * Cc), P[pre + ".down.bias"])
-        for j in range(hp["num_blocks"][i]):
-            x = _enc_resnet(P, f"{pre}.blocks.{j}", x, hp["resnet_groups"])
+    with _pack_plan(enc, y):
+        x = _enc_resnet(P, "to_in", x, 1)
         xs.append(x.transpose(1, 2))
+        for i, f in enumerate(hp["factors"]):
+            pre = f"downsamples.{i}"
+            w = P[pre + ".down.weight"]                                            # (N, C, 2f + 1), stride f, padding f
+            N, Cc, k = w.shape
+            cols = F.pad(x, (0, 0, f, f)).unfold(1, k, f)                           # (B, Lout, C, k) windows
+            Bq, Lout = cols.shape[:2]
+            cols = cols.permute(0, 1, 3, 2).reshape(Bq, Lout, k * Cc)
+            x = _pointwise(cols, w.permute(0, 2, 1).reshape(N, k * Cc), P[pre + ".down.bias"])
+            for j in range(hp["num_blocks"][i]):
+                x = _enc_resnet(P, f"{pre}.blocks.{j}", x, hp["resnet_groups"])
+            xs.append(x.transpose(1, 2))
     xs.append(xs[-1])
     return xs[-1], dict(xs=xs)
 

@@ -515,6 +515,53 @@ def test_training_step_optimizer_loop_lowers_the_loss_and_the_engine_follows_the
         m.training_step(batch, 0)
 
 
+def test_pack_plan_steps_are_bit_equal_to_per_convolution_packing_and_follow_the_weights(cuda, monkeypatch):
+    """``autograd.PackPlan``: from the second pass of a shape on, ONE launch packs the weight images of every convolution (recorded on the
+    first pass).  Five optimizer steps with the plan and five with every convolution packing its own images give the same losses and the
+    same final weights bit for bit -- the plan repacks from the CURRENT weights on every pass (optimizer steps in between, an in-place
+    ``load_state_dict`` at the end) and holds no values across passes."""
+    from syncfusion_amd import autograd as sfa, training
+
+    B, L0 = 4, 16 * 16
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(B, 1, L0, generator=g).to(cuda)
+    y = (torch.rand(B, 1, L0, generator=g) < 0.03).float().to(cuda)
+    batch = (x, y, x, None, None)
+
+    def run(self_pack):
+        monkeypatch.setattr(sfa, "_SELF_PACK", self_pack)
+        m = _small_training_model(cuda)
+        opt = m.configure_optimizers()
+        losses = []
+        for it in range(5):
+            torch.manual_seed(1000)
+            loss = m.training_step(batch, it)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        return m, losses
+
+    m_plan, l_plan = run(False)
+    plans = [p for ps in training._PACK_PLANS.get(m_plan.model.net, {}).values() for p in [ps]]
+    assert plans and all(p.state == "ready" and p.n_packed > 0 and p.misses == 0 for p in plans), [(p.state, p.n_packed, p.misses) for p in plans]
+    m_self, l_self = run(True)
+    assert l_plan == l_self, (l_plan, l_self)
+    for (n, a), (_, b_) in zip(m_plan.state_dict().items(), m_self.state_dict().items()):
+        assert torch.equal(a, b_), n
+    # new weight VALUES at the same addresses: the next pass must use them (nothing cached across passes)
+    monkeypatch.setattr(sfa, "_SELF_PACK", False)
+    sd = {k: (v * 0.5 if v.dtype.is_floating_point and ".conv" in k and k.endswith("weight") else v) for k, v in m_plan.state_dict().items()}
+    m_plan.load_state_dict(sd)
+    m_self.load_state_dict(sd)
+    torch.manual_seed(1000)
+    a = float(m_plan.training_step(batch, 0).detach())
+    monkeypatch.setattr(sfa, "_SELF_PACK", True)
+    torch.manual_seed(1000)
+    b_ = float(m_self.training_step(batch, 0).detach())
+    assert a == b_ and a != l_plan[-1]
+
+
 @pytest.mark.timeout(1500)
 def test_full_size_long_clip_gradients_against_oracle_autograd(cuda):
     """The reference-size U-Net on ONE clip of 2**16 samples (self-attention over 512 / 256 / 128 / 64 positions, 65 K rows at the
