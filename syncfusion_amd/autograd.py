@@ -59,7 +59,7 @@ class PackPlan:
         self.reset()
 
     def reset(self):
-        self.state, self.items, self.buf, self.desc, self.total_tiles, self.misses, self.n_packed = "record", {}, None, None, 0, 0, 0
+        self.state, self.items, self.buf, self.desc, self.total_tiles, self.misses, self.n_packed, self.hits = "record", {}, None, None, 0, 0, 0, 0
 
     @staticmethod
     def _key(w, N, C, taps):
@@ -76,11 +76,15 @@ class PackPlan:
         if it is None or it["geom"] != tuple(geom) or (need_dg and not it["need_dg"]):
             self.misses += 1
             return None
-        return None if it["mask"] < 0 else it   # (mask < 0: recorded as a convolution that packs its own images -- not a miss)
+        if it["mask"] < 0:   # recorded as a convolution that packs its own images -- not a miss
+            return None
+        self.hits += 1
+        return it
 
     def __enter__(self):
         global _ACTIVE_PLAN
         self._outer, _ACTIVE_PLAN = _ACTIVE_PLAN, self
+        self.hits = 0
         if self.state == "ready":
             _lib.check(_lib.load().sf_train_pack_many(self.desc.data_ptr(), self.n_packed, self.total_tiles, _lib.stream_ptr(self.buf.device)),
                        "sf_train_pack_many")
@@ -91,8 +95,8 @@ class PackPlan:
         _ACTIVE_PLAN = self._outer
         if exc[0] is not None:
             self.reset()
-        elif self.state == "ready" and self.misses:
-            self.reset()
+        elif self.state == "ready" and (self.misses or not self.hits):   # an unknown convolution, or a pass that used none of the images
+            self.reset()                                                   # (weights re-created, cast on the fly): record again
         elif self.state == "record" and self.items and not torch.cuda.is_current_stream_capturing():
             self._finalize()
         return False
