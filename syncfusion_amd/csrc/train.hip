@@ -142,23 +142,41 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   // wave w takes the row pairs w, w + 4, ...; inside a pair the half-wave picks the row (k index of the 32x32x2 MFMA).  The
   // operands of UNR row pairs are fetched before the first MFMA of the group, so UNR * (TN + TQ) loads are in flight per wave.
-  constexpr int UNR = 4;
-  auto fetch = [&](int r0, float (&av)[TN], float (&bv)[TQ]) {
-    const int r = r0 + fh;
-    const bool rv = r < r_end;
-    const int l = r % L;
+  // (16 pairs for the single-tile form: a wave of the 8-channel level walks 256 row pairs, and with 4 pairs in flight it spent 64
+  //  memory round trips doing so)
+  constexpr int UNR = TN * TQ == 1 ? 16 : (TN * TQ <= 3 ? 8 : 4);
+  // this lane's row walks r, r + 8, ...: its position inside the clip and its operand addresses advance incrementally (the first
+  // version recomputed r % L and two 64-bit products per fetch: ~80 vector instructions per row pair, the thin levels' whole cost)
+  int r = r_begin + 2 * wave + fh;
+  int l = r % L;
+  const float *pa[TN];
+  const float *pb[TQ];
+  bool nok[TN];
 #pragma unroll
-    for (int i = 0; i < TN; ++i) av[i] = (rv && n[i] < N) ? dy[(size_t)r * N + n[i]] : 0.f;
+  for (int i = 0; i < TN; ++i) {
+    nok[i] = n[i] < N;
+    pa[i] = dy + (size_t)r * N + (nok[i] ? n[i] : 0);
+  }
 #pragma unroll
-    for (int j = 0; j < TQ; ++j) {
-      const int ls = l + shift[j];
-      bv[j] = (rv && qok[j] && ls >= 0 && ls < L) ? act[(size_t)(r + shift[j]) * C + c[j]] : 0.f;
-    }
-  };
+  for (int j = 0; j < TQ; ++j) pb[j] = act + ((ptrdiff_t)r + shift[j]) * C + c[j];
+  const size_t stepA = (size_t)8 * N, stepB = (size_t)8 * C;
   for (int r0 = r_begin + 2 * wave; r0 < r_end; r0 += 8 * UNR) {
     float av[UNR][TN], bv[UNR][TQ];
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) fetch(r0 + 8 * u, av[u], bv[u]);   // rows past r_end load zeros
+    for (int u = 0; u < UNR; ++u) {   // rows past r_end load zeros
+      const bool rv = r < r_end;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) av[u][i] = (rv && nok[i]) ? *pa[i] : 0.f;
+#pragma unroll
+      for (int j = 0; j < TQ; ++j) bv[u][j] = (rv && qok[j] && (unsigned)(l + shift[j]) < (unsigned)L) ? *pb[j] : 0.f;
+      r += 8;
+      l += 8;
+      if (l >= L) l %= L;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) pa[i] += stepA;
+#pragma unroll
+      for (int j = 0; j < TQ; ++j) pb[j] += stepB;
+    }
 #pragma unroll
     for (int u = 0; u < UNR; ++u)
 #pragma unroll
@@ -1079,8 +1097,14 @@ hipError_t launch_conv_wgrad(const float *dy, const float *act, int B, int L, in
     hipLaunchKernelGGL(conv_wgrad_lds_kernel<2>, dim3((N + 127) / 128, (Q + 127) / 128, S), dim3(256), 0, s, dy, act, rows, L, C, N, taps, pad, rps, partial, direct);
   else if (fam == 1)
     hipLaunchKernelGGL(conv_wgrad_lds_kernel<1>, dim3((N + 63) / 64, (Q + 63) / 64, S), dim3(256), 0, s, dy, act, rows, L, C, N, taps, pad, rps, partial, direct);
-  else
-    hipLaunchKernelGGL((conv_wgrad_kernel<1, 1>), dim3((N + 31) / 32, (Q + 31) / 32, S), dim3(256), 0, s, dy, act, rows, L, C, N, taps, pad, rps, partial, direct);
+  else {
+    // thin layers: one workgroup takes up to three 32-column tiles of (tap, channel) -- the three taps of a 32-channel level: dy is fetched
+    // once instead of once per tile, the activation rows of the taps overlap in the cache (same accumulation order per tile: same bits)
+    const int qt = (Q + 31) / 32;
+    if (qt >= 3) hipLaunchKernelGGL((conv_wgrad_kernel<1, 3>), dim3((N + 31) / 32, (qt + 2) / 3, S), dim3(256), 0, s, dy, act, rows, L, C, N, taps, pad, rps, partial, direct);
+    else if (qt == 2) hipLaunchKernelGGL((conv_wgrad_kernel<1, 2>), dim3((N + 31) / 32, 1, S), dim3(256), 0, s, dy, act, rows, L, C, N, taps, pad, rps, partial, direct);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<1, 1>), dim3((N + 31) / 32, 1, S), dim3(256), 0, s, dy, act, rows, L, C, N, taps, pad, rps, partial, direct);
+  }
   if (!direct) {
     const int64_t total = (int64_t)N * Q;
     if (C % 4 == 0) {
