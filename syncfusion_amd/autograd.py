@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from typing import Optional
 
 import torch
@@ -82,8 +83,7 @@ class PackPlan:
         return it
 
     def __enter__(self):
-        global _ACTIVE_PLAN
-        self._outer, _ACTIVE_PLAN = _ACTIVE_PLAN, self
+        self._outer, _TLS.plan = getattr(_TLS, "plan", None), self
         self.hits = 0
         if self.state == "ready":
             _lib.check(_lib.load().sf_train_pack_many(self.desc.data_ptr(), self.n_packed, self.total_tiles, _lib.stream_ptr(self.buf.device)),
@@ -91,8 +91,7 @@ class PackPlan:
         return self
 
     def __exit__(self, *exc):
-        global _ACTIVE_PLAN
-        _ACTIVE_PLAN = self._outer
+        _TLS.plan = self._outer
         if exc[0] is not None:
             self.reset()
         elif self.state == "ready" and (self.misses or not self.hits):   # an unknown convolution, or a pass that used none of the images
@@ -134,7 +133,7 @@ class PackPlan:
         self.total_tiles, self.n_packed, self.state, self.misses = tiles, len(packed), "ready", 0
 
 
-_ACTIVE_PLAN: Optional[PackPlan] = None
+_TLS = threading.local()   # .plan: the PackPlan of the forward pass running on THIS thread (None outside ``with plan:``)
 
 
 class _ConvBlockFn(torch.autograd.Function):
@@ -202,7 +201,7 @@ class _ConvBlockFn(torch.autograd.Function):
             # per weight and step; the backward pass packs nothing), when a data gradient will be asked for
             dgp = None
             need_dg = taps <= 9 and (groups > 0 or ctx.needs_input_grad[0]) and not _SELF_PACK
-            plan, geom = _ACTIVE_PLAN, (B, L, Cc, N, taps, pad, gr)
+            plan, geom = getattr(_TLS, "plan", None), (B, L, Cc, N, taps, pad, gr)
             # (only weights that live across passes: a parameter or a view of one -- a matrix computed in this pass has a new address every time)
             stable_w = weight.is_leaf or (weight._base is not None and weight._base.is_leaf)
             plannable = plan is not None and not _SELF_PACK and c_real == Cc and n_real == N and taps <= 9 and stable_w and w.data_ptr() == weight.data_ptr()

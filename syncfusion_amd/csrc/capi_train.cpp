@@ -175,7 +175,7 @@ int sf_op_length_sums(const float *x, const float *y, int B, int L, int C, float
 
 int64_t sf_op_ln_modulate_bwd_workspace_bytes(int B, int L, int C) {
   if (B < 1 || L < 1 || C < 1) return -1;
-  return (int64_t)B * ln_mod_bwd_chunks(L) * 2 * C * (int64_t)sizeof(float);
+  return (int64_t)B * ln_mod_bwd_chunks(L, C) * 2 * C * (int64_t)sizeof(float);
 }
 
 static int ln_modulate_bwd_impl(const float *x, const float *scale_shift, const float *dy, const float *dx_add, float eps, int B, int L, int C, float *dx,

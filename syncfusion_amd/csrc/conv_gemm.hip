@@ -435,6 +435,8 @@ static const char *label_x3(const ConvGemmArgs &a, const char *f32_label) {
   s.replace(s.find("f32"), 3, "x3");
   return pool.insert(s).first->c_str();
 }
+// (engine_common.h conv_gemm_reads_split_only() keys on the "<x3" of these labels: a kernel family labelled so reads ConvGemmArgs::wx and
+//  never ConvGemmArgs::w -- the training step then does not pack the fp32 image at all, and hands the kernels a null `w`)
 const char *conv_gemm_variant_name(int dt, const ConvGemmArgs &a) {
   return dt == F32 ? label_x3(a, variant_name_bf16(dt, a)) : label_for_dtype(dt, variant_name_bf16(dt, a));
 }

@@ -427,8 +427,8 @@ hipError_t launch_gn_silu_recompute(const float *x, const float *gamma, const fl
 hipError_t launch_gn_bwd_stats(const float *x, int B, int L, int C, int G, float *ws, hipStream_t s);
 
 // backward of y = LayerNorm_C(x; eps) * (1 + ss[b][c]) + ss[b][C + c] (ss == nullptr: plain normalisation): dx and, when dss != nullptr,
-// dss (B, 2C) = [dscale | dshift];  dss_part: [B][ln_mod_bwd_chunks(L)][2C] scratch
-int ln_mod_bwd_chunks(int L);
+// dss (B, 2C) = [dscale | dshift];  dss_part: [B][ln_mod_bwd_chunks(L, C)][2C] scratch
+int ln_mod_bwd_chunks(int L, int C);
 hipError_t launch_ln_modulate_bwd(const float *x, const float *ss, const float *dy, float eps, int B, int L, int C, float *dx, float *dss_part,
                                   float *dss, hipStream_t s, const float *dx_add = nullptr /* added to dx in the same pass */);
 // backward of softmax attention on packed projections (head dim 64): dq (B,L,H*64), dkv (B,L,2*H*64); lse, dsum: (B,H,L) scratch

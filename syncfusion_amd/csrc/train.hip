@@ -513,8 +513,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(const float *__restr
 __device__ __forceinline__ float slice_sum_8(const float *__restrict__ part, int S, size_t stride, size_t col, bool valid, float *sh /* [256] */) {
   const int kq = threadIdx.x >> 5;
   float s = 0.f;
-  if (valid)
-    for (int k = kq; k < S; k += 8) s += part[(size_t)k * stride + col];
+  if (valid) {
+#pragma unroll 8
+    for (int k = kq; k < S; k += 8) s += part[(size_t)k * stride + col];   // (eight loads in flight per thread; the sum keeps its order)
+  }
   sh[threadIdx.x] = s;
   __syncthreads();
   float t = 0.f;
@@ -541,8 +543,13 @@ __device__ __forceinline__ void tail_reduce_block(const TailReduce &t, int block
 }
 
 // dw[n][c][t] (PyTorch layout) = sum_s partial[s][n][t * C + c]
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ partial, int S, int N, int C, int taps, float *__restrict__ dw) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ partial, int S, int N, int C, int taps, float *__restrict__ dw,
+                                                           const int nb_main, const TailReduce tail /* the bias gradient's slices */) {
   __shared__ float sh[256];
+  if ((int)blockIdx.x >= nb_main) {
+    tail_reduce_block(tail, (int)blockIdx.x - nb_main, sh);
+    return;
+  }
   const int64_t total = (int64_t)N * C * taps;
   const int Q = taps * C;
   const int64_t i = (int64_t)blockIdx.x * 32 + (threadIdx.x & 31);
@@ -804,12 +811,13 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_vec_kernel(const float *__rest
 }
 
 // out[b][j] = sum over chunks of part[b][chunk][j]
-__global__ void chunks_reduce_kernel(const float *__restrict__ part, int nchunk, int cols, float *__restrict__ out) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-  if (col >= cols) return;
-  float s = 0.f;
-  for (int k = 0; k < nchunk; ++k) s += part[((size_t)b * nchunk + k) * cols + col];
-  out[(size_t)b * cols + col] = s;
+// (32 outputs per workgroup, eight threads per output across the chunks: up to 256 chunks per clip)
+__global__ __launch_bounds__(256) void chunks_reduce_kernel(const float *__restrict__ part, int nchunk, int cols, float *__restrict__ out) {
+  __shared__ float sh[256];
+  const int col = blockIdx.x * 32 + (threadIdx.x & 31), b = blockIdx.y;
+  const bool valid = col < cols;
+  const float v = slice_sum_8(part + (size_t)b * nchunk * cols, nchunk, (size_t)cols, (size_t)(valid ? col : 0), valid, sh);
+  if (threadIdx.x < 32 && valid) out[(size_t)b * cols + col] = v;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -1107,19 +1115,23 @@ hipError_t launch_conv_wgrad(const float *dy, const float *act, int B, int L, in
   }
   if (!direct) {
     const int64_t total = (int64_t)N * Q;
-    if (C % 4 == 0) {
-      TailReduce tail;   // the bias gradient's slice sums (launch_col_sums_part ran before this call) ride on the reducer
-      if (bias_part && db) {
-        tail.part = bias_part;
-        tail.out = db;
-        tail.S = bias_slices;
-        tail.cols = N;
-        if (bias_done) *bias_done = true;
-      }
+    TailReduce tail;   // the bias gradient's slice sums (launch_col_sums_part ran before this call) ride on the reducer
+    if (bias_part && db) {
+      tail.part = bias_part;
+      tail.out = db;
+      tail.S = bias_slices;
+      tail.cols = N;
+      if (bias_done) *bias_done = true;
+    }
+    // many slices of a small matrix (the thin levels: 512 row splits of 8 x 24 ... 32 x 96 outputs): eight threads per output walk the
+    // slices side by side; the vector kernel's thread walks ALL slices of its four outputs, 128 dependent round trips at 512 slices
+    // (35-45 us per launch, as much as the weight-gradient kernel itself)
+    if (C % 4 == 0 && (S < 64 || total > 65536)) {
       const int nb = (int)((total / 4 + 255) / 256);
       hipLaunchKernelGGL(wgrad_reduce_vec_kernel, dim3((unsigned)(nb + tail.blocks())), dim3(256), 0, s, partial, S, N, C, taps, dw, nb, tail);
     } else {
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, s, partial, S, N, C, taps, dw);
+      const int nb = (int)((total + 31) / 32);
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(nb + tail.blocks())), dim3(256), 0, s, partial, S, N, C, taps, dw, nb, tail);
     }
   }
   return hipGetLastError();
@@ -1322,11 +1334,16 @@ hipError_t launch_gn_silu_bwd(const float *x, const float *da, const float *gamm
   return hipGetLastError();
 }
 
-int ln_mod_bwd_chunks(int L) { return std::max(1, std::min(64, (L + 63) / 64)); }
+// >= 8 K elements per workgroup (at least 8 rows), at most 256 chunks per clip.  (64-row chunks before: the 1024-channel levels of the
+// training step ran 4 clips x 4 chunks = 16 workgroups, 40 us for 16 MB of traffic.)
+int ln_mod_bwd_chunks(int L, int C) {
+  const int rows = std::max(8, 8192 / std::max(C, 1));
+  return std::max(1, std::min(256, (L + rows - 1) / rows));
+}
 
 hipError_t launch_ln_modulate_bwd(const float *x, const float *ss, const float *dy, float eps, int B, int L, int C, float *dx, float *dss_part,
                                   float *dss, hipStream_t s, const float *dx_add) {
-  const int nchunk = ln_mod_bwd_chunks(L);
+  const int nchunk = ln_mod_bwd_chunks(L, C);
   const int rpc = (L + nchunk - 1) / nchunk;
 #define SF_LNB(TPR, PER) hipLaunchKernelGGL((ln_mod_bwd_vec_kernel<TPR, PER>), dim3(B, nchunk), dim3(256), 0, s, x, ss, 2 * C, dy, L, eps, rpc, dx, dss_part, dx_add)
   switch (C) {
@@ -1342,7 +1359,7 @@ hipError_t launch_ln_modulate_bwd(const float *x, const float *ss, const float *
     default: return hipErrorInvalidValue;
   }
 #undef SF_LNB
-  if (dss) hipLaunchKernelGGL(chunks_reduce_kernel, dim3((2 * C + 63) / 64, B), dim3(64), 0, s, dss_part, nchunk, 2 * C, dss);
+  if (dss) hipLaunchKernelGGL(chunks_reduce_kernel, dim3((2 * C + 31) / 32, B), dim3(256), 0, s, dss_part, nchunk, 2 * C, dss);
   return hipGetLastError();
 }
 
