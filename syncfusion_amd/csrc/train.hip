@@ -582,6 +582,7 @@ __global__ __launch_bounds__(256) void col_sums_vec_kernel(const float *__restri
   float acc[V];
 #pragma unroll
   for (int j = 0; j < V; ++j) acc[j] = 0.f;
+#pragma unroll 4
   for (int64_t r = r0 + tid / vpr; r < r1; r += rstep) {
     if constexpr (V == 4) {
       const f32x4 v = *reinterpret_cast<const f32x4 *>(x + r * cols + 4 * cv);
@@ -831,15 +832,26 @@ __global__ __launch_bounds__(256) void chunks_reduce_kernel(const float *__restr
 // ---------------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void gn_group_stats(const float *__restrict__ slab_b, int nch, int G, int chunk_rows, int L, int cpg, float eps,
                                                float *mean_s, float *rstd_s) {
+  // (the chunk statistics are fetched eight at a time and merged in chunk order: one memory round trip per eight chunks instead of one per
+  //  chunk -- with 16-64 chunks this serial walk was most of the ~10 us floor of the GroupNorm backward launches)
   for (int g = threadIdx.x; g < G; g += 256) {
     float n = 0.f, mean = 0.f, m2 = 0.f;
-    for (int ch = 0; ch < nch; ++ch) {
-      const float nb = (float)min(chunk_rows, L - ch * chunk_rows) * (float)cpg;
-      const float mb = slab_b[((size_t)ch * G + g) * 2], qb = slab_b[((size_t)ch * G + g) * 2 + 1];
-      const float delta = mb - mean, tot = n + nb;
-      mean += delta * (nb / tot);
-      m2 += qb + delta * delta * (n * nb / tot);
-      n = tot;
+    for (int ch0 = 0; ch0 < nch; ch0 += 8) {
+      float2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        v[u] = ch0 + u < nch ? *reinterpret_cast<const float2 *>(slab_b + ((size_t)(ch0 + u) * G + g) * 2) : make_float2(0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int ch = ch0 + u;
+        if (ch < nch) {
+          const float nb = (float)min(chunk_rows, L - ch * chunk_rows) * (float)cpg;
+          const float delta = v[u].x - mean, tot = n + nb;
+          mean += delta * (nb / tot);
+          m2 += v[u].y + delta * delta * (n * nb / tot);
+          n = tot;
+        }
+      }
     }
     mean_s[g] = mean;
     rstd_s[g] = rsqrtf(m2 / n + eps);
@@ -875,6 +887,7 @@ __global__ __launch_bounds__(256) void gn_bwd_part_kernel(const float *__restric
   for (int qn = 0; qn < 4; ++qn)
 #pragma unroll
     for (int j = 0; j < V; ++j) a[qn][j] = 0.f;
+#pragma unroll 4
   for (int r = tid / vpr; r < rows; r += rstep) {
     float xv[V], dv[V];
     if constexpr (V == 4) {
@@ -943,9 +956,17 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const float *__restrict_
   gn_group_stats(slab + (size_t)b * nch * G * 2, nch, G, chunk_rows, L, cpg, eps, mean_s, rstd_s);
   for (int g = tid; g < G; g += 256) {
     float s1 = 0.f, s2 = 0.f;
-    for (int k = 0; k < nch; ++k) {
-      s1 += s12_part[(((size_t)b * nch + k) * G + g) * 2];
-      s2 += s12_part[(((size_t)b * nch + k) * G + g) * 2 + 1];
+    for (int k0 = 0; k0 < nch; k0 += 8) {   // eight chunk sums per memory round trip, added in chunk order
+      float2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        v[u] = k0 + u < nch ? *reinterpret_cast<const float2 *>(s12_part + (((size_t)b * nch + k0 + u) * G + g) * 2) : make_float2(0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (k0 + u < nch) {
+          s1 += v[u].x;
+          s2 += v[u].y;
+        }
     }
     const float inv_n = 1.0f / ((float)L * (float)cpg);
     m1_s[g] = s1 * inv_n;
@@ -966,6 +987,7 @@ __global__ __launch_bounds__(256) void gn_bwd_dx_kernel(const float *__restrict_
   }
   const int r0 = ch * chunk_rows, rows = min(chunk_rows, L - r0);
   const size_t base = ((size_t)b * L + r0) * C + c0;
+#pragma unroll 4
   for (int r = tid / vpr; r < rows; r += rstep) {
     float xv[V], dv[V], o[V];
     if constexpr (V == 4) {
@@ -1021,6 +1043,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__
   }
   const int r0 = ch * chunk_rows, rows = min(chunk_rows, L - r0);
   const size_t base = ((size_t)b * L + r0) * C + c0;
+#pragma unroll 4
   for (int r = tid / vpr; r < rows; r += rstep) {
     if constexpr (V == 4) {
       const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + base + (size_t)r * C);
@@ -1254,9 +1277,10 @@ static int gn_bwd_vec(int C, int G) {   // columns per access of the chunked ker
 static bool gn_bwd_chunked_ok(int C, int G) { return gn_bwd_vec(C, G) != 0; }
 
 static void gn_bwd_plan(int L, int C, int &nch, int &chunk_rows) {
-  // (>= 16 K elements per workgroup, <= 64 chunks per clip; 128 / 256 chunks and 8 K elements measured: the four GroupNorm kernels of the
-  //  training step 7.75 -> 8.0 / 8.1 / 9.1 ms, profiles/r6_g_prof_train_gn.txt)
-  int64_t n = ((int64_t)L * C + 16383) / 16384;
+  // (>= 8 K elements per workgroup, <= 64 chunks per clip.  Measured on the training step's four GroupNorm kernels, ms per step: 16 K / 64
+  //  6.86, 8 K / 64 6.46, 8 K / 128 6.85, 4 K / 256 10.5 -- every workgroup merges all chunk statistics of its clip in chunk order;
+  //  profiles/r6_m_prof_train_gn2.txt.  Before the merges fetched eight chunks per round trip: 7.75 / 8.0 / 9.1, r6_g_prof_train_gn.txt)
+  int64_t n = ((int64_t)L * C + 8191) / 8192;
   n = std::max<int64_t>(1, std::min<int64_t>(n, 64));
   chunk_rows = (int)((L + n - 1) / n);
   nch = (L + chunk_rows - 1) / chunk_rows;
