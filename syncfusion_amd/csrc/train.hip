@@ -621,6 +621,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_vec_kernel(const float *__re
   const float *p = partial + e;
   f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
   int k = 0;
+  for (; k + 8 <= S; k += 8) {   // eight slices per memory round trip (the partial sums keep their four interleaved chains: same bits)
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4 *>(p + (size_t)(k + u) * NQ);
+    a0 += v[0];
+    a1 += v[1];
+    a2 += v[2];
+    a3 += v[3];
+    a0 += v[4];
+    a1 += v[5];
+    a2 += v[6];
+    a3 += v[7];
+  }
   for (; k + 4 <= S; k += 4) {
     const f32x4 v0 = *reinterpret_cast<const f32x4 *>(p + (size_t)k * NQ);
     const f32x4 v1 = *reinterpret_cast<const f32x4 *>(p + (size_t)(k + 1) * NQ);
@@ -1173,6 +1186,7 @@ __global__ __launch_bounds__(256) void length_sums_kernel(const float *__restric
   float acc[V];
 #pragma unroll
   for (int j = 0; j < V; ++j) acc[j] = 0.f;
+#pragma unroll 4
   for (int r = r0 + tid / vpr; r < r1; r += rstep) {
     const size_t o = base + (size_t)r * cols + V * cv;
     if constexpr (V == 4) {
