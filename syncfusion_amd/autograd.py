@@ -45,6 +45,11 @@ _SELF_PACK = os.environ.get("SF_TRAIN_SELF_PACK") == "1"  # A/B aid: the backwar
 _FUSED_GN = os.environ.get("SF_TRAIN_FUSED_GN") == "1"   # A/B aid: GroupNorm+SiLU as the convolution kernel's prologue, recomputed in backward
 
 
+def _capturing(t: Tensor) -> bool:
+    """is the current stream of ``t``'s device recording a HIP graph?  (The plan is neither recorded nor built then: building uploads a table.)"""
+    return bool(t.is_cuda and torch.cuda.is_current_stream_capturing())
+
+
 class PackPlan:
     """The weight images of every convolution of one training forward, written by ONE launch at its start (``sf_train_pack_many``) instead of
     one launch per convolution (240 launches of ~8 us per step, mostly launch latency).
@@ -67,7 +72,7 @@ class PackPlan:
         return (w.data_ptr(), int(N), int(C), int(taps))
 
     def record(self, w, geom, mask, need_dg):
-        if self.state == "record" and not torch.cuda.is_current_stream_capturing():
+        if self.state == "record" and not _capturing(w):
             self.items.setdefault(self._key(w, geom[3], geom[2], geom[4]), dict(w=w, geom=tuple(geom), mask=int(mask), need_dg=bool(need_dg)))
 
     def lookup(self, w, geom, need_dg):
@@ -96,7 +101,7 @@ class PackPlan:
             self.reset()
         elif self.state == "ready" and (self.misses or not self.hits):   # an unknown convolution, or a pass that used none of the images
             self.reset()                                                   # (weights re-created, cast on the fly): record again
-        elif self.state == "record" and self.items and not torch.cuda.is_current_stream_capturing():
+        elif self.state == "record" and self.items and not _capturing(next(iter(self.items.values()))["w"]):
             self._finalize()
         return False
 

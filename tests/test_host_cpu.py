@@ -363,3 +363,59 @@ def test_params_version_sees_structural_edits_on_the_next_call():
     m, v = fresh()
     m.load_state_dict(sd)                                                 # in place: same objects, bumped versions
     assert v.changed(m)
+
+
+def test_pack_plan_state_machine_on_a_stub_library(monkeypatch):
+    """``autograd.PackPlan`` (the training step's one-launch weight pack): first pass records, ``with`` exit builds the buffer and the
+    descriptor table (7 words per weight: addresses, N | C << 32, taps | first_tile << 32; convolutions that pack their own images are
+    remembered but not packed), later passes issue ONE ``sf_train_pack_many`` on entry; an unknown weight or a pass that uses none of the
+    images sends the plan back to recording.  No GPU: the library call is a stub that records its arguments."""
+    from syncfusion_amd import _lib
+    from syncfusion_amd import autograd as sfa
+
+    calls = []
+
+    class Stub:
+        def sf_train_pack_many(self, desc, n, tiles, stream):
+            calls.append((int(desc), int(n), int(tiles)))
+            return 0
+
+    monkeypatch.setattr(_lib, "load", lambda: Stub())
+    monkeypatch.setattr(_lib, "stream_ptr", lambda dev: None)
+    w1, w2, w3 = torch.zeros(64, 32, 3), torch.zeros(40, 96, 1), torch.zeros(8, 8, 3)
+    g1, g2, g3 = (4, 100, 32, 64, 3, 1, 0), (4, 100, 96, 40, 1, 0, 0), (4, 100, 8, 8, 3, 1, 8)
+    plan = sfa.PackPlan()
+    with plan:
+        assert getattr(sfa._TLS, "plan") is plan and plan.lookup(w1, g1, True) is None        # recording: nothing to look up
+        plan.record(w1, g1, 1 | 2 | 8, True)      # fw + fwx + dgx
+        plan.record(w2, g2, 2 | 4, False)         # fwx; no data gradient asked for
+        plan.record(w3, g3, -1, True)             # packs its own images
+        plan.record(w1, g1, 1 | 2 | 8, True)      # second use of the same weight (guidance: two passes through the net)
+    assert getattr(sfa._TLS, "plan", None) is None
+    assert plan.state == "ready" and plan.n_packed == 2 and not calls
+    assert plan.total_tiles == 1 * 2 + 3 * 2      # ceil(C / 32) * ceil(N / 32) per packed weight
+    d = plan.desc.tolist()
+    base = plan.buf.data_ptr()
+    it1, it2 = plan.items[plan._key(w1, 64, 32, 3)], plan.items[plan._key(w2, 40, 96, 1)]
+    nk1 = 4 * 64 * 32 * 3
+    assert d[0] == [w1.data_ptr(), base + it1["fw_off"], base + it1["fwx_off"], 0, base + it1["dg_off"] + nk1, 64 | (32 << 32), 3 | (0 << 32)]
+    assert d[1] == [w2.data_ptr(), 0, base + it2["fwx_off"], 0, 0, 40 | (96 << 32), 1 | (2 << 32)]
+    assert all(o % 256 == 0 for o in (it1["fw_off"], it1["fwx_off"], it1["dg_off"], it2["fwx_off"])) and it2["dg_off"] is None
+    with plan:                                    # a later pass: one launch on entry, images by lookup
+        assert calls == [(plan.desc.data_ptr(), 2, 8)]
+        assert plan.lookup(w1, g1, True) is it1 and plan.lookup(w2, g2, False) is it2
+        assert plan.lookup(w3, g3, True) is None and plan.misses == 0       # self-packing: not a miss
+    assert plan.state == "ready"
+    with plan:                                    # a data gradient the plan holds no images for: miss -> record again next time
+        assert plan.lookup(w2, g2, True) is None and plan.misses == 1
+    assert plan.state == "record" and not plan.items and plan.buf is None
+    with plan:
+        plan.record(w1, g1, 3, False)
+    with plan:                                    # a pass that uses none of the images (weights cast on the fly, ...)
+        pass
+    assert plan.state == "record"
+    with pytest.raises(RuntimeError):             # an exception inside the pass: the plan starts over
+        with plan:
+            plan.record(w1, g1, 3, False)
+            raise RuntimeError("boom")
+    assert plan.state == "record" and not plan.items
