@@ -12,6 +12,7 @@
 //
 //   fp32 path : v_mfma_f32_32x32x2_f32  (exact fp32 fma chain; K order permuted {s, 16+s})
 //   bf16 path : v_mfma_f32_32x32x16_bf16 (fp32 accumulate)
+#include <cstring>
 #include <set>
 #include <string>
 
@@ -435,10 +436,17 @@ static const char *label_x3(const ConvGemmArgs &a, const char *f32_label) {
   s.replace(s.find("f32"), 3, "x3");
   return pool.insert(s).first->c_str();
 }
-// (engine_common.h conv_gemm_reads_split_only() keys on the "<x3" of these labels: a kernel family labelled so reads ConvGemmArgs::wx and
-//  never ConvGemmArgs::w -- the training step then does not pack the fp32 image at all, and hands the kernels a null `w`)
 const char *conv_gemm_variant_name(int dt, const ConvGemmArgs &a) {
   return dt == F32 ? label_x3(a, variant_name_bf16(dt, a)) : label_for_dtype(dt, variant_name_bf16(dt, a));
+}
+// With a split image at hand (ConvGemmArgs::wx), does launch_conv_gemm(dt, a) take a kernel family that reads ONLY that image -- the
+// macro tiles, the wave-private / lean 32x32 kernels and the register-staged kernel in split mode, exactly the families label_x3() and
+// variant_name_bf16() label "<x3" -- so that ConvGemmArgs::w need not exist?  (The training step then packs no fp32 image and passes a
+// null `w`: a wrong answer here is a memory fault at address 0, not a wrong number.)
+bool conv_gemm_reads_split_only(int dt, const ConvGemmArgs &a_in) {
+  ConvGemmArgs a = a_in;
+  a.w = a.wx = reinterpret_cast<const void *>(16);   // probe: the decision depends on shapes and flags only
+  return std::strstr(conv_gemm_variant_name(dt, a), "<x3") != nullptr;
 }
 
 // Macro tiles pay from ~80 tiles of 256x128 per launch: a launch then occupies ~1/3 of the CUs at 4+ TFLOP/s each, and the

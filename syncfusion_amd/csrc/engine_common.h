@@ -134,13 +134,6 @@ inline ConvGemmArgs conv1d_dgrad_args(const float *dy, int B, int L, int C, int 
   a.wx_mode = X3_BF16;   // gradients span the whole fp32 exponent range: bf16 hi / lo
   return a;
 }
-// would launch_conv_gemm(dt, a) with a split image at hand take a kernel that reads ONLY the split image (so that the fp32 image need not exist)?
-inline bool conv_gemm_reads_split_only(int dt, ConvGemmArgs a) {
-  a.w = a.wx = reinterpret_cast<const void *>(16);   // probe
-  const char *name = conv_gemm_variant_name(dt, a);
-  return std::strstr(name, "<x3") != nullptr;   // conv_gemm_mt<x3>, conv_gemm_wp<x3,..>, conv_gemm_fast<x3,..>, conv_gemm_rs<x3,..>
-}
-
 // Name lookup + packing helper shared by the Encoder1d and VideoOnsetNet engines.
 struct Packer {
   DeviceArena &arena;

@@ -150,6 +150,7 @@ struct ConvGemmForce {
 extern ConvGemmForce g_conv_gemm_force;
 // name of the tile variant launch_conv_gemm picks for these arguments (profiling labels)
 const char *conv_gemm_variant_name(int dt, const ConvGemmArgs &a);
+bool conv_gemm_reads_split_only(int dt, const ConvGemmArgs &a);   // with ConvGemmArgs::wx at hand, is ConvGemmArgs::w never read? (conv_gemm.hip)
 // the label of the bf16 build with the type renamed when dt == F16 (interned string)
 const char *label_for_dtype(int dt, const char *bf16_label);
 // bytes of dynamic LDS the GN table needs is bounded; returns false when the shape is unsupported.
