@@ -59,7 +59,9 @@ class PackPlan:
     LATER pass packs all of them from the CURRENT weight values with one launch on entry -- nothing is cached across passes, so an optimizer
     step, ``load_state_dict`` or any in-place update between passes is always seen -- and the convolutions read their images from the
     buffer.  A convolution the plan does not know (other shapes, a temporary weight) packs its own as before; any miss makes the plan
-    re-record on the next pass.  The plan keeps the recorded weight tensors alive, so the addresses in its table stay valid."""
+    re-record on the next pass.  The plan keeps the recorded weight tensors alive, so the addresses in its table stay valid.  Cost: the
+    buffer holds two 4-byte images per weight element (1.6 GB for the 215 M-parameter U-Net) per plan; ``training._pack_plan`` keeps at
+    most four plans (input shapes) per module.  ``SF_TRAIN_SELF_PACK=1`` turns plans (and the fused per-convolution pack) off."""
 
     def __init__(self):
         self.reset()
